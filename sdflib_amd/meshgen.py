@@ -1,0 +1,89 @@
+"""Synthetic closed manifold meshes for tests and bench.
+
+No Bunny / Armadillo file exists in this environment, so displaced icospheres stand in:
+``bumpy_icosphere(4)`` = 5 120 triangles (Bunny scale), ``(7)`` = 327 680 (Armadillo scale),
+``(8)`` = 1 310 720 (the "1 M triangle" mesh).  Everything is evaluated in float32 and is deterministic.
+The box follows SdfExporter: mesh bbox + 20 % of the largest extent on every side
+(reference src/tools/SdfExporter/main.cpp:92-95).
+"""
+import numpy as np
+
+_X = np.float32(0.525731112119133606)
+_Z = np.float32(0.850650808352039932)
+
+_ICO_V = np.array([
+    [-_X, 0, _Z], [_X, 0, _Z], [-_X, 0, -_Z], [_X, 0, -_Z],
+    [0, _Z, _X], [0, _Z, -_X], [0, -_Z, _X], [0, -_Z, -_X],
+    [_Z, _X, 0], [-_Z, _X, 0], [_Z, -_X, 0], [-_Z, -_X, 0]], dtype=np.float32)
+
+# outward (counter-clockwise seen from outside) winding
+_ICO_F = np.array([
+    [0, 1, 4], [0, 4, 9], [9, 4, 5], [4, 8, 5], [4, 1, 8],
+    [8, 1, 10], [8, 10, 3], [5, 8, 3], [5, 3, 2], [2, 3, 7],
+    [7, 3, 10], [7, 10, 6], [7, 6, 11], [11, 6, 0], [0, 6, 1],
+    [6, 10, 1], [9, 11, 0], [9, 2, 11], [9, 5, 2], [7, 11, 2]], dtype=np.uint32)
+
+
+def icosphere(subdivisions):
+    """Unit icosphere with 20*4**s triangles: (float32 [V,3], uint32 [T,3]), outward winding."""
+    v = _ICO_V.copy()
+    f = _ICO_F.copy()
+    for _ in range(subdivisions):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], axis=0).astype(np.int64)
+        e.sort(axis=1)
+        key = e[:, 0] * (len(v) + 1) + e[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        a = (uniq // (len(v) + 1)).astype(np.int64)
+        b = (uniq % (len(v) + 1)).astype(np.int64)
+        mid = np.float32(0.5) * (v[a] + v[b])
+        mid = mid / np.sqrt((mid * mid).sum(axis=1, dtype=np.float32))[:, None].astype(np.float32)
+        base = len(v)
+        v = np.concatenate([v, mid.astype(np.float32)], axis=0)
+        T = len(f)
+        m01 = (base + inv[0:T]).astype(np.uint32)
+        m12 = (base + inv[T:2 * T]).astype(np.uint32)
+        m20 = (base + inv[2 * T:3 * T]).astype(np.uint32)
+        f = np.concatenate([
+            np.stack([f[:, 0], m01, m20], axis=1),
+            np.stack([m01, f[:, 1], m12], axis=1),
+            np.stack([m20, m12, f[:, 2]], axis=1),
+            np.stack([m01, m12, m20], axis=1)], axis=0).astype(np.uint32)
+    return np.ascontiguousarray(v, dtype=np.float32), np.ascontiguousarray(f, dtype=np.uint32)
+
+
+def bumpy_icosphere(subdivisions):
+    """Icosphere radially displaced by r = 1 + 0.08 sin9x sin(7y+1) sin(8z+2) + 0.02 sin(31x+y) sin29z (fp32)."""
+    v, f = icosphere(subdivisions)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    f32 = np.float32
+    r = (f32(1.0) + f32(0.08) * np.sin(f32(9) * x) * np.sin(f32(7) * y + f32(1)) * np.sin(f32(8) * z + f32(2))
+         + f32(0.02) * np.sin(f32(31) * x + y) * np.sin(f32(29) * z)).astype(np.float32)
+    return np.ascontiguousarray(v * r[:, None], dtype=np.float32), f
+
+
+def cube_mesh():
+    """Axis-aligned unit cube (12 triangles, 8 shared vertices), outward winding."""
+    v = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5],
+                  [-.5, -.5, .5], [.5, -.5, .5], [.5, .5, .5], [-.5, .5, .5]], dtype=np.float32)
+    f = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7], [0, 1, 5], [0, 5, 4],
+                  [1, 2, 6], [1, 6, 5], [2, 3, 7], [2, 7, 6], [3, 0, 4], [3, 4, 7]], dtype=np.uint32)
+    return v, f
+
+
+def box_with_margin(vertices, margin=0.2):
+    """(min xyz, max xyz) float32[6]: mesh bbox grown by margin * largest extent on every side."""
+    lo = vertices.min(axis=0).astype(np.float32)
+    hi = vertices.max(axis=0).astype(np.float32)
+    m = np.float32(margin) * np.float32((hi - lo).max())
+    return np.concatenate([lo - m, hi + m]).astype(np.float32)
+
+
+def random_points_in_box(box6, n, seed=1234):
+    """n uniform float32 points inside the cube-ified box the octree will cover."""
+    lo, hi = box6[:3].astype(np.float32), box6[3:].astype(np.float32)
+    size = np.float32((hi - lo).max())
+    c = lo + np.float32(0.5) * (hi - lo)
+    cmin = c - np.float32(0.5) * size
+    rng = np.random.default_rng(seed)
+    u = rng.random((n, 3), dtype=np.float32)
+    return np.ascontiguousarray(cmin + u * size * np.float32(0.999999), dtype=np.float32)

@@ -1,0 +1,111 @@
+"""Dev-time pinning of the oracle's tricubic rules against the reference's literal expressions.
+
+Parses (never copies) the generated straight-line code in /root/reference/include/SdfLib/
+InterpolationMethods.h and checks, term by term, that the rule-based restatement in oracle/orc_tricubic.h
+(fit matrix = H(x)H(x)H in (vertex, slot) order; value / derivative sums in ascending coefficient order with
+left-to-right power products) generates exactly the same expressions.  Skips when the reference is absent.
+Run:  python tools/check_ref_expressions.py
+"""
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+REF = "/root/reference/include/SdfLib/InterpolationMethods.h"
+
+
+def parse_sum(expr):
+    """'a + b + c' -> list of terms; each term = (int factor or None, coeff index, [axis factors])."""
+    terms = []
+    for t in [s.strip() for s in expr.replace("\n", " ").split(" + ")]:
+        if t in ("0.0f", ""):
+            terms.append(("zero",)); continue
+        toks = [x.strip() for x in t.split("*")]
+        fac = None
+        if re.fullmatch(r"-?\d+", toks[0]):
+            fac = int(toks[0]); toks = toks[1:]
+        m = re.fullmatch(r"values\[(\d+)\]", toks[0])
+        assert m, t
+        axes = []
+        for x in toks[1:]:
+            mm = re.fullmatch(r"fracPart\[(\d)\]", x); assert mm, t
+            axes.append(int(mm.group(1)))
+        terms.append((fac, int(m.group(1)), axes))
+    return terms
+
+
+def gen_value():
+    out = [("zero",)]
+    for n in range(64):
+        i, j, k = n & 3, (n >> 2) & 3, n >> 4
+        out.append((None, n, [0] * i + [1] * j + [2] * k))
+    return out
+
+
+def gen_deriv(ex, ey, ez):
+    out = []
+    for n in range(64):
+        i, j, k = n & 3, (n >> 2) & 3, n >> 4
+        fac = (i if ex else 1) * (j if ey else 1) * (k if ez else 1)
+        if fac == 0:
+            continue
+        out.append((fac, n, [0] * (i - ex) + [1] * (j - ey) + [2] * (k - ez)))
+    return out
+
+
+def main():
+    if not os.path.exists(REF):
+        print("reference not present: skipped"); return 0
+    src = open(REF).read()
+    live = src[src.index("struct TriCubicInterpolation"):]
+    # ---- fit matrix
+    from oracle import pyoracle as O
+    M = O.fit_matrix()
+    rows = {}
+    for m in re.finditer(r"outCoeff\[(\d+)\] = (.*?);", live):
+        terms = re.findall(r"(-?\d+) \* inValues\[(\d)\]\[(\d)\]", m.group(2))
+        rows[int(m.group(1))] = [(int(c), int(v), int(q)) for c, v, q in terms]
+    assert len(rows) == 64
+    for r in range(64):
+        mine = [(int(M[r, 8 * v + q]), v, q) for v in range(8) for q in range(8) if M[r, 8 * v + q] != 0]
+        assert mine == rows[r], ("fit row", r)
+    print("fit matrix: 64 rows identical (coefficients and term order)")
+    # ---- scalar interpolateValue (ENOKI off)
+    scalar = live[live.index("#else"):live.index("#endif")]
+    body = re.search(r"return (.*?);", scalar, re.S).group(1)
+    assert parse_sum(body) == gen_value()
+    print("interpolateValue: identical")
+    # ---- gradient
+    ga = live.index("inline static glm::vec3 interpolateGradient")
+    gb = live.index("inline static void interpolateVertexValues", ga)
+    g = live[ga:gb]
+    body = re.search(r"return glm::vec3\((.*)\);", g, re.S).group(1)
+    # split the three components at top-level commas (no nested parentheses in the body)
+    comps = [c.strip() for c in body.split(",")]
+    assert len(comps) == 3
+    for comp, d in zip(comps, [(1, 0, 0), (0, 1, 0), (0, 0, 1)]):
+        assert parse_sum(comp) == gen_deriv(*d), d
+    print("interpolateGradient: identical")
+    # ---- vertex values
+    vv = live[gb:]
+    exprs = re.findall(r"outValues\[(\d)\] = (.*?);", vv, re.S)
+    want = {1: ((1, 0, 0), "nodeSize"), 2: ((0, 1, 0), "nodeSize"), 3: ((0, 0, 1), "nodeSize"),
+            4: ((1, 1, 0), "sqNodeSize"), 5: ((1, 0, 1), "sqNodeSize"), 6: ((0, 1, 1), "sqNodeSize"),
+            7: ((1, 1, 1), "(sqNodeSize * nodeSize)")}
+    seen = set()
+    for idx, e in exprs:
+        idx = int(idx); e = e.strip()
+        if idx == 0:
+            assert parse_sum(e) == gen_value(); seen.add(0); continue
+        m = re.fullmatch(r"\((.*)\) / (.*)", e, re.S)
+        assert m, e[:80]
+        assert m.group(2).strip() == want[idx][1], (idx, m.group(2))
+        assert parse_sum(m.group(1)) == gen_deriv(*want[idx][0]), idx
+        seen.add(idx)
+    assert seen == set(range(8))
+    print("interpolateVertexValues: 8 expressions identical")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
