@@ -1,0 +1,184 @@
+/* sdfhip.h — C ABI of the MI355X-native SDF engine (libsdfhip.so).
+ *
+ * Drop-in boundary for ONE hot path of UPC-ViRVIG/SdfLib: construction of OctreeSdf / ExactOctreeSdf from a
+ * triangle mesh and their getDistance() queries.  Plain pointers and sizes only; no C++/torch types.
+ * Every function returns 0 on success or a negative SDFHIP_E_* code; sdfhip_last_error() gives the text of the
+ * last failure on this thread.  Nothing here ever falls back to a CPU implementation: without a usable HIP
+ * device the context cannot be created and every call fails loudly.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   sdfhip_mesh_create        <- sdflib::Mesh(vec3*, n, u32*, n)                 src/utils/Mesh.cpp:34-42
+ *                                + TriangleUtils::calculateMeshTriangleData       src/utils/TriangleUtils.cpp:7-428
+ *                                + ICG(mesh) (tmd::TriangleMeshDistance BVH)      include/SdfLib/TrianglesInfluence.h:886-924
+ *   sdfhip_mesh_nearest       <- ICG::getNearestTriangle                          include/SdfLib/TrianglesInfluence.h:898-905
+ *   sdfhip_octree_build*      <- OctreeSdf::OctreeSdf / buildOctree / initOctree  include/SdfLib/OctreeSdf.h:156-172,
+ *                                                                                 src/sdf/OctreeSdf.cpp:17-86, src/sdf/OctreeSdfDepthFirst.h:32-558
+ *   sdfhip_octree_query       <- OctreeSdf::getDistance (both overloads)          src/sdf/OctreeSdf.cpp:93-152
+ *   sdfhip_octree_query_grid  <- the per-pixel/lattice loops of the tools         src/tools/SdfError/main.cpp:60-66
+ *   sdfhip_octree_download    <- OctreeSdf::getOctreeData / getters               include/SdfLib/OctreeSdf.h:177-219
+ *   sdfhip_exact_build        <- ExactOctreeSdf::ExactOctreeSdf / initOctree      src/sdf/ExactOctreeSdf.cpp:7-31,
+ *                                                                                 include/SdfLib/ExactOctreeSdfDepthFirst.h:28-681
+ *   sdfhip_exact_query        <- ExactOctreeSdf::getDistance (both overloads)     src/sdf/ExactOctreeSdf.cpp:38-320
+ *   The Unity-style handle API (createOctreeSdf, getDistance, ...) of src/tools/SdfLibUnity/SdfExportFunc.h:16-58
+ *   is provided on top of this header by include/SdfLib/SdfExportFunc.h.
+ */
+#ifndef SDFHIP_H
+#define SDFHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDFHIP_OK 0
+#define SDFHIP_E_INVALID (-1)     /* bad argument */
+#define SDFHIP_E_HIP (-2)         /* HIP runtime error (text in sdfhip_last_error) */
+#define SDFHIP_E_NO_DEVICE (-3)   /* no usable gfx950 device: there is no CPU fallback */
+#define SDFHIP_E_TOO_LARGE (-4)   /* structure exceeds the 30-bit node index of the reference layout */
+#define SDFHIP_E_UNSUPPORTED (-5)
+
+/* where a caller-supplied buffer lives */
+#define SDFHIP_HOST 0
+#define SDFHIP_DEVICE 1
+
+/* OctreeSdf::TerminationRule (include/SdfLib/OctreeSdf.h:100-106) */
+#define SDFHIP_RULE_NONE 0
+#define SDFHIP_RULE_TRAPEZOIDAL 1
+#define SDFHIP_RULE_SIMPSONS 2
+#define SDFHIP_RULE_BY_DISTANCE 3
+
+/* OctreeSdf::InitAlgorithm (include/SdfLib/OctreeSdf.h:23-28) */
+#define SDFHIP_ALG_UNIFORM 0        /* not provided (test-only in the reference) */
+#define SDFHIP_ALG_NO_CONTINUITY 1
+#define SDFHIP_ALG_CONTINUITY 2     /* not provided yet */
+
+/* node-array layout: which reference branch's array is reproduced */
+#define SDFHIP_LAYOUT_GLOBAL_DFS 0  /* numThreads < 2  (src/sdf/OctreeSdfDepthFirst.h:394-416) */
+#define SDFHIP_LAYOUT_SUBTREES 1    /* numThreads >= 2 (src/sdf/OctreeSdfDepthFirst.h:417-503): [grid][cell 0 body][cell 1 body]... */
+
+/* query arithmetic */
+#define SDFHIP_EVAL_EXACT 0   /* the reference's literal term order, no FMA: bit-identical to the CPU path */
+#define SDFHIP_EVAL_FAST 1    /* separable Horner with FMA: <= 1e-5 abs from EXACT, higher throughput */
+
+/* tricubic fit arithmetic during construction */
+#define SDFHIP_FIT_EXACT 0    /* scalar, reference summation order (defines the topology) */
+#define SDFHIP_FIT_MFMA 1     /* 64x64 fit on v_mfma_f32_32x32x2_f32; borderline decisions re-checked with EXACT */
+
+typedef struct sdfhip_ctx sdfhip_ctx;
+typedef struct sdfhip_mesh sdfhip_mesh;
+typedef struct sdfhip_octree sdfhip_octree;
+typedef struct sdfhip_exact sdfhip_exact;
+
+const char* sdfhip_last_error(void);
+const char* sdfhip_version(void);
+
+/* One context per (process, device).  stream = a hipStream_t owned by the caller (e.g. torch's current
+ * stream) or NULL for a private stream. */
+int sdfhip_ctx_create(int device_id, void* stream, sdfhip_ctx** out);
+int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
+int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
+void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
+
+/* ---- mesh: vertices (3 floats each), triangle indices (3 u32 each); host pointers, copied ------------- */
+int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
+                       uint32_t num_triangles, sdfhip_mesh** out);
+int sdfhip_mesh_destroy(sdfhip_mesh* mesh);
+/* 37 floats (148 B) per triangle, field order of TriangleUtils::TriangleData (TriangleUtils.h:56-71) */
+int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host);
+/* build (host planner, fp64) + upload the bounding-sphere BVH; implicit on first use. seconds may be NULL */
+int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds);
+/* nearest triangle id per point (fp64 BVH traversal on the device) */
+int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
+/* Hermite sample [d, gx, gy, gz, 0,0,0,0] at each point for a given triangle id
+ * (TriCubicInterpolation::calculatePointValues, InterpolationMethods.h:273-290) */
+int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t* tri_ids, uint64_t n, float* out8, int where);
+
+/* ---- OctreeSdf ------------------------------------------------------------------------------------------ */
+typedef struct sdfhip_octree_info {
+    float box_min[3], box_max[3];   /* cube-ified box (OctreeSdf.cpp:43-46) */
+    int32_t start_grid_size;
+    uint32_t max_depth;
+    float value_range;              /* mValueRange */
+    float min_border_value;         /* mMinBorderValue */
+    uint64_t num_words;             /* size of the full node array (u32 words) */
+    uint64_t num_leaves;
+    uint64_t num_nodes;             /* leaves + inner nodes from the start depth down */
+    uint64_t num_samples;           /* nearest-triangle queries issued by the build */
+    /* sharded builds: this shard's part of the array */
+    uint32_t cell_begin, cell_end;  /* start-grid cells [begin, end) owned (z-major cell index) */
+    uint64_t body_words;            /* words in this shard's bodies */
+    uint64_t body_offset;           /* absolute word offset of this shard's bodies in the full array */
+    double seconds_samples, seconds_decide, seconds_total;
+} sdfhip_octree_info;
+
+typedef struct sdfhip_octree_params {
+    float box_min[3], box_max[3];
+    uint32_t depth, start_depth;
+    int32_t rule;                   /* SDFHIP_RULE_* */
+    float rule_params[2];           /* [0] = expected error (threshold), [1] = decay for BY_DISTANCE */
+    int32_t algorithm;              /* SDFHIP_ALG_* */
+    int32_t layout;                 /* SDFHIP_LAYOUT_* */
+    int32_t fit_mode;               /* SDFHIP_FIT_* */
+    uint32_t cell_begin, cell_end;  /* shard: build only the subtrees of these start-grid cells; 0,0 = all */
+} sdfhip_octree_params;
+
+/* Whole build on one device. */
+int sdfhip_octree_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out);
+
+/* Sharded build (one process per GPU):
+ *   1. every rank:  sdfhip_octree_build_shard(...)           -> info.body_words for its cells
+ *   2. host:        exchange body_words (all-gather), prefix-sum -> body_offset of every rank
+ *   3. every rank:  sdfhip_octree_emit_shard(tree, body_offset, dst_grid, dst_body)
+ *                   writes its start-grid words and its bodies with ABSOLUTE indices
+ *   4. host:        RCCL all-gather of the bodies / grid slices, then sdfhip_octree_from_data on the result. */
+int sdfhip_octree_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out);
+int sdfhip_octree_emit_shard(sdfhip_octree* tree, uint64_t body_offset, uint32_t* dst_grid_words /* cell_end-cell_begin */,
+                             uint32_t* dst_body_words /* body_words */, int where);
+
+/* Wrap an existing node array (all-gathered shards, or a file) for queries; data is copied to the device. */
+int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num_words, int where, const float box_min[3],
+                            const float box_max[3], int32_t start_grid_size, uint32_t max_depth, float value_range,
+                            float min_border_value, sdfhip_octree** out);
+int sdfhip_octree_destroy(sdfhip_octree* tree);
+int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out);
+/* copy the node array (getOctreeData(): u32 words, leaf bit31, 64 float coefficients per leaf) */
+int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where);
+const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree);
+
+/* batched getDistance: xyz = n points (3 floats each); out_grad may be NULL (normalised gradient otherwise) */
+int sdfhip_octree_query(sdfhip_octree* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int where, int eval_mode);
+/* lattice of nx*ny*nz points origin + (i,j,k)*step, x fastest; outputs nx*ny*nz floats (+3x for the gradient) */
+int sdfhip_octree_query_grid(sdfhip_octree* tree, const float origin[3], const float step[3], uint32_t nx, uint32_t ny, uint32_t nz,
+                             float* out_dist, float* out_grad, int where, int eval_mode);
+
+/* ---- ExactOctreeSdf -------------------------------------------------------------------------------------- */
+typedef struct sdfhip_exact_info {
+    float box_min[3], box_max[3];
+    int32_t start_grid_size;
+    uint32_t start_depth, max_depth, bit_encoding_start_depth, bits_per_index;
+    uint32_t min_triangles_in_leafs, max_triangles_in_leafs, max_triangles_encoded_in_leafs;
+    uint64_t num_nodes, num_set_words, num_mask_bytes, num_triangles;
+    uint64_t cull_tests;            /* IsNearMinimize evaluations during the build */
+    double seconds_total;
+} sdfhip_exact_info;
+
+int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t max_depth,
+                       uint32_t start_depth, uint32_t min_triangles_per_node, sdfhip_exact** out);
+int sdfhip_exact_destroy(sdfhip_exact* tree);
+int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
+/* nodes: 2 u32 per node {childrenIndex, trianglesArrayIndex}; node_has_tri_idx: 1 where the reference writes
+ * trianglesArrayIndex (it leaves the others uninitialised; here they are 0) */
+int sdfhip_exact_download(sdfhip_exact* tree, uint32_t* nodes, uint8_t* node_has_tri_idx, uint32_t* sets, uint8_t* masks);
+int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad /* nullable */,
+                       uint32_t* out_triangle /* nullable */, int where);
+
+/* ---- building blocks exposed for parity tests (device execution, host pointers) --------------------------- */
+int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode);
+int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr,
+                            uint64_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFHIP_H */

@@ -1,0 +1,99 @@
+"""ctypes loader for libsdfhip.so (the hand-written HIP engine).
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is usable, every entry point fails
+loudly.  ``import torch`` happens first (when torch is installed) so that the library binds to the same HIP
+runtime (libamdhip64.so.7) torch already loaded — device pointers and streams can then be shared.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+_LIB = None
+
+
+class SdfHipError(RuntimeError):
+    pass
+
+
+class OctreeInfo(C.Structure):
+    _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("start_grid_size", C.c_int32), ("max_depth", C.c_uint32),
+                ("value_range", C.c_float), ("min_border_value", C.c_float), ("num_words", C.c_uint64), ("num_leaves", C.c_uint64),
+                ("num_nodes", C.c_uint64), ("num_samples", C.c_uint64), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32),
+                ("body_words", C.c_uint64), ("body_offset", C.c_uint64), ("seconds_samples", C.c_double), ("seconds_decide", C.c_double),
+                ("seconds_total", C.c_double)]
+
+
+class OctreeParams(C.Structure):
+    _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("depth", C.c_uint32), ("start_depth", C.c_uint32),
+                ("rule", C.c_int32), ("rule_params", C.c_float * 2), ("algorithm", C.c_int32), ("layout", C.c_int32),
+                ("fit_mode", C.c_int32), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32)]
+
+
+class ExactInfo(C.Structure):
+    _fields_ = [("box_min", C.c_float * 3), ("box_max", C.c_float * 3), ("start_grid_size", C.c_int32), ("start_depth", C.c_uint32),
+                ("max_depth", C.c_uint32), ("bit_encoding_start_depth", C.c_uint32), ("bits_per_index", C.c_uint32),
+                ("min_triangles_in_leafs", C.c_uint32), ("max_triangles_in_leafs", C.c_uint32),
+                ("max_triangles_encoded_in_leafs", C.c_uint32), ("num_nodes", C.c_uint64), ("num_set_words", C.c_uint64),
+                ("num_mask_bytes", C.c_uint64), ("num_triangles", C.c_uint64), ("cull_tests", C.c_uint64), ("seconds_total", C.c_double)]
+
+
+# every symbol include/sdfhip.h declares: name -> (restype, argtypes)
+_vp, _u32, _u64, _i32, _f32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_int
+SIGNATURES = {
+    "sdfhip_last_error": (C.c_char_p, []),
+    "sdfhip_version": (C.c_char_p, []),
+    "sdfhip_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "sdfhip_ctx_destroy": (_int, [_vp]),
+    "sdfhip_ctx_synchronize": (_int, [_vp]),
+    "sdfhip_ctx_stream": (_vp, [_vp]),
+    "sdfhip_mesh_create": (_int, [_vp, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
+    "sdfhip_mesh_destroy": (_int, [_vp]),
+    "sdfhip_mesh_triangle_data": (_int, [_vp, _vp]),
+    "sdfhip_mesh_build_bvh": (_int, [_vp, C.POINTER(C.c_double)]),
+    "sdfhip_mesh_nearest": (_int, [_vp, _vp, _u64, _vp, _int]),
+    "sdfhip_mesh_point_values": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
+    "sdfhip_octree_build": (_int, [_vp, _vp, C.POINTER(OctreeParams), C.POINTER(_vp)]),
+    "sdfhip_octree_build_shard": (_int, [_vp, _vp, C.POINTER(OctreeParams), C.POINTER(_vp)]),
+    "sdfhip_octree_emit_shard": (_int, [_vp, _u64, _vp, _vp, _int]),
+    "sdfhip_octree_from_data": (_int, [_vp, _vp, _u64, _int, _vp, _vp, _i32, _u32, _f32, _f32, C.POINTER(_vp)]),
+    "sdfhip_octree_destroy": (_int, [_vp]),
+    "sdfhip_octree_get_info": (_int, [_vp, C.POINTER(OctreeInfo)]),
+    "sdfhip_octree_download": (_int, [_vp, _vp, _int]),
+    "sdfhip_octree_device_words": (_vp, [_vp]),
+    "sdfhip_octree_query": (_int, [_vp, _vp, _u64, _vp, _vp, _int, _int]),
+    "sdfhip_octree_query_grid": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _int, _int]),
+    "sdfhip_exact_build": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "sdfhip_exact_destroy": (_int, [_vp]),
+    "sdfhip_exact_get_info": (_int, [_vp, C.POINTER(ExactInfo)]),
+    "sdfhip_exact_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdfhip_exact_query": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _int]),
+    "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
+    "sdfhip_is_near_minimize": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
+}
+
+
+def lib():
+    """Load libsdfhip.so; raises SdfHipError if it has not been built (no fallback of any kind)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise SdfHipError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950).  sdflib_amd has no CPU fallback.")
+        try:
+            import torch  # noqa: F401  (share torch's HIP runtime when present)
+        except Exception:
+            pass
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().sdfhip_last_error()
+        raise SdfHipError(f"sdfhip error {rc}: {msg.decode() if msg else ''}")

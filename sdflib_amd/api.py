@@ -1,0 +1,334 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the libsdfhip C ABI.
+
+Names and argument meaning follow the reference (include/SdfLib/OctreeSdf.h:156-219,
+include/SdfLib/ExactOctreeSdf.h:91-134, include/SdfLib/SdfFunction.h:12-58); the batched entry points
+(`get_distance` over arrays / torch tensors / a lattice) are the data-parallel form of `getDistance`.
+"""
+import ctypes as C
+import numpy as np
+
+from ._lib import lib, check, OctreeInfo, OctreeParams, ExactInfo, SdfHipError  # noqa: F401
+
+HOST, DEVICE = 0, 1
+RULE_NONE, RULE_TRAPEZOIDAL, RULE_SIMPSONS, RULE_BY_DISTANCE = 0, 1, 2, 3
+ALG_UNIFORM, ALG_NO_CONTINUITY, ALG_CONTINUITY = 0, 1, 2
+LAYOUT_GLOBAL_DFS, LAYOUT_SUBTREES = 0, 1
+EVAL_EXACT, EVAL_FAST = 0, 1
+FIT_EXACT, FIT_MFMA = 0, 1
+
+_TERMINATION_RULES = {"none": RULE_NONE, "trapezoidal_rule": RULE_TRAPEZOIDAL, "simpsons_rule": RULE_SIMPSONS,
+                      "by_distance_rule": RULE_BY_DISTANCE}
+
+
+def string_to_termination_rule(text):
+    """OctreeSdf::stringToTerminationRule (include/SdfLib/OctreeSdf.h:128-148); None when unknown."""
+    return _TERMINATION_RULES.get(text.lower())
+
+
+def _np(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Context:
+    """One (process, device) context.  With ``use_torch_stream`` the engine runs on torch's current stream."""
+
+    def __init__(self, device=0, stream=None, use_torch_stream=False):
+        if use_torch_stream and stream is None:
+            import torch
+            stream = torch.cuda.current_stream(device).cuda_stream
+        h = C.c_void_p()
+        check(lib().sdfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self.h, self.device = h, int(device)
+
+    def synchronize(self):
+        check(lib().sdfhip_ctx_synchronize(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_ctx_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class Mesh:
+    """sdflib::Mesh(vertices, indices) + the per-mesh acceleration data (TriangleData, sphere BVH) on the device."""
+
+    def __init__(self, vertices, indices, ctx=None):
+        self.ctx = ctx or default_context()
+        self.vertices = _np(vertices, np.float32).reshape(-1, 3)
+        self.indices = _np(indices, np.uint32).reshape(-1, 3)
+        h = C.c_void_p()
+        check(lib().sdfhip_mesh_create(self.ctx.h, _ptr(self.vertices), len(self.vertices), _ptr(self.indices), len(self.indices), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_mesh_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def triangle_data(self):
+        out = np.empty((len(self.indices), 37), dtype=np.float32)
+        check(lib().sdfhip_mesh_triangle_data(self.h, _ptr(out)))
+        return out
+
+    def build_bvh(self):
+        s = C.c_double()
+        check(lib().sdfhip_mesh_build_bvh(self.h, C.byref(s)))
+        return s.value
+
+    def nearest_triangle(self, points):
+        pts = _np(points, np.float32).reshape(-1, 3)
+        out = np.empty(len(pts), dtype=np.uint32)
+        check(lib().sdfhip_mesh_nearest(self.h, _ptr(pts), len(pts), _ptr(out), HOST))
+        return out
+
+    def point_values(self, points, triangle_ids):
+        pts = _np(points, np.float32).reshape(-1, 3); t = _np(triangle_ids, np.uint32)
+        out = np.empty((len(pts), 8), dtype=np.float32)
+        check(lib().sdfhip_mesh_point_values(self.h, _ptr(pts), _ptr(t), len(pts), _ptr(out), HOST))
+        return out
+
+
+def _params(box, depth, start_depth, rule, rule_params, algorithm, layout, fit_mode, cells):
+    p = OctreeParams()
+    box = _np(box, np.float32).reshape(6)
+    for i in range(3):
+        p.box_min[i] = box[i]; p.box_max[i] = box[3 + i]
+    p.depth, p.start_depth, p.rule = depth, start_depth, rule
+    p.rule_params[0] = rule_params[0]; p.rule_params[1] = rule_params[1] if len(rule_params) > 1 else 0.0
+    p.algorithm, p.layout, p.fit_mode = algorithm, layout, fit_mode
+    p.cell_begin, p.cell_end = cells
+    return p
+
+
+class OctreeSdf:
+    """sdflib::OctreeSdf built on the GPU.
+
+    OctreeSdf(mesh, box, depth, start_depth, max_error=1e-3, init_algorithm=NO_CONTINUITY, num_threads=1)
+    mirrors the reference constructor (include/SdfLib/OctreeSdf.h:156-160); ``num_threads`` selects which of the
+    reference's two array layouts is produced (1 -> numThreads<2 array, >=2 -> per-start-cell sub-octrees).
+    """
+
+    def __init__(self, mesh=None, box=None, depth=None, start_depth=None, max_error=1e-3, init_algorithm=ALG_NO_CONTINUITY,
+                 num_threads=2, termination_rule=RULE_TRAPEZOIDAL, rule_params=None, fit_mode=FIT_EXACT, _handle=None, _ctx=None):
+        if _handle is not None:
+            self.h, self.ctx = _handle, _ctx
+        else:
+            self.ctx = mesh.ctx
+            rp = rule_params if rule_params is not None else (max_error, 0.0)
+            layout = LAYOUT_GLOBAL_DFS if num_threads < 2 else LAYOUT_SUBTREES
+            p = _params(box, depth, start_depth, termination_rule, rp, init_algorithm, layout, fit_mode, (0, 0))
+            h = C.c_void_p()
+            check(lib().sdfhip_octree_build(self.ctx.h, mesh.h, C.byref(p), C.byref(h)))
+            self.h = h
+        self._info = None
+
+    @classmethod
+    def from_data(cls, ctx, words, box_min, box_max, start_grid_size, max_depth, value_range, min_border_value, where=HOST):
+        h = C.c_void_p()
+        bmin, bmax = _np(box_min, np.float32), _np(box_max, np.float32)
+        if where == HOST:
+            words = _np(words, np.uint32); ptr, n = _ptr(words), len(words)
+        else:
+            ptr, n = C.c_void_p(words.data_ptr()), words.numel()
+        check(lib().sdfhip_octree_from_data(ctx.h, ptr, n, where, _ptr(bmin), _ptr(bmax), int(start_grid_size), int(max_depth),
+                                            float(value_range), float(min_border_value), C.byref(h)))
+        return cls(_handle=h, _ctx=ctx)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_octree_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self):
+        i = OctreeInfo()
+        check(lib().sdfhip_octree_get_info(self.h, C.byref(i)))
+        return i
+
+    # reference getters
+    def get_octree_value_range(self): return self.info.value_range
+    def get_octree_min_border_value(self): return self.info.min_border_value
+    def get_start_grid_size(self): return (self.info.start_grid_size,) * 3
+    def get_grid_bounding_box(self): i = self.info; return np.array(list(i.box_min) + list(i.box_max), dtype=np.float32)
+    get_sample_area = get_grid_bounding_box
+    def get_octree_max_depth(self): return self.info.max_depth
+
+    def get_octree_data(self):
+        """getOctreeData(): the flat u32 node array (host copy)."""
+        out = np.empty(self.info.num_words, dtype=np.uint32)
+        check(lib().sdfhip_octree_download(self.h, _ptr(out), HOST))
+        return out
+
+    def get_distance(self, points, gradient=False, eval_mode=EVAL_EXACT, out=None, out_grad=None):
+        """Batched getDistance.  numpy in -> numpy out; torch CUDA tensor in -> torch tensors out (async on the ctx stream)."""
+        if _is_torch(points):
+            import torch
+            pts = points.contiguous()
+            assert pts.is_cuda and pts.dtype == torch.float32 and pts.shape[-1] == 3
+            n = pts.numel() // 3
+            d = out if out is not None else torch.empty(n, dtype=torch.float32, device=pts.device)
+            g = (out_grad if out_grad is not None else torch.empty((n, 3), dtype=torch.float32, device=pts.device)) if gradient else None
+            check(lib().sdfhip_octree_query(self.h, C.c_void_p(pts.data_ptr()), n, C.c_void_p(d.data_ptr()),
+                                            C.c_void_p(g.data_ptr()) if gradient else None, DEVICE, eval_mode))
+            return (d, g) if gradient else d
+        pts = _np(points, np.float32).reshape(-1, 3)
+        d = np.empty(len(pts), dtype=np.float32)
+        g = np.zeros((len(pts), 3), dtype=np.float32) if gradient else None
+        check(lib().sdfhip_octree_query(self.h, _ptr(pts), len(pts), _ptr(d), _ptr(g), HOST, eval_mode))
+        return (d, g) if gradient else d
+
+    def get_distance_grid(self, origin, step, shape, gradient=False, eval_mode=EVAL_EXACT, device_out=False):
+        """Lattice origin + (i,j,k)*step, x fastest; shape = (nx, ny, nz)."""
+        o, s = _np(origin, np.float32), _np(step, np.float32)
+        nx, ny, nz = (int(v) for v in shape)
+        n = nx * ny * nz
+        if device_out:
+            import torch
+            dev = torch.device("cuda", self.ctx.device)
+            d = torch.empty(n, dtype=torch.float32, device=dev)
+            g = torch.empty((n, 3), dtype=torch.float32, device=dev) if gradient else None
+            check(lib().sdfhip_octree_query_grid(self.h, _ptr(o), _ptr(s), nx, ny, nz, C.c_void_p(d.data_ptr()),
+                                                 C.c_void_p(g.data_ptr()) if gradient else None, DEVICE, eval_mode))
+            return (d, g) if gradient else d
+        d = np.empty(n, dtype=np.float32)
+        g = np.zeros((n, 3), dtype=np.float32) if gradient else None
+        check(lib().sdfhip_octree_query_grid(self.h, _ptr(o), _ptr(s), nx, ny, nz, _ptr(d), _ptr(g), HOST, eval_mode))
+        return (d, g) if gradient else d
+
+
+class OctreeShard:
+    """One rank's part of a sharded OctreeSdf build (start-grid cells [cell_begin, cell_end))."""
+
+    def __init__(self, mesh, box, depth, start_depth, max_error=1e-3, cells=(0, 0), termination_rule=RULE_TRAPEZOIDAL, rule_params=None):
+        self.ctx = mesh.ctx
+        rp = rule_params if rule_params is not None else (max_error, 0.0)
+        p = _params(box, depth, start_depth, termination_rule, rp, ALG_NO_CONTINUITY, LAYOUT_SUBTREES, FIT_EXACT, cells)
+        h = C.c_void_p()
+        check(lib().sdfhip_octree_build_shard(self.ctx.h, mesh.h, C.byref(p), C.byref(h)))
+        self.h = h
+
+    @property
+    def info(self):
+        i = OctreeInfo()
+        check(lib().sdfhip_octree_get_info(self.h, C.byref(i)))
+        return i
+
+    def emit(self, body_offset, dst_grid, dst_body):
+        """Write this shard's start-grid words and bodies (absolute indices) into numpy arrays or torch CUDA tensors."""
+        if _is_torch(dst_grid):
+            check(lib().sdfhip_octree_emit_shard(self.h, int(body_offset), C.c_void_p(dst_grid.data_ptr()), C.c_void_p(dst_body.data_ptr()), DEVICE))
+        else:
+            check(lib().sdfhip_octree_emit_shard(self.h, int(body_offset), _ptr(dst_grid), _ptr(dst_body), HOST))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_octree_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ExactOctreeSdf:
+    """sdflib::ExactOctreeSdf(mesh, box, maxDepth, startDepth=1, minTrianglesPerNode=128) on the GPU."""
+
+    def __init__(self, mesh, box, max_depth, start_depth=1, min_triangles_per_node=128, num_threads=1):
+        self.ctx = mesh.ctx
+        box = _np(box, np.float32).reshape(6)
+        bmin, bmax = box[:3].copy(), box[3:].copy()
+        h = C.c_void_p()
+        check(lib().sdfhip_exact_build(self.ctx.h, mesh.h, _ptr(bmin), _ptr(bmax), int(max_depth), int(start_depth),
+                                       int(min_triangles_per_node), C.byref(h)))
+        self.h = h
+
+    @property
+    def info(self):
+        i = ExactInfo()
+        check(lib().sdfhip_exact_get_info(self.h, C.byref(i)))
+        return i
+
+    def get_start_grid_size(self): return (self.info.start_grid_size,) * 3
+    def get_grid_bounding_box(self): i = self.info; return np.array(list(i.box_min) + list(i.box_max), dtype=np.float32)
+    get_sample_area = get_grid_bounding_box
+    def get_max_triangles_in_leafs(self): return self.info.max_triangles_in_leafs
+    def get_min_triangles_in_leafs(self): return self.info.min_triangles_in_leafs
+    def get_octree_max_depth(self): return self.info.max_depth
+
+    def download(self):
+        i = self.info
+        nodes = np.zeros((i.num_nodes, 2), dtype=np.uint32); has = np.zeros(i.num_nodes, dtype=np.uint8)
+        sets = np.zeros(i.num_set_words, dtype=np.uint32); masks = np.zeros(max(i.num_mask_bytes, 1), dtype=np.uint8)
+        check(lib().sdfhip_exact_download(self.h, _ptr(nodes), _ptr(has), _ptr(sets), _ptr(masks)))
+        return nodes, has, sets, masks[:i.num_mask_bytes]
+
+    def get_distance(self, points, gradient=False, triangle=False):
+        if _is_torch(points):
+            import torch
+            pts = points.contiguous(); n = pts.numel() // 3
+            d = torch.empty(n, dtype=torch.float32, device=pts.device)
+            g = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if gradient else None
+            t = torch.empty(n, dtype=torch.int32, device=pts.device) if triangle else None
+            check(lib().sdfhip_exact_query(self.h, C.c_void_p(pts.data_ptr()), n, C.c_void_p(d.data_ptr()),
+                                           C.c_void_p(g.data_ptr()) if gradient else None, C.c_void_p(t.data_ptr()) if triangle else None, DEVICE))
+        else:
+            pts = _np(points, np.float32).reshape(-1, 3)
+            d = np.empty(len(pts), dtype=np.float32)
+            g = np.zeros((len(pts), 3), dtype=np.float32) if gradient else None
+            t = np.empty(len(pts), dtype=np.uint32) if triangle else None
+            check(lib().sdfhip_exact_query(self.h, _ptr(pts), len(pts), _ptr(d), _ptr(g), _ptr(t), HOST))
+        res = [d]
+        if gradient: res.append(g)
+        if triangle: res.append(t)
+        return res[0] if len(res) == 1 else tuple(res)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_exact_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def tricubic_fit(values_8x8, node_sizes, ctx=None, fit_mode=FIT_EXACT):
+    ctx = ctx or default_context()
+    v = _np(values_8x8, np.float32).reshape(-1, 64); ns = _np(node_sizes, np.float32).reshape(-1)
+    out = np.empty_like(v)
+    check(lib().sdfhip_tricubic_fit(ctx.h, _ptr(v), _ptr(ns), len(v), _ptr(out), fit_mode))
+    return out

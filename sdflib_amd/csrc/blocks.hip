@@ -1,0 +1,41 @@
+// Building blocks exposed through the C ABI for parity tests.  PRODUCT code — independent of oracle/.
+#include "sdfhip_internal.h"
+#include "dev_tricubic.h"
+
+namespace sdfhip {
+
+__global__ void __launch_bounds__(128) k_fit_exact(const float* __restrict__ in, const float* __restrict__ nodeSize, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s[64], c[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) s[k] = in[64 * i + k];
+    tricubicFit(s, nodeSize[i], c);
+#pragma unroll
+    for (int k = 0; k < 64; k++) out[64 * i + k] = c[k];
+}
+
+}  // namespace sdfhip
+
+using namespace sdfhip;
+
+extern "C" {
+
+int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode) {
+    SDF_REQUIRE(ctx && values_8x8 && node_sizes && out64, "NULL argument");
+    if (fit_mode != SDFHIP_FIT_EXACT) { setError("fit_mode %d not provided", fit_mode); return SDFHIP_E_UNSUPPORTED; }
+    if (n == 0) return SDFHIP_OK;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<float> din, dns, dout;
+    SDF_TRY(din.reserve(64 * n)); SDF_TRY(dns.reserve(n)); SDF_TRY(dout.reserve(64 * n));
+    SDF_HIP_CHECK(hipMemcpyAsync(din.p, values_8x8, 256 * n, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dns.p, node_sizes, 4 * n, hipMemcpyHostToDevice, st));
+    k_fit_exact<<<gridFor(n, 128), 128, 0, st>>>(din.p, dns.p, n, dout.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipMemcpyAsync(out64, dout.p, 256 * n, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,201 @@
+// Context + mesh preparation (TriangleData on the device).  PRODUCT code — independent of oracle/.
+//
+// Reproduces TriangleUtils::calculateMeshTriangleData (reference src/utils/TriangleUtils.cpp:7-86, 422-427) as
+// sort/scan passes instead of the reference's serial std::map walk:
+//   k_triangle_frames : one lane per triangle, TriangleData ctor (TriangleUtils.h:23-42)
+//   edge pseudonormals: 64-bit key (vmin,vmax) per half-edge, stable radix sort, consecutive entries of one key
+//                       are paired (1st,2nd),(3rd,4th)... exactly like the map's insert/erase sequence (:63-83)
+//   vertex pseudonormals: (vertex, 3t+k) pairs stable-sorted by vertex, then ONE lane sums a vertex's
+//                       contributions sequentially in ascending 3t+k — the reference's float addition order (:85-86)
+// Not reproduced: degenerate-triangle branches (dead in the reference: `if(false && ...)`, :45) and non-manifold
+// seam welding (:292-420); single-owner edges keep the default (0,0,1) and are counted in mesh->unmatchedEdges.
+#include "sdfhip_internal.h"
+#include "dev_math.h"
+#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+namespace sdfhip {
+
+static thread_local std::string g_lastError;
+
+void setError(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_lastError = buf;
+}
+
+__global__ void k_triangle_frames(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numTriangles, float* __restrict__ td) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= numTriangles) return;
+    const uint32_t a = idx[3 * t], b = idx[3 * t + 1], c = idx[3 * t + 2];
+    const F3 p1 = F3{verts[3 * a], verts[3 * a + 1], verts[3 * a + 2]};
+    const F3 p2 = F3{verts[3 * b], verts[3 * b + 1], verts[3 * b + 2]};
+    const F3 p3 = F3{verts[3 * c], verts[3 * c + 1], verts[3 * c + 2]};
+    float out[TD_FLOATS];
+    makeTriangleData(p1, p2, p3, out);
+    float* dst = td + (size_t)TD_FLOATS * t;
+#pragma unroll
+    for (int i = 0; i < TD_FLOATS; i++) dst[i] = out[i];
+}
+
+__global__ void k_halfedge_keys(const uint32_t* __restrict__ idx, uint32_t numHalfEdges, uint64_t* __restrict__ edgeKey,
+                                uint32_t* __restrict__ vertKey, uint32_t* __restrict__ value) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numHalfEdges) return;
+    const uint32_t t = i / 3, k = i - 3 * t;
+    const uint32_t a = idx[i], b = idx[3 * t + (k + 1) % 3];
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    edgeKey[i] = ((uint64_t)lo << 32) | hi;
+    vertKey[i] = a;
+    value[i] = i;
+}
+
+__global__ void k_edge_pair(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t n, float* __restrict__ td,
+                            uint32_t* __restrict__ unmatched) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    uint32_t r = 0;                              // position inside the run of equal keys
+    while (r < i && key[i - 1 - r] == k) r++;
+    if (r & 1u) {
+        const uint32_t later = val[i], earlier = val[i - 1];
+        const uint32_t t = later / 3, t2 = earlier / 3;
+        const float* A = td + (size_t)TD_FLOATS * t;
+        const float* B = td + (size_t)TD_FLOATS * t2;
+        const F3 en = triNormal(A + 3) + triNormal(B + 3);
+        const F3 ea = mulM(A + 3, en), eb = mulM(B + 3, en);
+        float* da = td + (size_t)TD_FLOATS * t + 19 + 3 * (later % 3);
+        float* db = td + (size_t)TD_FLOATS * t2 + 19 + 3 * (earlier % 3);
+        da[0] = ea.x; da[1] = ea.y; da[2] = ea.z;
+        db[0] = eb.x; db[1] = eb.y; db[2] = eb.z;
+    } else {
+        const bool last = (i + 1 == n) || key[i + 1] != k;
+        if (last) atomicAdd(unmatched, 1u);      // odd run: this half-edge has no partner
+    }
+}
+
+__global__ void k_vertex_normal_sum(const uint32_t* __restrict__ vkey, const uint32_t* __restrict__ val, uint32_t n,
+                                    const float* __restrict__ verts, const uint32_t* __restrict__ idx, const float* __restrict__ td,
+                                    float* __restrict__ vnormal) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = vkey[i];
+    if (i > 0 && vkey[i - 1] == v) return;       // only the head of a run works
+    F3 acc = F3{0.f, 0.f, 0.f};
+    const F3 pa = F3{verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]};
+    for (uint32_t j = i; j < n && vkey[j] == v; j++) {
+        const uint32_t he = val[j], t = he / 3, k = he - 3 * t;
+        const uint32_t b = idx[3 * t + (k + 1) % 3], c = idx[3 * t + (k + 2) % 3];
+        const F3 pb = F3{verts[3 * b], verts[3 * b + 1], verts[3 * b + 2]};
+        const F3 pc = F3{verts[3 * c], verts[3 * c + 1], verts[3 * c + 2]};
+        const float cs = gclamp(dot(normalize(pb - pa), normalize(pc - pa)), -1.0f, 1.0f);
+        const float angle = acosf(cs);
+        acc = acc + angle * triNormal(td + (size_t)TD_FLOATS * t + 3);
+    }
+    vnormal[3 * v] = acc.x; vnormal[3 * v + 1] = acc.y; vnormal[3 * v + 2] = acc.z;
+}
+
+__global__ void k_vertex_normal_apply(const uint32_t* __restrict__ idx, uint32_t numHalfEdges, const float* __restrict__ vnormal, float* __restrict__ td) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numHalfEdges) return;
+    const uint32_t t = i / 3, k = i - 3 * t, v = idx[i];
+    float* T = td + (size_t)TD_FLOATS * t;
+    const F3 r = mulM(T + 3, F3{vnormal[3 * v], vnormal[3 * v + 1], vnormal[3 * v + 2]});
+    T[28 + 3 * k] = r.x; T[29 + 3 * k] = r.y; T[30 + 3 * k] = r.z;
+}
+
+}  // namespace sdfhip
+
+using namespace sdfhip;
+
+extern "C" {
+
+const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
+const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
+
+int sdfhip_ctx_create(int device_id, void* stream, sdfhip_ctx** out) {
+    SDF_REQUIRE(out != nullptr, "out is NULL");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        setError("no HIP device available (%s); libsdfhip has no CPU fallback", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return SDFHIP_E_NO_DEVICE;
+    }
+    SDF_REQUIRE(device_id >= 0 && device_id < count, "device_id out of range");
+    SDF_HIP_CHECK(hipSetDevice(device_id));
+    sdfhip_ctx* c = new sdfhip_ctx();
+    c->device = device_id;
+    SDF_HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
+    if (stream) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
+    else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
+    *out = c;
+    return SDFHIP_OK;
+}
+
+int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
+    if (!ctx) return SDFHIP_OK;
+    if (ctx->ownsStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SDFHIP_OK;
+}
+
+int sdfhip_ctx_synchronize(sdfhip_ctx* ctx) {
+    SDF_REQUIRE(ctx != nullptr, "ctx is NULL");
+    SDF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SDFHIP_OK;
+}
+
+void* sdfhip_ctx_stream(sdfhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, sdfhip_mesh** out) {
+    SDF_REQUIRE(ctx && xyz && indices && out, "NULL argument");
+    SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
+    SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
+    for (uint64_t i = 0; i < 3ull * nt; i++) SDF_REQUIRE(indices[i] < nv, "triangle index out of range");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    sdfhip_mesh* m = new sdfhip_mesh();
+    m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;
+    m->hVerts.assign(xyz, xyz + 3ull * nv);
+    m->hIdx.assign(indices, indices + 3ull * nt);
+    hipStream_t st = ctx->stream;
+    const uint32_t nhe = 3 * nt;
+    int rc = SDFHIP_OK;
+    auto fail = [&](int code) { delete m; return code; };
+    if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt))) return fail(rc);
+    SDF_HIP_CHECK(hipMemcpyAsync(m->dVerts.p, xyz, sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(m->dIdx.p, indices, sizeof(uint32_t) * nhe, hipMemcpyHostToDevice, st));
+    k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
+
+    DevBuf<uint64_t> eKey, eKeyS; DevBuf<uint32_t> vKey, vKeyS, val, valS, valS2, counter; DevBuf<float> vnormal; DevBuf<unsigned char> tmp;
+    if ((rc = eKey.reserve(nhe)) || (rc = eKeyS.reserve(nhe)) || (rc = vKey.reserve(nhe)) || (rc = vKeyS.reserve(nhe)) ||
+        (rc = val.reserve(nhe)) || (rc = valS.reserve(nhe)) || (rc = valS2.reserve(nhe)) || (rc = counter.reserve(1)) ||
+        (rc = vnormal.reserve(3ull * nv))) return fail(rc);
+    k_halfedge_keys<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, eKey.p, vKey.p, val.p);
+    size_t tb1 = 0, tb2 = 0;
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, eKey.p, eKeyS.p, val.p, valS.p, (int)nhe, 0, 64, st));
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
+    if ((rc = tmp.reserve(tb1 > tb2 ? tb1 : tb2))) return fail(rc);
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (int)nhe, 0, 64, st));
+    SDF_HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), st));
+    k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p);
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
+    SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
+    k_vertex_normal_sum<<<gridFor(nhe, 256), 256, 0, st>>>(vKeyS.p, valS2.p, nhe, m->dVerts.p, m->dIdx.p, m->dTri.p, vnormal.p);
+    k_vertex_normal_apply<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, vnormal.p, m->dTri.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipMemcpyAsync(&m->unmatchedEdges, counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    *out = m;
+    return SDFHIP_OK;
+}
+
+int sdfhip_mesh_destroy(sdfhip_mesh* mesh) { delete mesh; return SDFHIP_OK; }
+
+int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host) {
+    SDF_REQUIRE(mesh && out_host, "NULL argument");
+    SDF_HIP_CHECK(hipMemcpyAsync(out_host, mesh->dTri.p, sizeof(float) * TD_FLOATS * (size_t)mesh->numTriangles, hipMemcpyDeviceToHost, mesh->ctx->stream));
+    SDF_HIP_CHECK(hipStreamSynchronize(mesh->ctx->stream));
+    return SDFHIP_OK;
+}
+
+}  // extern "C"

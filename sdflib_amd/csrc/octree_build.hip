@@ -1,0 +1,521 @@
+// OctreeSdf construction on the device (NO_CONTINUITY algorithm).  PRODUCT code — independent of oracle/.
+//
+// Reference behaviour reproduced: OctreeSdf::buildOctree (src/sdf/OctreeSdf.cpp:37-86), initOctree<VHQueries<TriCubic>>
+// and its processNode (src/sdf/OctreeSdfDepthFirst.h:32-558), VHQueries::calculateVerticesInfo with the lattice
+// cache disabled ("canonical" mode, include/SdfLib/TrianglesInfluence.h:951-996), computeMinBorderValue
+// (src/sdf/OctreeSdf.cpp:155-230).
+//
+// MI355X formulation.  The reference walks the tree depth-first, one node at a time; here the tree is grown
+// LEVEL-SYNCHRONOUSLY (all nodes of a depth at once = 10^2..10^5.5 nodes x 19 samples of parallelism):
+//   k_corner_samples / k_level_samples : one lane per sample point: fp64 BVH nearest triangle + fp32 Hermite datum
+//   k_decide          : one lane per node: 64x64 fit (reference summation order), 19-point error rule, leaf/inner
+//   hipcub ExclusiveSum + k_scatter_children : child slots; the 27-point stencil is handed down to the 8 children
+// and afterwards the breadth-first arrays are relabelled into the reference's array layout:
+//   k_alloc (bottom-up) : words needed by every subtree ; k_emit (top-down) : pre-order offsets, children 7..0,
+// which is exactly the order in which the reference's DFS stack appends blocks (OctreeSdfDepthFirst.h:213-336).
+// Results do not depend on the breadth-first order, only on the tree, so they equal the reference's array.
+// All fp32 arithmetic follows the reference's operation order; compile with -ffp-contract=off.
+#include "octree_internal.h"
+#include "dev_bvh.h"
+#include "dev_tricubic.h"
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <cstring>
+
+namespace sdfhip {
+
+struct MeshDev { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
+
+SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4) {
+    const uint32_t t = bvhNearest(m.bvh, m.verts, m.idx, p);
+    const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
+    F3 g;
+    const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t,
+                                                F3{m.verts[3 * a], m.verts[3 * a + 1], m.verts[3 * a + 2]},
+                                                F3{m.verts[3 * b], m.verts[3 * b + 1], m.verts[3 * b + 2]},
+                                                F3{m.verts[3 * c], m.verts[3 * c + 1], m.verts[3 * c + 2]}, g);
+    *reinterpret_cast<float4*>(out4) = make_float4(d, g.x, g.y, g.z);
+}
+
+// 8 corners of every node (only the root level evaluates corners; deeper levels inherit them).
+__global__ void __launch_bounds__(128) k_corner_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ corner) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 8u * n) return;
+    const uint32_t node = gid >> 3, c = gid & 7u;
+    const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
+    const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
+    sampleAt(m, ce + rel * half, corner + 4 * (size_t)gid);
+}
+
+// 19 mid-points of every node of a level: the build's hot kernel.
+__global__ void __launch_bounds__(128) k_level_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ mid) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 19u * n) return;
+    const uint32_t node = gid / 19u, mi = gid - 19u * node;
+    const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
+    sampleAt(m, ce + midRel((int)mi) * half, mid + 4 * (size_t)gid);
+}
+
+SDF_DEV uint32_t floatOrderKey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+SDF_HD float floatFromOrderKey(uint32_t k) { const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); return f; }
+
+struct DecideArgs {
+    const float* corner; const float* mid; const uint32_t* coord;
+    uint32_t n, depth, maxDepth; float half; int rule; float sqThreshold, param1;
+    uint32_t* flag; uint32_t* inner; float* coeff;
+    uint32_t* valueRangeBits;   // atomicMax over |corner value| bits
+    uint32_t* minBorderKey;     // atomicMin over order keys
+};
+
+// One lane per node: fit, error rule, leaf/inner decision, leaf payload.
+__global__ void __launch_bounds__(128) k_decide(DecideArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    float s[64], c[64];
+    const float4* cr = reinterpret_cast<const float4*>(a.corner) + 8 * (size_t)i;
+    float absMax = 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const float4 q = cr[v];
+        s[8 * v] = q.x; s[8 * v + 1] = q.y; s[8 * v + 2] = q.z; s[8 * v + 3] = q.w;
+        s[8 * v + 4] = 0.f; s[8 * v + 5] = 0.f; s[8 * v + 6] = 0.f; s[8 * v + 7] = 0.f;
+        absMax = gmax(absMax, fabsf(q.x));
+    }
+    tricubicFit(s, 2.0f * a.half, c);
+    bool terminal = true;
+    if (a.depth < a.maxDepth) {
+        const float4* md = reinterpret_cast<const float4*>(a.mid) + 19 * (size_t)i;
+        const float v = ruleValue(a.rule, [&](int n) { return c[n]; }, [&](int m) { return md[m].x; }, a.param1);
+        terminal = v < a.sqThreshold;
+    }
+    a.flag[i] = terminal ? 1u : 0u;
+    a.inner[i] = terminal ? 0u : 1u;
+    if (!terminal) return;
+    float4* dst = reinterpret_cast<float4*>(a.coeff) + 16 * (size_t)i;
+#pragma unroll
+    for (int q = 0; q < 16; q++) dst[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    atomicMax(a.valueRangeBits, __float_as_uint(absMax));
+    // border corners (computeMinBorderValue): a leaf corner lying on the box boundary contributes P(corner)
+    const uint32_t co = a.coord[i];
+    const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
+    const uint32_t last = (1u << a.depth) - 1u;
+    if (x == 0 || y == 0 || z == 0 || x == last || y == last || z == last) {
+        float mn = INFINITY;
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t bx = k & 1u, by = (k >> 1) & 1u, bz = k >> 2;
+            const bool onBorder = (x + bx == 0) || (y + by == 0) || (z + bz == 0) || (x + bx == last + 1) || (y + by == last + 1) || (z + bz == last + 1);
+            if (!onBorder) continue;
+            const float v = tricubicValueExact([&](int n) { return c[n]; }, F3{(float)bx, (float)by, (float)bz});
+            mn = gmin(mn, v);
+        }
+        if (mn < INFINITY) atomicMin(a.minBorderKey, floatOrderKey(mn));
+    }
+}
+
+__global__ void k_fill_all_inner(uint32_t n, uint32_t* __restrict__ flag, uint32_t* __restrict__ inner, uint32_t* __restrict__ childBase) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = 0u; inner[i] = 1u; childBase[i] = 8u * i;
+}
+
+__global__ void k_scale8(uint32_t n, uint32_t* __restrict__ v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] *= 8u;
+}
+
+struct ScatterArgs {
+    const float* center; const uint32_t* coord; const float* corner; const float* mid; const uint32_t* inner; const uint32_t* childBase;
+    uint32_t n; float half;
+    float* ncenter; uint32_t* ncoord; float* ncorner;
+};
+
+// One lane per (node, child, corner): hand the 27-point stencil down (OctreeSdfDepthFirst.h:225-336 tables).
+__global__ void __launch_bounds__(256) k_scatter_children(ScatterArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 6;
+    if (i >= a.n || !a.inner[i]) return;
+    const uint32_t c = (gid >> 3) & 7u, j = gid & 7u;
+    const uint32_t child = a.childBase[i] + c;
+    const int src = kStencilDev.src[c][j];
+    const float4 v = (src >= 0) ? reinterpret_cast<const float4*>(a.mid)[19 * (size_t)i + src]
+                                : reinterpret_cast<const float4*>(a.corner)[8 * (size_t)i + (-src - 1)];
+    reinterpret_cast<float4*>(a.ncorner)[8 * (size_t)child + j] = v;
+    if (j == 0) {
+        const float ns = 0.5f * a.half;
+        a.ncenter[3 * (size_t)child] = a.center[3 * (size_t)i] + ((c & 1u) ? ns : -ns);
+        a.ncenter[3 * (size_t)child + 1] = a.center[3 * (size_t)i + 1] + ((c & 2u) ? ns : -ns);
+        a.ncenter[3 * (size_t)child + 2] = a.center[3 * (size_t)i + 2] + ((c & 4u) ? ns : -ns);
+        const uint32_t co = a.coord[i];
+        const uint32_t x = 2u * (co & 1023u) + (c & 1u), y = 2u * ((co >> 10) & 1023u) + ((c >> 1) & 1u), z = 2u * (co >> 20) + (c >> 2);
+        a.ncoord[child] = x | (y << 10) | (z << 20);
+    }
+}
+
+// Move the start-depth level into start-grid cell order (z-major) and keep only cells [cellBegin, cellEnd).
+__global__ void k_to_cell_order(const float* __restrict__ center, const uint32_t* __restrict__ coord, const float* __restrict__ corner, uint32_t n,
+                                uint32_t G, uint32_t cellBegin, uint32_t cellEnd, float* __restrict__ ocenter, uint32_t* __restrict__ ocoord, float* __restrict__ ocorner) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, j = gid & 7u;
+    if (i >= n) return;
+    const uint32_t co = coord[i];
+    const uint32_t cell = (co >> 20) * G * G + ((co >> 10) & 1023u) * G + (co & 1023u);
+    if (cell < cellBegin || cell >= cellEnd) return;
+    const uint32_t d = cell - cellBegin;
+    reinterpret_cast<float4*>(ocorner)[8 * (size_t)d + j] = reinterpret_cast<const float4*>(corner)[8 * (size_t)i + j];
+    if (j == 0) {
+        ocenter[3 * (size_t)d] = center[3 * (size_t)i]; ocenter[3 * (size_t)d + 1] = center[3 * (size_t)i + 1]; ocenter[3 * (size_t)d + 2] = center[3 * (size_t)i + 2];
+        ocoord[d] = co;
+    }
+}
+
+// bottom-up: words of a node's block plus all descendants' blocks
+__global__ void k_alloc(uint32_t n, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ childBase, const uint32_t* __restrict__ nextAlloc, uint32_t* __restrict__ alloc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) { alloc[i] = 64u; return; }
+    uint32_t s = 8u;
+    const uint32_t cb = childBase[i];
+#pragma unroll
+    for (int c = 0; c < 8; c++) s += nextAlloc[cb + c];
+    alloc[i] = s;
+}
+
+struct EmitArgs {
+    uint32_t n; const uint32_t* flag; const uint32_t* childBase; const float* coeff; const uint32_t* pos; const uint32_t* blk;
+    const uint32_t* nextAlloc; uint32_t* nextPos; uint32_t* nextBlk;
+    // destination: absolute index a < gridEnd lives in grid[a - gridBegin], otherwise in body[a - bodyOffset]
+    uint32_t* grid; uint32_t gridBegin, gridEnd; uint32_t* body; uint64_t bodyOffset;
+};
+
+// top-down: write node words and leaf payloads at their reference positions; children are laid out 7..0
+__global__ void __launch_bounds__(256) k_emit(EmitArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 4, q = gid & 15u;     // 16 lanes per node: each copies one float4 of a leaf payload
+    if (i >= a.n) return;
+    const uint32_t pos = a.pos[i], blk = a.blk[i];
+    const bool leaf = a.flag[i] != 0u;
+    if (q == 0) {
+        const uint32_t word = (blk & INDEX_MASK) | (leaf ? LEAF_BIT : 0u);
+        if (pos < a.gridEnd) a.grid[pos - a.gridBegin] = word; else a.body[pos - a.bodyOffset] = word;
+    }
+    if (leaf) {
+        const float4 v = reinterpret_cast<const float4*>(a.coeff)[16 * (size_t)i + q];
+        uint32_t* d = a.body + (blk - a.bodyOffset) + 4 * q;      // blocks always live in the body
+        d[0] = __float_as_uint(v.x); d[1] = __float_as_uint(v.y); d[2] = __float_as_uint(v.z); d[3] = __float_as_uint(v.w);
+    } else if (q < 8) {
+        const uint32_t cb = a.childBase[i];
+        uint32_t off = blk + 8u;
+        for (uint32_t c = 7; c > q; c--) off += a.nextAlloc[cb + c];
+        a.nextPos[cb + q] = blk + q;
+        a.nextBlk[cb + q] = off;
+    }
+}
+
+__global__ void k_init_start_pos(uint32_t n, uint32_t cellBegin, const uint32_t* __restrict__ blkIn, uint32_t* __restrict__ pos, uint32_t* __restrict__ blk) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pos[i] = cellBegin + i; blk[i] = blkIn[i];
+}
+
+static int allocLevelCommon(BuildLevel& L) {
+    SDF_TRY(L.center.reserve(3ull * L.n));
+    SDF_TRY(L.coord.reserve(L.n));
+    SDF_TRY(L.corner.reserve(32ull * L.n));
+    return SDFHIP_OK;
+}
+
+// Rank of a start-grid cell in the reference's single-thread DFS (roots and children are popped 7..0).
+static uint32_t dfsRankOfCell(uint32_t x, uint32_t y, uint32_t z, uint32_t startDepth, uint32_t sod) {
+    uint32_t rank = 0;
+    for (uint32_t l = 0; l < startDepth; l++) {          // l = 0 is the most significant level
+        const uint32_t sh = startDepth - 1 - l;
+        const uint32_t c = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
+        rank = rank * 8u + (7u - c);
+    }
+    (void)sod;
+    return rank;
+}
+
+static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, bool shardOnly, sdfhip_octree** out) {
+    SDF_REQUIRE(ctx && mesh && P && out, "NULL argument");
+    SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
+    if (P->algorithm != SDFHIP_ALG_NO_CONTINUITY) { setError("algorithm %d is not provided (only NO_CONTINUITY)", P->algorithm); return SDFHIP_E_UNSUPPORTED; }
+    SDF_REQUIRE(P->depth >= 1 && P->depth <= 10, "depth must be in [1,10]");
+    SDF_REQUIRE(P->start_depth <= P->depth, "start_depth > depth");
+    SDF_REQUIRE(P->rule >= SDFHIP_RULE_NONE && P->rule <= SDFHIP_RULE_BY_DISTANCE, "unknown termination rule");
+    SDF_REQUIRE(P->layout == SDFHIP_LAYOUT_GLOBAL_DFS || P->layout == SDFHIP_LAYOUT_SUBTREES, "unknown layout");
+    if (P->fit_mode != SDFHIP_FIT_EXACT) { setError("fit_mode %d is not provided by this build entry", P->fit_mode); return SDFHIP_E_UNSUPPORTED; }
+    const uint32_t maxDepth = P->depth, startDepth = P->start_depth;
+    const uint32_t G = 1u << startDepth, G3 = G * G * G;
+    uint32_t cellBegin = P->cell_begin, cellEnd = P->cell_end;
+    if (cellBegin == 0 && cellEnd == 0) cellEnd = G3;
+    SDF_REQUIRE(cellBegin < cellEnd && cellEnd <= G3, "bad cell range");
+    const bool partial = !(cellBegin == 0 && cellEnd == G3);
+    SDF_REQUIRE(!partial || P->layout == SDFHIP_LAYOUT_SUBTREES, "sharded builds use the SUBTREES layout");
+    SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double tStart = nowSeconds();
+
+    std::unique_ptr<sdfhip_octree> T(new sdfhip_octree());
+    T->ctx = ctx; T->params = *P; T->params.cell_begin = cellBegin; T->params.cell_end = cellEnd;
+    // cube-ify the box (OctreeSdf.cpp:43-46)
+    const float sx = P->box_max[0] - P->box_min[0], sy = P->box_max[1] - P->box_min[1], sz = P->box_max[2] - P->box_min[2];
+    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0, "empty box");
+    const float maxSize = gmax(gmax(sx, sy), sz);
+    const float cx = P->box_min[0] + 0.5f * sx, cy = P->box_min[1] + 0.5f * sy, cz = P->box_min[2] + 0.5f * sz;
+    float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};
+    float bmax[3] = {cx + 0.5f * maxSize, cy + 0.5f * maxSize, cz + 0.5f * maxSize};
+    memcpy(T->info.box_min, bmin, 12); memcpy(T->info.box_max, bmax, 12);
+    T->info.start_grid_size = (int32_t)G; T->info.max_depth = maxDepth;
+    T->cellSize = maxSize / (float)G;
+    const uint32_t sod = startDepth < 1u ? startDepth : 1u;
+    T->startOctreeDepth = sod;
+
+    MeshDev md{mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    DevBuf<uint32_t> stats;            // [0] valueRange bits, [1] minBorder key
+    SDF_TRY(stats.reserve(2));
+    { const uint32_t init[2] = {0u, 0xFFFFFFFFu}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 8, hipMemcpyHostToDevice, st)); }
+    DevBuf<unsigned char> scanTmp; size_t scanTmpBytes = 0;
+
+    // root level
+    T->levels.resize(maxDepth - sod + 1);
+    {
+        std::unique_ptr<BuildLevel> L(new BuildLevel());
+        L->depth = sod; L->n = 1u << (3 * sod);
+        const float newSize = (float)(0.5f * (bmax[0] - bmin[0]) * std::pow(0.5f, sod));
+        L->half = newSize;
+        SDF_TRY(allocLevelCommon(*L));
+        std::vector<float> hc(3 * L->n); std::vector<uint32_t> hco(L->n);
+        const float scx = bmin[0] + newSize, scy = bmin[1] + newSize, scz = bmin[2] + newSize;
+        const uint32_t vpa = 1u << sod;
+        for (uint32_t k = 0; k < vpa; k++) for (uint32_t j = 0; j < vpa; j++) for (uint32_t i = 0; i < vpa; i++) {
+            const uint32_t r = i + vpa * j + vpa * vpa * k;
+            hc[3 * r] = scx + ((float)i * 2.0f) * newSize; hc[3 * r + 1] = scy + ((float)j * 2.0f) * newSize; hc[3 * r + 2] = scz + ((float)k * 2.0f) * newSize;
+            hco[r] = i | (j << 10) | (k << 20);
+        }
+        SDF_HIP_CHECK(hipMemcpyAsync(L->center.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->coord.p, hco.data(), hco.size() * 4, hipMemcpyHostToDevice, st));
+        k_corner_samples<<<gridFor(8ull * L->n, 128), 128, 0, st>>>(md, L->center.p, L->half, L->n, L->corner.p);
+        SDF_HIP_CHECK(hipStreamSynchronize(st));   // hc/hco go out of scope
+        T->info.num_samples += 8ull * L->n;
+        T->levels[0] = std::move(L);
+    }
+
+    double tSamples = 0, tDecide = 0;
+    for (uint32_t d = sod; d <= maxDepth; d++) {
+        BuildLevel* L = T->levels[d - sod].get();
+        if (!L || L->n == 0) break;
+        if (d == startDepth) {
+            // bring the level into cell order and restrict it to this shard's cells
+            std::unique_ptr<BuildLevel> R(new BuildLevel());
+            R->depth = d; R->n = cellEnd - cellBegin; R->half = L->half;
+            SDF_TRY(allocLevelCommon(*R));
+            k_to_cell_order<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->corner.p, L->n, G, cellBegin, cellEnd, R->center.p, R->coord.p, R->corner.p);
+            T->levels[d - sod] = std::move(R);
+            L = T->levels[d - sod].get();
+        }
+        SDF_TRY(L->flag.reserve(L->n)); SDF_TRY(L->inner.reserve(L->n)); SDF_TRY(L->childBase.reserve(L->n));
+        if (d < maxDepth) {
+            SDF_TRY(L->mid.reserve(76ull * L->n));
+            const double t0 = nowSeconds();
+            k_level_samples<<<gridFor(19ull * L->n, 128), 128, 0, st>>>(md, L->center.p, L->half, L->n, L->mid.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            tSamples += nowSeconds() - t0;
+            T->info.num_samples += 19ull * L->n;
+        }
+        if (d >= startDepth) {
+            SDF_TRY(L->coeff.reserve(64ull * L->n));
+            DecideArgs a{L->corner.p, L->mid.p, L->coord.p, L->n, d, maxDepth, L->half, P->rule, P->rule_params[0] * P->rule_params[0], P->rule_params[1],
+                         L->flag.p, L->inner.p, L->coeff.p, stats.p, stats.p + 1};
+            const double t0 = nowSeconds();
+            k_decide<<<gridFor(L->n, 128), 128, 0, st>>>(a);
+            if (d < maxDepth) {
+                size_t need = 0;
+                SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, L->inner.p, L->childBase.p, (int)L->n, st));
+                if (need > scanTmpBytes) { SDF_TRY(scanTmp.reserve(need)); scanTmpBytes = need; }
+                SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.p, need, L->inner.p, L->childBase.p, (int)L->n, st));
+                uint32_t lastScan = 0, lastInner = 0;
+                SDF_HIP_CHECK(hipMemcpyAsync(&lastScan, L->childBase.p + (L->n - 1), 4, hipMemcpyDeviceToHost, st));
+                SDF_HIP_CHECK(hipMemcpyAsync(&lastInner, L->inner.p + (L->n - 1), 4, hipMemcpyDeviceToHost, st));
+                SDF_HIP_CHECK(hipStreamSynchronize(st));
+                L->numInner = lastScan + lastInner;
+                k_scale8<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->childBase.p);
+            } else { SDF_HIP_CHECK(hipStreamSynchronize(st)); L->numInner = 0; }
+            tDecide += nowSeconds() - t0;
+            L->numLeaves = L->n - L->numInner;
+        } else {
+            k_fill_all_inner<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->flag.p, L->inner.p, L->childBase.p);
+            L->numInner = L->n; L->numLeaves = 0;
+        }
+        SDF_HIP_CHECK(hipGetLastError());
+        if (d >= startDepth) { T->info.num_nodes += L->n; T->info.num_leaves += L->numLeaves; }
+        if (d < maxDepth && L->numInner > 0) {
+            SDF_REQUIRE(L->numInner <= (1u << 24), "level too large");
+            std::unique_ptr<BuildLevel> N(new BuildLevel());
+            N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
+            SDF_TRY(allocLevelCommon(*N));
+            ScatterArgs sa{L->center.p, L->coord.p, L->corner.p, L->mid.p, L->inner.p, L->childBase.p, L->n, L->half, N->center.p, N->coord.p, N->corner.p};
+            k_scatter_children<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(sa);
+            SDF_HIP_CHECK(hipGetLastError());
+            T->levels[d + 1 - sod] = std::move(N);
+        }
+        // this level's mid-points are no longer needed once the children exist
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        L->mid.release();
+        if (d < startDepth) { L->corner.release(); }
+    }
+
+    // subtree sizes, bottom-up
+    uint64_t bodyWords = 0;
+    {
+        const uint32_t* nextAlloc = nullptr;
+        uint64_t total = 0;
+        for (int d = (int)maxDepth; d >= (int)startDepth; d--) {
+            BuildLevel* L = T->levels[d - sod].get();
+            if (!L || L->n == 0) continue;
+            total += 64ull * L->numLeaves + 8ull * L->numInner;
+            SDF_TRY(L->alloc.reserve(L->n)); SDF_TRY(L->pos.reserve(L->n)); SDF_TRY(L->blk.reserve(L->n));
+            k_alloc<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->flag.p, L->childBase.p, nextAlloc, L->alloc.p);
+            nextAlloc = L->alloc.p;
+        }
+        bodyWords = total;
+        SDF_HIP_CHECK(hipGetLastError());
+    }
+    if ((uint64_t)G3 + bodyWords > (uint64_t)INDEX_MASK) { setError("octree needs %llu words: exceeds the 30-bit node index of the reference layout", (unsigned long long)(G3 + bodyWords)); return SDFHIP_E_TOO_LARGE; }
+
+    uint32_t stat[2];
+    SDF_HIP_CHECK(hipMemcpyAsync(stat, stats.p, 8, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(&T->info.value_range, &stat[0], 4);
+    T->info.min_border_value = (stat[1] == 0xFFFFFFFFu) ? INFINITY : floatFromOrderKey(stat[1]);
+    T->info.cell_begin = cellBegin; T->info.cell_end = cellEnd;
+    T->info.body_words = bodyWords;
+    T->info.body_offset = G3;     // provisional (single shard); emit_shard overrides it
+    T->info.num_words = partial ? 0 : (uint64_t)G3 + bodyWords;
+    T->info.seconds_samples = tSamples; T->info.seconds_decide = tDecide;
+    T->built = true;
+
+    if (!shardOnly) {
+        SDF_TRY(T->data.reserve((size_t)G3 + bodyWords));
+        int rc = sdfhip_octree_emit_shard(T.get(), G3, T->data.p, T->data.p + G3, SDFHIP_DEVICE);
+        if (rc != SDFHIP_OK) return rc;
+        T->hasData = true;
+        T->levels.clear();
+    }
+    T->info.seconds_total = nowSeconds() - tStart;
+    *out = T.release();
+    return SDFHIP_OK;
+}
+
+}  // namespace sdfhip
+
+using namespace sdfhip;
+
+extern "C" {
+
+int sdfhip_octree_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out) {
+    SDF_REQUIRE(params != nullptr, "params is NULL");
+    SDF_REQUIRE(params->cell_begin == 0 && (params->cell_end == 0 || params->cell_end == (1u << (3 * params->start_depth))), "sdfhip_octree_build builds all cells; use sdfhip_octree_build_shard");
+    return buildImpl(ctx, mesh, params, false, out);
+}
+
+int sdfhip_octree_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out) {
+    return buildImpl(ctx, mesh, params, true, out);
+}
+
+int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* dst_grid, uint32_t* dst_body, int where) {
+    SDF_REQUIRE(T && dst_grid && dst_body, "NULL argument");
+    SDF_REQUIRE(T->built && !T->levels.empty(), "construction state is no longer available");
+    sdfhip_ctx* ctx = T->ctx;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t sod = T->startOctreeDepth, startDepth = T->params.start_depth, maxDepth = T->params.depth;
+    const uint32_t G = 1u << startDepth, G3 = G * G * G;
+    const uint32_t cellBegin = T->info.cell_begin, cellEnd = T->info.cell_end, nCells = cellEnd - cellBegin;
+    SDF_REQUIRE(body_offset >= G3 && body_offset + T->info.body_words <= (uint64_t)INDEX_MASK, "body_offset out of range");
+    DevBuf<uint32_t> tmpGrid, tmpBody;
+    uint32_t* dGrid = dst_grid; uint32_t* dBody = dst_body;
+    if (where == SDFHIP_HOST) {
+        SDF_TRY(tmpGrid.reserve(nCells)); SDF_TRY(tmpBody.reserve(T->info.body_words));
+        dGrid = tmpGrid.p; dBody = tmpBody.p;
+    }
+    BuildLevel* S = T->levels[startDepth - sod].get();
+    SDF_REQUIRE(S && S->n == nCells, "internal: start level missing");
+    // body offsets of the cells: prefix sums of the root subtree sizes in body order
+    std::vector<uint32_t> rootAlloc(nCells), rootBlk(nCells);
+    SDF_HIP_CHECK(hipMemcpyAsync(rootAlloc.data(), S->alloc.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    if (T->params.layout == SDFHIP_LAYOUT_SUBTREES) {
+        uint64_t off = body_offset;
+        for (uint32_t c = 0; c < nCells; c++) { rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
+    } else {
+        std::vector<uint32_t> cellOfRank(G3);
+        for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++)
+            cellOfRank[dfsRankOfCell(x, y, z, startDepth, sod)] = z * G * G + y * G + x;
+        uint64_t off = body_offset;
+        for (uint32_t r = 0; r < G3; r++) { const uint32_t c = cellOfRank[r]; rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
+    }
+    DevBuf<uint32_t> dRootBlk; SDF_TRY(dRootBlk.reserve(nCells));
+    SDF_HIP_CHECK(hipMemcpyAsync(dRootBlk.p, rootBlk.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
+    k_init_start_pos<<<gridFor(nCells, 256), 256, 0, st>>>(nCells, cellBegin, dRootBlk.p, S->pos.p, S->blk.p);
+    for (uint32_t d = startDepth; d <= maxDepth; d++) {
+        BuildLevel* L = T->levels[d - sod].get();
+        if (!L || L->n == 0) break;
+        BuildLevel* N = (d < maxDepth) ? T->levels[d + 1 - sod].get() : nullptr;
+        EmitArgs ea{L->n, L->flag.p, L->childBase.p, L->coeff.p, L->pos.p, L->blk.p,
+                    N ? N->alloc.p : nullptr, N ? N->pos.p : nullptr, N ? N->blk.p : nullptr,
+                    dGrid, cellBegin, G3, dBody, body_offset};
+        // grid words exist only for the start level; deeper node words always live in bodies
+        if (d > startDepth) { ea.gridBegin = 0; ea.gridEnd = 0; }
+        k_emit<<<gridFor(16ull * L->n, 256), 256, 0, st>>>(ea);
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    if (where == SDFHIP_HOST) {
+        SDF_HIP_CHECK(hipMemcpyAsync(dst_grid, dGrid, 4ull * nCells, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(dst_body, dBody, 4ull * T->info.body_words, hipMemcpyDeviceToHost, st));
+    }
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    T->info.body_offset = body_offset;
+    return SDFHIP_OK;
+}
+
+int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num_words, int where, const float box_min[3], const float box_max[3],
+                            int32_t start_grid_size, uint32_t max_depth, float value_range, float min_border_value, sdfhip_octree** out) {
+    SDF_REQUIRE(ctx && words && box_min && box_max && out, "NULL argument");
+    SDF_REQUIRE(start_grid_size >= 1 && (uint64_t)start_grid_size * start_grid_size * start_grid_size <= num_words, "start grid does not fit");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    std::unique_ptr<sdfhip_octree> T(new sdfhip_octree());
+    T->ctx = ctx;
+    memcpy(T->info.box_min, box_min, 12); memcpy(T->info.box_max, box_max, 12);
+    T->info.start_grid_size = start_grid_size; T->info.max_depth = max_depth;
+    T->info.value_range = value_range; T->info.min_border_value = min_border_value; T->info.num_words = num_words;
+    T->cellSize = (box_max[0] - box_min[0]) / (float)start_grid_size;       // load(): mBox.getSize().x / mStartGridSize (OctreeSdf.h:232)
+    SDF_TRY(T->data.reserve(num_words));
+    SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, words, 4ull * num_words, where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+    SDF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    T->hasData = true;
+    *out = T.release();
+    return SDFHIP_OK;
+}
+
+int sdfhip_octree_destroy(sdfhip_octree* tree) { delete tree; return SDFHIP_OK; }
+
+int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out) {
+    SDF_REQUIRE(tree && out, "NULL argument");
+    *out = tree->info;
+    return SDFHIP_OK;
+}
+
+int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where) {
+    SDF_REQUIRE(tree && out_words, "NULL argument");
+    SDF_REQUIRE(tree->hasData, "tree has no assembled node array (sharded build: emit + from_data first)");
+    SDF_HIP_CHECK(hipMemcpyAsync(out_words, tree->data.p, 4ull * tree->info.num_words, where == SDFHIP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, tree->ctx->stream));
+    SDF_HIP_CHECK(hipStreamSynchronize(tree->ctx->stream));
+    return SDFHIP_OK;
+}
+
+const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) { return (tree && tree->hasData) ? tree->data.p : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// OctreeSdf device object shared by the build and query translation units.  PRODUCT code.
+#pragma once
+#include "sdfhip_internal.h"
+#include <memory>
+
+namespace sdfhip {
+
+constexpr uint32_t LEAF_BIT = 1u << 31;
+constexpr uint32_t MARK_BIT = 1u << 30;
+constexpr uint32_t INDEX_MASK = ~(LEAF_BIT | MARK_BIT);
+
+// One breadth-first level of the construction (structure of arrays in HBM).
+struct BuildLevel {
+    uint32_t depth = 0;
+    uint32_t n = 0;                 // nodes at this level
+    float half = 0.f;               // half edge length of a node (same for the whole level)
+    DevBuf<float> center;           // 3 n
+    DevBuf<uint32_t> coord;         // n : x | y << 10 | z << 20 (integer cell coordinates at this depth)
+    DevBuf<float> corner;           // 32 n : 8 corners x [f, fx, fy, fz]   (mixed derivatives are 0 in NO_CONTINUITY)
+    DevBuf<float> mid;              // 76 n : 19 mid-points x [f, fx, fy, fz]
+    DevBuf<uint32_t> flag;          // n : 1 = leaf
+    DevBuf<uint32_t> inner;         // n : 1 = inner (scan input)
+    DevBuf<uint32_t> childBase;     // n : index of child 0 in the next level (inner nodes)
+    DevBuf<float> coeff;            // 64 n : coefficients of leaves
+    DevBuf<uint32_t> alloc;         // n : words of the node's block + all descendants' blocks
+    DevBuf<uint32_t> pos, blk;      // n : absolute position of the node word / of its block
+    uint32_t numInner = 0, numLeaves = 0;
+};
+
+}  // namespace sdfhip
+
+struct sdfhip_octree {
+    sdfhip_ctx* ctx = nullptr;
+    sdfhip_octree_info info{};
+    sdfhip_octree_params params{};
+    sdfhip::DevBuf<uint32_t> data;          // full node array (when available)
+    bool hasData = false;
+    // construction state kept between build_shard and emit_shard
+    std::vector<std::unique_ptr<sdfhip::BuildLevel>> levels;   // index = depth - startOctreeDepth
+    uint32_t startOctreeDepth = 0;
+    bool built = false;
+    float cellSize = 0.f;
+};

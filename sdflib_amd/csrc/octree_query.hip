@@ -1,0 +1,205 @@
+// Batched OctreeSdf::getDistance on the device.  PRODUCT code — independent of oracle/.
+//
+// Reference behaviour reproduced: OctreeSdf::getDistance(vec3) / (vec3, vec3&) (src/sdf/OctreeSdf.cpp:93-152),
+// roundFloat '>= 0.5' (:88-91), BoundingBox::getDistance for points outside the start grid
+// (include/SdfLib/utils/Mesh.h:42-63, reproduced as written including the gradient overload's quirks).
+//
+// One lane per query: start-grid cell -> dependent 4-byte loads down the node array -> 256-byte coefficient
+// block (16 x dwordx4) -> 64-term polynomial.  HBM/L2-gather bound: ~292 B of algorithmic traffic per query.
+// EVAL_EXACT evaluates in the reference's literal order without FMA (bit-identical results); EVAL_FAST uses a
+// separable Horner scheme with FMA.  Compile with -ffp-contract=off.
+#include "octree_internal.h"
+#include "dev_tricubic.h"
+
+namespace sdfhip {
+
+struct QueryTree {
+    const uint32_t* data;
+    float bminx, bminy, bminz, bmaxx, bmaxy, bmaxz;
+    float cellSize, minBorder;
+    int G;
+};
+
+SDF_DEV float boxDistance(const QueryTree& t, F3 p) {
+    const F3 size = F3{t.bmaxx - t.bminx, t.bmaxy - t.bminy, t.bmaxz - t.bminz};
+    const F3 center = F3{t.bminx, t.bminy, t.bminz} + 0.5f * size;
+    const F3 d = p - center;
+    const F3 q = F3{fabsf(d.x), fabsf(d.y), fabsf(d.z)} - 0.5f * size;
+    const F3 qm = F3{gmax(q.x, 0.f), gmax(q.y, 0.f), gmax(q.z, 0.f)};
+    return length(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f);
+}
+
+// BoundingBox::getDistance(point, outGradient) as written in the reference (full size, uncentred point; only
+// the selected component is written in the 'inside' branch).
+SDF_DEV float boxDistanceGrad(const QueryTree& t, F3 p, float* g) {
+    const float size[3] = {t.bmaxx - t.bminx, t.bmaxy - t.bminy, t.bmaxz - t.bminz};
+    const float pt[3] = {p.x, p.y, p.z};
+    float a[3];
+    for (int i = 0; i < 3; i++) a[i] = fabsf(pt[i]) - size[i];
+    const int k = a[0] > a[1] ? 0 : 1;
+    const int l = a[2] > a[k] ? 2 : k;
+    if (a[l] < 0) g[l] = pt[l] / fabsf(pt[l]);
+    else {
+        float b[3];
+        for (int i = 0; i < 3; i++) b[i] = gmax(a[i], 0.0f);
+        const float c = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+        for (int i = 0; i < 3; i++) g[i] = a[i] > 0 ? b[i] / c * pt[i] / fabsf(pt[i]) : 0.0f;
+    }
+    return boxDistance(t, p);
+}
+
+template <int EVAL, bool GRAD>
+SDF_DEV float queryOne(const QueryTree& t, F3 p, float* grad) {
+    F3 f = F3{(p.x - t.bminx) / t.cellSize, (p.y - t.bminy) / t.cellSize, (p.z - t.bminz) / t.cellSize};
+    const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
+    const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    f = F3{f.x - flx, f.y - fly, f.z - flz};
+    if (ix < 0 || ix >= t.G || iy < 0 || iy >= t.G || iz < 0 || iz >= t.G) {
+        if (GRAD) return boxDistanceGrad(t, p, grad) + t.minBorder;
+        return boxDistance(t, p) + t.minBorder;
+    }
+    uint32_t w = t.data[(iz * t.G + iy) * t.G + ix];
+    while (!(w & LEAF_BIT)) {
+        const uint32_t child = ((f.z >= 0.5f) ? 4u : 0u) + ((f.y >= 0.5f) ? 2u : 0u) + ((f.x >= 0.5f) ? 1u : 0u);
+        w = t.data[(w & INDEX_MASK) + child];
+        f = F3{gfract(2.0f * f.x), gfract(2.0f * f.y), gfract(2.0f * f.z)};
+    }
+    const uint32_t at = w & INDEX_MASK;
+    float c[64];
+    if ((at & 3u) == 0u) {
+        const float4* src = reinterpret_cast<const float4*>(t.data + at);
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const float4 v = src[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 64; q++) c[q] = __uint_as_float(t.data[at + q]);
+    }
+    auto cf = [&](int n) { return c[n]; };
+    if (EVAL == SDFHIP_EVAL_EXACT) {
+        if (GRAD) {
+            const F3 g = normalize(F3{tricubicDerivExact<1, 0, 0>(cf, f), tricubicDerivExact<0, 1, 0>(cf, f), tricubicDerivExact<0, 0, 1>(cf, f)});
+            grad[0] = g.x; grad[1] = g.y; grad[2] = g.z;
+        }
+        return tricubicValueExact(cf, f);
+    } else {
+        if (GRAD) {
+            F3 g;
+            const float v = tricubicValueGradFast(cf, f, g);
+            g = normalize(g);
+            grad[0] = g.x; grad[1] = g.y; grad[2] = g.z;
+            return v;
+        }
+        return tricubicValueFast(cf, f);
+    }
+}
+
+template <int EVAL, bool GRAD>
+__global__ void __launch_bounds__(256) k_octree_query(QueryTree t, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float g[3] = {0.f, 0.f, 0.f};
+    const float d = queryOne<EVAL, GRAD>(t, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, g);
+    dist[i] = d;
+    if (GRAD) { grad[3 * i] = g[0]; grad[3 * i + 1] = g[1]; grad[3 * i + 2] = g[2]; }
+}
+
+template <int EVAL, bool GRAD>
+__global__ void __launch_bounds__(256) k_octree_query_grid(QueryTree t, F3 origin, F3 step, uint32_t nx, uint32_t ny, uint32_t nz,
+                                                           float* __restrict__ dist, float* __restrict__ grad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = (uint64_t)nx * ny * nz;
+    if (i >= n) return;
+    const uint32_t x = (uint32_t)(i % nx), y = (uint32_t)((i / nx) % ny), z = (uint32_t)(i / ((uint64_t)nx * ny));
+    const F3 p = F3{origin.x + (float)x * step.x, origin.y + (float)y * step.y, origin.z + (float)z * step.z};
+    float g[3] = {0.f, 0.f, 0.f};
+    const float d = queryOne<EVAL, GRAD>(t, p, g);
+    dist[i] = d;
+    if (GRAD) { grad[3 * i] = g[0]; grad[3 * i + 1] = g[1]; grad[3 * i + 2] = g[2]; }
+}
+
+static QueryTree makeQueryTree(const sdfhip_octree* T) {
+    QueryTree q;
+    q.data = T->data.p;
+    q.bminx = T->info.box_min[0]; q.bminy = T->info.box_min[1]; q.bminz = T->info.box_min[2];
+    q.bmaxx = T->info.box_max[0]; q.bmaxy = T->info.box_max[1]; q.bmaxz = T->info.box_max[2];
+    q.cellSize = T->cellSize; q.minBorder = T->info.min_border_value; q.G = T->info.start_grid_size;
+    return q;
+}
+
+}  // namespace sdfhip
+
+using namespace sdfhip;
+
+extern "C" {
+
+int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int where, int eval_mode) {
+    SDF_REQUIRE(T && xyz && out_dist, "NULL argument");
+    SDF_REQUIRE(T->hasData, "tree has no assembled node array");
+    SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
+    if (n == 0) return SDFHIP_OK;
+    sdfhip_ctx* ctx = T->ctx;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<float> dp, dd, dg;
+    const float* p = xyz; float* d = out_dist; float* g = out_grad;
+    if (where == SDFHIP_HOST) {
+        SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dd.reserve(n));
+        if (out_grad) SDF_TRY(dg.reserve(3 * n));
+        SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, 12 * n, hipMemcpyHostToDevice, st));
+        p = dp.p; d = dd.p; g = out_grad ? dg.p : nullptr;
+    }
+    const QueryTree q = makeQueryTree(T);
+    const unsigned blocks = gridFor(n, 256);
+    if (eval_mode == SDFHIP_EVAL_EXACT) {
+        if (g) k_octree_query<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(q, p, n, d, g);
+        else k_octree_query<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(q, p, n, d, nullptr);
+    } else {
+        if (g) k_octree_query<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(q, p, n, d, g);
+        else k_octree_query<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(q, p, n, d, nullptr);
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    if (where == SDFHIP_HOST) {
+        SDF_HIP_CHECK(hipMemcpyAsync(out_dist, d, 4 * n, hipMemcpyDeviceToHost, st));
+        if (out_grad) SDF_HIP_CHECK(hipMemcpyAsync(out_grad, g, 12 * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return SDFHIP_OK;
+}
+
+int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const float step[3], uint32_t nx, uint32_t ny, uint32_t nz,
+                             float* out_dist, float* out_grad, int where, int eval_mode) {
+    SDF_REQUIRE(T && origin && step && out_dist, "NULL argument");
+    SDF_REQUIRE(T->hasData, "tree has no assembled node array");
+    SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
+    const uint64_t n = (uint64_t)nx * ny * nz;
+    if (n == 0) return SDFHIP_OK;
+    sdfhip_ctx* ctx = T->ctx;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<float> dd, dg;
+    float* d = out_dist; float* g = out_grad;
+    if (where == SDFHIP_HOST) {
+        SDF_TRY(dd.reserve(n));
+        if (out_grad) SDF_TRY(dg.reserve(3 * n));
+        d = dd.p; g = out_grad ? dg.p : nullptr;
+    }
+    const QueryTree q = makeQueryTree(T);
+    const F3 o = F3{origin[0], origin[1], origin[2]}, s = F3{step[0], step[1], step[2]};
+    const unsigned blocks = gridFor(n, 256);
+    if (eval_mode == SDFHIP_EVAL_EXACT) {
+        if (g) k_octree_query_grid<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, g);
+        else k_octree_query_grid<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, nullptr);
+    } else {
+        if (g) k_octree_query_grid<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, g);
+        else k_octree_query_grid<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, nullptr);
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    if (where == SDFHIP_HOST) {
+        SDF_HIP_CHECK(hipMemcpyAsync(out_dist, d, 4 * n, hipMemcpyDeviceToHost, st));
+        if (out_grad) SDF_HIP_CHECK(hipMemcpyAsync(out_grad, g, 12 * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    return SDFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Internal host-side plumbing of libsdfhip (context, error handling, device buffers).  PRODUCT code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <chrono>
+#include "../../include/sdfhip.h"
+
+namespace sdfhip {
+
+void setError(const char* fmt, ...);
+
+#define SDF_HIP_CHECK(expr)                                                                        \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            sdfhip::setError("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SDFHIP_E_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+#define SDF_REQUIRE(cond, msg)                                                  \
+    do {                                                                        \
+        if (!(cond)) { sdfhip::setError("invalid argument: %s", msg); return SDFHIP_E_INVALID; } \
+    } while (0)
+
+#define SDF_TRY(expr) do { int _r = (expr); if (_r != SDFHIP_OK) return _r; } while (0)
+
+static inline double nowSeconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Plain device allocation owned by one object; freed in the destructor.
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; return *this; }
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    // grows only; contents are NOT preserved
+    int reserve(size_t count) {
+        if (count <= n && p) return SDFHIP_OK;
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; setError("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); return SDFHIP_E_HIP; }
+        n = count;
+        return SDFHIP_OK;
+    }
+};
+
+static inline unsigned gridFor(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
+
+}  // namespace sdfhip
+
+struct sdfhip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownsStream = false;
+    hipDeviceProp_t prop;
+};
+
+struct sdfhip_mesh {
+    sdfhip_ctx* ctx = nullptr;
+    uint32_t numVertices = 0, numTriangles = 0;
+    std::vector<float> hVerts;            // host copies (BVH planner input)
+    std::vector<uint32_t> hIdx;
+    sdfhip::DevBuf<float> dVerts;         // 3 floats per vertex
+    sdfhip::DevBuf<uint32_t> dIdx;        // 3 per triangle
+    sdfhip::DevBuf<float> dTri;           // 37 floats per triangle (TriangleData)
+    // bounding-sphere BVH (fp64), 10 doubles per node: left sphere (c, r), right sphere (c, r), {left,right} ints, pad
+    sdfhip::DevBuf<double> dBvh;
+    uint64_t numBvhNodes = 0;
+    bool hasBvh = false;
+    uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
+};
+
+int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh);
