@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the hot path on MI355X.
+
+Workload (BASELINE.json configs[1], synthetic stand-in because no Armadillo file exists here):
+  bumpy icosphere s=7 (327 680 triangles), OctreeSdf depth 8, start depth 3, threshold 1e-3 (NO_CONTINUITY),
+  built on the GPU; a "step" is ONE batched getDistance() pass over 10 M uniform-random points resident in HBM.
+value = whole-job M queries/s (all ranks' points / max-over-ranks time).  With N > 1 every rank holds the tree
+(built SHARDED by start-grid cell + RCCL all-gather) and its own 10 M points: weak scaling, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import sdflib_amd as S  # noqa: E402
+from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin  # noqa: E402
+from sdflib_amd import distributed as sdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--subdiv", type=int, default=7, help="icosphere subdivisions (7 -> 327 680 triangles)")
+    ap.add_argument("--depth", type=int, default=8)
+    ap.add_argument("--start-depth", type=int, default=3)
+    ap.add_argument("--queries", type=int, default=10_000_000)
+    ap.add_argument("--eval", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--gradient", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="queries timed on the host cores for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--build-1m", action="store_true", help="also time the depth-8 build of the 1.31 M-triangle mesh")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- setup (untimed): mesh, context on torch's stream, tree -------------------------------------------
+    v, f = bumpy_icosphere(args.subdiv)
+    box = box_with_margin(v)
+    ctx = S.Context(local_rank, use_torch_stream=True)
+    mesh = S.Mesh(v, f, ctx)
+    bvh_s = mesh.build_bvh()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if world > 1:
+        tree, binfo = sdist.build_octree_sharded(mesh, box, args.depth, args.start_depth, 1e-3, rank, world, dev)
+    else:
+        tree = S.OctreeSdf(mesh, box, args.depth, args.start_depth, 1e-3, num_threads=2)
+        binfo = {"shard_build_s": tree.info.seconds_total, "exchange_s": 0.0}
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    info = tree.info
+
+    gen = torch.Generator(device=dev); gen.manual_seed(1234 + rank)
+    bb = tree.get_grid_bounding_box()
+    lo = torch.tensor(bb[:3], device=dev)
+    size = float(bb[3] - bb[0])
+    pts = (lo + torch.rand((args.queries, 3), generator=gen, device=dev) * (size * 0.999999)).contiguous()
+    out = torch.empty(args.queries, dtype=torch.float32, device=dev)
+    outg = torch.empty((args.queries, 3), dtype=torch.float32, device=dev) if args.gradient else None
+    mode = S.EVAL_EXACT if args.eval == "exact" else S.EVAL_FAST
+
+    def step():
+        tree.get_distance(pts, gradient=args.gradient, eval_mode=mode, out=out, out_grad=outg)
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides ------------------------------
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(); step(); b.record()     # events on the stream the kernel is launched on (ctx = torch's stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    # ---- algorithmic bytes per query: point + result + path words + 256 B coefficients ----
+    lpd = np.array(list(info.leaves_per_depth), dtype=np.float64)
+    prob = np.array([lpd[d] / 8.0 ** d for d in range(16)])
+    mean_loads = float(sum(prob[d] * (d - args.start_depth + 1) for d in range(16)) / max(prob.sum(), 1e-30))
+    bytes_per_query = 12 + 4 + (12 if args.gradient else 0) + 256 + 4 * mean_loads
+    achieved_gbs = bytes_per_query * args.queries / (kernel_ms * 1e-3) / 1e9
+
+    total_queries = args.queries * world * args.steps
+    value = total_queries / elapsed / 1e6
+
+    result = {
+        "metric": "Mqueries/sec getDistance() (OctreeSdf, whole job)", "value": round(value, 2), "unit": "Mqueries/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"bumpy icosphere s={args.subdiv} ({len(f)} tris, Armadillo-scale stand-in) OctreeSdf depth {args.depth} "
+                               f"start {args.start_depth} thr 1e-3 NO_CONTINUITY; {args.queries} uniform-random getDistance per GPU per step",
+                   "eval": args.eval, "gradient": bool(args.gradient), "queries_per_gpu": args.queries,
+                   "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
+        "per_gpu_mqueries_s": round(value / world, 2),
+        "roofline": {"bound": "hbm", "kernel": "k_octree_query", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
+                     "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
+        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), **{k: round(v, 4) for k, v in binfo.items()}},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
+    if args.build_1m:
+        result["build_1m"] = build_1m(ctx, rank, world, dev)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(v, f, box, args, pts):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores: bounded sample."""
+    from oracle import pyoracle as O
+    cores = os.cpu_count() or 1
+    om = O.Mesh(v, f)
+    t0 = time.perf_counter()
+    # build at the bench depth is minutes of CPU on few cores: bound it by building one level shallower if needed
+    cpu_depth = args.depth if cores >= 32 else min(args.depth, 7)
+    ot = O.Octree(om, box, cpu_depth, args.start_depth, 1e-3, vertex_cache=False, layout=O.LAYOUT_SUBTREES)
+    cpu_build_s = time.perf_counter() - t0
+    sample = pts[:args.cpu_sample].cpu().numpy()
+    ot.query(sample[:10000], grad=args.gradient, threads=cores)
+    t0 = time.perf_counter()
+    ot.query(sample, grad=args.gradient, threads=cores)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ot.query(sample[:len(sample) // 8], grad=args.gradient, threads=1)
+    dt1 = time.perf_counter() - t0
+    return {"value": round(len(sample) / dt / 1e6, 3), "unit": "Mqueries/s", "cores": cores, "kind": "port",
+            "sample": f"{len(sample)} of the same random points, oracle getDistance under OpenMP static schedule, {cores} threads; "
+                      f"tree = oracle build depth {cpu_depth} ({cpu_build_s:.1f} s, OpenMP over start cells)",
+            "single_thread_mqueries_s": round(len(sample) // 8 / dt1 / 1e6, 3), "cpu_build_s": round(cpu_build_s, 2), "cpu_build_depth": cpu_depth}
+
+
+def build_1m(ctx, rank, world, dev):
+    v, f = bumpy_icosphere(8)
+    box = box_with_margin(v)
+    t0 = time.perf_counter()
+    mesh = S.Mesh(v, f, ctx)
+    prep = time.perf_counter() - t0
+    bvh_s = mesh.build_bvh()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        tree, binfo = sdist.build_octree_sharded(mesh, box, 8, 3, 1e-3, rank, world, dev)
+    else:
+        tree = S.OctreeSdf(mesh, box, 8, 3, 1e-3, num_threads=2); binfo = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    i = tree.info
+    return {"triangles": int(len(f)), "octree_build_s": round(dt, 4), "mesh_prep_s": round(prep, 4), "bvh_host_planner_s": round(bvh_s, 4),
+            "words": int(i.num_words), "leaves": int(i.num_leaves), **{k: round(v, 4) for k, v in binfo.items()}}
+
+
+if __name__ == "__main__":
+    main()

@@ -73,9 +73,13 @@ typedef struct sdfhip_exact sdfhip_exact;
 const char* sdfhip_last_error(void);
 const char* sdfhip_version(void);
 
-/* One context per (process, device).  stream = a hipStream_t owned by the caller (e.g. torch's current
- * stream) or NULL for a private stream. */
-int sdfhip_ctx_create(int device_id, void* stream, sdfhip_ctx** out);
+/* One context per (process, device).
+ * stream_mode SDFHIP_STREAM_PRIVATE: the context creates its own non-blocking stream (`stream` ignored).
+ * stream_mode SDFHIP_STREAM_BORROWED: run on the caller's hipStream_t `stream` (e.g. torch's current stream);
+ *                                     NULL then means the device's default (null) stream. */
+#define SDFHIP_STREAM_PRIVATE 0
+#define SDFHIP_STREAM_BORROWED 1
+int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx** out);
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
@@ -110,6 +114,7 @@ typedef struct sdfhip_octree_info {
     uint64_t body_words;            /* words in this shard's bodies */
     uint64_t body_offset;           /* absolute word offset of this shard's bodies in the full array */
     double seconds_samples, seconds_decide, seconds_total;
+    uint64_t leaves_per_depth[16];  /* leaves at each depth (this shard) */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {

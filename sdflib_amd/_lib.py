@@ -21,7 +21,7 @@ class OctreeInfo(C.Structure):
                 ("value_range", C.c_float), ("min_border_value", C.c_float), ("num_words", C.c_uint64), ("num_leaves", C.c_uint64),
                 ("num_nodes", C.c_uint64), ("num_samples", C.c_uint64), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32),
                 ("body_words", C.c_uint64), ("body_offset", C.c_uint64), ("seconds_samples", C.c_double), ("seconds_decide", C.c_double),
-                ("seconds_total", C.c_double)]
+                ("seconds_total", C.c_double), ("leaves_per_depth", C.c_uint64 * 16)]
 
 
 class OctreeParams(C.Structure):
@@ -43,7 +43,7 @@ _vp, _u32, _u64, _i32, _f32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int3
 SIGNATURES = {
     "sdfhip_last_error": (C.c_char_p, []),
     "sdfhip_version": (C.c_char_p, []),
-    "sdfhip_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "sdfhip_ctx_create": (_int, [_int, _vp, _int, C.POINTER(_vp)]),
     "sdfhip_ctx_destroy": (_int, [_vp]),
     "sdfhip_ctx_synchronize": (_int, [_vp]),
     "sdfhip_ctx_stream": (_vp, [_vp]),

@@ -41,11 +41,13 @@ class Context:
     """One (process, device) context.  With ``use_torch_stream`` the engine runs on torch's current stream."""
 
     def __init__(self, device=0, stream=None, use_torch_stream=False):
+        borrowed = stream is not None
         if use_torch_stream and stream is None:
             import torch
-            stream = torch.cuda.current_stream(device).cuda_stream
+            stream = torch.cuda.current_stream(device).cuda_stream     # 0 = the default (null) stream
+            borrowed = True
         h = C.c_void_p()
-        check(lib().sdfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        check(lib().sdfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, 1 if borrowed else 0, C.byref(h)))
         self.h, self.device = h, int(device)
 
     def synchronize(self):
@@ -175,6 +177,11 @@ class OctreeSdf:
     def info(self):
         i = OctreeInfo()
         check(lib().sdfhip_octree_get_info(self.h, C.byref(i)))
+        ov = getattr(self, "_override", None)
+        if ov:
+            for d, n in enumerate(ov["leaves_per_depth"]):
+                i.leaves_per_depth[d] = n
+            i.num_leaves, i.num_nodes, i.num_samples = ov["num_leaves"], ov["num_nodes"], ov["num_samples"]
         return i
 
     # reference getters

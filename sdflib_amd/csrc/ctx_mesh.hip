@@ -113,7 +113,7 @@ extern "C" {
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
 const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
 
-int sdfhip_ctx_create(int device_id, void* stream, sdfhip_ctx** out) {
+int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx** out) {
     SDF_REQUIRE(out != nullptr, "out is NULL");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -126,7 +126,7 @@ int sdfhip_ctx_create(int device_id, void* stream, sdfhip_ctx** out) {
     sdfhip_ctx* c = new sdfhip_ctx();
     c->device = device_id;
     SDF_HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
-    if (stream) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
+    if (stream_mode == SDFHIP_STREAM_BORROWED) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
     else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
     *out = c;
     return SDFHIP_OK;

@@ -350,7 +350,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
             L->numInner = L->n; L->numLeaves = 0;
         }
         SDF_HIP_CHECK(hipGetLastError());
-        if (d >= startDepth) { T->info.num_nodes += L->n; T->info.num_leaves += L->numLeaves; }
+        if (d >= startDepth) { T->info.num_nodes += L->n; T->info.num_leaves += L->numLeaves; T->info.leaves_per_depth[d] = L->numLeaves; }
         if (d < maxDepth && L->numInner > 0) {
             SDF_REQUIRE(L->numInner <= (1u << 24), "level too large");
             std::unique_ptr<BuildLevel> N(new BuildLevel());

@@ -1,0 +1,73 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/sdfhip.h declares; it fails loudly
+(no CPU fallback) when no HIP device is present.  No compute calls are made here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "sdfhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdfhip_[a-z0-9_]+)\s*\(", hdr)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import sdflib_amd
+    if not os.path.exists(sdflib_amd.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "sdflib_amd", "csrc"), "-j8"])
+    return sdflib_amd.lib()
+
+
+def test_every_declared_symbol_is_exported_and_bound(built_lib):
+    from sdflib_amd._lib import SIGNATURES
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(built_lib, name), f"{name} declared in sdfhip.h but not exported by libsdfhip.so"
+        assert name in SIGNATURES, f"{name} has no ctypes signature in sdflib_amd/_lib.py"
+    assert sorted(SIGNATURES) == declared
+
+
+def test_code_object_targets_gfx950(built_lib):
+    import sdflib_amd
+    blob = open(sdflib_amd.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_no_device_fails_loudly_without_fallback(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import sdflib_amd as S
+    with pytest.raises(S.SdfHipError) as e:
+        S.Context(0)
+    assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path (sdflib_amd/, include/) must not reference oracle/ in any way."""
+    bad = []
+    for base in ("sdflib_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for fn in files:
+                if fn.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"import\s+oracle|from\s+oracle|pyoracle|sdf_oracle|orc_[a-z]+\.h|liboracle|libsdf_oracle", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+
+
+def test_struct_sizes_match_the_header(built_lib):
+    """ctypes mirrors of the info/params structs must have the C sizes (compiled probe)."""
+    from sdflib_amd._lib import OctreeInfo, OctreeParams, ExactInfo
+    src = '#include "sdfhip.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu\\n", sizeof(sdfhip_octree_info), sizeof(sdfhip_octree_params), sizeof(sdfhip_exact_info));return 0;}\n'
+    exe = "/tmp/_sdfhip_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    a, b, c = (int(x) for x in subprocess.check_output([exe]).split())
+    assert (ctypes.sizeof(OctreeInfo), ctypes.sizeof(OctreeParams), ctypes.sizeof(ExactInfo)) == (a, b, c)
