@@ -1,0 +1,17 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): kernel-trace stats of the bench command + separate PMC passes.
+# Usage: tools/profile_bench.sh <round-tag>
+TAG=${1:-r01}
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
+# PMC passes: counters only, with kernel-trace only (no sys/hip/hsa traces)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o bench -- $CMD > $OUT/bench_pmc_l2.log 2>&1
+cd $REPO
+find gpurun_out/prof_$TAG -name "*.csv" | head -30

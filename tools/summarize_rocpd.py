@@ -1,0 +1,60 @@
+"""Turn the rocprofv3 (rocpd sqlite) outputs of tools/profile_bench.sh into small text summaries for profiles/.
+
+Usage: python tools/summarize_rocpd.py gpurun_out/prof_r01 profiles/r01
+Writes <prefix>_kernel_stats.csv (rocprofv3 --kernel-trace --stats equivalent) and <prefix>_pmc.csv
+(per-kernel averages of FETCH_SIZE / WRITE_SIZE / TCC hit+miss from the separate --pmc passes)."""
+import csv
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "")
+    if "rocprim" in name:
+        m = re.search(r"detail::(\w+?)(?:_config|_impl|<)", name)
+        return "rocprim::" + (m.group(1) if m else "kernel")
+    return name[:90]
+
+
+def main(src, prefix):
+    os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
+    db = sqlite3.connect(os.path.join(src, "trace", "bench_results.db"))
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows)
+    with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "percent"])
+        agg = {}
+        for name, n, s, a, mn, mx in rows:
+            k = short(name)
+            e = agg.setdefault(k, [0, 0, 1e30, 0])
+            e[0] += n; e[1] += s; e[2] = min(e[2], mn); e[3] = max(e[3], mx)
+        for k, (n, s, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, n, int(s), int(s / n), int(mn), int(mx), f"{100 * s / tot:.3f}"])
+    out = {}
+    for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+        p = os.path.join(src, sub, "bench_results.db")
+        if not os.path.exists(p):
+            continue
+        d = sqlite3.connect(p)
+        for name, cname, n, avg in d.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+            if cname in counters:
+                out.setdefault(short(name), {})[cname] = (n, avg)
+    with open(prefix + "_pmc.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        cols = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
+        w.writerow(["kernel", "dispatches"] + [c + "_avg_per_dispatch" for c in cols] + ["note"])
+        for k, v in sorted(out.items()):
+            if not k.startswith("sdfhip"):
+                continue
+            n = max(x[0] for x in v.values())
+            w.writerow([k, n] + [f"{v[c][1]:.3f}" if c in v else "" for c in cols] + ["FETCH/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE under-reports wide streaming reads by 2x)"])
+    print(open(prefix + "_kernel_stats.csv").read()[:3000])
+    print(open(prefix + "_pmc.csv").read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
