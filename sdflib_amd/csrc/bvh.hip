@@ -91,11 +91,12 @@ struct HostBvhBuilder {
     }
 };
 
-__global__ void k_nearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx,
+__global__ void __launch_bounds__(128) k_nearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx,
                           const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_stack[BVH_STACK * 128];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = bvhNearest(nodes, verts, idx, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]});
+    out[i] = bvhNearest<128>(nodes, verts, idx, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, s_stack + threadIdx.x);
 }
 
 __global__ void k_point_values(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const float* __restrict__ td,
@@ -125,6 +126,7 @@ extern "C" {
 
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
+    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
     const uint64_t nn = 2ull * mesh->numTriangles - 1;
     std::vector<double> nodes((size_t)BVH_NODE_DOUBLES * nn, 0.0);

@@ -15,7 +15,6 @@
 namespace sdfhip {
 
 constexpr int BVH_NODE_DOUBLES = 10;
-constexpr int BVH_STACK = 48;
 
 struct D3 { double x, y, z; };
 SDF_DEV D3 operator-(D3 a, D3 b) { return D3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -88,13 +87,26 @@ SDF_DEV D3 loadVertexD(const float* __restrict__ verts, uint32_t v) {
     return D3{(double)verts[3 * v], (double)verts[3 * v + 1], (double)verts[3 * v + 2]};
 }
 
-// Nearest triangle id for a float point (widened to double), root = node 0.
-SDF_DEV uint32_t bvhNearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx, F3 pf) {
+// Traversal stack: one 4-byte entry per deferred child = (parent node index << 1) | (deferred child is the RIGHT one).
+// It lives in LDS (column `threadIdx` of a [BVH_STACK][blockDim] array, so lanes never conflict) instead of scratch:
+// the first profile showed the per-lane scratch stack turning 94 MB of algorithmic output into 35 GB of writes per
+// launch.  The deferred child's distance is RECOMPUTED at pop time from the parent's sphere (same inputs, same
+// rounding), so nothing but the index needs to be kept.
+constexpr int BVH_STACK = 32;          // >= tree depth; the median-split tree over T triangles has depth ceil(log2 T) + 1
+
+SDF_DEV double sphereDist(const double2* nd, int which, D3 p) {
+    const double2 a = nd[2 * which], b = nd[2 * which + 1];
+    const D3 d = p - D3{a.x, a.y, b.x};
+    return sqrt(ddot(d, d)) - b.y;
+}
+
+// Nearest triangle id for a float point (widened to double), root = node 0.  STRIDE = LDS stride between entries.
+template <int STRIDE>
+SDF_DEV uint32_t bvhNearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx, F3 pf,
+                            uint32_t* __restrict__ stk) {
     const D3 p = D3{(double)pf.x, (double)pf.y, (double)pf.z};
     double best = 1.7976931348623157e308;     // std::numeric_limits<double>::max()
     int bestTri = -1;
-    int stackNode[BVH_STACK];
-    double stackDist[BVH_STACK];
     int sp = 0;
     int cur = 0;
     for (;;) {
@@ -107,22 +119,26 @@ SDF_DEV uint32_t bvhNearest(const double* __restrict__ nodes, const float* __res
             const double d2 = pointTriangleSq(p, loadVertexD(verts, idx[3 * t]), loadVertexD(verts, idx[3 * t + 1]), loadVertexD(verts, idx[3 * t + 2]));
             if (d2 < best * best) { best = sqrt(d2); bestTri = right; }
         } else {
-            const double2 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-            const D3 dl = p - D3{q0.x, q0.y, q1.x};
-            const D3 dr = p - D3{q2.x, q2.y, q3.x};
-            const double distL = sqrt(ddot(dl, dl)) - q1.y;
-            const double distR = sqrt(ddot(dr, dr)) - q3.y;
-            int first, second; double dFirst, dSecond;
-            if (distL < distR) { first = left; dFirst = distL; second = right; dSecond = distR; }
-            else { first = right; dFirst = distR; second = left; dSecond = distL; }
-            stackNode[sp] = second; stackDist[sp] = dSecond; sp++;
-            if (dFirst < best) { cur = first; descend = true; }
+            const double distL = sphereDist(nd, 0, p);
+            const double distR = sphereDist(nd, 1, p);
+            const bool leftFirst = distL < distR;
+            const double dFirst = leftFirst ? distL : distR;
+            stk[sp * STRIDE] = ((uint32_t)cur << 1) | (leftFirst ? 1u : 0u);     // deferred = right if the left goes first
+            sp++;
+            if (dFirst < best) { cur = leftFirst ? left : right; descend = true; }
         }
         if (descend) continue;
         bool found = false;
         while (sp > 0) {
             sp--;
-            if (stackDist[sp] < best) { cur = stackNode[sp]; found = true; break; }
+            const uint32_t e = stk[sp * STRIDE];
+            const double2* pn = reinterpret_cast<const double2*>(nodes + (size_t)BVH_NODE_DOUBLES * (e >> 1));
+            const int which = (int)(e & 1u);
+            if (sphereDist(pn, which, p) < best) {
+                const double2 c4 = pn[4];
+                cur = which ? __double2hiint(c4.x) : __double2loint(c4.x);
+                found = true; break;
+            }
         }
         if (!found) break;
     }

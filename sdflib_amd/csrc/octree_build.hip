@@ -26,8 +26,8 @@ namespace sdfhip {
 
 struct MeshDev { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
 
-SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4) {
-    const uint32_t t = bvhNearest(m.bvh, m.verts, m.idx, p);
+SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4, uint32_t* __restrict__ stk) {
+    const uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);
     const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
     F3 g;
     const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t,
@@ -39,21 +39,23 @@ SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4) {
 
 // 8 corners of every node (only the root level evaluates corners; deeper levels inherit them).
 __global__ void __launch_bounds__(128) k_corner_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ corner) {
+    __shared__ uint32_t s_stack[BVH_STACK * 128];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 8u * n) return;
     const uint32_t node = gid >> 3, c = gid & 7u;
     const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
     const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
-    sampleAt(m, ce + rel * half, corner + 4 * (size_t)gid);
+    sampleAt(m, ce + rel * half, corner + 4 * (size_t)gid, s_stack + threadIdx.x);
 }
 
 // 19 mid-points of every node of a level: the build's hot kernel.
 __global__ void __launch_bounds__(128) k_level_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ mid) {
+    __shared__ uint32_t s_stack[BVH_STACK * 128];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 19u * n) return;
     const uint32_t node = gid / 19u, mi = gid - 19u * node;
     const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
-    sampleAt(m, ce + midRel((int)mi) * half, mid + 4 * (size_t)gid);
+    sampleAt(m, ce + midRel((int)mi) * half, mid + 4 * (size_t)gid, s_stack + threadIdx.x);
 }
 
 SDF_DEV uint32_t floatOrderKey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
