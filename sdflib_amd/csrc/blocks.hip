@@ -1,6 +1,7 @@
 // Building blocks exposed through the C ABI for parity tests.  PRODUCT code — independent of oracle/.
 #include "sdfhip_internal.h"
 #include "dev_tricubic.h"
+#include "dev_gjk.h"
 
 namespace sdfhip {
 
@@ -13,6 +14,15 @@ __global__ void __launch_bounds__(128) k_fit_exact(const float* __restrict__ in,
     tricubicFit(s, nodeSize[i], c);
 #pragma unroll
     for (int k = 0; k < 64; k++) out[64 * i + k] = c[k];
+}
+
+__global__ void k_is_near(const float* __restrict__ half, const float* __restrict__ radius8, const float* __restrict__ tri9, const float* __restrict__ thr, uint64_t n, uint8_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r[8];
+    for (int k = 0; k < 8; k++) r[k] = radius8[8 * i + k];
+    const float* t = tri9 + 9 * i;
+    out[i] = isNearMinimize(half[i], r, F3{t[0], t[1], t[2]}, F3{t[3], t[4], t[5]}, F3{t[6], t[7], t[8]}, thr[i]) ? 1 : 0;
 }
 
 }  // namespace sdfhip
@@ -34,6 +44,24 @@ int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* n
     k_fit_exact<<<gridFor(n, 128), 128, 0, st>>>(din.p, dns.p, n, dout.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(out64, dout.p, 256 * n, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+}
+
+int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr, uint64_t n, uint8_t* out) {
+    SDF_REQUIRE(ctx && half && radius8 && tri9 && thr && out, "NULL argument");
+    if (n == 0) return SDFHIP_OK;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<float> dh, dr, dt, dth; DevBuf<uint8_t> dout;
+    SDF_TRY(dh.reserve(n)); SDF_TRY(dr.reserve(8 * n)); SDF_TRY(dt.reserve(9 * n)); SDF_TRY(dth.reserve(n)); SDF_TRY(dout.reserve(n));
+    SDF_HIP_CHECK(hipMemcpyAsync(dh.p, half, 4 * n, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dr.p, radius8, 32 * n, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dt.p, tri9, 36 * n, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dth.p, thr, 4 * n, hipMemcpyHostToDevice, st));
+    k_is_near<<<gridFor(n, 256), 256, 0, st>>>(dh.p, dr.p, dt.p, dth.p, n, dout.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipMemcpyAsync(out, dout.p, n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
 }

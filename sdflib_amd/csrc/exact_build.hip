@@ -1,0 +1,691 @@
+// ExactOctreeSdf construction on the device.  PRODUCT code — independent of oracle/.
+//
+// Reference behaviour reproduced (single-thread semantics, lattice cache disabled):
+//   ExactOctreeSdf::ExactOctreeSdf                               src/sdf/ExactOctreeSdf.cpp:7-31
+//   initOctree<PerNodeRegionTrianglesInfluence<None>> + processNode   include/SdfLib/ExactOctreeSdfDepthFirst.h:28-510
+//   PerNodeRegionTrianglesInfluence::calculateVerticesInfo / filterTriangles   include/SdfLib/TrianglesInfluence.h:692-860
+//   GJK::IsNearMinimize                                           src/utils/GJK.cpp:830-866
+//
+// MI355X formulation: the reference's depth-first walk becomes level-synchronous passes.
+//   k_node_regions  : one wave per node, lane (i,c) -> distance from corner c to the triangle nearest to corner i
+//   k_cull          : the hot kernel. Work item = 1024-entry chunk of a node's PARENT list; one wave per chunk, lanes
+//                     stride the chunk, gather 3 indices + 3 vertices per triangle, run the Frank-Wolfe test, and
+//                     compact the survivors IN ORDER with __ballot + mbcnt prefix (lists stay ascending by id)
+//   hipcub scan + k_compact : chunk counts -> packed per-node lists
+//   k_brute_nearest : wave per (node, sample point): first-minimum nearest triangle over the node's list
+//   k_merge_*       : the "second visit" of the last two levels: sorted union of the children's lists + per-child
+//                     MSB-first byte masks (ExactOctreeSdfDepthFirst.h:195-259), as binary-search membership tests
+//   k_ex_sizes / k_ex_offsets / k_ex_emit_* : pre/post-order offsets of the reference's three arrays (nodes, bit-packed
+//                     sets, masks) in its DFS order (children 7..0), then the bit-packing itself (:261-283, 448-468)
+// Compile with -ffp-contract=off.
+#include "exact_internal.h"
+#include "dev_gjk.h"
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace sdfhip {
+
+constexpr uint32_t CHUNK = 1024;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct ExMesh { const float* verts; const uint32_t* idx; const float* td; };
+
+SDF_DEV F3 ldv(const float* __restrict__ v, uint32_t i) { return F3{v[3 * i], v[3 * i + 1], v[3 * i + 2]}; }
+
+// triangles whose frame normal is usable (ExactOctreeSdfDepthFirst.h:104-108)
+__global__ void k_valid_triangles(const float* __restrict__ td, uint32_t T, uint32_t* __restrict__ valid) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const F3 n = triNormal(td + (size_t)TD_FLOATS * t + 3);
+    valid[t] = (dot(n, n) > 1e-3f) ? 1u : 0u;
+}
+__global__ void k_compact_valid(const uint32_t* __restrict__ valid, const uint32_t* __restrict__ scan, uint32_t T, uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < T && valid[t]) out[scan[t]] = t;
+}
+
+// wave-wide first-minimum: smallest distance, ties -> smallest list position
+SDF_DEV void waveArgMin(float& d, uint32_t& pos) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float od = __shfl_xor(d, off);
+        const uint32_t op = __shfl_xor(pos, off);
+        if (od < d || (od == d && op < pos)) { d = od; pos = op; }
+    }
+}
+
+// Nearest triangle (first minimum in list order) for sample points of nodes.  One block of TPB threads per (node, point).
+// pointsPerNode = 8 (corners) or 19 (mid-points).  skipFlag: nodes with skip[i] != 0 are not evaluated.
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_brute_nearest(ExMesh m, const float* __restrict__ center, float half, uint32_t n, int pointsPerNode,
+                                                       const uint32_t* __restrict__ list, const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
+                                                       const uint32_t* __restrict__ skip, uint32_t* __restrict__ outTri) {
+    const uint32_t item = blockIdx.x;
+    const uint32_t node = item / (uint32_t)pointsPerNode, pi = item - node * (uint32_t)pointsPerNode;
+    if (node >= n) return;
+    if (skip && skip[node]) return;
+    const F3 ce = ldv(center, node);
+    const F3 rel = (pointsPerNode == 8) ? cornerRel((int)pi) : midRel((int)pi);
+    const F3 p = ce + rel * half;
+    const uint32_t off = listOff[node], len = listLen[node];
+    float best = INFINITY; uint32_t bestPos = NONE;
+    for (uint32_t k = threadIdx.x; k < len; k += TPB) {
+        const uint32_t t = list[off + k];
+        TriFrame f; loadFrame(m.td + (size_t)TD_FLOATS * t, f);
+        const float d = sqDistPointTriangle(p, f);
+        if (d < best) { best = d; bestPos = k; }
+    }
+    waveArgMin(best, bestPos);
+    if (TPB > 64) {
+        __shared__ float sd[TPB / 64]; __shared__ uint32_t sp[TPB / 64];
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sd[w] = best; sp[w] = bestPos; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < TPB / 64; k++) if (sd[k] < best || (sd[k] == best && sp[k] < bestPos)) { best = sd[k]; bestPos = sp[k]; }
+        }
+    }
+    if (threadIdx.x == 0) outTri[(size_t)node * pointsPerNode + pi] = (bestPos == NONE) ? (len ? list[off] : 0u) : list[off + bestPos];
+}
+
+// 8x8 corner-sphere radii of a node: lane l = 8*i + c  ->  dist(corner c, nearest triangle of corner i) - min_c
+__global__ void __launch_bounds__(256) k_node_regions(ExMesh m, const float* __restrict__ center, float half, uint32_t n,
+                                                      const uint32_t* __restrict__ cornerTri, float* __restrict__ region /*64 n*/, float* __restrict__ minDist /*8 n*/) {
+    const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (node >= n) return;
+    const int i = lane >> 3, c = lane & 7;
+    const uint32_t t = cornerTri[8 * (size_t)node + i];
+    TriFrame f; loadFrame(m.td + (size_t)TD_FLOATS * t, f);
+    const F3 p = ldv(center, node) + cornerRel(c) * half;
+    const float r = sqrtf(sqDistPointTriangle(p, f));
+    // min over the 8 lanes of group i in ascending c with glm::min(a,b) = (b<a)?b:a semantics (order-independent for non-NaN)
+    float mn = r;
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) { const float o = __shfl_xor(mn, off); mn = (o < mn) ? o : mn; }
+    region[64 * (size_t)node + lane] = r - mn;
+    if (c == 0) minDist[8 * (size_t)node + i] = mn;
+}
+
+// chunk table: chunkNode[chunkBase[i] + k] = i
+__global__ void k_chunk_counts(uint32_t n, const uint32_t* __restrict__ pLen, uint32_t* __restrict__ nChunks) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) nChunks[i] = (pLen[i] + CHUNK - 1) / CHUNK;
+}
+__global__ void k_chunk_fill(uint32_t n, const uint32_t* __restrict__ nChunks, const uint32_t* __restrict__ chunkBase, uint32_t* __restrict__ chunkNode) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = chunkBase[i], c = nChunks[i];
+    for (uint32_t k = 0; k < c; k++) chunkNode[b + k] = i;
+}
+
+struct CullArgs {
+    ExMesh m; const float* center; float half;
+    const uint32_t* cornerTri; const float* region; const float* minDist;
+    const uint32_t* plist; const uint32_t* pOff; const uint32_t* pLen;      // parent list of every node
+    const uint32_t* chunkNode; const uint32_t* chunkBase; uint32_t numChunks;
+    uint32_t* tmp;            // survivors of chunk q, compacted at tmp[q * CHUNK ...]
+    uint32_t* chunkCount;     // survivors per chunk
+    unsigned long long* cullTests;
+};
+
+// THE hot kernel of the Exact build: one wave per chunk of a node's parent list.
+__global__ void __launch_bounds__(256) k_cull(CullArgs a) {
+    __shared__ float s_region[4][64];
+    __shared__ float s_min[4][8];
+    __shared__ uint32_t s_corner[4][8];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t q = blockIdx.x * 4u + (uint32_t)w;
+    if (q >= a.numChunks) return;
+    const uint32_t node = a.chunkNode[q];
+    const uint32_t ck = q - a.chunkBase[node];
+    s_region[w][lane] = a.region[64 * (size_t)node + lane];
+    if (lane < 8) { s_min[w][lane] = a.minDist[8 * (size_t)node + lane]; s_corner[w][lane] = a.cornerTri[8 * (size_t)node + lane]; }
+    __builtin_amdgcn_wave_barrier();
+    const F3 ce = ldv(a.center, node);
+    const uint32_t off = a.pOff[node], len = a.pLen[node];
+    const uint32_t begin = ck * CHUNK, end = (begin + CHUNK < len) ? begin + CHUNK : len;
+    uint32_t kept = 0; unsigned long long tests = 0;
+    for (uint32_t base = begin; base < end; base += 64) {
+        const uint32_t k = base + lane;
+        bool keep = false; uint32_t t = 0; bool tested = false;
+        if (k < end) {
+            t = a.plist[off + k];
+            const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
+            const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
+            const F3 pt = 0.3333333f * ((t0 + t1) + t2);
+            const int vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
+            if (s_corner[w][vId] == t) keep = true;
+            else { tested = true; keep = isNearMinimize(a.half, &s_region[w][8 * vId], t0, t1, t2, s_min[w][vId]); }
+        }
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (keep) a.tmp[(size_t)q * CHUNK + kept + before] = t;
+        kept += (uint32_t)__popcll(mask);
+        tests += (unsigned long long)__popcll(__ballot(tested));
+    }
+    if (lane == 0) { a.chunkCount[q] = kept; if (tests) atomicAdd(a.cullTests, tests); }
+}
+
+// packed lists: survivors of chunk q go to list[chunkScan[q] ...]; listOff[node] = chunkScan[first chunk of node]
+__global__ void __launch_bounds__(256) k_compact(const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ chunkCount, const uint32_t* __restrict__ chunkScan,
+                                                 uint32_t numChunks, uint32_t* __restrict__ list) {
+    const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= numChunks) return;
+    const uint32_t c = chunkCount[q], o = chunkScan[q];
+    for (uint32_t k = lane; k < c; k += 64) list[o + k] = tmp[(size_t)q * CHUNK + k];
+}
+__global__ void k_node_list_ranges(uint32_t n, const uint32_t* __restrict__ nChunks, const uint32_t* __restrict__ chunkBase, const uint32_t* __restrict__ chunkScan,
+                                   const uint32_t* __restrict__ chunkCount, uint32_t numChunks, uint32_t* __restrict__ listOff, uint32_t* __restrict__ listLen) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = chunkBase[i], c = nChunks[i];
+    if (c == 0) { listOff[i] = (b < numChunks) ? chunkScan[b] : (numChunks ? chunkScan[numChunks - 1] + chunkCount[numChunks - 1] : 0u); listLen[i] = 0; return; }
+    const uint32_t last = b + c - 1;
+    listOff[i] = chunkScan[b];
+    listLen[i] = chunkScan[last] + chunkCount[last] - chunkScan[b];
+}
+
+__global__ void k_ex_decide(uint32_t n, uint32_t depth, uint32_t startDepth, uint32_t maxDepth, uint32_t minTri, const uint32_t* __restrict__ listLen,
+                            uint32_t* __restrict__ flag, uint32_t* __restrict__ inner, uint32_t* __restrict__ maxLeaf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool terminal = false;
+    if (depth >= startDepth) terminal = listLen[i] <= minTri;
+    const bool leaf = terminal || depth >= maxDepth;
+    flag[i] = leaf ? 1u : 0u; inner[i] = leaf ? 0u : 1u;
+    if (leaf) atomicMax(maxLeaf, listLen[i]);
+}
+
+struct ExChildArgs {
+    const float* center; const uint32_t* coord; const uint32_t* cornerTri; const uint32_t* midTri; const uint32_t* inner; const uint32_t* childBase;
+    const uint32_t* listOff; const uint32_t* listLen; uint32_t n; float half;
+    float* ncenter; uint32_t* ncoord; uint32_t* ncornerTri; uint32_t* npOff; uint32_t* npLen;
+};
+__global__ void __launch_bounds__(256) k_ex_children(ExChildArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 6;
+    if (i >= a.n || !a.inner[i]) return;
+    const uint32_t c = (gid >> 3) & 7u, j = gid & 7u;
+    const uint32_t child = a.childBase[i] + c;
+    const int src = kStencilDev.src[c][j];
+    a.ncornerTri[8 * (size_t)child + j] = (src >= 0) ? a.midTri[19 * (size_t)i + src] : a.cornerTri[8 * (size_t)i + (-src - 1)];
+    if (j == 0) {
+        const float ns = 0.5f * a.half;
+        a.ncenter[3 * (size_t)child] = a.center[3 * (size_t)i] + ((c & 1u) ? ns : -ns);
+        a.ncenter[3 * (size_t)child + 1] = a.center[3 * (size_t)i + 1] + ((c & 2u) ? ns : -ns);
+        a.ncenter[3 * (size_t)child + 2] = a.center[3 * (size_t)i + 2] + ((c & 4u) ? ns : -ns);
+        const uint32_t co = a.coord[i];
+        const uint32_t x = 2u * (co & 1023u) + (c & 1u), y = 2u * ((co >> 10) & 1023u) + ((c >> 1) & 1u), z = 2u * (co >> 20) + (c >> 2);
+        a.ncoord[child] = x | (y << 10) | (z << 20);
+        a.npOff[child] = a.listOff[i]; a.npLen[child] = a.listLen[i];
+    }
+}
+
+__global__ void k_ex_to_cell_order(const float* __restrict__ center, const uint32_t* __restrict__ coord, const uint32_t* __restrict__ cornerTri,
+                                   const uint32_t* __restrict__ pOff, const uint32_t* __restrict__ pLen, uint32_t n, uint32_t G,
+                                   float* __restrict__ ocenter, uint32_t* __restrict__ ocoord, uint32_t* __restrict__ ocornerTri, uint32_t* __restrict__ opOff, uint32_t* __restrict__ opLen) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, j = gid & 7u;
+    if (i >= n) return;
+    const uint32_t co = coord[i];
+    const uint32_t d = (co >> 20) * G * G + ((co >> 10) & 1023u) * G + (co & 1023u);
+    ocornerTri[8 * (size_t)d + j] = cornerTri[8 * (size_t)i + j];
+    if (j == 0) {
+        ocenter[3 * (size_t)d] = center[3 * (size_t)i]; ocenter[3 * (size_t)d + 1] = center[3 * (size_t)i + 1]; ocenter[3 * (size_t)d + 2] = center[3 * (size_t)i + 2];
+        ocoord[d] = co; opOff[d] = pOff[i]; opLen[d] = pLen[i];
+    }
+}
+
+// ---- merge step ("second visit") ---------------------------------------------------------------------------------
+SDF_DEV bool sortedContains(const uint32_t* __restrict__ l, uint32_t len, uint32_t v) {
+    uint32_t lo = 0, hi = len;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (l[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo < len && l[lo] == v;
+}
+struct MergeArgs {
+    uint32_t n; const uint32_t* inner; const uint32_t* childBase;
+    const uint32_t* list; const uint32_t* listOff; const uint32_t* listLen;                 // this level's filtered lists
+    uint32_t* ulist; uint32_t* uLen;                                                         // union lists (same offsets as list)
+    // children level
+    const uint32_t* cflag; const uint32_t* clist; const uint32_t* clistOff; const uint32_t* clistLen; const uint32_t* culist; const uint32_t* cuLen;
+    const uint32_t* maskOff; uint8_t* masks;                                                 // phase 2
+    uint32_t* maxEncoded; int trackEncoded;
+};
+SDF_DEV void childFinal(const MergeArgs& a, uint32_t child, const uint32_t*& l, uint32_t& len) {
+    if (a.cflag[child]) { l = a.clist + a.clistOff[child]; len = a.clistLen[child]; }
+    else { l = a.culist + a.clistOff[child]; len = a.cuLen[child]; }
+}
+// phase 1: union = elements of the node's filtered list present in any child's final list (order kept)
+__global__ void __launch_bounds__(256) k_merge_union(MergeArgs a) {
+    const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (node >= a.n || !a.inner[node]) return;
+    const uint32_t off = a.listOff[node], len = a.listLen[node], cb = a.childBase[node];
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t k = base + lane;
+        bool keep = false; uint32_t v = 0;
+        if (k < len) {
+            v = a.list[off + k];
+            for (uint32_t c = 0; c < 8 && !keep; c++) { const uint32_t* l; uint32_t ll; childFinal(a, cb + c, l, ll); keep = sortedContains(l, ll, v); }
+        }
+        const unsigned long long mask = __ballot(keep);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (keep) a.ulist[off + kept + before] = v;
+        kept += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) { a.uLen[node] = kept; if (a.trackEncoded) atomicMax(a.maxEncoded, kept); }
+}
+__global__ void k_mask_sizes(uint32_t n, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ uLen, uint32_t* __restrict__ maskBytes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) maskBytes[i] = inner[i] ? 8u * ((uLen[i] + 7u) / 8u) : 0u;
+}
+// phase 2: per-child MSB-first byte masks over the union list; one wave per (node, child)
+__global__ void __launch_bounds__(256) k_merge_masks(MergeArgs a) {
+    const uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t node = item >> 3, c = item & 7u;
+    if (node >= a.n || !a.inner[node]) return;
+    const uint32_t off = a.listOff[node], ul = a.uLen[node], nb = (ul + 7u) / 8u;
+    const uint32_t* l; uint32_t ll; childFinal(a, a.childBase[node] + c, l, ll);
+    uint8_t* dst = a.masks + a.maskOff[node] + (size_t)c * nb;
+    for (uint32_t base = 0; base < ul; base += 64) {
+        const uint32_t k = base + lane;
+        const bool in = (k < ul) && sortedContains(l, ll, a.ulist[off + k]);
+        const unsigned long long m = __ballot(in);
+        if (lane < 8) {
+            const uint32_t byteIdx = (base >> 3) + (uint32_t)lane;
+            if (byteIdx < nb) dst[byteIdx] = (uint8_t)(__brev((uint32_t)((m >> (8 * lane)) & 0xFFull)) >> 24);
+        }
+    }
+}
+
+// ---- sizes (bottom-up) and offsets (top-down) of the three output arrays -------------------------------------------
+struct SizeArgs {
+    uint32_t n, depth, bitEnc, bits; const uint32_t* flag; const uint32_t* childBase; const uint32_t* listLen; const uint32_t* uLen;
+    const uint32_t* cNode; const uint32_t* cSet; const uint32_t* cMask;     // children level sizes (may be null)
+    uint32_t* aNode; uint32_t* aSet; uint32_t* aMask;
+};
+SDF_DEV uint32_t setWords(uint32_t count, uint32_t bits) { return (count * bits + 31u) / 32u + 2u; }
+__global__ void k_ex_sizes(SizeArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    if (a.flag[i]) { a.aNode[i] = 0; a.aMask[i] = 0; a.aSet[i] = (a.depth <= a.bitEnc) ? setWords(a.listLen[i], a.bits) : 0u; return; }
+    uint32_t sn = 8, ss = 0, sm = 0;
+    const uint32_t cb = a.childBase[i];
+    for (int c = 0; c < 8; c++) { sn += a.cNode[cb + c]; ss += a.cSet[cb + c]; sm += a.cMask[cb + c]; }
+    if (a.depth >= a.bitEnc) sm += 8u * ((a.uLen[i] + 7u) / 8u);
+    if (a.depth == a.bitEnc) ss = setWords(a.uLen[i], a.bits);
+    a.aNode[i] = sn; a.aSet[i] = ss; a.aMask[i] = sm;
+}
+struct OffArgs {
+    uint32_t n, depth, bitEnc; const uint32_t* flag; const uint32_t* childBase; const uint32_t* uLen;
+    const uint32_t* pos; const uint32_t* blk; const uint32_t* setPos; const uint32_t* maskPos;
+    const uint32_t* cNode; const uint32_t* cSet; const uint32_t* cMask;
+    uint32_t* cpos; uint32_t* cblk; uint32_t* csetPos; uint32_t* cmaskPos; uint32_t* cmaskIdx;   // children outputs
+    uint32_t* nodes; uint8_t* hasTri;   // final node array (2 words per node)
+};
+__global__ void k_ex_offsets(OffArgs a) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, c = gid & 7u;
+    if (i >= a.n) return;
+    const uint32_t pos = a.pos[i];
+    if (a.flag[i]) {
+        if (c == 0) {
+            a.nodes[2 * (size_t)pos] = 0xFFFFFFFFu;
+            if (a.depth <= a.bitEnc) { a.nodes[2 * (size_t)pos + 1] = a.setPos[i]; a.hasTri[pos] = 1; }
+        }
+        return;
+    }
+    const uint32_t blk = a.blk[i], cb = a.childBase[i];
+    uint32_t nb = blk + 8u, sp = a.setPos[i], mp = a.maskPos[i], allMask = 0;
+    for (uint32_t k = 7; k > c; k--) { nb += a.cNode[cb + k]; sp += a.cSet[cb + k]; mp += a.cMask[cb + k]; }
+    for (uint32_t k = 0; k < 8; k++) allMask += a.cMask[cb + k];
+    a.cpos[cb + c] = blk + c; a.cblk[cb + c] = nb; a.csetPos[cb + c] = sp; a.cmaskPos[cb + c] = mp;
+    if (a.depth >= a.bitEnc) {
+        const uint32_t nbytes = (a.uLen[i] + 7u) / 8u;
+        const uint32_t own = a.maskPos[i] + allMask;                 // the node's own 8 masks follow its children's
+        a.cmaskIdx[cb + c] = own + c * nbytes;
+        a.nodes[2 * (size_t)(blk + c) + 1] = own + c * nbytes; a.hasTri[blk + c] = 1;
+    }
+    if (c == 0) {
+        a.nodes[2 * (size_t)pos] = blk & 0x7FFFFFFFu;
+        if (a.depth == a.bitEnc) { a.nodes[2 * (size_t)pos + 1] = a.setPos[i]; a.hasTri[pos] = 1; }
+    }
+}
+// bit-packed set of a node: [count][indices, `bits` each, MSB-first across words][spare]; one wave per node
+struct PackArgs { uint32_t n, depth, bitEnc, bits; const uint32_t* flag; const uint32_t* list; const uint32_t* ulist; const uint32_t* listOff; const uint32_t* listLen; const uint32_t* uLen; const uint32_t* setPos; uint32_t* sets; };
+__global__ void __launch_bounds__(256) k_ex_pack_sets(PackArgs a) {
+    const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (node >= a.n) return;
+    const bool leaf = a.flag[node] != 0u;
+    if (!((leaf && a.depth <= a.bitEnc) || (!leaf && a.depth == a.bitEnc))) return;
+    const uint32_t* l = (leaf ? a.list : a.ulist) + a.listOff[node];
+    const uint32_t cnt = leaf ? a.listLen[node] : a.uLen[node];
+    uint32_t* dst = a.sets + a.setPos[node];
+    if (lane == 0) dst[0] = cnt;
+    const uint32_t inv = 32u - a.bits;
+    for (uint32_t t = lane; t < cnt; t += 64) {
+        const uint32_t index = l[t], bIdx = t * a.bits, w = bIdx >> 5, bit = bIdx & 31u;
+        atomicOr(dst + 1 + w, (index << inv) >> bit);
+        const uint32_t hi = (uint32_t)((unsigned long long)index << (64u - (bit + a.bits)));
+        if (hi) atomicOr(dst + 2 + w, hi);
+    }
+}
+__global__ void __launch_bounds__(256) k_ex_copy_masks(uint32_t n, uint32_t depth, uint32_t bitEnc, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ uLen,
+                                                       const uint32_t* __restrict__ maskOff, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ maskPos,
+                                                       const uint32_t* __restrict__ childBase, const uint32_t* __restrict__ cMask, uint8_t* __restrict__ out) {
+    const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (node >= n || !inner[node] || depth < bitEnc) return;
+    uint32_t allMask = 0;
+    for (uint32_t k = 0; k < 8; k++) allMask += cMask[childBase[node] + k];
+    const uint32_t bytes = 8u * ((uLen[node] + 7u) / 8u);
+    const uint8_t* src = masks + maskOff[node];
+    uint8_t* dst = out + maskPos[node] + allMask;
+    for (uint32_t k = lane; k < bytes; k += 64) dst[k] = src[k];
+}
+__global__ void k_ex_init_cells(uint32_t nCells, const uint32_t* __restrict__ blkIn, const uint32_t* __restrict__ setIn, const uint32_t* __restrict__ maskIn,
+                                uint32_t* __restrict__ pos, uint32_t* __restrict__ blk, uint32_t* __restrict__ setPos, uint32_t* __restrict__ maskPos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nCells) return;
+    pos[i] = i; blk[i] = blkIn[i]; setPos[i] = setIn[i]; maskPos[i] = maskIn[i];
+}
+__global__ void k_fill_inner(uint32_t n, uint32_t* __restrict__ flag, uint32_t* __restrict__ inner, uint32_t* __restrict__ childBase) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { flag[i] = 0u; inner[i] = 1u; childBase[i] = 8u * i; }
+}
+__global__ void k_mul8(uint32_t n, uint32_t* __restrict__ v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] *= 8u; }
+
+static uint32_t dfsRank(uint32_t x, uint32_t y, uint32_t z, uint32_t startDepth) {
+    uint32_t r = 0;
+    for (uint32_t l = 0; l < startDepth; l++) {
+        const uint32_t sh = startDepth - 1 - l;
+        const uint32_t c = ((x >> sh) & 1u) | (((y >> sh) & 1u) << 1) | (((z >> sh) & 1u) << 2);
+        r = r * 8u + (7u - c);
+    }
+    return r;
+}
+
+struct ScanHelper {
+    DevBuf<unsigned char> tmp; size_t bytes = 0; hipStream_t st;
+    int exclusive(const uint32_t* in, uint32_t* out, uint32_t n) {
+        if (n == 0) return SDFHIP_OK;
+        size_t need = 0;
+        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, st));
+        if (need > bytes) { SDF_TRY(tmp.reserve(need)); bytes = need; }
+        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, in, out, (int)n, st));
+        return SDFHIP_OK;
+    }
+};
+
+static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
+    total = 0;
+    if (n == 0) return SDFHIP_OK;
+    uint32_t a = 0, b = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&a, scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&b, val + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    total = a + b;
+    return SDFHIP_OK;
+}
+
+}  // namespace sdfhip
+
+using namespace sdfhip;
+
+extern "C" {
+
+int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
+                       uint32_t minTri, sdfhip_exact** out) {
+    SDF_REQUIRE(ctx && mesh && box_min && box_max && out, "NULL argument");
+    SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
+    SDF_REQUIRE(maxDepth >= 2 && maxDepth <= 10, "max_depth must be in [2,10]");
+    SDF_REQUIRE(startDepth + 2 <= maxDepth, "start_depth must be <= max_depth - 2 (the reference dereferences a null node otherwise)");
+    SDF_REQUIRE(mesh->numTriangles >= 2, "at least 2 triangles are needed (bits per index)");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double tStart = nowSeconds();
+    std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
+    E->ctx = ctx; E->mesh = mesh;
+    const float sx = box_max[0] - box_min[0], sy = box_max[1] - box_min[1], sz = box_max[2] - box_min[2];
+    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0, "empty box");
+    const float maxSize = gmax(gmax(sx, sy), sz);
+    const float cx = box_min[0] + 0.5f * sx, cy = box_min[1] + 0.5f * sy, cz = box_min[2] + 0.5f * sz;
+    float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};
+    float bmax[3] = {cx + 0.5f * maxSize, cy + 0.5f * maxSize, cz + 0.5f * maxSize};
+    sdfhip_exact_info& I = E->info;
+    memcpy(I.box_min, bmin, 12); memcpy(I.box_max, bmax, 12);
+    const uint32_t G = 1u << startDepth, G3 = G * G * G;
+    I.start_grid_size = (int32_t)G; I.start_depth = startDepth; I.max_depth = maxDepth;
+    I.bit_encoding_start_depth = maxDepth - 2; I.min_triangles_in_leafs = minTri; I.num_triangles = mesh->numTriangles;
+    I.bits_per_index = (uint32_t)(int32_t)std::ceil(std::log2((float)mesh->numTriangles));
+    E->cellSize = maxSize / (float)G;
+    const uint32_t bitEnc = maxDepth - 2, bits = I.bits_per_index;
+    const uint32_t sod = startDepth < 1u ? startDepth : 1u;
+    const uint32_t T = mesh->numTriangles;
+    ExMesh md{mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    ScanHelper scan; scan.st = st;
+
+    DevBuf<uint32_t> stats;          // [0] maxLeaf, [1] maxEncoded
+    DevBuf<unsigned long long> cullTests;
+    SDF_TRY(stats.reserve(2)); SDF_TRY(cullTests.reserve(1));
+    SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 8, st)); SDF_HIP_CHECK(hipMemsetAsync(cullTests.p, 0, 8, st));
+
+    // the root list: every triangle with a usable normal, ascending
+    DevBuf<uint32_t> allList, valid, vscan;
+    uint32_t allLen = 0;
+    SDF_TRY(valid.reserve(T)); SDF_TRY(vscan.reserve(T)); SDF_TRY(allList.reserve(T));
+    k_valid_triangles<<<gridFor(T, 256), 256, 0, st>>>(md.td, T, valid.p);
+    SDF_TRY(scan.exclusive(valid.p, vscan.p, T));
+    k_compact_valid<<<gridFor(T, 256), 256, 0, st>>>(valid.p, vscan.p, T, allList.p);
+    SDF_TRY(lastPlus(st, vscan.p, valid.p, T, allLen));
+    SDF_REQUIRE(allLen > 0, "mesh has no usable triangle");
+
+    std::vector<std::unique_ptr<ExLevel>>& LV = E->levels;
+    LV.resize(maxDepth - sod + 1);
+    {   // root level
+        std::unique_ptr<ExLevel> L(new ExLevel());
+        L->depth = sod; L->n = 1u << (3 * sod);
+        const float newSize = (float)(0.5f * (bmax[0] - bmin[0]) * std::pow(0.5f, sod));
+        L->half = newSize;
+        SDF_TRY(L->center.reserve(3ull * L->n)); SDF_TRY(L->coord.reserve(L->n)); SDF_TRY(L->cornerTri.reserve(8ull * L->n));
+        SDF_TRY(L->pOff.reserve(L->n)); SDF_TRY(L->pLen.reserve(L->n));
+        std::vector<float> hc(3 * L->n); std::vector<uint32_t> hco(L->n), hz(L->n, 0u), hl(L->n, allLen);
+        const float scx = bmin[0] + newSize, scy = bmin[1] + newSize, scz = bmin[2] + newSize;
+        const uint32_t vpa = 1u << sod;
+        for (uint32_t k = 0; k < vpa; k++) for (uint32_t j = 0; j < vpa; j++) for (uint32_t i = 0; i < vpa; i++) {
+            const uint32_t r = i + vpa * j + vpa * vpa * k;
+            hc[3 * r] = scx + ((float)i * 2.0f) * newSize; hc[3 * r + 1] = scy + ((float)j * 2.0f) * newSize; hc[3 * r + 2] = scz + ((float)k * 2.0f) * newSize;
+            hco[r] = i | (j << 10) | (k << 20);
+        }
+        SDF_HIP_CHECK(hipMemcpyAsync(L->center.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->coord.p, hco.data(), hco.size() * 4, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->pOff.p, hz.data(), hz.size() * 4, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->pLen.p, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, st));
+        // 8 corners of every root: brute force over ALL usable triangles
+        k_brute_nearest<256><<<8 * L->n, 256, 0, st>>>(md, L->center.p, L->half, L->n, 8, allList.p, L->pOff.p, L->pLen.p, nullptr, L->cornerTri.p);
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        LV[0] = std::move(L);
+    }
+
+    const uint32_t* prevList = allList.p;
+    for (uint32_t d = sod; d <= maxDepth; d++) {
+        ExLevel* L = LV[d - sod].get();
+        if (!L || L->n == 0) break;
+        if (d == startDepth && d > sod) {
+            std::unique_ptr<ExLevel> R(new ExLevel());
+            R->depth = d; R->n = G3; R->half = L->half;
+            SDF_REQUIRE(L->n == G3, "internal: start level is not a full grid");
+            SDF_TRY(R->center.reserve(3ull * G3)); SDF_TRY(R->coord.reserve(G3)); SDF_TRY(R->cornerTri.reserve(8ull * G3));
+            SDF_TRY(R->pOff.reserve(G3)); SDF_TRY(R->pLen.reserve(G3));
+            k_ex_to_cell_order<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->cornerTri.p, L->pOff.p, L->pLen.p, L->n, G,
+                                                                           R->center.p, R->coord.p, R->cornerTri.p, R->pOff.p, R->pLen.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            LV[d - sod] = std::move(R);
+            L = LV[d - sod].get();
+        }
+        const uint32_t n = L->n;
+        // ---- cull the parent lists into this level's lists
+        DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp;
+        SDF_TRY(region.reserve(64ull * n)); SDF_TRY(minDist.reserve(8ull * n)); SDF_TRY(nChunks.reserve(n)); SDF_TRY(chunkBase.reserve(n));
+        k_node_regions<<<gridFor(64ull * n, 256), 256, 0, st>>>(md, L->center.p, L->half, n, L->cornerTri.p, region.p, minDist.p);
+        k_chunk_counts<<<gridFor(n, 256), 256, 0, st>>>(n, L->pLen.p, nChunks.p);
+        SDF_TRY(scan.exclusive(nChunks.p, chunkBase.p, n));
+        uint32_t numChunks = 0;
+        SDF_TRY(lastPlus(st, chunkBase.p, nChunks.p, n, numChunks));
+        SDF_TRY(chunkNode.reserve(numChunks)); SDF_TRY(chunkCount.reserve(numChunks)); SDF_TRY(chunkScan.reserve(numChunks)); SDF_TRY(tmp.reserve((size_t)numChunks * CHUNK));
+        SDF_TRY(L->listOff.reserve(n)); SDF_TRY(L->listLen.reserve(n));
+        uint32_t total = 0;
+        if (numChunks) {
+            k_chunk_fill<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkNode.p);
+            CullArgs ca{md, L->center.p, L->half, L->cornerTri.p, region.p, minDist.p, prevList, L->pOff.p, L->pLen.p, chunkNode.p, chunkBase.p, numChunks,
+                        tmp.p, chunkCount.p, cullTests.p};
+            k_cull<<<gridFor(numChunks, 4), 256, 0, st>>>(ca);
+            SDF_TRY(scan.exclusive(chunkCount.p, chunkScan.p, numChunks));
+            SDF_TRY(lastPlus(st, chunkScan.p, chunkCount.p, numChunks, total));
+            SDF_TRY(L->list.reserve(total));
+            k_compact<<<gridFor(numChunks, 4), 256, 0, st>>>(tmp.p, chunkCount.p, chunkScan.p, numChunks, L->list.p);
+        } else SDF_TRY(L->list.reserve(1));
+        k_node_list_ranges<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkScan.p, chunkCount.p, numChunks, L->listOff.p, L->listLen.p);
+        L->listTotal = total;
+        // ---- leaf / inner
+        SDF_TRY(L->flag.reserve(n)); SDF_TRY(L->inner.reserve(n)); SDF_TRY(L->childBase.reserve(n));
+        k_ex_decide<<<gridFor(n, 256), 256, 0, st>>>(n, d, startDepth, maxDepth, minTri, L->listLen.p, L->flag.p, L->inner.p, stats.p);
+        if (d < maxDepth) {
+            SDF_TRY(scan.exclusive(L->inner.p, L->childBase.p, n));
+            SDF_TRY(lastPlus(st, L->childBase.p, L->inner.p, n, L->numInner));
+            k_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childBase.p);
+        } else L->numInner = 0;
+        SDF_HIP_CHECK(hipGetLastError());
+        if (L->numInner > 0) {
+            SDF_TRY(L->midTri.reserve(19ull * n));
+            k_brute_nearest<64><<<19 * n, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
+            std::unique_ptr<ExLevel> N(new ExLevel());
+            N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
+            SDF_TRY(N->center.reserve(3ull * N->n)); SDF_TRY(N->coord.reserve(N->n)); SDF_TRY(N->cornerTri.reserve(8ull * N->n));
+            SDF_TRY(N->pOff.reserve(N->n)); SDF_TRY(N->pLen.reserve(N->n));
+            ExChildArgs xa{L->center.p, L->coord.p, L->cornerTri.p, L->midTri.p, L->inner.p, L->childBase.p, L->listOff.p, L->listLen.p, n, L->half,
+                           N->center.p, N->coord.p, N->cornerTri.p, N->pOff.p, N->pLen.p};
+            k_ex_children<<<gridFor(64ull * n, 256), 256, 0, st>>>(xa);
+            SDF_HIP_CHECK(hipGetLastError());
+            LV[d + 1 - sod] = std::move(N);
+        }
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        L->midTri.release(); L->center.release(); L->cornerTri.release();
+        prevList = L->list.p;
+    }
+
+    // ---- merge steps, deepest first: depth maxDepth-1 then maxDepth-2
+    for (int d = (int)maxDepth - 1; d >= (int)bitEnc; d--) {
+        ExLevel* L = LV[d - sod].get();
+        ExLevel* C = ((uint32_t)d + 1 <= maxDepth) ? LV[d + 1 - sod].get() : nullptr;
+        if (!L || L->n == 0) continue;
+        SDF_TRY(L->ulist.reserve(L->listTotal ? L->listTotal : 1)); SDF_TRY(L->uLen.reserve(L->n)); SDF_TRY(L->maskBytes.reserve(L->n)); SDF_TRY(L->maskOff.reserve(L->n));
+        SDF_HIP_CHECK(hipMemsetAsync(L->uLen.p, 0, 4ull * L->n, st));
+        if (L->numInner == 0 || !C) { SDF_HIP_CHECK(hipMemsetAsync(L->maskBytes.p, 0, 4ull * L->n, st)); SDF_HIP_CHECK(hipMemsetAsync(L->maskOff.p, 0, 4ull * L->n, st)); L->maskTotal = 0; SDF_TRY(L->masks.reserve(1)); continue; }
+        MergeArgs ma{L->n, L->inner.p, L->childBase.p, L->list.p, L->listOff.p, L->listLen.p, L->ulist.p, L->uLen.p,
+                     C->flag.p, C->list.p, C->listOff.p, C->listLen.p, C->ulist.p, C->uLen.p, nullptr, nullptr, stats.p + 1, (uint32_t)d == bitEnc ? 1 : 0};
+        k_merge_union<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(ma);
+        k_mask_sizes<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->inner.p, L->uLen.p, L->maskBytes.p);
+        SDF_TRY(scan.exclusive(L->maskBytes.p, L->maskOff.p, L->n));
+        SDF_TRY(lastPlus(st, L->maskOff.p, L->maskBytes.p, L->n, L->maskTotal));
+        SDF_TRY(L->masks.reserve(L->maskTotal ? L->maskTotal : 1));
+        ma.maskOff = L->maskOff.p; ma.masks = L->masks.p;
+        k_merge_masks<<<gridFor(64ull * 8ull * L->n, 256), 256, 0, st>>>(ma);
+        SDF_HIP_CHECK(hipGetLastError());
+    }
+
+    // ---- sizes bottom-up
+    const uint32_t* cN = nullptr; const uint32_t* cS = nullptr; const uint32_t* cM = nullptr;
+    for (int d = (int)maxDepth; d >= (int)startDepth; d--) {
+        ExLevel* L = LV[d - sod].get();
+        if (!L || L->n == 0) continue;
+        SDF_TRY(L->aNode.reserve(L->n)); SDF_TRY(L->aSet.reserve(L->n)); SDF_TRY(L->aMask.reserve(L->n));
+        SDF_TRY(L->pos.reserve(L->n)); SDF_TRY(L->blk.reserve(L->n)); SDF_TRY(L->setPos.reserve(L->n)); SDF_TRY(L->maskPos.reserve(L->n)); SDF_TRY(L->maskIdx.reserve(L->n));
+        SizeArgs sa{L->n, (uint32_t)d, bitEnc, bits, L->flag.p, L->childBase.p, L->listLen.p, L->uLen.p, cN, cS, cM, L->aNode.p, L->aSet.p, L->aMask.p};
+        k_ex_sizes<<<gridFor(L->n, 256), 256, 0, st>>>(sa);
+        cN = L->aNode.p; cS = L->aSet.p; cM = L->aMask.p;
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    // ---- cell offsets in the reference's single-thread DFS order
+    ExLevel* S = LV[startDepth - sod].get();
+    SDF_REQUIRE(S && S->n == G3, "internal: start level missing");
+    std::vector<uint32_t> hN(G3), hS(G3), hM(G3), oB(G3), oS(G3), oM(G3);
+    SDF_HIP_CHECK(hipMemcpyAsync(hN.data(), S->aNode.p, 4ull * G3, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hS.data(), S->aSet.p, 4ull * G3, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hM.data(), S->aMask.p, 4ull * G3, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    {
+        std::vector<uint32_t> cellOfRank(G3);
+        for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++) cellOfRank[dfsRank(x, y, z, startDepth)] = z * G * G + y * G + x;
+        uint64_t b = G3, s = 0, m = 0;
+        for (uint32_t r = 0; r < G3; r++) { const uint32_t c = cellOfRank[r]; oB[c] = (uint32_t)b; oS[c] = (uint32_t)s; oM[c] = (uint32_t)m; b += hN[c]; s += hS[c]; m += hM[c]; }
+        SDF_REQUIRE(b < (1ull << 31) && s < (1ull << 32) && m < (1ull << 32), "structure too large");
+        I.num_nodes = b; I.num_set_words = s; I.num_mask_bytes = m;
+    }
+    SDF_TRY(E->nodes.reserve(2 * I.num_nodes)); SDF_TRY(E->hasTri.reserve(I.num_nodes)); SDF_TRY(E->sets.reserve(I.num_set_words ? I.num_set_words : 1)); SDF_TRY(E->masks.reserve(I.num_mask_bytes ? I.num_mask_bytes : 1));
+    SDF_HIP_CHECK(hipMemsetAsync(E->nodes.p, 0, 8ull * I.num_nodes, st)); SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 0, I.num_nodes, st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4ull * (I.num_set_words ? I.num_set_words : 1), st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->masks.p, 0, I.num_mask_bytes ? I.num_mask_bytes : 1, st));
+    DevBuf<uint32_t> dB, dS, dM;
+    SDF_TRY(dB.reserve(G3)); SDF_TRY(dS.reserve(G3)); SDF_TRY(dM.reserve(G3));
+    SDF_HIP_CHECK(hipMemcpyAsync(dB.p, oB.data(), 4ull * G3, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dS.p, oS.data(), 4ull * G3, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dM.p, oM.data(), 4ull * G3, hipMemcpyHostToDevice, st));
+    k_ex_init_cells<<<gridFor(G3, 256), 256, 0, st>>>(G3, dB.p, dS.p, dM.p, S->pos.p, S->blk.p, S->setPos.p, S->maskPos.p);
+    // ---- offsets top-down + payloads
+    for (uint32_t d = startDepth; d <= maxDepth; d++) {
+        ExLevel* L = LV[d - sod].get();
+        if (!L || L->n == 0) break;
+        ExLevel* C = (d < maxDepth) ? LV[d + 1 - sod].get() : nullptr;
+        OffArgs oa{L->n, d, bitEnc, L->flag.p, L->childBase.p, L->uLen.p, L->pos.p, L->blk.p, L->setPos.p, L->maskPos.p,
+                   C ? C->aNode.p : nullptr, C ? C->aSet.p : nullptr, C ? C->aMask.p : nullptr,
+                   C ? C->pos.p : nullptr, C ? C->blk.p : nullptr, C ? C->setPos.p : nullptr, C ? C->maskPos.p : nullptr, C ? C->maskIdx.p : nullptr,
+                   E->nodes.p, E->hasTri.p};
+        k_ex_offsets<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(oa);
+        if (d <= bitEnc) {
+            PackArgs pa{L->n, d, bitEnc, bits, L->flag.p, L->list.p, L->ulist.p, L->listOff.p, L->listLen.p, L->uLen.p, L->setPos.p, E->sets.p};
+            k_ex_pack_sets<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(pa);
+        }
+        if (d >= bitEnc && C && L->numInner > 0)
+            k_ex_copy_masks<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(L->n, d, bitEnc, L->inner.p, L->uLen.p, L->maskOff.p, L->masks.p, L->maskPos.p, L->childBase.p, C->aMask.p, E->masks.p);
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    uint32_t hstats[2]; unsigned long long hcull = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(hstats, stats.p, 8, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&hcull, cullTests.p, 8, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    I.max_triangles_in_leafs = hstats[0]; I.max_triangles_encoded_in_leafs = hstats[1]; I.cull_tests = hcull;
+    E->levels.clear();
+    E->built = true;
+    I.seconds_total = nowSeconds() - tStart;
+    *out = E.release();
+    return SDFHIP_OK;
+}
+
+int sdfhip_exact_destroy(sdfhip_exact* tree) { delete tree; return SDFHIP_OK; }
+
+int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out) {
+    SDF_REQUIRE(tree && out, "NULL argument");
+    *out = tree->info;
+    return SDFHIP_OK;
+}
+
+int sdfhip_exact_download(sdfhip_exact* T, uint32_t* nodes, uint8_t* has, uint32_t* sets, uint8_t* masks) {
+    SDF_REQUIRE(T && nodes && has && sets && masks, "NULL argument");
+    hipStream_t st = T->ctx->stream;
+    SDF_HIP_CHECK(hipMemcpyAsync(nodes, T->nodes.p, 8ull * T->info.num_nodes, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(has, T->hasTri.p, T->info.num_nodes, hipMemcpyDeviceToHost, st));
+    if (T->info.num_set_words) SDF_HIP_CHECK(hipMemcpyAsync(sets, T->sets.p, 4ull * T->info.num_set_words, hipMemcpyDeviceToHost, st));
+    if (T->info.num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(masks, T->masks.p, T->info.num_mask_bytes, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// ExactOctreeSdf device object shared by the build and query translation units.  PRODUCT code.
+#pragma once
+#include "sdfhip_internal.h"
+#include "dev_math.h"
+#include "dev_tricubic.h"   // stencil tables (child corner sources, mid-point positions)
+#include <memory>
+
+namespace sdfhip {
+
+// One breadth-first level of the Exact construction.
+struct ExLevel {
+    uint32_t depth = 0, n = 0; float half = 0.f;
+    DevBuf<float> center; DevBuf<uint32_t> coord;
+    DevBuf<uint32_t> cornerTri;             // 8 n : nearest triangle of every corner
+    DevBuf<uint32_t> pOff, pLen;            // n : the PARENT's list (input of the culling), offsets into the previous level's list
+    DevBuf<uint32_t> list, listOff, listLen; uint32_t listTotal = 0;    // this level's culled lists, packed
+    DevBuf<uint32_t> flag, inner, childBase; uint32_t numInner = 0;
+    DevBuf<uint32_t> midTri;                // 19 n
+    DevBuf<uint32_t> ulist, uLen;           // merge step: sorted union of the children's lists (same offsets as `list`)
+    DevBuf<uint32_t> maskBytes, maskOff; uint32_t maskTotal = 0; DevBuf<uint8_t> masks;   // 8 masks per merged node
+    DevBuf<uint32_t> aNode, aSet, aMask;    // sizes of the subtree in the three output arrays
+    DevBuf<uint32_t> pos, blk, setPos, maskPos, maskIdx;
+};
+
+}  // namespace sdfhip
+
+struct sdfhip_exact {
+    sdfhip_ctx* ctx = nullptr;
+    sdfhip_mesh* mesh = nullptr;           // TriangleData lives in the mesh; it must outlive the tree
+    sdfhip_exact_info info{};
+    float cellSize = 0.f;
+    sdfhip::DevBuf<uint32_t> nodes;        // 2 words per node
+    sdfhip::DevBuf<uint8_t> hasTri;
+    sdfhip::DevBuf<uint32_t> sets;
+    sdfhip::DevBuf<uint8_t> masks;
+    std::vector<std::unique_ptr<sdfhip::ExLevel>> levels;
+    bool built = false;
+};
