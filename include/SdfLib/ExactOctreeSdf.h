@@ -1,0 +1,62 @@
+// sdflib::ExactOctreeSdf — API-compatible with the reference class (include/SdfLib/ExactOctreeSdf.h:16-134) for the hot
+// path: constructor, getDistance (scalar and batched), getters.  Everything runs on the MI355X through libsdfhip; unlike
+// the reference (mutable scratch, ExactOctreeSdf.h:178) queries are re-entrant.
+#ifndef SDFLIB_EXACT_OCTREE_SDF_H
+#define SDFLIB_EXACT_OCTREE_SDF_H
+#include <vector>
+#include "SdfFunction.h"
+
+namespace sdflib {
+class ExactOctreeSdf : public SdfFunction {
+public:
+    struct OctreeNode {
+        static constexpr uint32_t IS_LEAF_MASK = 1u << 31;
+        static constexpr uint32_t CHILDREN_INDEX_MASK = ~IS_LEAF_MASK;
+        uint32_t childrenIndex;
+        uint32_t trianglesArrayIndex;
+        bool isLeaf() const { return childrenIndex & IS_LEAF_MASK; }
+        uint32_t getChildrenIndex() const { return childrenIndex & CHILDREN_INDEX_MASK; }
+    };
+    ExactOctreeSdf() {}
+    ExactOctreeSdf(const Mesh& mesh, BoundingBox box, uint32_t maxDepth, uint32_t startDepth = 1, uint32_t minTrianglesPerNode = 128, uint32_t numThreads = 1) {
+        (void)numThreads;   // the GPU build always produces the single-thread (correct) array
+        sdfhip_ctx* ctx = detail::defaultContext();
+        detail::check(sdfhip_mesh_create(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                         mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3), &mMesh));
+        const float bmin[3] = {box.min.x, box.min.y, box.min.z}, bmax[3] = {box.max.x, box.max.y, box.max.z};
+        detail::check(sdfhip_exact_build(ctx, mMesh, bmin, bmax, maxDepth, startDepth, minTrianglesPerNode, &mTree));
+        detail::check(sdfhip_exact_get_info(mTree, &mInfo));
+        mBox = BoundingBox(glm::vec3(mInfo.box_min[0], mInfo.box_min[1], mInfo.box_min[2]), glm::vec3(mInfo.box_max[0], mInfo.box_max[1], mInfo.box_max[2]));
+    }
+    ~ExactOctreeSdf() override { if (mTree) sdfhip_exact_destroy(mTree); if (mMesh) sdfhip_mesh_destroy(mMesh); }
+    ExactOctreeSdf(const ExactOctreeSdf&) = delete;
+    ExactOctreeSdf& operator=(const ExactOctreeSdf&) = delete;
+
+    glm::ivec3 getStartGridSize() const { return glm::ivec3(mInfo.start_grid_size, mInfo.start_grid_size, mInfo.start_grid_size); }
+    const BoundingBox& getGridBoundingBox() const { return mBox; }
+    BoundingBox getSampleArea() const override { return mBox; }
+    uint32_t getMaxTrianglesInLeafs() const { return mInfo.max_triangles_in_leafs; }
+    uint32_t getMinTrianglesInLeafs() const { return mInfo.min_triangles_in_leafs; }
+    uint32_t getOctreeMaxDepth() const { return mInfo.max_depth; }
+    SdfFormat getFormat() const override { return SdfFormat::EXACT_OCTREE; }
+    // host copy of the node array, fetched on demand
+    std::vector<OctreeNode> getOctreeData() const {
+        std::vector<OctreeNode> nodes(mInfo.num_nodes); std::vector<uint8_t> has(mInfo.num_nodes), masks(mInfo.num_mask_bytes + 1); std::vector<uint32_t> sets(mInfo.num_set_words + 1);
+        detail::check(sdfhip_exact_download(mTree, reinterpret_cast<uint32_t*>(nodes.data()), has.data(), sets.data(), masks.data()));
+        return nodes;
+    }
+    float getDistance(glm::vec3 sample) const override { float d; getDistances(&sample, 1, &d); return d; }
+    float getDistance(glm::vec3 sample, glm::vec3& outGradient) const override { float d; getDistances(&sample, 1, &d, &outGradient); return d; }
+    void getDistances(const glm::vec3* samples, size_t n, float* outDistances, glm::vec3* outGradients = nullptr) const override {
+        detail::check(sdfhip_exact_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), nullptr, SDFHIP_HOST));
+    }
+    sdfhip_exact* handle() const { return mTree; }
+
+private:
+    sdfhip_mesh* mMesh = nullptr;
+    sdfhip_exact* mTree = nullptr;
+    sdfhip_exact_info mInfo{};
+    BoundingBox mBox;
+};
+}  // namespace sdflib
+#endif

@@ -1,0 +1,156 @@
+// sdflib::OctreeSdf — API-compatible with the reference class (include/SdfLib/OctreeSdf.h:20-300) for the hot path:
+// constructors, getDistance (scalar and batched), getters, OctreeNode layout.  Construction and batched queries run on
+// the MI355X through the libsdfhip C ABI; the scalar getDistance(vec3) reads the host copy of the node array that
+// getOctreeData() exposes (same array the reference's viewers upload), evaluated in the reference's literal order.
+#ifndef SDFLIB_OCTREE_SDF_H
+#define SDFLIB_OCTREE_SDF_H
+#include <array>
+#include <optional>
+#include <string>
+#include <vector>
+#include "SdfFunction.h"
+
+namespace sdflib {
+class OctreeSdf : public SdfFunction {
+public:
+    enum InitAlgorithm { UNIFORM, NO_CONTINUITY, CONTINUITY };
+    struct OctreeNode {
+        static constexpr uint32_t IS_LEAF_MASK = 1u << 31;
+        static constexpr uint32_t MARK_MASK = 1u << 30;
+        static constexpr uint32_t CHILDREN_INDEX_MASK = ~(IS_LEAF_MASK | MARK_MASK);
+        union { uint32_t childrenIndex; float value; };
+        bool isLeaf() const { return childrenIndex & IS_LEAF_MASK; }
+        uint32_t getChildrenIndex() const { return childrenIndex & CHILDREN_INDEX_MASK; }
+    };
+    enum TerminationRule { NONE, TRAPEZOIDAL_RULE, SIMPSONS_RULE, BY_DISTANCE_RULE };
+    class TerminationRuleParams {
+    public:
+        std::array<float, 2> params;
+        static TerminationRuleParams setNoneRuleParams() { return TerminationRuleParams(); }
+        static TerminationRuleParams setTrapezoidalRuleParams(float e) { return TerminationRuleParams{{e, 0.f}}; }
+        static TerminationRuleParams setSimpsonRuleParams(float e) { return TerminationRuleParams{{e, 0.f}}; }
+        static TerminationRuleParams setByDistanceRuleParams(float e, float decay) { return TerminationRuleParams{{e, decay}}; }
+        float& operator[](int p) { return params[p]; }
+    };
+    static std::optional<TerminationRule> stringToTerminationRule(std::string text) {
+        if (text == "none" || text == "NONE") return TerminationRule::NONE;
+        if (text == "trapezoidal_rule" || text == "TRAPEZOIDAL_RULE") return TerminationRule::TRAPEZOIDAL_RULE;
+        if (text == "simpsons_rule" || text == "SIMPSONS_RULE") return TerminationRule::SIMPSONS_RULE;
+        if (text == "by_distance_rule" || text == "BY_DISTANCE_RULE") return TerminationRule::BY_DISTANCE_RULE;
+        return std::optional<TerminationRule>();
+    }
+
+    OctreeSdf() {}
+    OctreeSdf(const Mesh& mesh, BoundingBox box, uint32_t depth, uint32_t startDepth, float maxError = 1e-3,
+              InitAlgorithm initAlgorithm = InitAlgorithm::NO_CONTINUITY, uint32_t numThreads = 1) {
+        build(mesh, box, depth, startDepth, TerminationRule::TRAPEZOIDAL_RULE, TerminationRuleParams::setTrapezoidalRuleParams(maxError), initAlgorithm, numThreads);
+    }
+    OctreeSdf(const Mesh& mesh, BoundingBox box, uint32_t depth, uint32_t startDepth, TerminationRule rule, TerminationRuleParams params,
+              InitAlgorithm initAlgorithm, uint32_t numThreads = 1) {
+        build(mesh, box, depth, startDepth, rule, params, initAlgorithm, numThreads);
+    }
+    ~OctreeSdf() override { if (mTree) sdfhip_octree_destroy(mTree); }
+    OctreeSdf(const OctreeSdf&) = delete;
+    OctreeSdf& operator=(const OctreeSdf&) = delete;
+    OctreeSdf(OctreeSdf&& o) noexcept { *this = std::move(o); }
+    OctreeSdf& operator=(OctreeSdf&& o) noexcept {
+        if (this != &o) {
+            if (mTree) sdfhip_octree_destroy(mTree);
+            mTree = o.mTree; o.mTree = nullptr; mBox = o.mBox; mValueRange = o.mValueRange; mMinBorderValue = o.mMinBorderValue;
+            mStartGridSize = o.mStartGridSize; mStartGridXY = o.mStartGridXY; mStartGridCellSize = o.mStartGridCellSize; mMaxDepth = o.mMaxDepth;
+            mOctreeData = std::move(o.mOctreeData);
+        }
+        return *this;
+    }
+
+    float getOctreeValueRange() const { return mValueRange; }
+    float getOctreeMinBorderValue() const { return mMinBorderValue; }
+    glm::ivec3 getStartGridSize() const { return glm::ivec3(mStartGridSize, mStartGridSize, mStartGridSize); }
+    const BoundingBox& getGridBoundingBox() const { return mBox; }
+    BoundingBox getSampleArea() const override { return mBox; }
+    uint32_t getOctreeMaxDepth() const { return mMaxDepth; }
+    const std::vector<OctreeNode>& getOctreeData() const { return mOctreeData; }
+    std::vector<OctreeNode>& getOctreeData() { return mOctreeData; }
+    SdfFunction::SdfFormat getFormat() const override { return SdfFunction::SdfFormat::OCTREE; }
+
+    // scalar queries: host walk of the node array (src/sdf/OctreeSdf.cpp:93-152 semantics)
+    float getDistance(glm::vec3 sample) const override { glm::vec3 g; return eval(sample, nullptr, g); }
+    float getDistance(glm::vec3 sample, glm::vec3& outGradient) const override { return eval(sample, &outGradient, outGradient); }
+    // batched queries on the GPU
+    void getDistances(const glm::vec3* samples, size_t n, float* outDistances, glm::vec3* outGradients = nullptr) const override {
+        detail::check(sdfhip_octree_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), SDFHIP_HOST, SDFHIP_EVAL_EXACT));
+    }
+    sdfhip_octree* handle() const { return mTree; }
+
+private:
+    void build(const Mesh& mesh, BoundingBox box, uint32_t depth, uint32_t startDepth, TerminationRule rule, TerminationRuleParams params,
+               InitAlgorithm alg, uint32_t numThreads) {
+        sdfhip_ctx* ctx = detail::defaultContext();
+        sdfhip_mesh* m = nullptr;
+        detail::check(sdfhip_mesh_create(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                         mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3), &m));
+        sdfhip_octree_params p{};
+        p.box_min[0] = box.min.x; p.box_min[1] = box.min.y; p.box_min[2] = box.min.z;
+        p.box_max[0] = box.max.x; p.box_max[1] = box.max.y; p.box_max[2] = box.max.z;
+        p.depth = depth; p.start_depth = startDepth; p.rule = (int32_t)rule; p.rule_params[0] = params[0]; p.rule_params[1] = params[1];
+        p.algorithm = (int32_t)alg; p.layout = numThreads < 2 ? SDFHIP_LAYOUT_GLOBAL_DFS : SDFHIP_LAYOUT_SUBTREES; p.fit_mode = SDFHIP_FIT_EXACT;
+        int rc = sdfhip_octree_build(ctx, m, &p, &mTree);
+        sdfhip_mesh_destroy(m);
+        detail::check(rc);
+        sdfhip_octree_info info;
+        detail::check(sdfhip_octree_get_info(mTree, &info));
+        mBox = BoundingBox(glm::vec3(info.box_min[0], info.box_min[1], info.box_min[2]), glm::vec3(info.box_max[0], info.box_max[1], info.box_max[2]));
+        mValueRange = info.value_range; mMinBorderValue = info.min_border_value; mStartGridSize = info.start_grid_size;
+        mStartGridXY = mStartGridSize * mStartGridSize; mMaxDepth = info.max_depth;
+        mStartGridCellSize = (mBox.max.x - mBox.min.x) / static_cast<float>(mStartGridSize);
+        mOctreeData.resize(info.num_words);
+        detail::check(sdfhip_octree_download(mTree, reinterpret_cast<uint32_t*>(mOctreeData.data()), SDFHIP_HOST));
+    }
+    static float fractf(float x) { return x - std::floor(x); }
+    float eval(glm::vec3 p, glm::vec3* grad, glm::vec3& g) const {
+        float f[3] = {(p.x - mBox.min.x) / mStartGridCellSize, (p.y - mBox.min.y) / mStartGridCellSize, (p.z - mBox.min.z) / mStartGridCellSize};
+        int ip[3];
+        for (int a = 0; a < 3; a++) { const float fl = std::floor(f[a]); ip[a] = (int)fl; f[a] = f[a] - fl; }
+        if (ip[0] < 0 || ip[0] >= mStartGridSize || ip[1] < 0 || ip[1] >= mStartGridSize || ip[2] < 0 || ip[2] >= mStartGridSize) {
+            // outside the start grid: same value as the batched kernel (box distance + min border value)
+            float d; glm::vec3 gg;
+            getDistances(&p, 1, &d, grad ? &gg : nullptr);
+            if (grad) g = gg;
+            return d;
+        }
+        const OctreeNode* node = &mOctreeData[ip[2] * mStartGridXY + ip[1] * mStartGridSize + ip[0]];
+        while (!node->isLeaf()) {
+            const uint32_t c = ((f[2] >= 0.5f) ? 4u : 0u) + ((f[1] >= 0.5f) ? 2u : 0u) + ((f[0] >= 0.5f) ? 1u : 0u);
+            node = &mOctreeData[node->getChildrenIndex() + c];
+            for (int a = 0; a < 3; a++) f[a] = fractf(2.0f * f[a]);
+        }
+        const float* c = &mOctreeData[node->getChildrenIndex()].value;
+        auto term = [&](float t, int i, int j, int k) { for (int a = 0; a < i; a++) t = t * f[0]; for (int a = 0; a < j; a++) t = t * f[1]; for (int a = 0; a < k; a++) t = t * f[2]; return t; };
+        if (grad) {
+            float gr[3] = {0, 0, 0}; bool first[3] = {true, true, true};
+            for (int n = 0; n < 64; n++) {
+                const int e[3] = {n & 3, (n >> 2) & 3, n >> 4};
+                for (int a = 0; a < 3; a++) {
+                    if (e[a] == 0) continue;
+                    const float t = term((float)e[a] * c[n], e[0] - (a == 0), e[1] - (a == 1), e[2] - (a == 2));
+                    if (first[a]) { gr[a] = t; first[a] = false; } else gr[a] = gr[a] + t;
+                }
+            }
+            const float inv = 1.0f / std::sqrt(gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2]);
+            g = glm::vec3(gr[0] * inv, gr[1] * inv, gr[2] * inv);
+        }
+        float acc = 0.0f;
+        for (int n = 0; n < 64; n++) acc = acc + term(c[n], n & 3, (n >> 2) & 3, n >> 4);
+        return acc;
+    }
+
+    sdfhip_octree* mTree = nullptr;
+    BoundingBox mBox;
+    float mValueRange = 0.f, mMinBorderValue = 0.f;
+    int mStartGridSize = 0, mStartGridXY = 0;
+    float mStartGridCellSize = 0.f;
+    uint32_t mMaxDepth = 0;
+    std::vector<OctreeNode> mOctreeData;
+};
+}  // namespace sdflib
+#endif

@@ -1,0 +1,46 @@
+// Handle-style C interface of the reference's Unity plugin (src/tools/SdfLibUnity/SdfExportFunc.h:16-58), implemented on
+// top of the C++ classes above.  Differences from the reference, on purpose: createOctreeSdf uses NO_CONTINUITY (the
+// CONTINUITY builder is not provided yet) and deleteSdf frees every format (the reference leaks OCTREE objects,
+// SdfExportFunc.cpp:170-182).  Include in exactly one translation unit of the plugin.
+#ifndef SDFLIB_EXPORT_FUNC_H
+#define SDFLIB_EXPORT_FUNC_H
+#include "OctreeSdf.h"
+#include "ExactOctreeSdf.h"
+#ifndef EXPORT
+#define EXPORT extern "C" __attribute__((visibility("default")))
+#endif
+
+EXPORT sdflib::SdfFunction* createExactOctreeSdf(glm::vec3* vertices, uint32_t numVertices, uint32_t* indices, uint32_t numIndices,
+                                                 float bbMinX, float bbMinY, float bbMinZ, float bbMaxX, float bbMaxY, float bbMaxZ,
+                                                 uint32_t startOctreeDepth, uint32_t maxOctreeDepth, uint32_t minTrianglesPerNode, uint32_t numThreads) {
+    sdflib::Mesh mesh(vertices, numVertices, indices, numIndices);
+    return new sdflib::ExactOctreeSdf(mesh, sdflib::BoundingBox(glm::vec3(bbMinX, bbMinY, bbMinZ), glm::vec3(bbMaxX, bbMaxY, bbMaxZ)), maxOctreeDepth,
+                                      startOctreeDepth, minTrianglesPerNode, numThreads);
+}
+EXPORT sdflib::SdfFunction* createOctreeSdf(glm::vec3* vertices, uint32_t numVertices, uint32_t* indices, uint32_t numIndices,
+                                            float bbMinX, float bbMinY, float bbMinZ, float bbMaxX, float bbMaxY, float bbMaxZ,
+                                            uint32_t startOctreeDepth, uint32_t maxOctreeDepth, float maxError, uint32_t numThreads) {
+    sdflib::Mesh mesh(vertices, numVertices, indices, numIndices);
+    return new sdflib::OctreeSdf(mesh, sdflib::BoundingBox(glm::vec3(bbMinX, bbMinY, bbMinZ), glm::vec3(bbMaxX, bbMaxY, bbMaxZ)), maxOctreeDepth,
+                                 startOctreeDepth, maxError, sdflib::OctreeSdf::InitAlgorithm::NO_CONTINUITY, numThreads);
+}
+EXPORT float getDistance(sdflib::SdfFunction* sdf, float x, float y, float z) { return sdf->getDistance(glm::vec3(x, y, z)); }
+EXPORT float getDistanceAndGradient(sdflib::SdfFunction* sdf, float x, float y, float z, glm::vec3* outGradient) { return sdf->getDistance(glm::vec3(x, y, z), *outGradient); }
+EXPORT void getDistances(sdflib::SdfFunction* sdf, const glm::vec3* points, uint64_t n, float* outDistances, glm::vec3* outGradients) { sdf->getDistances(points, n, outDistances, outGradients); }
+EXPORT glm::vec3 getBBMinPoint(sdflib::SdfFunction* sdf) { return sdf->getSampleArea().min; }
+EXPORT glm::vec3 getBBSize(sdflib::SdfFunction* sdf) { return sdf->getSampleArea().getSize(); }
+EXPORT glm::ivec3 getStartGridSize(sdflib::SdfFunction* sdf) {
+    if (sdf->getFormat() == sdflib::SdfFunction::OCTREE) return static_cast<sdflib::OctreeSdf*>(sdf)->getStartGridSize();
+    if (sdf->getFormat() == sdflib::SdfFunction::EXACT_OCTREE) return static_cast<sdflib::ExactOctreeSdf*>(sdf)->getStartGridSize();
+    return glm::ivec3(0, 0, 0);
+}
+EXPORT uint32_t getOctreeDataSize(sdflib::SdfFunction* sdf) {
+    return sdf->getFormat() == sdflib::SdfFunction::OCTREE ? (uint32_t)static_cast<sdflib::OctreeSdf*>(sdf)->getOctreeData().size() : 0u;
+}
+EXPORT void getOctreeData(sdflib::SdfFunction* sdf, uint32_t* dst) {
+    if (sdf->getFormat() != sdflib::SdfFunction::OCTREE) return;
+    const auto& d = static_cast<sdflib::OctreeSdf*>(sdf)->getOctreeData();
+    std::memcpy(dst, d.data(), d.size() * sizeof(uint32_t));
+}
+EXPORT void deleteSdf(sdflib::SdfFunction* sdf) { delete sdf; }
+#endif
