@@ -115,6 +115,7 @@ typedef struct sdfhip_octree_info {
     uint64_t body_offset;           /* absolute word offset of this shard's bodies in the full array */
     double seconds_samples, seconds_decide, seconds_total;
     uint64_t leaves_per_depth[16];  /* leaves at each depth (this shard) */
+    uint64_t fit_rechecks;          /* FIT_MFMA: nodes whose decision was re-evaluated with the reference-ordered fit */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {

@@ -2,6 +2,7 @@
 #include "sdfhip_internal.h"
 #include "dev_tricubic.h"
 #include "dev_gjk.h"
+#include "dev_fit_mfma.h"
 
 namespace sdfhip {
 
@@ -33,7 +34,7 @@ extern "C" {
 
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode) {
     SDF_REQUIRE(ctx && values_8x8 && node_sizes && out64, "NULL argument");
-    if (fit_mode != SDFHIP_FIT_EXACT) { setError("fit_mode %d not provided", fit_mode); return SDFHIP_E_UNSUPPORTED; }
+    SDF_REQUIRE(fit_mode == SDFHIP_FIT_EXACT || fit_mode == SDFHIP_FIT_MFMA, "unknown fit_mode");
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -41,7 +42,8 @@ int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* n
     SDF_TRY(din.reserve(64 * n)); SDF_TRY(dns.reserve(n)); SDF_TRY(dout.reserve(64 * n));
     SDF_HIP_CHECK(hipMemcpyAsync(din.p, values_8x8, 256 * n, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(dns.p, node_sizes, 4 * n, hipMemcpyHostToDevice, st));
-    k_fit_exact<<<gridFor(n, 128), 128, 0, st>>>(din.p, dns.p, n, dout.p);
+    if (fit_mode == SDFHIP_FIT_EXACT) k_fit_exact<<<gridFor(n, 128), 128, 0, st>>>(din.p, dns.p, n, dout.p);
+    else k_fit_mfma<8><<<gridFor(n, 128), 256, 0, st>>>(din.p, dns.p, 0.f, (uint32_t)n, dout.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(out64, dout.p, 256 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));

@@ -26,6 +26,12 @@ constexpr int fitCoef(int n, int col) {
     const int v = col >> 3, q = col & 7;
     return kH[i][2 * (v & 1) + kSlotD[q][0]] * kH[j][2 * ((v >> 1) & 1) + kSlotD[q][1]] * kH[k][2 * ((v >> 2) & 1) + kSlotD[q][2]];
 }
+SDF_HD int fitCoefRuntime(int n, int col) {      // same entry, evaluated at run time (fills the MFMA B operand)
+    const int h[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {-3, -2, 3, -1}, {2, 1, -2, 1}};
+    const int sd[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+    const int i = n & 3, j = (n >> 2) & 3, k = n >> 4, v = col >> 3, q = col & 7;
+    return h[i][2 * (v & 1) + sd[q][0]] * h[j][2 * ((v >> 1) & 1) + sd[q][1]] * h[k][2 * ((v >> 2) & 1) + sd[q][2]];
+}
 constexpr int fitFirstCol(int n) {
     for (int c = 0; c < 64; c++) if (fitCoef(n, c) != 0) return c;
     return 64;

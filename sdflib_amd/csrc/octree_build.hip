@@ -18,6 +18,7 @@
 #include "octree_internal.h"
 #include "dev_bvh.h"
 #include "dev_tricubic.h"
+#include "dev_fit_mfma.h"
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <cstring>
@@ -67,35 +68,67 @@ struct DecideArgs {
     uint32_t* flag; uint32_t* inner; float* coeff;
     uint32_t* valueRangeBits;   // atomicMax over |corner value| bits
     uint32_t* minBorderKey;     // atomicMin over order keys
+    uint32_t* recheckCount;     // FIT_MFMA: decisions re-evaluated with the exact fit
 };
 
 // One lane per node: fit, error rule, leaf/inner decision, leaf payload.
+// MFMA = false: the 64x64 fit is computed here in the reference's summation order (defines the topology).
+// MFMA = true : the coefficients were produced by k_fit_mfma; decisions closer to the threshold than the fit's rounding
+//               uncertainty are re-evaluated with the reference-ordered fit, so the topology is the same as with MFMA = false.
+template <bool MFMA>
 __global__ void __launch_bounds__(128) k_decide(DecideArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
     float s[64], c[64];
     const float4* cr = reinterpret_cast<const float4*>(a.corner) + 8 * (size_t)i;
     float absMax = 0.f;
+    auto loadCorners = [&]() {
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const float4 q = cr[v];
-        s[8 * v] = q.x; s[8 * v + 1] = q.y; s[8 * v + 2] = q.z; s[8 * v + 3] = q.w;
-        s[8 * v + 4] = 0.f; s[8 * v + 5] = 0.f; s[8 * v + 6] = 0.f; s[8 * v + 7] = 0.f;
-        absMax = gmax(absMax, fabsf(q.x));
+        for (int v = 0; v < 8; v++) {
+            const float4 q = cr[v];
+            s[8 * v] = q.x; s[8 * v + 1] = q.y; s[8 * v + 2] = q.z; s[8 * v + 3] = q.w;
+            s[8 * v + 4] = 0.f; s[8 * v + 5] = 0.f; s[8 * v + 6] = 0.f; s[8 * v + 7] = 0.f;
+        }
+    };
+#pragma unroll
+    for (int v = 0; v < 8; v++) absMax = gmax(absMax, fabsf(cr[v].x));
+    if (MFMA) {
+        const float4* src = reinterpret_cast<const float4*>(a.coeff) + 16 * (size_t)i;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const float4 v4 = src[q]; c[4 * q] = v4.x; c[4 * q + 1] = v4.y; c[4 * q + 2] = v4.z; c[4 * q + 3] = v4.w; }
+    } else {
+        loadCorners();
+        tricubicFit(s, 2.0f * a.half, c);
     }
-    tricubicFit(s, 2.0f * a.half, c);
     bool terminal = true;
+    bool rechecked = false;
     if (a.depth < a.maxDepth) {
         const float4* md = reinterpret_cast<const float4*>(a.mid) + 19 * (size_t)i;
-        const float v = ruleValue(a.rule, [&](int n) { return c[n]; }, [&](int m) { return md[m].x; }, a.param1);
+        float v = ruleValue(a.rule, [&](int n) { return c[n]; }, [&](int m) { return md[m].x; }, a.param1);
+        if (MFMA) {
+            float cmax = 0.f;
+#pragma unroll
+            for (int n = 0; n < 64; n++) cmax = gmax(cmax, fabsf(c[n]));
+            const float eps = 1e-5f * cmax;
+            const float tol = 8.0f * sqrtf(gmax(v, a.sqThreshold)) * eps + eps * eps;
+            if (!(fabsf(v - a.sqThreshold) > tol)) {          // close to the threshold (or NaN): decide with the reference-ordered fit
+                loadCorners();
+                tricubicFit(s, 2.0f * a.half, c);
+                v = ruleValue(a.rule, [&](int n) { return c[n]; }, [&](int m) { return md[m].x; }, a.param1);
+                rechecked = true;
+                atomicAdd(a.recheckCount, 1u);
+            }
+        }
         terminal = v < a.sqThreshold;
     }
     a.flag[i] = terminal ? 1u : 0u;
     a.inner[i] = terminal ? 0u : 1u;
     if (!terminal) return;
-    float4* dst = reinterpret_cast<float4*>(a.coeff) + 16 * (size_t)i;
+    if (!MFMA || rechecked) {
+        float4* dst = reinterpret_cast<float4*>(a.coeff) + 16 * (size_t)i;
 #pragma unroll
-    for (int q = 0; q < 16; q++) dst[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+        for (int q = 0; q < 16; q++) dst[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
+    }
     atomicMax(a.valueRangeBits, __float_as_uint(absMax));
     // border corners (computeMinBorderValue): a leaf corner lying on the box boundary contributes P(corner)
     const uint32_t co = a.coord[i];
@@ -247,7 +280,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     SDF_REQUIRE(P->start_depth <= P->depth, "start_depth > depth");
     SDF_REQUIRE(P->rule >= SDFHIP_RULE_NONE && P->rule <= SDFHIP_RULE_BY_DISTANCE, "unknown termination rule");
     SDF_REQUIRE(P->layout == SDFHIP_LAYOUT_GLOBAL_DFS || P->layout == SDFHIP_LAYOUT_SUBTREES, "unknown layout");
-    if (P->fit_mode != SDFHIP_FIT_EXACT) { setError("fit_mode %d is not provided by this build entry", P->fit_mode); return SDFHIP_E_UNSUPPORTED; }
+    SDF_REQUIRE(P->fit_mode == SDFHIP_FIT_EXACT || P->fit_mode == SDFHIP_FIT_MFMA, "unknown fit_mode");
     const uint32_t maxDepth = P->depth, startDepth = P->start_depth;
     const uint32_t G = 1u << startDepth, G3 = G * G * G;
     uint32_t cellBegin = P->cell_begin, cellEnd = P->cell_end;
@@ -276,9 +309,9 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     T->startOctreeDepth = sod;
 
     MeshDev md{mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
-    DevBuf<uint32_t> stats;            // [0] valueRange bits, [1] minBorder key
-    SDF_TRY(stats.reserve(2));
-    { const uint32_t init[2] = {0u, 0xFFFFFFFFu}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 8, hipMemcpyHostToDevice, st)); }
+    DevBuf<uint32_t> stats;            // [0] valueRange bits, [1] minBorder key, [2] MFMA re-checks
+    SDF_TRY(stats.reserve(3));
+    { const uint32_t init[3] = {0u, 0xFFFFFFFFu, 0u}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 12, hipMemcpyHostToDevice, st)); }
     DevBuf<unsigned char> scanTmp; size_t scanTmpBytes = 0;
 
     // root level
@@ -330,9 +363,12 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         if (d >= startDepth) {
             SDF_TRY(L->coeff.reserve(64ull * L->n));
             DecideArgs a{L->corner.p, L->mid.p, L->coord.p, L->n, d, maxDepth, L->half, P->rule, P->rule_params[0] * P->rule_params[0], P->rule_params[1],
-                         L->flag.p, L->inner.p, L->coeff.p, stats.p, stats.p + 1};
+                         L->flag.p, L->inner.p, L->coeff.p, stats.p, stats.p + 1, stats.p + 2};
             const double t0 = nowSeconds();
-            k_decide<<<gridFor(L->n, 128), 128, 0, st>>>(a);
+            if (P->fit_mode == SDFHIP_FIT_MFMA) {
+                k_fit_mfma<4><<<gridFor(L->n, 128), 256, 0, st>>>(L->corner.p, nullptr, 2.0f * L->half, L->n, L->coeff.p);
+                k_decide<true><<<gridFor(L->n, 128), 128, 0, st>>>(a);
+            } else k_decide<false><<<gridFor(L->n, 128), 128, 0, st>>>(a);
             if (d < maxDepth) {
                 size_t need = 0;
                 SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, L->inner.p, L->childBase.p, (int)L->n, st));
@@ -387,12 +423,13 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     }
     if ((uint64_t)G3 + bodyWords > (uint64_t)INDEX_MASK) { setError("octree needs %llu words: exceeds the 30-bit node index of the reference layout", (unsigned long long)(G3 + bodyWords)); return SDFHIP_E_TOO_LARGE; }
 
-    uint32_t stat[2];
-    SDF_HIP_CHECK(hipMemcpyAsync(stat, stats.p, 8, hipMemcpyDeviceToHost, st));
+    uint32_t stat[3];
+    SDF_HIP_CHECK(hipMemcpyAsync(stat, stats.p, 12, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     memcpy(&T->info.value_range, &stat[0], 4);
     T->info.min_border_value = (stat[1] == 0xFFFFFFFFu) ? INFINITY : floatFromOrderKey(stat[1]);
     T->info.cell_begin = cellBegin; T->info.cell_end = cellEnd;
+    T->info.fit_rechecks = stat[2];
     T->info.body_words = bodyWords;
     T->info.body_offset = G3;     // provisional (single shard); emit_shard overrides it
     T->info.num_words = partial ? 0 : (uint64_t)G3 + bodyWords;

@@ -143,3 +143,52 @@ def test_sharded_build_emits_the_same_array(small, oracle):
         off += n
     assert np.array_equal(out, full)
     assert max(s.info.value_range for s in shards) == S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3).info.value_range
+
+
+def test_mfma_fit_is_the_correctly_rounded_product(oracle, gpu_ctx):
+    """FIT_MFMA (hi/lo split, exact hi pass) reproduces the fp64 product to ~1 ulp; the reference-ordered fp32 sum carries
+    ~1e-5 of rounding noise at unit scale, so the two differ by the REFERENCE's noise, not by MFMA's."""
+    import sdflib_amd as S
+    rng = np.random.default_rng(13)
+    n = 2000
+    vals = np.zeros((n, 8, 8), np.float32)
+    vals[:, :, 0] = (0.7 + 0.01 * rng.standard_normal((n, 8))).astype(np.float32)
+    g = rng.standard_normal((n, 8, 3)); g /= np.linalg.norm(g, axis=2, keepdims=True); vals[:, :, 1:4] = g
+    vals[:, :, 4:] = (0.1 * rng.standard_normal((n, 8, 4))).astype(np.float32)
+    ns = np.full(n, 0.05, np.float32)
+    exact = S.tricubic_fit(vals, ns, gpu_ctx, fit_mode=S.FIT_EXACT)
+    mfma = S.tricubic_fit(vals, ns, gpu_ctx, fit_mode=S.FIT_MFMA)
+    s32 = vals.copy()
+    sq = (ns * ns).astype(np.float32); cu = (sq * ns).astype(np.float32)
+    s32[:, :, 1:4] *= ns[:, None, None]; s32[:, :, 4:7] *= sq[:, None, None]; s32[:, :, 7] *= cu[:, None]
+    truth = s32.reshape(n, 64).astype(np.float64) @ oracle.fit_matrix().astype(np.float64).T
+    err_mfma = np.abs(mfma - truth).max(); err_exact = np.abs(exact - truth).max()
+    assert err_mfma < 1e-6 and err_mfma < 0.2 * err_exact
+    assert np.abs(mfma - exact).max() < 5e-5
+
+
+def test_mfma_build_has_identical_topology_and_close_coefficients(small):
+    import sdflib_amd as S
+    a = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_EXACT)
+    b = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_MFMA)
+    da, db = a.get_octree_data(), b.get_octree_data()
+    assert da.shape == db.shape
+    # walk: node words identical (bit-exact topology); leaf payloads agree to the fp32 rounding noise of the 64-term sums
+    G3 = 512
+    stack = list(range(G3)); maxrel = 0.0
+    while stack:
+        at = stack.pop(); w = int(da[at])
+        assert w == int(db[at])
+        base = w & 0x3FFFFFFF
+        if w & 0x80000000:
+            ca, cb = da[base:base + 64].view(np.float32), db[base:base + 64].view(np.float32)
+            maxrel = max(maxrel, float(np.abs(ca - cb).max() / np.abs(ca).max()))
+        else:
+            stack.extend(range(base, base + 8))
+    # the difference is the reference-ordered sum's own fp32 noise (see test_mfma_fit_is_the_correctly_rounded_product)
+    assert maxrel < 1e-4
+    from sdflib_amd.meshgen import random_points_in_box
+    pts = random_points_in_box(small["box"], 200000, seed=77)
+    np.testing.assert_allclose(a.get_distance(pts), b.get_distance(pts), rtol=0, atol=5e-5)
+    assert 0 < b.info.fit_rechecks < 0.5 * b.info.num_nodes
+    assert abs(a.info.min_border_value - b.info.min_border_value) < 5e-5 and a.info.value_range == b.info.value_range
