@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--gradient", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries timed on the host cores for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--build-1m", action="store_true", help="also time the depth-8 build of the 1.31 M-triangle mesh")
+    ap.add_argument("--no-build-1m", action="store_true", help="skip the depth-8 build of the 1.31 M-triangle mesh (BASELINE configs[3])")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (gradient, fast eval, 256^3 grid, ExactOctreeSdf)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,7 +132,9 @@ def main():
 
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
-    if args.build_1m:
+    if not args.no_extras:
+        result["extras"] = extras(tree, mesh, box, pts, out, dev, rank)
+    if not args.no_build_1m:
         result["build_1m"] = build_1m(ctx, rank, world, dev)
     if rank == 0:
         print(json.dumps(result), flush=True)
@@ -164,6 +167,44 @@ def cpu_baseline(v, f, box, args, pts):
             "sample": f"{len(sample)} of the same random points, oracle getDistance under OpenMP static schedule, {cores} threads; "
                       f"tree = oracle build depth {cpu_depth} ({cpu_build_s:.1f} s, OpenMP over start cells)",
             "single_thread_mqueries_s": round(len(sample) // 8 / dt1 / 1e6, 3), "cpu_build_s": round(cpu_build_s, 2), "cpu_build_depth": cpu_depth}
+
+
+def _time_ms(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def extras(tree, mesh, box, pts, out, dev, rank):
+    """Secondary per-GPU measurements (rank-local, untimed region): the other BASELINE.json configs on the same mesh."""
+    n = pts.shape[0]
+    outg = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    r = {}
+    ms = _time_ms(lambda: tree.get_distance(pts, gradient=True, eval_mode=S.EVAL_EXACT, out=out, out_grad=outg))
+    r["value_and_gradient_exact"] = {"ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
+    ms = _time_ms(lambda: tree.get_distance(pts, gradient=False, eval_mode=S.EVAL_FAST, out=out))
+    r["value_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
+    bb = tree.get_grid_bounding_box(); size = float(bb[3] - bb[0])
+    step = np.full(3, size / 256, dtype=np.float32); origin = (bb[:3] + 0.5 * step).astype(np.float32)
+    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_EXACT, device_out=True))
+    words = int(tree.info.num_words)
+    gbytes = 256 ** 3 * 16 + words * 4          # SURVEY 8(d) "G": 16 B written per point + the tree read once
+    r["grid256_value_and_gradient"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1)}
+    # ExactOctreeSdf (BASELINE configs[2]): depth 7, start 3, min_triangles_per_node 128
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ex = S.ExactOctreeSdf(mesh, box, 7, 3, 128)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    i = ex.info
+    q = pts[:2_000_000]
+    ms = _time_ms(lambda: ex.get_distance(q), reps=3)
+    r["exact_octree_d7_min128"] = {"build_s": round(dt, 4), "nodes": int(i.num_nodes), "cull_tests": int(i.cull_tests), "max_triangles_in_leafs": int(i.max_triangles_in_leafs),
+                                  "query_ms_2M": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1)}
+    ex.close()
+    return r
 
 
 def build_1m(ctx, rank, world, dev):

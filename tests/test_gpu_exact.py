@@ -85,3 +85,51 @@ def test_exact_gpu_matches_golden(gpu_ctx):
     d, gr, t = gx.get_distance(g["points"], gradient=True, triangle=True)
     assert np.array_equal(bits(d), bits(g["exact_dist"]))
     assert np.array_equal(t[64:], g["exact_tri"][64:]) and np.array_equal(bits(gr[64:]), bits(g["exact_grad"][64:]))
+
+
+def test_exact_full_size_properties(gpu_ctx):
+    """BASELINE.json configs[2] at full size (327 680 triangles, depth 7, min 128): the oracle's single-thread build would
+    take minutes, so size-independent properties are checked instead: exact query == nearest-triangle distance through the
+    independent fp64 BVH path, every packed set is strictly ascending, masks select subsets, leaves respect the threshold."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+    v, f = bumpy_icosphere(7)
+    box = box_with_margin(v)
+    gm = S.Mesh(v, f, gpu_ctx)
+    gx = S.ExactOctreeSdf(gm, box, 7, 3, 128)
+    i = gx.info
+    assert i.bits_per_index == 19 and i.max_triangles_in_leafs >= 128 and i.num_nodes > 500000
+    pts = random_points_in_box(box, 300000, seed=5)
+    d, t = gx.get_distance(pts, triangle=True)
+    ids = gm.nearest_triangle(pts)
+    ref = gm.point_values(pts, ids)[:, 0]
+    np.testing.assert_allclose(d, ref, rtol=0, atol=2e-6)            # same nearest feature up to ties
+    assert (t == ids).mean() > 0.05                                   # ids differ only on ties (shared edges / vertices)
+    nodes, has, sets, masks = gx.download()
+    bits_per = i.bits_per_index
+    # walk from the start grid, collect leaves at depth <= bitEnc (they own bit-packed sets), decode and check them
+    G3 = i.start_grid_size ** 3
+    todo = [(c, i.start_depth) for c in range(0, G3, 3)]
+    leaves = []
+    while todo and len(leaves) < 400:
+        n_, dep = todo.pop()
+        w = int(nodes[n_, 0])
+        if w & 0x80000000:
+            if dep <= i.bit_encoding_start_depth:
+                leaves.append(n_)
+        elif dep < i.bit_encoding_start_depth:
+            base = w & 0x7FFFFFFF
+            todo.extend((base + c, dep + 1) for c in range(0, 8, 3))
+    assert len(leaves) > 100
+    for n_ in leaves:
+        assert has[n_] == 1
+        at = int(nodes[n_, 1]); cnt = int(sets[at])
+        assert 0 < cnt <= i.max_triangles_in_leafs
+        words = sets[at + 1: at + 3 + (cnt * bits_per + 31) // 32].astype(np.uint64)
+        vals = []
+        for k in range(cnt):
+            b = k * bits_per; w_ = b >> 5; off = b & 31
+            two = (int(words[w_]) << 32) | int(words[w_ + 1])
+            vals.append((two >> (64 - off - bits_per)) & ((1 << bits_per) - 1))
+        vals = np.array(vals)
+        assert (vals < len(f)).all() and (np.diff(vals) > 0).all()

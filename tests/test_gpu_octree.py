@@ -192,3 +192,29 @@ def test_mfma_build_has_identical_topology_and_close_coefficients(small):
     np.testing.assert_allclose(a.get_distance(pts), b.get_distance(pts), rtol=0, atol=5e-5)
     assert 0 < b.info.fit_rechecks < 0.5 * b.info.num_nodes
     assert abs(a.info.min_border_value - b.info.min_border_value) < 5e-5 and a.info.value_range == b.info.value_range
+
+
+@pytest.mark.parametrize("subdiv,depth,start", [(6, 7, 3), (7, 8, 3)])
+def test_full_size_octree_matches_oracle(oracle, gpu_ctx, subdiv, depth, start):
+    """BASELINE.json configs[1] at full size (s=7: 327 680 triangles, depth 8): whole node array + 10 M queries."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+    v, f = bumpy_icosphere(subdiv)
+    box = box_with_margin(v)
+    gm = S.Mesh(v, f, gpu_ctx)
+    gt = S.OctreeSdf(gm, box, depth, start, 1e-3)
+    om = oracle.Mesh(v, f)
+    ot = oracle.Octree(om, box, depth, start, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    assert np.array_equal(ot.data(), gt.get_octree_data())
+    assert np.float32(gt.info.value_range) == np.float32(ot.value_range) and np.float32(gt.info.min_border_value) == np.float32(ot.min_border)
+    n = 10_000_000 if subdiv == 7 else 1_000_000
+    pts = random_points_in_box(box, n, seed=1234)
+    d0 = ot.query(pts); d1 = gt.get_distance(pts, eval_mode=S.EVAL_EXACT)
+    assert np.array_equal(bits(d0), bits(d1))
+    # size-independent properties: |gradient| = 1, error against the exact distance bounded by a few thresholds
+    d2, g2 = gt.get_distance(pts[:200000], gradient=True, eval_mode=S.EVAL_FAST)
+    np.testing.assert_allclose(np.linalg.norm(g2, axis=1), 1.0, atol=1e-4)
+    np.testing.assert_allclose(d2, d1[:200000], rtol=0, atol=1e-5)
+    ids = gm.nearest_triangle(pts[:200000])
+    ex = gm.point_values(pts[:200000], ids)[:, 0]
+    assert np.sqrt(((d1[:200000] - ex) ** 2).mean()) < 2e-3
