@@ -218,3 +218,27 @@ def test_full_size_octree_matches_oracle(oracle, gpu_ctx, subdiv, depth, start):
     ids = gm.nearest_triangle(pts[:200000])
     ex = gm.point_values(pts[:200000], ids)[:, 0]
     assert np.sqrt(((d1[:200000] - ex) ** 2).mean()) < 2e-3
+
+
+def test_sharded_build_through_rccl_world1(small):
+    """The N>1 code path (shard build -> all-gather over the 'nccl' = RCCL backend -> from_data) with a 1-rank group:
+    exercises the real collectives on the GPU; the 2-rank logic is covered on CPU by tests/test_distributed_cpu.py."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import sdflib_amd as S
+    from sdflib_amd import distributed as sdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29611")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0)); created = True
+    try:
+        dev = torch.device("cuda", 0)
+        tree, info = sdist.build_octree_sharded(small["gm"], small["box"], 5, 2, 1e-3, 0, 1, dev)
+        full = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3)
+        assert np.array_equal(tree.get_octree_data(), full.get_octree_data())
+        assert tree.info.value_range == full.info.value_range and tree.info.min_border_value == full.info.min_border_value
+        assert list(tree.info.leaves_per_depth) == list(full.info.leaves_per_depth)
+    finally:
+        if created:
+            dist.destroy_process_group()
