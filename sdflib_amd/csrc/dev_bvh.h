@@ -100,12 +100,22 @@ SDF_DEV double sphereDist(const double2* nd, int which, D3 p) {
     return sqrt(ddot(d, d)) - b.y;
 }
 
+constexpr double BVH_NO_BOUND = 1.7976931348623157e308;     // std::numeric_limits<double>::max(): the reference's start value
+
 // Nearest triangle id for a float point (widened to double), root = node 0.  STRIDE = LDS stride between entries.
+//
+// initBest: an UPPER bound on the distance from the point to the mesh that is strictly larger than the true nearest
+// distance (BVH_NO_BOUND reproduces the reference literally).  Starting from a finite bound returns the SAME triangle as
+// the reference's traversal: the visiting order is unchanged; a subtree skipped only because of the bound has a sphere
+// lower bound >= initBest > nearest distance, so it holds no triangle that the reference could end up with; the first
+// triangle closer than the bound is adopted by both traversals (the reference holds either +inf or a farther triangle at
+// that moment) and from then on both carry the identical `best`, hence take identical decisions.  If the bound turns
+// out to be wrong (no triangle adopted) the caller falls back to the unbounded traversal.
 template <int STRIDE>
 SDF_DEV uint32_t bvhNearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx, F3 pf,
-                            uint32_t* __restrict__ stk) {
+                            uint32_t* __restrict__ stk, double initBest = BVH_NO_BOUND) {
     const D3 p = D3{(double)pf.x, (double)pf.y, (double)pf.z};
-    double best = 1.7976931348623157e308;     // std::numeric_limits<double>::max()
+    double best = initBest;
     int bestTri = -1;
     int sp = 0;
     int cur = 0;

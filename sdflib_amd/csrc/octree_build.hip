@@ -27,8 +27,9 @@ namespace sdfhip {
 
 struct MeshDev { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
 
-SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4, uint32_t* __restrict__ stk) {
-    const uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);
+SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4, uint32_t* __restrict__ stk, double bound = BVH_NO_BOUND) {
+    uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk, bound);
+    if (t == 0xFFFFFFFFu) t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);      // bound was not an upper bound: literal traversal
     const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
     F3 g;
     const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t,
@@ -50,13 +51,30 @@ __global__ void __launch_bounds__(128) k_corner_samples(MeshDev m, const float* 
 }
 
 // 19 mid-points of every node of a level: the build's hot kernel.
-__global__ void __launch_bounds__(128) k_level_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ mid) {
-    __shared__ uint32_t s_stack[BVH_STACK * 128];
+// The node's 8 corner distances are already known, so dist(p) <= |f(corner)| + |p - corner| bounds the search from the
+// start (triangle inequality); see bvhNearest for why the result is unchanged.  The bound is inflated by 1e-4 relative
+// (+ tiny absolute) to stay strictly above the true distance despite the fp32 rounding of |f| and of the offset length.
+__global__ void __launch_bounds__(128) k_level_samples(MeshDev m, const float* __restrict__ center, const float* __restrict__ corner, float half, uint32_t n,
+                                                       float* __restrict__ mid, int useBound) {
+    extern __shared__ uint32_t s_stack[];        // [stackDepth][128], stackDepth = BVH depth + 1 (smaller stack -> more waves per CU)
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 19u * n) return;
     const uint32_t node = gid / 19u, mi = gid - 19u * node;
     const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
-    sampleAt(m, ce + midRel((int)mi) * half, mid + 4 * (size_t)gid, s_stack + threadIdx.x);
+    const F3 rel = midRel((int)mi);
+    double bound = BVH_NO_BOUND;
+    if (useBound) {
+        float u = INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const float f = fabsf(corner[4 * (8 * (size_t)node + c)]);
+            const F3 d = F3{(rel.x - ((c & 1) ? 1.f : -1.f)) * half, (rel.y - ((c & 2) ? 1.f : -1.f)) * half, (rel.z - ((c & 4) ? 1.f : -1.f)) * half};
+            const float cand = f + sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+            u = (cand < u) ? cand : u;
+        }
+        if (u < INFINITY) bound = (double)u * 1.0001 + 1e-30;
+    }
+    sampleAt(m, ce + rel * half, mid + 4 * (size_t)gid, s_stack + threadIdx.x, bound);
 }
 
 SDF_DEV uint32_t floatOrderKey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -339,6 +357,8 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     }
 
     double tSamples = 0, tDecide = 0;
+    size_t stackBytes;
+    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; stackBytes = (size_t)(depth + 2) * 128 * sizeof(uint32_t); }
     for (uint32_t d = sod; d <= maxDepth; d++) {
         BuildLevel* L = T->levels[d - sod].get();
         if (!L || L->n == 0) break;
@@ -355,7 +375,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         if (d < maxDepth) {
             SDF_TRY(L->mid.reserve(76ull * L->n));
             const double t0 = nowSeconds();
-            k_level_samples<<<gridFor(19ull * L->n, 128), 128, 0, st>>>(md, L->center.p, L->half, L->n, L->mid.p);
+            k_level_samples<<<gridFor(19ull * L->n, 128), 128, stackBytes, st>>>(md, L->center.p, L->corner.p, L->half, L->n, L->mid.p, 1);
             SDF_HIP_CHECK(hipStreamSynchronize(st));
             tSamples += nowSeconds() - t0;
             T->info.num_samples += 19ull * L->n;

@@ -6,7 +6,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
 # PMC passes: counters only, with kernel-trace only (no sys/hip/hsa traces)
@@ -14,4 +14,6 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $CMD > $
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_pmc_write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o bench -- $CMD > $OUT/bench_pmc_l2.log 2>&1
 cd $REPO
-find gpurun_out/prof_$TAG -name "*.csv" | head -30
+python tools/summarize_rocpd.py gpurun_out/prof_$TAG gpurun_out/prof_$TAG/summary > gpurun_out/prof_$TAG/summary.txt 2>&1
+rm -f gpurun_out/prof_$TAG/*/bench_results.db          # keep only the text summaries (gpurun_out is capped at 64 MiB)
+ls gpurun_out/prof_$TAG
