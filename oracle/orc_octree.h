@@ -127,6 +127,8 @@ struct BuildNode {
     float vv[8][8]; uint32_t vi[8];
 };
 
+static inline void computeMinBorder(OctreeSdfData& out);
+
 struct OctreeBuilder {
     const MeshView mesh;
     const std::vector<TriangleData>& td;
@@ -271,7 +273,11 @@ struct OctreeBuilder {
         computeMinBorderValue();
     }
 
-    void computeMinBorderValue() {
+    void computeMinBorderValue() { computeMinBorder(out); }
+};
+
+static inline void computeMinBorder(OctreeSdfData& out) {
+    {
         const std::vector<uint32_t>& d = out.data;
         std::function<float(uint32_t, V3, float)> rec = [&](uint32_t at, V3 pos, float half) -> float {
             float mn = INFINITY;
@@ -301,7 +307,7 @@ struct OctreeBuilder {
         }
         out.minBorderValue = mn;
     }
-};
+}
 
 static inline uint32_t roundFloatGE(float a) { return (a >= 0.5f) ? 1u : 0u; }
 

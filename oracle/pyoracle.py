@@ -45,6 +45,7 @@ def lib():
             "orc_tricubic_vertex_values": (None, [vp, vp, f32, vp]), "orc_rule_value": (f32, [C.c_int, vp, vp, f32]),
             "orc_stencil": (None, [vp, vp, vp]), "orc_is_near_minimize": (C.c_int, [f32, vp, vp, f32, vp]),
             "orc_octree_build": (vp, [vp, vp, u32, u32, C.c_int, f32, f32, C.c_int, C.c_int]),
+            "orc_octree_build_continuity": (vp, [vp, vp, u32, u32, C.c_int, f32, f32]),
             "orc_octree_destroy": (None, [vp]), "orc_octree_size": (u64, [vp]), "orc_octree_data": (None, [vp, vp]),
             "orc_octree_info": (None, [vp, vp, vp, vp, vp, vp, vp]),
             "orc_octree_query": (None, [vp, vp, u64, vp, vp, C.c_int]),
@@ -158,10 +159,13 @@ class Octree:
     """Oracle OctreeSdf (NO_CONTINUITY)."""
 
     def __init__(self, mesh, box6, depth, start_depth, threshold=1e-3, rule=RULE_TRAPEZOIDAL, param1=0.0,
-                 vertex_cache=False, layout=LAYOUT_SUBTREES):
+                 vertex_cache=False, layout=LAYOUT_SUBTREES, continuity=False):
         self.mesh = mesh
-        self.h = lib().orc_octree_build(mesh.h, _p(_f32(box6)), depth, start_depth, rule, np.float32(threshold),
-                                        np.float32(param1), int(vertex_cache), int(layout))
+        if continuity:
+            self.h = lib().orc_octree_build_continuity(mesh.h, _p(_f32(box6)), depth, start_depth, rule, np.float32(threshold), np.float32(param1))
+        else:
+            self.h = lib().orc_octree_build(mesh.h, _p(_f32(box6)), depth, start_depth, rule, np.float32(threshold),
+                                            np.float32(param1), int(vertex_cache), int(layout))
         box = np.empty(6, dtype=np.float32); g = C.c_int32(); cell = C.c_float(); vr = C.c_float(); mb = C.c_float(); nq = C.c_uint64()
         lib().orc_octree_info(self.h, _p(box), C.byref(g), C.byref(cell), C.byref(vr), C.byref(mb), C.byref(nq))
         self.box, self.start_grid_size, self.cell_size = box, g.value, cell.value

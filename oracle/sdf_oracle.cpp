@@ -1,6 +1,7 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  C ABI over oracle/orc_*.h (see sdf_oracle.h).
 #include "sdf_oracle.h"
 #include "orc_exact.h"
+#include "orc_continuity.h"
 #include <chrono>
 #include <memory>
 #ifdef _OPENMP
@@ -105,6 +106,15 @@ orc_octree* orc_octree_build(orc_mesh* m, const float box6[6], uint32_t depth, u
     b.run(ldbox(box6), depth, startDepth, rule, p0, p1, cache != 0, layout);
     return o;
 }
+orc_octree* orc_octree_build_continuity(orc_mesh* m, const float box6[6], uint32_t depth, uint32_t startDepth, int rule, float p0, float p1) {
+    m->ensureBvh();
+    orc_octree* o = new orc_octree();
+    ContinuityBuilder b(m->view(), m->td, m->bvh, o->d);
+    b.run(ldbox(box6), depth, startDepth, rule, p0, p1);
+    computeMinBorder(o->d);
+    return o;
+}
+void orc_neighbour_masks(uint32_t* out24) { const NeighbourMasks& n = neighbourMasks(); for (int i = 0; i < 24; i++) out24[i] = n.m[i]; }
 void orc_octree_destroy(orc_octree* o) { delete o; }
 uint64_t orc_octree_size(orc_octree* o) { return o->d.data.size(); }
 void orc_octree_data(orc_octree* o, uint32_t* out) { std::memcpy(out, o->d.data.data(), o->d.data.size() * 4); }

@@ -41,6 +41,9 @@ int orc_is_near_minimize(float half, const float radius[8], const float tri[9], 
 /* OctreeSdf (NO_CONTINUITY).  box6 = min xyz, max xyz.  layout: 0 = numThreads<2 array, 1 = numThreads>=2 array. */
 orc_octree* orc_octree_build(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, int rule,
                              float p0, float p1, int vertex_cache, int layout);
+/* OctreeSdf CONTINUITY builder (canonical mode, single layout) */
+orc_octree* orc_octree_build_continuity(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, int rule, float p0, float p1);
+void orc_neighbour_masks(uint32_t* out24);
 void orc_octree_destroy(orc_octree*);
 uint64_t orc_octree_size(orc_octree*);
 void orc_octree_data(orc_octree*, uint32_t* out);

@@ -197,3 +197,37 @@ def test_golden_vectors(oracle):
     nodes, has, sets, masks = ex.data()
     assert np.array_equal(nodes[:, 0], g["exact_nodes"][:, 0]) and np.array_equal(sets, g["exact_sets"]) and np.array_equal(masks, g["exact_masks"])
     assert np.array_equal(bits(ex.query(g["points"])), bits(g["exact_dist"]))
+
+
+def _leaf_histogram(data, G3, start):
+    hist = {}
+    stack = [(i, start) for i in range(G3)]
+    while stack:
+        at, d = stack.pop()
+        w = int(data[at])
+        assert not (w & 0x40000000), "mark bit left set"
+        if w & 0x80000000:
+            hist[d] = hist.get(d, 0) + 1
+        else:
+            stack.extend(((w & 0x3FFFFFFF) + c, d + 1) for c in range(8))
+    return hist
+
+
+def test_continuity_builder_reproduces_the_reference_probe_counts(oracle):
+    """The only numbers the survey measured on the REAL reference (shim-compiled, SURVEY.md section 6 / BASELINE.md P1, P18):
+    CONTINUITY build of the 5 120-triangle bumpy sphere, depth 6, start 3, thr 1e-3 -> 10.76 M words, leaves per depth
+    d4 252 / d5 11 582 / d6 153 360.  The mesh here has the same geometry but another triangle order, so agreement is
+    expected up to a few borderline node flips (the reference's own 1-vs-N-thread spread is of that size)."""
+    v, f = bumpy_icosphere(4)
+    box = box_with_margin(v)
+    m = oracle.Mesh(v, f)
+    oc = oracle.Octree(m, box, 6, 3, 1e-3, continuity=True)
+    data = oc.data()
+    hist = _leaf_histogram(data, 512, 3)
+    assert abs(len(data) - 10.76e6) < 0.01e6
+    assert hist[4] == 252 and abs(hist[5] - 11582) <= 5 and abs(hist[6] - 153360) <= 40
+    # NO_CONTINUITY on the same input is a coarser tree, and both approximate the same field
+    on = oracle.Octree(m, box, 6, 3, 1e-3)
+    assert len(on.data()) < len(data)
+    pts = random_points_in_box(box, 20000, seed=8)
+    assert np.abs(oc.query(pts) - on.query(pts)).max() < 1e-2

@@ -104,6 +104,20 @@ def main():
         seen.add(idx)
     assert seen == set(range(8))
     print("interpolateVertexValues: 8 expressions identical")
+    # ---- CONTINUITY builder: the 24-entry neighbour-mask table is derived from the stencil geometry in the oracle
+    nd = open("/root/reference/src/sdf/OctreeSdfBreadthFirstNoDelay.h").read()
+    blk = nd[nd.index("neigbourMasks ="):]
+    blk = blk[:blk.index("};")]
+    lits = [int(x, 2) for x in re.findall(r"0b([01]{20})", blk)]
+    assert len(lits) == 24
+    import ctypes as C
+    import numpy as np
+    L = O.lib()
+    L.orc_neighbour_masks.restype = None; L.orc_neighbour_masks.argtypes = [C.c_void_p]
+    mine = np.zeros(24, dtype=np.uint32)
+    L.orc_neighbour_masks(mine.ctypes.data_as(C.c_void_p))
+    assert [int(x) for x in mine] == lits, (list(mine), lits)
+    print("neighbour masks: 24 entries identical")
     return 0
 
 
