@@ -51,7 +51,7 @@ extern "C" {
 /* OctreeSdf::InitAlgorithm (include/SdfLib/OctreeSdf.h:23-28) */
 #define SDFHIP_ALG_UNIFORM 0        /* not provided (test-only in the reference) */
 #define SDFHIP_ALG_NO_CONTINUITY 1
-#define SDFHIP_ALG_CONTINUITY 2     /* not provided yet */
+#define SDFHIP_ALG_CONTINUITY 2     /* SdfExporter / Unity default; single device, FIT_EXACT only */
 
 /* node-array layout: which reference branch's array is reproduced */
 #define SDFHIP_LAYOUT_GLOBAL_DFS 0  /* numThreads < 2  (src/sdf/OctreeSdfDepthFirst.h:394-416) */

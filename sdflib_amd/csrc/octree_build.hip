@@ -271,6 +271,8 @@ __global__ void k_init_start_pos(uint32_t n, uint32_t cellBegin, const uint32_t*
     pos[i] = cellBegin + i; blk[i] = blkIn[i];
 }
 
+int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, sdfhip_octree** out);   // octree_continuity.hip
+
 static int allocLevelCommon(BuildLevel& L) {
     SDF_TRY(L.center.reserve(3ull * L.n));
     SDF_TRY(L.coord.reserve(L.n));
@@ -293,7 +295,11 @@ static uint32_t dfsRankOfCell(uint32_t x, uint32_t y, uint32_t z, uint32_t start
 static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, bool shardOnly, sdfhip_octree** out) {
     SDF_REQUIRE(ctx && mesh && P && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
-    if (P->algorithm != SDFHIP_ALG_NO_CONTINUITY) { setError("algorithm %d is not provided (only NO_CONTINUITY)", P->algorithm); return SDFHIP_E_UNSUPPORTED; }
+    if (P->algorithm == SDFHIP_ALG_CONTINUITY) {
+        SDF_REQUIRE(!shardOnly, "the CONTINUITY builder is not sharded (Iter 2 couples neighbouring start cells)");
+        return continuityBuildImpl(ctx, mesh, P, out);
+    }
+    if (P->algorithm != SDFHIP_ALG_NO_CONTINUITY) { setError("algorithm %d is not provided (UNIFORM is test-only in the reference)", P->algorithm); return SDFHIP_E_UNSUPPORTED; }
     SDF_REQUIRE(P->depth >= 1 && P->depth <= 10, "depth must be in [1,10]");
     SDF_REQUIRE(P->start_depth <= P->depth, "start_depth > depth");
     SDF_REQUIRE(P->rule >= SDFHIP_RULE_NONE && P->rule <= SDFHIP_RULE_BY_DISTANCE, "unknown termination rule");

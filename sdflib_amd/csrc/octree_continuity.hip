@@ -1,0 +1,884 @@
+// OctreeSdf construction, CONTINUITY algorithm (SdfExporter's and the Unity plugin's default).  PRODUCT code —
+// independent of oracle/.
+//
+// Reference behaviour reproduced: OctreeSdf::initOctreeWithContinuityNoDelay<VHQueries<TriCubic>> (src/sdf/
+// OctreeSdfBreadthFirstNoDelay.h:84-1224; neighbour helpers src/sdf/OctreeSdfBreadthFirst.h:35-89), lattice cache
+// disabled ("canonical" mode).  The reference runs, per depth: Iter 1 (parallel over nodes), Iter 2 (serial over nodes),
+// and a serial post-pass that re-subdivides coarse leaves next to finer neighbours.
+//
+// MI355X split — plan on the host, compute on the device:
+//   * everything that touches a float runs in HIP kernels: exact samples (fp64 BVH), 8-slot 64x64 fits, termination
+//     rule, the "can the coarse neighbour's polynomial stand in for this sample" tests, Hermite interpolation of the
+//     replaced samples, the hand-down of the 27-point stencil to children;
+//   * Iter 2 is NOT serial here: within one level the leaf flags it reads are final after Iter 1, so neighbour masks are
+//     order independent and the only serial thing, the allocation order, is an exclusive scan in node order;
+//   * the post-pass is split: its control flow depends only on INTEGER state (leaf / mark bits, child indices, neighbour
+//     words), never on float values, so the host replays it on a mirror of the node words and emits a list of float-free
+//     "ops" (subdivide with sample mask / finalise leaf at slot) grouped by local BFS generation; the device then executes
+//     every generation of all scheduled leaves at once.
+// The reference's quirks are kept where they shape the output: child paths are truncated to 8 bits (its node constructor
+// takes a uint8_t), re-created leaves are registered under parentChildrenIndex + childId even at the start depth, mark
+// bits are cleared at the end.  mValueRange (never initialised in the reference) starts at 0.
+// Compile with -ffp-contract=off.
+#include "octree_internal.h"
+#include "dev_bvh.h"
+#include "dev_tricubic.h"
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace sdfhip {
+
+constexpr uint32_t NONE32 = 0xFFFFFFFFu;
+constexpr uint32_t B31 = 1u << 31, B30 = 1u << 30;
+
+struct CMesh { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
+
+// mask of mid-points (bit 18-i) on the face / edge in direction dir (axis bits) with side code sign
+SDF_HD uint32_t neighbourMask(uint32_t dir, uint32_t sign) {
+    const unsigned char grid[19] = {1, 3, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 21, 22, 23, 25};
+    int axes[3], na = 0;
+    for (int a = 0; a < 3; a++) if (dir & (1u << a)) axes[na++] = a;
+    if (sign >= (1u << na)) return 0;
+    uint32_t m = 0;
+    for (int i = 0; i < 19; i++) {
+        const int g = grid[i];
+        const int rel[3] = {g % 3 - 1, (g / 3) % 3 - 1, g / 9 - 1};
+        bool on = true;
+        for (int k = 0; k < na; k++) on = on && rel[axes[k]] == (((sign >> k) & 1u) ? 1 : -1);
+        if (na == 2) for (int a = 0; a < 3; a++) if (!(dir & (1u << a))) on = on && rel[a] == 0;
+        if (on) m |= 1u << (18 - i);
+    }
+    return m;
+}
+struct MaskTable { uint32_t m[24]; };
+static MaskTable makeMaskTable() { MaskTable t; for (uint32_t d = 1; d <= 6; d++) for (uint32_t s = 0; s < 4; s++) t.m[4 * (d - 1) + s] = neighbourMask(d, s); return t; }
+
+// the 18 face/edge neighbours of a node with child id c: f(blockSelector, dir, sign); blockSelector 0..5 = outward
+// neighbour word nIdx[k], 6 = the node's own parent block (siblings)
+template <typename F> SDF_HD void forEach18(uint32_t c, F f) {
+    const uint32_t nc = ~c;
+    f(0, 1u, c & 1u); f(0, 3u, 2u ^ (c & 3u)); f(0, 5u, ((nc >> 1) & 2u) + (c & 1u));
+    f(1, 2u, (c >> 1) & 1u); f(1, 3u, 1u ^ (c & 3u)); f(1, 6u, 2u ^ ((c >> 1) & 3u));
+    f(2, 3u, c & 3u);
+    f(3, 4u, (c >> 2) & 1u); f(3, 5u, ((c >> 1) & 2u) + (nc & 1u)); f(3, 6u, 1u ^ ((c >> 1) & 3u));
+    f(4, 5u, ((c >> 1) & 2u) + (c & 1u));
+    f(5, 6u, (c >> 1) & 3u);
+    f(6, 1u, nc & 1u); f(6, 2u, (nc >> 1) & 1u); f(6, 4u, (nc >> 2) & 1u);
+    f(6, 3u, nc & 3u); f(6, 5u, ((nc >> 1) & 2u) + (nc & 1u)); f(6, 6u, (nc >> 1) & 3u);
+}
+template <typename F> SDF_HD void forEach18Grid(F f) {
+    f(-1, 0, 0, 1u, 0u); f(1, 0, 0, 1u, 1u); f(0, -1, 0, 2u, 0u); f(0, 1, 0, 2u, 1u);
+    f(-1, -1, 0, 3u, 0u); f(1, -1, 0, 3u, 1u); f(-1, 1, 0, 3u, 2u); f(1, 1, 0, 3u, 3u);
+    f(0, 0, -1, 4u, 0u); f(0, 0, 1, 4u, 1u);
+    f(-1, 0, -1, 5u, 0u); f(1, 0, -1, 5u, 1u); f(-1, 0, 1, 5u, 2u); f(1, 0, 1, 5u, 3u);
+    f(0, -1, -1, 6u, 0u); f(0, 1, -1, 6u, 1u); f(0, -1, 1, 6u, 2u); f(0, 1, 1, 6u, 3u);
+}
+SDF_HD void neighboursVector(uint32_t o, uint32_t childId, uint32_t pci, uint32_t depth, const uint32_t* pN, const uint8_t* pD, uint32_t* oN, uint8_t* oD) {
+    for (uint32_t n = 1; n <= 6; n++) {
+        const uint32_t k = (~(o ^ childId)) & n;
+        oN[n - 1] = k != 0 ? pN[k - 1] + (n ^ childId) * (1u - (pN[k - 1] >> 31)) : pci + (n ^ childId);
+        oD[n - 1] = k != 0 ? pD[k - 1] : (uint8_t)depth;
+    }
+}
+SDF_HD void neighboursInGrid(uint32_t o, int gx, int gy, int gz, int G, uint32_t* oN) {
+    for (uint32_t n = 1; n <= 6; n++) {
+        const int x = gx + ((n & 1) ? ((o & 1) ? 1 : -1) : 0), y = gy + ((n & 2) ? ((o & 2) ? 1 : -1) : 0), z = gz + ((n & 4) ? ((o & 4) ? 1 : -1) : 0);
+        oN[n - 1] = (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) ? (uint32_t)(z * G * G + y * G + x) : B30;
+    }
+}
+
+// ---- device-side float helpers ---------------------------------------------------------------------------------------
+// interpolateVertexValues (InterpolationMethods.h:457-497)
+template <typename CF>
+SDF_DEV void vertexValuesExact(CF c, F3 f, float nodeSize, float* __restrict__ out8) {
+    out8[0] = tricubicValueExact(c, f);
+    out8[1] = tricubicDerivExact<1, 0, 0>(c, f) / nodeSize;
+    out8[2] = tricubicDerivExact<0, 1, 0>(c, f) / nodeSize;
+    out8[3] = tricubicDerivExact<0, 0, 1>(c, f) / nodeSize;
+    const float sq = nodeSize * nodeSize;
+    out8[4] = tricubicDerivExact<1, 1, 0>(c, f) / sq;
+    out8[5] = tricubicDerivExact<1, 0, 1>(c, f) / sq;
+    out8[6] = tricubicDerivExact<0, 1, 1>(c, f) / sq;
+    out8[7] = tricubicDerivExact<1, 1, 1>(c, f) / (sq * nodeSize);
+}
+SDF_DEV F3 midFrac(int i) { const F3 r = midRel(i); return F3{0.5f * r.x + 0.5f, 0.5f * r.y + 0.5f, 0.5f * r.z + 0.5f}; }
+
+SDF_DEV void exactSample(const CMesh& m, F3 p, float* __restrict__ out8, uint32_t* __restrict__ stk, double bound) {
+    uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk, bound);
+    if (t == NONE32) t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);
+    const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
+    F3 g;
+    const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t, F3{m.verts[3 * a], m.verts[3 * a + 1], m.verts[3 * a + 2]},
+                                                F3{m.verts[3 * b], m.verts[3 * b + 1], m.verts[3 * b + 2]}, F3{m.verts[3 * c], m.verts[3 * c + 1], m.verts[3 * c + 2]}, g);
+    out8[0] = d; out8[1] = g.x; out8[2] = g.y; out8[3] = g.z; out8[4] = 0.f; out8[5] = 0.f; out8[6] = 0.f; out8[7] = 0.f;
+}
+// upper bound of dist(p) from the 8 corner values (which may be interpolated: off by at most thr)
+SDF_DEV double cornerBound(const float* __restrict__ vv, F3 rel, float half, float thr) {
+    float u = INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const float f = fabsf(vv[8 * c]);
+        const F3 d = F3{(rel.x - ((c & 1) ? 1.f : -1.f)) * half, (rel.y - ((c & 2) ? 1.f : -1.f)) * half, (rel.z - ((c & 4) ? 1.f : -1.f)) * half};
+        const float cand = f + sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
+        u = (cand < u) ? cand : u;
+    }
+    return (u < INFINITY) ? ((double)u + (double)thr) * 1.0001 + 1e-30 : BVH_NO_BOUND;
+}
+
+// ---- level state (structure of arrays) --------------------------------------------------------------------------------
+struct CLevelDev {
+    uint32_t n; float half;
+    float* center; uint32_t* coord; uint8_t* path; uint32_t* pci; uint32_t* nIdx; uint8_t* nDepth; uint32_t* word;
+    float* vv; float* coeff; float* mid; uint8_t* terminal;
+    uint32_t* cand; uint32_t* allocSize; uint32_t* allocOff; uint32_t* inner; uint32_t* childSlot;
+};
+
+__global__ void kc_root_corners(CMesh m, CLevelDev L) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 8u * L.n) return;
+    const uint32_t node = gid >> 3, c = gid & 7u;
+    const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
+    const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
+    exactSample(m, ce + rel * L.half, L.vv + 64 * (size_t)node + 8 * c, s_stack + threadIdx.x, BVH_NO_BOUND);
+}
+
+// Iter 1a: refresh the six outward neighbour words (OctreeSdfBreadthFirstNoDelay.h:295-330)
+__global__ void kc_refresh(CLevelDev L, uint32_t cd, const uint32_t* __restrict__ oc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    const uint32_t path = L.path[i];
+    for (uint32_t nb = 1; nb <= 6; nb++) {
+        uint32_t ix = L.nIdx[6 * (size_t)i + nb - 1];
+        uint32_t nd = L.nDepth[6 * (size_t)i + nb - 1];
+        if (((ix >> 30) & 1u) == 0) {
+            if (oc[ix & ~B31] & LEAF_BIT) ix = B31 | ix;
+            else {
+                ix = oc[ix & ~B31] & INDEX_MASK; nd++;
+                while (nd < cd) {
+                    const uint32_t dd = cd - nd;
+                    const uint32_t cid = (3 * dd < 32) ? ((path >> (3 * dd)) & 7u) : 0u;
+                    ix += (nb ^ cid);
+                    if (oc[ix & ~B31] & LEAF_BIT) { ix = B31 | ix; break; }
+                    ix = oc[ix & ~B31] & INDEX_MASK; nd++;
+                }
+            }
+        }
+        L.nIdx[6 * (size_t)i + nb - 1] = ix; L.nDepth[6 * (size_t)i + nb - 1] = (uint8_t)nd;
+    }
+}
+
+// Iter 1b: 19 exact mid-point samples per node
+__global__ void __launch_bounds__(128) kc_samples(CMesh m, CLevelDev L, float thr) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 19u * L.n) return;
+    const uint32_t node = gid / 19u, mi = gid - 19u * node;
+    const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
+    const F3 rel = midRel((int)mi);
+    exactSample(m, ce + rel * L.half, L.mid + 152 * (size_t)node + 8 * mi, s_stack + threadIdx.x, cornerBound(L.vv + 64 * (size_t)node, rel, L.half, thr));
+}
+
+// Iter 1c: fit (8 slots), termination rule, provisional node word
+__global__ void __launch_bounds__(128) kc_fit_rule(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t maxDepth, int rule, float sqThr, float param1, uint32_t* __restrict__ oc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    bool terminal = false;
+    if (cd >= startDepth) {
+        float s[64], c[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) s[k] = L.vv[64 * (size_t)i + k];
+        tricubicFit(s, 2.0f * L.half, c);
+#pragma unroll
+        for (int k = 0; k < 64; k++) L.coeff[64 * (size_t)i + k] = c[k];
+        if (cd < maxDepth && rule != 0) {
+            const float* md = L.mid + 152 * (size_t)i;
+            terminal = ruleValue(rule, [&](int n) { return c[n]; }, [&](int mm) { return md[8 * mm]; }, param1) < sqThr;
+        }
+    }
+    if (cd >= maxDepth) return;            // the deepest level has no Iter 1 (its nodes become leaves in Iter 2)
+    L.terminal[i] = terminal ? 1 : 0;
+    const uint32_t w = L.word[i];
+    if (w != NONE32) oc[w] = INDEX_MASK | (terminal ? LEAF_BIT : 0u);
+}
+
+// Iter 2a: which shared samples can be taken from this node's own polynomial, which coarse neighbours must be refined
+__global__ void __launch_bounds__(128) kc_iter2_masks(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t maxDepth, int G, float sqThr, MaskTable NM,
+                                                      const uint32_t* __restrict__ oc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n) return;
+    uint32_t* cand = L.cand + 24 * (size_t)i;
+#pragma unroll
+    for (int k = 0; k < 24; k++) cand[k] = NONE32;
+    const bool inner = !(cd >= maxDepth) && !L.terminal[i];
+    L.inner[i] = inner ? 1u : 0u;
+    L.allocSize[i] = inner ? (cd >= startDepth ? 8u : 0u) : 64u;
+    if (!inner || cd < startDepth) return;
+    uint32_t samplesMask = 0; uint32_t nb[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) nb[k] = NONE32;
+    if (cd > startDepth) {
+        const uint32_t c = L.path[i] & 7u, pci = L.pci[i];
+        const uint32_t* N = L.nIdx + 6 * (size_t)i;
+        forEach18(c, [&](int sel, uint32_t dir, uint32_t sign) {
+            const uint32_t nodeId = (sel < 6) ? N[sel] : pci;
+            if ((nodeId >> 31) || (!(nodeId >> 30) && (oc[nodeId + (dir ^ c)] & LEAF_BIT))) {
+                nb[4 * (dir - 1) + sign] = (nodeId >> 31) ? (nodeId & ~B31) : nodeId + (dir ^ c);
+                samplesMask |= NM.m[4 * (dir - 1) + sign];
+            }
+        });
+    } else {
+        const uint32_t co = L.coord[i];
+        const int gx = (int)(co & 1023u), gy = (int)((co >> 10) & 1023u), gz = (int)(co >> 20);
+        forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) {
+            const int x = gx + dx, y = gy + dy, z = gz + dz;
+            if (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) {
+                const uint32_t at = (uint32_t)(z * G * G + y * G + x);
+                if (oc[at] & LEAF_BIT) { nb[4 * (dir - 1) + sign] = at; samplesMask |= NM.m[4 * (dir - 1) + sign]; }
+            }
+        });
+    }
+    if (samplesMask == 0) return;
+    float c[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) c[k] = L.coeff[64 * (size_t)i + k];
+    auto cf = [&](int n) { return c[n]; };
+    uint32_t subdivisionMask = 0;
+#pragma unroll 1
+    for (int mi = 0; mi < 19; mi++) {
+        if (!(samplesMask & (1u << (18 - mi)))) continue;
+        float* md = L.mid + 152 * (size_t)i + 8 * mi;
+        const F3 f = midFrac(mi);
+        const float iv = tricubicValueExact(cf, f);
+        const float e = md[0] - iv;
+        if (e * e > sqThr) subdivisionMask |= (samplesMask & (1u << (18 - mi)));
+        else vertexValuesExact(cf, f, 2.0f * L.half, md);
+    }
+#pragma unroll
+    for (int k = 0; k < 24; k++) if ((subdivisionMask & NM.m[k]) && !(nb[k] >> 30)) cand[k] = nb[k];
+}
+
+// Iter 2b: node words, children blocks, leaf payloads
+__global__ void __launch_bounds__(256) kc_iter2_write(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t base, uint32_t* __restrict__ oc, uint32_t* __restrict__ valueRangeBits) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 6, lane = gid & 63u;
+    if (i >= L.n) return;
+    const uint32_t w = L.word[i];
+    const uint32_t at = base + L.allocOff[i];
+    if (L.inner[i]) {
+        if (cd < startDepth) return;
+        if (lane == 0) oc[w] = at & INDEX_MASK;
+        if (lane < 8) oc[at + lane] = ~(7u << 29);
+    } else {
+        if (lane == 0) oc[w] = (at & INDEX_MASK) | LEAF_BIT;
+        oc[at + lane] = __float_as_uint(L.coeff[64 * (size_t)i + lane]);
+        if (lane < 8) atomicMax(valueRangeBits, __float_as_uint(fabsf(L.vv[64 * (size_t)i + 8 * lane])));
+    }
+}
+
+// children of the inner nodes of a level -> next level
+__global__ void __launch_bounds__(256) kc_children(CLevelDev L, CLevelDev N, uint32_t cd, uint32_t startDepth, uint32_t base, int G) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 6;
+    if (i >= L.n || !L.inner[i]) return;
+    const uint32_t c = (gid >> 3) & 7u, j = gid & 7u;
+    const uint32_t child = L.childSlot[i] + c;
+    const int src = kStencilDev.src[c][j];
+    const float* s = (src >= 0) ? (L.mid + 152 * (size_t)i + 8 * src) : (L.vv + 64 * (size_t)i + 8 * (-src - 1));
+    float* d = N.vv + 64 * (size_t)child + 8 * j;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = s[k];
+    if (j != 0) return;
+    const float ns = 0.5f * L.half;
+    N.center[3 * (size_t)child] = L.center[3 * (size_t)i] + ((c & 1u) ? ns : -ns);
+    N.center[3 * (size_t)child + 1] = L.center[3 * (size_t)i + 1] + ((c & 2u) ? ns : -ns);
+    N.center[3 * (size_t)child + 2] = L.center[3 * (size_t)i + 2] + ((c & 4u) ? ns : -ns);
+    const uint32_t co = L.coord[i];
+    const uint32_t x = 2u * (co & 1023u) + (c & 1u), y = 2u * ((co >> 10) & 1023u) + ((c >> 1) & 1u), z = 2u * (co >> 20) + (c >> 2);
+    N.coord[child] = x | (y << 10) | (z << 20);
+    N.path[child] = (uint8_t)((L.path[i] << 3) | c);
+    const uint32_t childIndex = (cd >= startDepth) ? base + L.allocOff[i] : NONE32;
+    N.pci[child] = childIndex;
+    N.terminal[child] = 0;
+    uint32_t oN[6]; uint8_t oD[6];
+    if (cd == startDepth) {
+        neighboursInGrid(c, (int)(co & 1023u), (int)((co >> 10) & 1023u), (int)(co >> 20), G, oN);
+        for (int k = 0; k < 6; k++) oD[k] = (uint8_t)cd;
+    } else {
+        uint32_t pN[6]; uint8_t pD[6];
+        for (int k = 0; k < 6; k++) { pN[k] = L.nIdx[6 * (size_t)i + k]; pD[k] = L.nDepth[6 * (size_t)i + k]; }
+        neighboursVector(c, L.path[i] & 7u, L.pci[i], cd, pN, pD, oN, oD);
+    }
+    for (int k = 0; k < 6; k++) { N.nIdx[6 * (size_t)child + k] = oN[k]; N.nDepth[6 * (size_t)child + k] = oD[k]; }
+    // word of the child: inside its parent's block, or its start-grid slot when the NEXT level is the start depth
+    if (cd >= startDepth) N.word[child] = childIndex + c;
+    else if (cd + 1 == startDepth) N.word[child] = z * (uint32_t)G * (uint32_t)G + y * (uint32_t)G + x;
+    else N.word[child] = NONE32;
+}
+
+__global__ void kc_flag_cand(const uint32_t* __restrict__ cand, uint32_t n, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (cand[i] != NONE32) ? 1u : 0u;
+}
+__global__ void kc_compact_cand(const uint32_t* __restrict__ cand, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ scan, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[scan[i]] = cand[i];
+}
+__global__ void kc_mul8(uint32_t n, uint32_t* __restrict__ v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] *= 8u; }
+__global__ void kc_patch(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t n, uint32_t* __restrict__ oc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) oc[idx[i]] = val[i];
+}
+
+// ---- post-pass ops (float part) ------------------------------------------------------------------------------------------
+// A node of the post-pass lives either in a level (src = depth << 26 | slot is NOT used; see refs below) or in the pool.
+struct PoolDev { float* center; float* half; float* vv; };
+struct OpDev {
+    uint32_t kind;          // 0 = subdivide, 1 = leaf
+    uint32_t srcLevel;      // depth of the level holding the source node, or NONE32 for a pool node
+    uint32_t srcSlot;
+    uint32_t samplesMask;   // subdivide: bit (18-i) set -> mid-point i is interpolated, clear -> exact sample
+    uint32_t recycle;       // subdivide: reuse the level node's Iter-1 coefficients and samples
+    uint32_t childPool;     // subdivide: first of 8 pool slots for the children
+    uint32_t coeffIndex;    // leaf: where the 64 coefficients go in the node array
+    uint32_t scratch;       // index into the per-generation scratch (coeff 64 + mid 152 floats)
+};
+struct LevelPtrs { const float* center; const float* vv; const float* coeff; const float* mid; float half; };
+struct LevelTable { LevelPtrs lv[12]; };
+
+SDF_DEV void opSource(const OpDev& op, const LevelTable& LT, const PoolDev& P, const float*& vv, F3& center, float& half) {
+    if (op.srcLevel != NONE32) {
+        const LevelPtrs& l = LT.lv[op.srcLevel];
+        vv = l.vv + 64 * (size_t)op.srcSlot; half = l.half;
+        center = F3{l.center[3 * (size_t)op.srcSlot], l.center[3 * (size_t)op.srcSlot + 1], l.center[3 * (size_t)op.srcSlot + 2]};
+    } else {
+        vv = P.vv + 64 * (size_t)op.srcSlot; half = P.half[op.srcSlot];
+        center = F3{P.center[3 * (size_t)op.srcSlot], P.center[3 * (size_t)op.srcSlot + 1], P.center[3 * (size_t)op.srcSlot + 2]};
+    }
+}
+// fit for every op that needs one (all leaves; subdivisions that do not recycle)
+__global__ void __launch_bounds__(128) kc_pp_fit(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ scratch, uint32_t* __restrict__ oc) {
+    const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nOps) return;
+    const OpDev op = ops[o];
+    float* sc = scratch + 216 * (size_t)op.scratch;
+    if (op.kind == 0 && op.recycle) {
+        const float* c = LT.lv[op.srcLevel].coeff + 64 * (size_t)op.srcSlot;
+        for (int k = 0; k < 64; k++) sc[k] = c[k];
+        return;
+    }
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    float s[64], c[64];
+#pragma unroll
+    for (int k = 0; k < 64; k++) s[k] = vv[k];
+    tricubicFit(s, 2.0f * half, c);
+    if (op.kind == 1) {
+#pragma unroll
+        for (int k = 0; k < 64; k++) oc[op.coeffIndex + k] = __float_as_uint(c[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 64; k++) sc[k] = c[k];
+    }
+}
+// the 19 mid-points of every subdividing op
+__global__ void __launch_bounds__(128) kc_pp_mid(CMesh m, const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ scratch, float thr, float sqThr) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 19u * nOps) return;
+    const uint32_t o = gid / 19u, mi = gid - 19u * o;
+    const OpDev op = ops[o];
+    if (op.kind != 0) return;
+    float* sc = scratch + 216 * (size_t)op.scratch;
+    float* md = sc + 64 + 8 * mi;
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    auto cf = [&](int n) { return sc[n]; };
+    const F3 f = midFrac((int)mi);
+    const bool masked = (op.samplesMask & (1u << (18 - mi))) != 0;
+    if (op.recycle) {
+        const float* src = LT.lv[op.srcLevel].mid + 152 * (size_t)op.srcSlot + 8 * mi;
+        for (int k = 0; k < 8; k++) md[k] = src[k];
+    } else if (masked) vertexValuesExact(cf, f, 2.0f * half, md);
+    else exactSample(m, ce + midRel((int)mi) * half, md, s_stack + threadIdx.x, cornerBound(vv, midRel((int)mi), half, thr));
+    if (!masked) {
+        const float iv = tricubicValueExact(cf, f);
+        const float e = md[0] - iv;
+        if (e * e < sqThr) vertexValuesExact(cf, f, 2.0f * half, md);
+    } else if (op.recycle) vertexValuesExact(cf, f, 2.0f * half, md);
+}
+// children of every subdividing op -> pool
+__global__ void __launch_bounds__(256) kc_pp_children(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, const float* __restrict__ scratch,
+                                                      float* __restrict__ pcenter, float* __restrict__ phalf, float* __restrict__ pvv) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t o = gid >> 6;
+    if (o >= nOps) return;
+    const OpDev op = ops[o];
+    if (op.kind != 0) return;
+    const uint32_t c = (gid >> 3) & 7u, j = gid & 7u;
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    const float* sc = scratch + 216 * (size_t)op.scratch;
+    const int src = kStencilDev.src[c][j];
+    const float* s = (src >= 0) ? (sc + 64 + 8 * src) : (vv + 8 * (-src - 1));
+    const uint32_t child = op.childPool + c;
+    float* d = pvv + 64 * (size_t)child + 8 * j;
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = s[k];
+    if (j == 0) {
+        const float ns = 0.5f * half;
+        pcenter[3 * (size_t)child] = ce.x + ((c & 1u) ? ns : -ns);
+        pcenter[3 * (size_t)child + 1] = ce.y + ((c & 2u) ? ns : -ns);
+        pcenter[3 * (size_t)child + 2] = ce.z + ((c & 4u) ? ns : -ns);
+        phalf[child] = ns;
+    }
+}
+
+// final walk: leaf histogram + min border value (computeMinBorderValue, OctreeSdf.cpp:155-230); one lane per start cell
+__global__ void kc_final_walk(const uint32_t* __restrict__ oc, int G, uint32_t startDepth, unsigned long long* __restrict__ leavesPerDepth, uint32_t* __restrict__ minBorderKey) {
+    const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t G3 = (uint32_t)(G * G * G);
+    if (cell >= G3) return;
+    uint32_t stackAt[80], stackCo[80], stackD[80];
+    int sp = 0;
+    stackAt[0] = cell; stackCo[0] = (cell % G) | (((cell / G) % G) << 10) | ((cell / (G * G)) << 20); stackD[0] = startDepth; sp = 1;
+    while (sp > 0) {
+        sp--;
+        const uint32_t at = stackAt[sp], co = stackCo[sp], d = stackD[sp];
+        const uint32_t w = oc[at];
+        const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
+        if (!(w & LEAF_BIT)) {
+            for (uint32_t c = 0; c < 8; c++) {
+                stackAt[sp] = (w & INDEX_MASK) + c; stackD[sp] = d + 1;
+                stackCo[sp] = (2 * x + (c & 1u)) | ((2 * y + ((c >> 1) & 1u)) << 10) | ((2 * z + (c >> 2)) << 20);
+                sp++;
+            }
+            continue;
+        }
+        atomicAdd(&leavesPerDepth[d], 1ull);
+        const uint32_t last = (1u << d) - 1u;
+        if (!(x == 0 || y == 0 || z == 0 || x == last || y == last || z == last)) continue;
+        const uint32_t* cw = oc + (w & INDEX_MASK);
+        auto cf = [&](int n) { return __uint_as_float(cw[n]); };
+        float mn = INFINITY;
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t bx = k & 1u, by = (k >> 1) & 1u, bz = k >> 2;
+            const bool onBorder = (x + bx == 0) || (y + by == 0) || (z + bz == 0) || (x + bx == last + 1) || (y + by == last + 1) || (z + bz == last + 1);
+            if (!onBorder) continue;
+            const float v = tricubicValueExact(cf, F3{(float)bx, (float)by, (float)bz});
+            mn = gmin(mn, v);
+        }
+        if (mn < INFINITY) { const uint32_t b = __float_as_uint(mn); atomicMin(minBorderKey, (b & 0x80000000u) ? ~b : (b | 0x80000000u)); }
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+struct CLevelHost {
+    uint32_t depth = 0, n = 0; float half = 0.f;
+    DevBuf<float> center, vv, coeff, mid; DevBuf<uint32_t> coord, pci, nIdx, word, cand, allocSize, allocOff, inner, childSlot; DevBuf<uint8_t> path, nDepth, terminal;
+    // host mirrors of the integer state (the post-pass planner reads them)
+    std::vector<uint32_t> hCoord, hPci, hNIdx, hWord; std::vector<uint8_t> hPath, hNDepth, hTerminal;
+    int alloc(uint32_t count) {
+        n = count;
+        SDF_TRY(center.reserve(3ull * n)); SDF_TRY(vv.reserve(64ull * n)); SDF_TRY(coeff.reserve(64ull * n)); SDF_TRY(mid.reserve(152ull * n));
+        SDF_TRY(coord.reserve(n)); SDF_TRY(pci.reserve(n)); SDF_TRY(nIdx.reserve(6ull * n)); SDF_TRY(word.reserve(n)); SDF_TRY(cand.reserve(24ull * n));
+        SDF_TRY(allocSize.reserve(n)); SDF_TRY(allocOff.reserve(n)); SDF_TRY(inner.reserve(n)); SDF_TRY(childSlot.reserve(n));
+        SDF_TRY(path.reserve(n)); SDF_TRY(nDepth.reserve(6ull * n)); SDF_TRY(terminal.reserve(n));
+        return SDFHIP_OK;
+    }
+    CLevelDev dev() { return CLevelDev{n, half, center.p, coord.p, path.p, pci.p, nIdx.p, nDepth.p, word.p, vv.p, coeff.p, mid.p, terminal.p, cand.p, allocSize.p, allocOff.p, inner.p, childSlot.p}; }
+};
+
+// integer state of a node the post-pass can visit (level node or pool node)
+struct PNode { uint32_t path, pci, nIdx[6]; uint8_t nDepth[6]; uint32_t coord, depth; bool ignore; uint32_t srcLevel, srcSlot; };
+struct LeafRef { uint32_t level, slot; };        // level == NONE32 -> pool slot
+
+struct Planner {
+    std::vector<uint32_t> hoc;                    // host mirror of the node words (payload regions are don't-care)
+    std::unordered_map<uint32_t, LeafRef> leaves; // octree word -> node (first registration wins, like std::map::insert)
+    std::vector<PNode> pool;                      // nodes created by the post-pass
+    std::vector<std::pair<uint32_t, uint32_t>> patches;   // (index, value) for words that existed before this post-pass
+    std::vector<uint32_t> marked;
+    uint32_t startDepth = 0; int G = 1; MaskTable NM;
+    bool isLeaf(uint32_t at) const { return (hoc[at] & LEAF_BIT) != 0; }
+    bool isMarked(uint32_t at) const { return (hoc[at] & MARK_BIT) != 0; }
+    uint32_t childrenIndex(uint32_t at) const { return hoc[at] & INDEX_MASK; }
+    void setWord(uint32_t at, uint32_t v, uint32_t sizeBefore) { hoc[at] = v; if (at < sizeBefore) patches.push_back(std::make_pair(at, v)); }
+};
+
+static uint32_t outwardSign(uint32_t n, uint32_t c) {
+    return ((((n & c) >> 2) & 1u) << ((n & 1u) | ((n & 2u) >> 1))) + ((((n & c) >> 1) & 1u) << (n & 1u)) + (n & c & 1u);
+}
+
+static int scanExclusive(hipStream_t st, DevBuf<unsigned char>& tmp, size_t& tmpBytes, const uint32_t* in, uint32_t* out, uint32_t n) {
+    if (n == 0) return SDFHIP_OK;
+    size_t need = 0;
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, st));
+    if (need > tmpBytes) { SDF_TRY(tmp.reserve(need)); tmpBytes = need; }
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, in, out, (int)n, st));
+    return SDFHIP_OK;
+}
+static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
+    total = 0;
+    if (n == 0) return SDFHIP_OK;
+    uint32_t a = 0, b = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&a, scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&b, val + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    total = a + b;
+    return SDFHIP_OK;
+}
+
+int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, sdfhip_octree** out) {
+    SDF_REQUIRE(P->depth >= 1 && P->depth <= 10, "depth must be in [1,10]");
+    SDF_REQUIRE(P->start_depth <= P->depth, "start_depth > depth");
+    SDF_REQUIRE(P->rule >= SDFHIP_RULE_NONE && P->rule <= SDFHIP_RULE_BY_DISTANCE, "unknown termination rule");
+    SDF_REQUIRE(P->fit_mode == SDFHIP_FIT_EXACT, "the CONTINUITY builder feeds coefficients back into the tree: only FIT_EXACT is provided");
+    SDF_REQUIRE(P->cell_begin == 0 && (P->cell_end == 0 || P->cell_end == (1u << (3 * P->start_depth))), "the CONTINUITY builder is not sharded");
+    SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const double tStart = nowSeconds();
+    const uint32_t maxDepth = P->depth, startDepth = P->start_depth;
+    const int G = 1 << startDepth; const uint32_t G3 = (uint32_t)(G * G * G);
+    std::unique_ptr<sdfhip_octree> T(new sdfhip_octree());
+    T->ctx = ctx; T->params = *P;
+    const float sx = P->box_max[0] - P->box_min[0], sy = P->box_max[1] - P->box_min[1], sz = P->box_max[2] - P->box_min[2];
+    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0, "empty box");
+    const float maxSize = gmax(gmax(sx, sy), sz);
+    const float cx = P->box_min[0] + 0.5f * sx, cy = P->box_min[1] + 0.5f * sy, cz = P->box_min[2] + 0.5f * sz;
+    float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};
+    float bmax[3] = {cx + 0.5f * maxSize, cy + 0.5f * maxSize, cz + 0.5f * maxSize};
+    memcpy(T->info.box_min, bmin, 12); memcpy(T->info.box_max, bmax, 12);
+    T->info.start_grid_size = G; T->info.max_depth = maxDepth; T->cellSize = maxSize / (float)G;
+    const uint32_t sod = startDepth < 1u ? startDepth : 1u;
+    const float thr = P->rule_params[0], sqThr = thr * thr, param1 = P->rule_params[1];
+    CMesh md{mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    size_t stackBytes; { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; stackBytes = (size_t)(depth + 2) * 128 * sizeof(uint32_t); }
+    DevBuf<unsigned char> scanTmp; size_t scanTmpBytes = 0;
+    DevBuf<uint32_t> stats; SDF_TRY(stats.reserve(2));
+    { const uint32_t init[2] = {0u, 0xFFFFFFFFu}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 8, hipMemcpyHostToDevice, st)); }
+
+    // the node array grows on the device; the host keeps a mirror of its node words for the post-pass planner
+    DevBuf<uint32_t> oc; size_t ocCap = 0; uint32_t ocSize = G3;
+    auto ensureOc = [&](size_t need) -> int {
+        if (need <= ocCap) return SDFHIP_OK;
+        size_t cap = ocCap ? ocCap : (size_t)1 << 22;
+        while (cap < need) cap *= 2;
+        DevBuf<uint32_t> bigger; SDF_TRY(bigger.reserve(cap));
+        if (oc.p) SDF_HIP_CHECK(hipMemcpyAsync(bigger.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        oc = std::move(bigger); ocCap = cap;
+        return SDFHIP_OK;
+    };
+    SDF_TRY(ensureOc(G3));
+    SDF_HIP_CHECK(hipMemsetAsync(oc.p, 0, 4ull * G3, st));
+    Planner pl; pl.startDepth = startDepth; pl.G = G; pl.NM = makeMaskTable(); pl.hoc.assign(G3, 0u);
+    // pool of post-pass nodes on the device
+    DevBuf<float> pCenter, pHalf, pVv; size_t poolCap = 0;
+    auto ensurePool = [&](size_t need) -> int {
+        if (need <= poolCap) return SDFHIP_OK;
+        size_t cap = poolCap ? poolCap : 4096;
+        while (cap < need) cap *= 2;
+        DevBuf<float> c2, h2, v2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
+        if (poolCap) {
+            SDF_HIP_CHECK(hipMemcpyAsync(c2.p, pCenter.p, 12 * poolCap, hipMemcpyDeviceToDevice, st));
+            SDF_HIP_CHECK(hipMemcpyAsync(h2.p, pHalf.p, 4 * poolCap, hipMemcpyDeviceToDevice, st));
+            SDF_HIP_CHECK(hipMemcpyAsync(v2.p, pVv.p, 256 * poolCap, hipMemcpyDeviceToDevice, st));
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        pCenter = std::move(c2); pHalf = std::move(h2); pVv = std::move(v2); poolCap = cap;
+        return SDFHIP_OK;
+    };
+
+    std::vector<std::unique_ptr<CLevelHost>> LV(maxDepth + 1);
+    {   // root level
+        std::unique_ptr<CLevelHost> L(new CLevelHost());
+        L->depth = sod; SDF_TRY(L->alloc(1u << (3 * sod)));
+        const float newSize = (float)(0.5f * (bmax[0] - bmin[0]) * std::pow(0.5f, sod));
+        L->half = newSize;
+        const uint32_t n = L->n, vpa = 1u << sod;
+        std::vector<float> hc(3 * n); std::vector<uint32_t> hco(n), hpci(n, NONE32), hword(n, NONE32), hn(6 * n, 0u); std::vector<uint8_t> hp(n, 0), hnd(6 * n, 0), ht(n, 0);
+        const float scx = bmin[0] + newSize, scy = bmin[1] + newSize, scz = bmin[2] + newSize;
+        for (uint32_t k = 0; k < vpa; k++) for (uint32_t j = 0; j < vpa; j++) for (uint32_t i = 0; i < vpa; i++) {
+            const uint32_t r = i + vpa * j + vpa * vpa * k;
+            hc[3 * r] = scx + ((float)i * 2.0f) * newSize; hc[3 * r + 1] = scy + ((float)j * 2.0f) * newSize; hc[3 * r + 2] = scz + ((float)k * 2.0f) * newSize;
+            hco[r] = i | (j << 10) | (k << 20);
+            if (sod == startDepth) hword[r] = k * G * G + j * G + i;
+        }
+        SDF_HIP_CHECK(hipMemcpyAsync(L->center.p, hc.data(), 4 * hc.size(), hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->coord.p, hco.data(), 4 * n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->pci.p, hpci.data(), 4 * n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->word.p, hword.data(), 4 * n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->nIdx.p, hn.data(), 24 * n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->path.p, hp.data(), n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->nDepth.p, hnd.data(), 6 * n, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->terminal.p, ht.data(), n, hipMemcpyHostToDevice, st));
+        kc_root_corners<<<gridFor(8ull * n, 128), 128, stackBytes, st>>>(md, L->dev());
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        T->info.num_samples += 8ull * n;
+        LV[sod] = std::move(L);
+    }
+
+    uint64_t numRescheduled = 0;
+    for (uint32_t cd = sod; cd <= maxDepth; cd++) {
+        CLevelHost* L = LV[cd].get();
+        if (!L || L->n == 0) continue;
+        const uint32_t n = L->n;
+        CLevelDev Ld = L->dev();
+        // ---------------- Iter 1
+        if (cd < maxDepth) {
+            if (cd > startDepth) kc_refresh<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, oc.p);
+            kc_samples<<<gridFor(19ull * n, 128), 128, stackBytes, st>>>(md, Ld, thr);
+            T->info.num_samples += 19ull * n;
+        }
+        kc_fit_rule<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, P->rule, sqThr, param1, oc.p);
+        // ---------------- Iter 2
+        kc_iter2_masks<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, pl.NM, oc.p);
+        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->allocSize.p, L->allocOff.p, n));
+        uint32_t allocTotal = 0; SDF_TRY(lastPlus(st, L->allocOff.p, L->allocSize.p, n, allocTotal));
+        SDF_REQUIRE((uint64_t)ocSize + allocTotal < (uint64_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
+        const uint32_t base = ocSize;
+        SDF_TRY(ensureOc((size_t)ocSize + allocTotal));
+        kc_iter2_write<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, cd, startDepth, base, oc.p, stats.p);
+        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->inner.p, L->childSlot.p, n));
+        uint32_t numInner = 0; SDF_TRY(lastPlus(st, L->childSlot.p, L->inner.p, n, numInner));
+        kc_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childSlot.p);
+        if (numInner > 0) {
+            std::unique_ptr<CLevelHost> N(new CLevelHost());
+            N->depth = cd + 1; N->half = 0.5f * L->half; SDF_TRY(N->alloc(8u * numInner));
+            kc_children<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, N->dev(), cd, startDepth, base, G);
+            LV[cd + 1] = std::move(N);
+        }
+        // candidates of the post-pass, in node order then slot order
+        DevBuf<uint32_t> cflag, cscan, clist; uint32_t numCand = 0;
+        SDF_TRY(cflag.reserve(24ull * n)); SDF_TRY(cscan.reserve(24ull * n));
+        kc_flag_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, 24 * n, cflag.p);
+        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, cflag.p, cscan.p, 24 * n));
+        SDF_TRY(lastPlus(st, cscan.p, cflag.p, 24 * n, numCand));
+        std::vector<uint32_t> toSubdivide(numCand);
+        if (numCand) {
+            SDF_TRY(clist.reserve(numCand));
+            kc_compact_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, cflag.p, cscan.p, 24 * n, clist.p);
+            SDF_HIP_CHECK(hipMemcpyAsync(toSubdivide.data(), clist.p, 4ull * numCand, hipMemcpyDeviceToHost, st));
+        }
+        SDF_HIP_CHECK(hipGetLastError());
+        ocSize += allocTotal;
+        // ---------------- mirrors for the planner: integer node state of this level + the words written so far
+        L->hCoord.resize(n); L->hPci.resize(n); L->hNIdx.resize(6ull * n); L->hWord.resize(n); L->hPath.resize(n); L->hNDepth.resize(6ull * n); L->hTerminal.resize(n);
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hCoord.data(), L->coord.p, 4ull * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hPci.data(), L->pci.p, 4ull * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hNIdx.data(), L->nIdx.p, 24ull * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hWord.data(), L->word.p, 4ull * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hPath.data(), L->path.p, n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hNDepth.data(), L->nDepth.p, 6ull * n, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(L->hTerminal.data(), L->terminal.p, n, hipMemcpyDeviceToHost, st));
+        const size_t mirroredFrom = pl.hoc.size();
+        pl.hoc.resize(ocSize);
+        // words of this level's nodes live in blocks appended by the previous level (or in the grid): re-read from there on
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        {
+            uint32_t lo = (uint32_t)mirroredFrom;
+            if (cd >= startDepth) for (uint32_t i = 0; i < n; i++) if (L->hWord[i] != NONE32 && L->hWord[i] < lo) lo = L->hWord[i];
+            SDF_HIP_CHECK(hipMemcpyAsync(pl.hoc.data() + lo, oc.p + lo, 4ull * (ocSize - lo), hipMemcpyDeviceToHost, st));
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        for (uint32_t i = 0; i < n; i++) {
+            const bool leaf = (cd >= maxDepth) || L->hTerminal[i];
+            if (leaf) pl.leaves.emplace(L->hWord[i], LeafRef{cd, i});
+        }
+        numRescheduled += numCand;
+        if (numCand == 0) continue;
+
+        // ---------------- post-pass, integer part on the host
+        const uint32_t sizeBefore = ocSize;
+        pl.patches.clear();
+        std::vector<std::vector<OpDev>> gens;
+        auto addOp = [&](uint32_t gen, const OpDev& op) { if (gens.size() <= gen) gens.resize(gen + 1); gens[gen].push_back(op); };
+        for (uint32_t si = 0; si < numCand; si++) {
+            auto it = pl.leaves.find(toSubdivide[si]);
+            if (it == pl.leaves.end()) continue;
+            // materialise the integer state of the scheduled leaf
+            PNode root;
+            if (it->second.level != NONE32) {
+                CLevelHost* S = LV[it->second.level].get(); const uint32_t s = it->second.slot;
+                root.path = S->hPath[s]; root.pci = S->hPci[s]; root.coord = S->hCoord[s]; root.depth = it->second.level; root.ignore = false;
+                for (int k = 0; k < 6; k++) { root.nIdx[k] = S->hNIdx[6ull * s + k]; root.nDepth[k] = S->hNDepth[6ull * s + k]; }
+                root.srcLevel = it->second.level; root.srcSlot = s;
+            } else { root = pl.pool[it->second.slot]; }
+            uint32_t pword;
+            if (root.depth > startDepth) pword = root.pci + (root.path & 7u);
+            else pword = (root.coord >> 20) * G * G + ((root.coord >> 10) & 1023u) * G + (root.coord & 1023u);
+            if (!pl.isLeaf(pword)) continue;
+            bool recycled = false; const uint32_t oldCoeffIndex = pl.childrenIndex(pword);
+            bool first = true;
+            std::vector<PNode> cache; std::vector<uint32_t> genOf;
+            cache.push_back(root); genOf.push_back(0);
+            size_t ci = 0;
+            while (ci < cache.size()) {
+                PNode node = cache[ci]; const uint32_t gen = genOf[ci]; ci++;
+                const uint32_t depthN = node.depth, c = node.path & 7u;
+                const int gx = (int)(node.coord & 1023u), gy = (int)((node.coord >> 10) & 1023u), gz = (int)(node.coord >> 20);
+                uint32_t word = NONE32;
+                if (depthN > startDepth) word = node.pci + c; else if (depthN == startDepth) word = (uint32_t)(gz * G * G + gy * G + gx);
+                uint32_t samplesMask = 0, subdividedMask = 0;
+                if (depthN > startDepth) {
+                    for (uint32_t nb = 1; nb <= 6; nb++) {
+                        const uint32_t sign = outwardSign(nb, c);
+                        uint32_t& ix = node.nIdx[nb - 1];
+                        if (((ix >> 30) & 1u) != 0) continue;
+                        if ((!first || (ix >> 31)) && pl.isLeaf(ix & ~B31)) { ix = B31 | ix; samplesMask |= pl.NM.m[4 * (nb - 1) + sign]; }
+                        else {
+                            if (!first || (ix >> 31)) { ix = pl.childrenIndex(ix & ~B31); node.nDepth[nb - 1]++; }
+                            while (node.nDepth[nb - 1] < depthN && node.nDepth[nb - 1] < cd) {
+                                const uint32_t dd = depthN - node.nDepth[nb - 1];
+                                const uint32_t cid = (3 * dd < 32) ? ((node.path >> (3 * dd)) & 7u) : 0u;
+                                ix += (nb ^ cid);
+                                if (pl.isLeaf(ix & ~B31)) { ix = B31 | ix; samplesMask |= pl.NM.m[4 * (nb - 1) + sign]; break; }
+                                ix = pl.childrenIndex(ix & ~B31); node.nDepth[nb - 1]++;
+                            }
+                            if (cd >= depthN && !(ix >> 31)) {
+                                const uint32_t next = (ix & ~B31) + (nb ^ c);
+                                subdividedMask |= (pl.isLeaf(next) || pl.isMarked(next)) ? 0u : pl.NM.m[4 * (nb - 1) + sign];
+                            }
+                        }
+                    }
+                }
+                if (cd >= depthN) {
+                    if (depthN > startDepth) {
+                        const uint32_t nc = ~c, pci = node.pci; const uint32_t* N = node.nIdx;
+                        auto upd = [&](uint32_t nid, uint32_t dir, uint32_t sign) {
+                            const bool leafish = (nid >> 31) || (nid >> 30) || pl.isLeaf(nid + (dir ^ c)) || pl.isMarked(nid + (dir ^ c));
+                            subdividedMask |= leafish ? 0u : pl.NM.m[4 * (dir - 1) + sign];
+                        };
+                        upd(pci, 1u, nc & 1u); upd(pci, 2u, (nc >> 1) & 1u); upd(pci, 4u, (nc >> 2) & 1u);
+                        upd(pci, 3u, nc & 3u); upd(pci, 5u, ((nc >> 1) & 2u) + (nc & 1u)); upd(pci, 6u, (nc >> 1) & 3u);
+                        upd(N[0], 3u, 2u ^ (c & 3u)); upd(N[0], 5u, ((nc >> 1) & 2u) + (c & 1u));
+                        upd(N[1], 3u, 1u ^ (c & 3u)); upd(N[1], 6u, 2u ^ ((c >> 1) & 3u));
+                        upd(N[3], 5u, ((c >> 1) & 2u) + (nc & 1u)); upd(N[3], 6u, 1u ^ ((c >> 1) & 3u));
+                    } else if (depthN == startDepth) {
+                        forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) {
+                            const int x = gx + dx, y = gy + dy, z = gz + dz;
+                            if (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) {
+                                const uint32_t at = (uint32_t)(z * G * G + y * G + x);
+                                subdividedMask |= (pl.isLeaf(at) || pl.isMarked(at)) ? 0u : pl.NM.m[4 * (dir - 1) + sign];
+                            }
+                        });
+                    }
+                    samplesMask = ~subdividedMask;
+                }
+                OpDev op{}; op.srcLevel = node.srcLevel; op.srcSlot = node.srcSlot;
+                if (cd >= depthN && samplesMask != 0xFFFFFFFFu) {
+                    op.kind = 0; op.samplesMask = samplesMask; op.recycle = (first && !node.ignore) ? 1u : 0u;
+                    const uint32_t childIndex = (uint32_t)pl.hoc.size();
+                    pl.setWord(word, (childIndex & INDEX_MASK) | MARK_BIT, sizeBefore);
+                    pl.marked.push_back(word);
+                    pl.hoc.resize(pl.hoc.size() + 8, LEAF_BIT);
+                    op.childPool = (uint32_t)pl.pool.size();
+                    for (uint32_t ch = 0; ch < 8; ch++) {
+                        PNode k{};
+                        k.path = (uint8_t)((node.path << 3) | ch); k.pci = childIndex; k.depth = depthN + 1; k.ignore = false;
+                        k.coord = (2u * (uint32_t)gx + (ch & 1u)) | ((2u * (uint32_t)gy + ((ch >> 1) & 1u)) << 10) | ((2u * (uint32_t)gz + (ch >> 2)) << 20);
+                        if (depthN == startDepth) { neighboursInGrid(ch, gx, gy, gz, G, k.nIdx); for (int q = 0; q < 6; q++) k.nDepth[q] = (uint8_t)depthN; }
+                        else neighboursVector(ch, c, node.pci, depthN, node.nIdx, node.nDepth, k.nIdx, k.nDepth);
+                        k.srcLevel = NONE32; k.srcSlot = (uint32_t)pl.pool.size();
+                        pl.pool.push_back(k);
+                        cache.push_back(k); genOf.push_back(gen + 1);
+                    }
+                    addOp(gen, op);
+                } else {
+                    op.kind = 1;
+                    uint32_t at = (uint32_t)pl.hoc.size();
+                    if (recycled) { pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); pl.hoc.resize(pl.hoc.size() + 64, 0u); }
+                    else { at = oldCoeffIndex; pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); recycled = true; }
+                    op.coeffIndex = at;
+                    addOp(gen, op);
+                    // the finalised node stays reachable for later post-passes (first registration of a key wins)
+                    node.ignore = true;
+                    if (node.srcLevel == NONE32) pl.pool[node.srcSlot] = node;      // its refreshed neighbour words travel with it
+                    const uint32_t key = node.pci + c;
+                    if (node.srcLevel == NONE32) pl.leaves.emplace(key, LeafRef{NONE32, node.srcSlot});
+                    else {
+                        // a level leaf re-finalised in place: the reference pushes an `ignore` copy that is only reachable if its
+                        // key was free; that happens at the start depth, where the key wraps to pci + childId
+                        if (pl.leaves.find(key) == pl.leaves.end()) {
+                            PNode copy = node; copy.srcLevel = node.srcLevel; copy.srcSlot = node.srcSlot;
+                            pl.pool.push_back(copy);
+                            pl.leaves.emplace(key, LeafRef{NONE32, (uint32_t)pl.pool.size() - 1});
+                        }
+                    }
+                }
+                first = false;
+            }
+        }
+        SDF_REQUIRE(pl.hoc.size() < (size_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
+        // ---------------- upload the integer result, then run the float part generation by generation
+        SDF_TRY(ensureOc(pl.hoc.size()));
+        if (pl.hoc.size() > sizeBefore)
+            SDF_HIP_CHECK(hipMemcpyAsync(oc.p + sizeBefore, pl.hoc.data() + sizeBefore, 4ull * (pl.hoc.size() - sizeBefore), hipMemcpyHostToDevice, st));
+        ocSize = (uint32_t)pl.hoc.size();
+        if (!pl.patches.empty()) {
+            std::vector<uint32_t> pi(pl.patches.size()), pv(pl.patches.size());
+            for (size_t k = 0; k < pl.patches.size(); k++) { pi[k] = pl.patches[k].first; pv[k] = pl.patches[k].second; }
+            DevBuf<uint32_t> dpi, dpv; SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
+            SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
+            SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
+            kc_patch<<<gridFor(pi.size(), 256), 256, 0, st>>>(dpi.p, dpv.p, (uint32_t)pi.size(), oc.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        SDF_TRY(ensurePool(pl.pool.size()));
+        LevelTable LT{};
+        for (uint32_t d = 0; d <= maxDepth && d < 12; d++) if (LV[d]) LT.lv[d] = LevelPtrs{LV[d]->center.p, LV[d]->vv.p, LV[d]->coeff.p, LV[d]->mid.p, LV[d]->half};
+        PoolDev PD{pCenter.p, pHalf.p, pVv.p};
+        for (size_t g = 0; g < gens.size(); g++) {
+            std::vector<OpDev>& ops = gens[g];
+            if (ops.empty()) continue;
+            for (size_t k = 0; k < ops.size(); k++) ops[k].scratch = (uint32_t)k;
+            DevBuf<OpDev> dops; DevBuf<float> scratch;
+            SDF_TRY(dops.reserve(ops.size())); SDF_TRY(scratch.reserve(216 * ops.size()));
+            SDF_HIP_CHECK(hipMemcpyAsync(dops.p, ops.data(), sizeof(OpDev) * ops.size(), hipMemcpyHostToDevice, st));
+            const uint32_t no = (uint32_t)ops.size();
+            kc_pp_fit<<<gridFor(no, 128), 128, 0, st>>>(dops.p, no, LT, PD, scratch.p, oc.p);
+            kc_pp_mid<<<gridFor(19ull * no, 128), 128, stackBytes, st>>>(md, dops.p, no, LT, PD, scratch.p, thr, sqThr);
+            kc_pp_children<<<gridFor(64ull * no, 256), 256, 0, st>>>(dops.p, no, LT, PD, scratch.p, pCenter.p, pHalf.p, pVv.p);
+            SDF_HIP_CHECK(hipGetLastError());
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            T->info.num_samples += 19ull * no;
+        }
+    }
+    // clear the mark bits (OctreeSdfBreadthFirstNoDelay.h:1191-1217)
+    if (!pl.marked.empty()) {
+        std::vector<uint32_t> pi(pl.marked), pv(pl.marked.size());
+        for (size_t k = 0; k < pi.size(); k++) { pl.hoc[pi[k]] &= ~MARK_BIT; pv[k] = pl.hoc[pi[k]]; }
+        DevBuf<uint32_t> dpi, dpv; SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
+        SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
+        kc_patch<<<gridFor(pi.size(), 256), 256, 0, st>>>(dpi.p, dpv.p, (uint32_t)pi.size(), oc.p);
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    // final statistics on the device
+    DevBuf<unsigned long long> lpd; SDF_TRY(lpd.reserve(16));
+    SDF_HIP_CHECK(hipMemsetAsync(lpd.p, 0, 128, st));
+    kc_final_walk<<<gridFor(G3, 64), 64, 0, st>>>(oc.p, G, startDepth, lpd.p, stats.p + 1);
+    unsigned long long hl[16]; uint32_t hs[2];
+    SDF_HIP_CHECK(hipMemcpyAsync(hl, lpd.p, 128, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hs, stats.p, 8, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    for (int d = 0; d < 16; d++) { T->info.leaves_per_depth[d] = hl[d]; T->info.num_leaves += hl[d]; }
+    memcpy(&T->info.value_range, &hs[0], 4);
+    { const uint32_t k = hs[1]; const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); T->info.min_border_value = (k == 0xFFFFFFFFu) ? INFINITY : f; }
+    T->info.num_words = ocSize; T->info.cell_end = G3; T->info.body_words = ocSize - G3; T->info.body_offset = G3;
+    T->info.fit_rechecks = numRescheduled;      // (re-used field: leaves scheduled for re-subdivision by Iter 2)
+    // shrink to fit
+    SDF_TRY(T->data.reserve(ocSize));
+    SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    T->hasData = true; T->built = true;
+    T->info.seconds_total = nowSeconds() - tStart;
+    *out = T.release();
+    return SDFHIP_OK;
+}
+
+}  // namespace sdfhip
