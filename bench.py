@@ -204,6 +204,14 @@ def extras(tree, mesh, box, pts, out, dev, rank):
     r["exact_octree_d7_min128"] = {"build_s": round(dt, 4), "nodes": int(i.num_nodes), "cull_tests": int(i.cull_tests), "max_triangles_in_leafs": int(i.max_triangles_in_leafs),
                                   "query_ms_2M": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1)}
     ex.close()
+    # CONTINUITY builder (SdfExporter's default) on the same mesh / depth
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ct = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ci = ct.info
+    ms = _time_ms(lambda: ct.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out))
+    r["continuity_octree"] = {"build_s": round(dt, 4), "words": int(ci.num_words), "leaves": int(ci.num_leaves), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
+    ct.close()
     return r
 
 

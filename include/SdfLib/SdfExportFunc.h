@@ -1,7 +1,7 @@
 // Handle-style C interface of the reference's Unity plugin (src/tools/SdfLibUnity/SdfExportFunc.h:16-58), implemented on
-// top of the C++ classes above.  Differences from the reference, on purpose: createOctreeSdf uses NO_CONTINUITY (the
-// CONTINUITY builder is not provided yet) and deleteSdf frees every format (the reference leaks OCTREE objects,
-// SdfExportFunc.cpp:170-182).  Include in exactly one translation unit of the plugin.
+// top of the C++ classes above.  createOctreeSdf uses the CONTINUITY builder like the reference (SdfExportFunc.cpp:84-113).
+// One difference, on purpose: deleteSdf frees every format (the reference leaks OCTREE objects, SdfExportFunc.cpp:170-182).
+// Include in exactly one translation unit of the plugin.
 #ifndef SDFLIB_EXPORT_FUNC_H
 #define SDFLIB_EXPORT_FUNC_H
 #include "OctreeSdf.h"
@@ -22,7 +22,7 @@ EXPORT sdflib::SdfFunction* createOctreeSdf(glm::vec3* vertices, uint32_t numVer
                                             uint32_t startOctreeDepth, uint32_t maxOctreeDepth, float maxError, uint32_t numThreads) {
     sdflib::Mesh mesh(vertices, numVertices, indices, numIndices);
     return new sdflib::OctreeSdf(mesh, sdflib::BoundingBox(glm::vec3(bbMinX, bbMinY, bbMinZ), glm::vec3(bbMaxX, bbMaxY, bbMaxZ)), maxOctreeDepth,
-                                 startOctreeDepth, maxError, sdflib::OctreeSdf::InitAlgorithm::NO_CONTINUITY, numThreads);
+                                 startOctreeDepth, maxError, sdflib::OctreeSdf::InitAlgorithm::CONTINUITY, numThreads);
 }
 EXPORT float getDistance(sdflib::SdfFunction* sdf, float x, float y, float z) { return sdf->getDistance(glm::vec3(x, y, z)); }
 EXPORT float getDistanceAndGradient(sdflib::SdfFunction* sdf, float x, float y, float z, glm::vec3* outGradient) { return sdf->getDistance(glm::vec3(x, y, z), *outGradient); }
