@@ -242,3 +242,36 @@ def test_sharded_build_through_rccl_world1(small):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rule,params", [(2, (1e-3, 0.0)), (3, (1e-3, 0.05)), (0, (1e-3, 0.0))])
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_other_termination_rules_match_oracle(small, oracle, rule, params, algorithm):
+    """SIMPSONS_RULE, BY_DISTANCE_RULE and NONE (OctreeSdfUtils.h:213-238, 87-138) through both builders."""
+    import sdflib_amd as S
+    depth, start = (4, 2) if rule == 0 else (5, 2)
+    oc = oracle.Octree(small["om"], small["box"], depth, start, params[0], rule=rule, param1=params[1], continuity=(algorithm == 2))
+    gt = S.OctreeSdf(small["gm"], small["box"], depth, start, init_algorithm=algorithm, termination_rule=rule, rule_params=params)
+    assert np.array_equal(oc.data(), gt.get_octree_data())
+    if rule == 0:
+        assert gt.info.num_leaves == 8 ** depth
+
+
+def test_edge_cases_and_error_codes(small, gpu_ctx):
+    import sdflib_amd as S
+    t = S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3)
+    # empty query batch, single query, queries far outside the box (box distance + min border value)
+    assert len(t.get_distance(np.zeros((0, 3), np.float32))) == 0
+    d = t.get_distance(np.array([[100.0, 0.0, 0.0]], np.float32))
+    assert 90 < d[0] < 110
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], small["box"], 3, 5, 1e-3)                       # start depth > depth
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, init_algorithm=S.ALG_UNIFORM)
+    with pytest.raises(S.SdfHipError):
+        S.Mesh(small["v"], np.array([[0, 1, 10 ** 6]], np.uint32), gpu_ctx)     # index out of range
+    with pytest.raises(S.SdfHipError):
+        S.ExactOctreeSdf(small["gm"], small["box"], 4, 3, 16)                   # start depth must be <= depth - 2
+    bad = small["box"].copy(); bad[3] = bad[0]
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], bad, 4, 2, 1e-3)                                # empty box
