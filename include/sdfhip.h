@@ -171,6 +171,10 @@ typedef struct sdfhip_exact_info {
 
 int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t max_depth,
                        uint32_t start_depth, uint32_t min_triangles_per_node, sdfhip_exact** out);
+/* Wrap existing arrays (e.g. read from a .bin file) for queries; everything is copied to the device.
+ * nodes: 2 u32 per node; triangle_data: 37 floats per triangle. */
+int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const uint32_t* nodes, const uint32_t* sets, const uint8_t* masks,
+                           const float* triangle_data, sdfhip_exact** out);
 int sdfhip_exact_destroy(sdfhip_exact* tree);
 int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
 /* nodes: 2 u32 per node {childrenIndex, trianglesArrayIndex}; node_has_tri_idx: 1 where the reference writes

@@ -192,6 +192,13 @@ class OctreeSdf:
     get_sample_area = get_grid_bounding_box
     def get_octree_max_depth(self): return self.info.max_depth
 
+    def save_to_file(self, path):
+        """SdfFunction::saveToFile (cereal PortableBinary layout, see sdflib_amd/serialization.py)."""
+        from . import serialization
+        i = self.info
+        serialization.save_octree(path, self.get_grid_bounding_box(), i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, self.get_octree_data())
+        return True
+
     def get_octree_data(self):
         """getOctreeData(): the flat u32 node array (host copy)."""
         out = np.empty(self.info.num_words, dtype=np.uint32)
@@ -235,6 +242,16 @@ class OctreeSdf:
         return (d, g) if gradient else d
 
 
+def load_from_file(path, ctx=None):
+    """SdfFunction::loadFromFile: returns an OctreeSdf or an ExactOctreeSdf living on the GPU."""
+    from . import serialization
+    ctx = ctx or default_context()
+    kind, d = serialization.load(path)
+    if kind == "octree":
+        return OctreeSdf.from_data(ctx, d["words"], d["box"][:3], d["box"][3:], d["start_grid_size"], d["max_depth"], d["value_range"], d["min_border_value"])
+    return ExactOctreeSdf.from_data(ctx, d)
+
+
 class OctreeShard:
     """One rank's part of a sharded OctreeSdf build (start-grid cells [cell_begin, cell_end))."""
 
@@ -273,7 +290,10 @@ class OctreeShard:
 class ExactOctreeSdf:
     """sdflib::ExactOctreeSdf(mesh, box, maxDepth, startDepth=1, minTrianglesPerNode=128) on the GPU."""
 
-    def __init__(self, mesh, box, max_depth, start_depth=1, min_triangles_per_node=128, num_threads=1):
+    def __init__(self, mesh=None, box=None, max_depth=None, start_depth=1, min_triangles_per_node=128, num_threads=1, _handle=None, _ctx=None):
+        if _handle is not None:
+            self.h, self.ctx = _handle, _ctx
+            return
         self.ctx = mesh.ctx
         box = _np(box, np.float32).reshape(6)
         bmin, bmax = box[:3].copy(), box[3:].copy()
@@ -287,6 +307,32 @@ class ExactOctreeSdf:
         i = ExactInfo()
         check(lib().sdfhip_exact_get_info(self.h, C.byref(i)))
         return i
+
+    @classmethod
+    def from_data(cls, ctx, d):
+        i = ExactInfo()
+        for k in range(3):
+            i.box_min[k] = d["box"][k]; i.box_max[k] = d["box"][3 + k]
+        for key in ("start_grid_size", "start_depth", "max_depth", "bit_encoding_start_depth", "bits_per_index", "min_triangles_in_leafs",
+                    "max_triangles_in_leafs", "max_triangles_encoded_in_leafs"):
+            setattr(i, key, int(d[key]))
+        nodes = _np(d["nodes"], np.uint32); sets = _np(d["sets"], np.uint32); masks = _np(d["masks"], np.uint8); td = _np(d["triangle_data"], np.float32)
+        i.num_nodes, i.num_set_words, i.num_mask_bytes, i.num_triangles = len(nodes), len(sets), len(masks), len(td)
+        if len(masks) == 0:
+            masks = np.zeros(1, np.uint8)
+        h = C.c_void_p()
+        check(lib().sdfhip_exact_from_data(ctx.h, C.byref(i), _ptr(nodes), _ptr(sets), _ptr(masks), _ptr(td), C.byref(h)))
+        return cls(_handle=h, _ctx=ctx)
+
+    def save_to_file(self, path, mesh):
+        """SdfFunction::saveToFile; `mesh` supplies the TriangleData block the reference stores in the file."""
+        from . import serialization
+        i = self.info
+        nodes, has, sets, masks = self.download()
+        info = {k: getattr(i, k) for k in ("start_grid_size", "start_depth", "min_triangles_in_leafs", "max_triangles_in_leafs",
+                                           "max_triangles_encoded_in_leafs", "bit_encoding_start_depth", "bits_per_index", "max_depth")}
+        serialization.save_exact(path, self.get_grid_bounding_box(), info, nodes, sets, masks, mesh.triangle_data())
+        return True
 
     def get_start_grid_size(self): return (self.info.start_grid_size,) * 3
     def get_grid_bounding_box(self): i = self.info; return np.array(list(i.box_min) + list(i.box_max), dtype=np.float32)

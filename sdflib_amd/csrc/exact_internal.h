@@ -26,7 +26,9 @@ struct ExLevel {
 
 struct sdfhip_exact {
     sdfhip_ctx* ctx = nullptr;
-    sdfhip_mesh* mesh = nullptr;           // TriangleData lives in the mesh; it must outlive the tree
+    sdfhip_mesh* mesh = nullptr;           // TriangleData lives in the mesh (it must outlive the tree) ...
+    sdfhip::DevBuf<float> ownTri;          // ... or in this buffer for trees created by sdfhip_exact_from_data
+    const float* tri() const { return ownTri.p ? ownTri.p : mesh->dTri.p; }
     sdfhip_exact_info info{};
     float cellSize = 0.f;
     sdfhip::DevBuf<uint32_t> nodes;        // 2 words per node

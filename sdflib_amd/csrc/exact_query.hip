@@ -7,6 +7,7 @@
 // streams the set through the mask chain with two running rank counters instead, so it needs no scratch at all.
 // Compile with -ffp-contract=off.
 #include "exact_internal.h"
+#include <memory>
 
 namespace sdfhip {
 
@@ -104,7 +105,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         if (out_grad) SDF_HIP_CHECK(hipMemsetAsync(dg.p, 0, 12 * n, st));
     }
     const sdfhip_exact_info& I = T->info;
-    ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->mesh->dTri.p, I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
+    ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
                 T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
     if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
     else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
@@ -115,6 +116,30 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         if (out_tri) SDF_HIP_CHECK(hipMemcpyAsync(out_tri, t, 4 * n, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
+    return SDFHIP_OK;
+}
+
+int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const uint32_t* nodes, const uint32_t* sets, const uint8_t* masks,
+                           const float* triangle_data, sdfhip_exact** out) {
+    SDF_REQUIRE(ctx && info && nodes && sets && masks && triangle_data && out, "NULL argument");
+    SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
+    SDF_REQUIRE(info->bits_per_index >= 1 && info->bits_per_index <= 32 && info->num_triangles >= 1, "bad header");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
+    E->ctx = ctx; E->info = *info;
+    E->cellSize = (info->box_max[0] - info->box_min[0]) / (float)info->start_grid_size;     // load(): mBox.getSize().x / mStartGridSize
+    SDF_TRY(E->nodes.reserve(2 * info->num_nodes)); SDF_TRY(E->hasTri.reserve(info->num_nodes));
+    SDF_TRY(E->sets.reserve(info->num_set_words + 2)); SDF_TRY(E->masks.reserve(info->num_mask_bytes + 1)); SDF_TRY(E->ownTri.reserve((size_t)TD_FLOATS * info->num_triangles));
+    SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 1, info->num_nodes, st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4 * (info->num_set_words + 2), st));
+    SDF_HIP_CHECK(hipMemcpyAsync(E->nodes.p, nodes, 8 * info->num_nodes, hipMemcpyHostToDevice, st));
+    if (info->num_set_words) SDF_HIP_CHECK(hipMemcpyAsync(E->sets.p, sets, 4 * info->num_set_words, hipMemcpyHostToDevice, st));
+    if (info->num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(E->masks.p, masks, info->num_mask_bytes, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(E->ownTri.p, triangle_data, sizeof(float) * TD_FLOATS * info->num_triangles, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    E->built = true;
+    *out = E.release();
     return SDFHIP_OK;
 }
 
