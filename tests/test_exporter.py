@@ -1,0 +1,50 @@
+"""Mesh readers (CPU) and the SdfExporter-compatible CLI (GPU)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+
+def test_mesh_readers_round_trip(tmp_path):
+    from sdflib_amd import meshio
+    from sdflib_amd.meshgen import bumpy_icosphere
+    v, f = bumpy_icosphere(1)
+    p = str(tmp_path / "m.ply")
+    meshio.write_ply(p, v, f)
+    v2, f2 = meshio.read_mesh(p)
+    assert np.array_equal(v, v2) and np.array_equal(f, f2)
+    obj = str(tmp_path / "m.obj")
+    with open(obj, "w") as fh:
+        for a in v:
+            fh.write(f"v {float(a[0])!r} {float(a[1])!r} {float(a[2])!r}\n")
+        fh.write("f 1/1/1 2/2/2 3/3/3 4/4/4\n")            # a quad: fan-triangulated like assimp's aiProcess_Triangulate
+        for t in f[2:]:
+            fh.write(f"f {t[0] + 1} {t[1] + 1} {t[2] + 1}\n")
+    v3, f3 = meshio.read_mesh(obj)
+    assert np.array_equal(v3, v) and len(f3) == len(f) and np.array_equal(f3[:2], [[0, 1, 2], [0, 2, 3]])
+    asc = str(tmp_path / "a.ply")
+    with open(asc, "w") as fh:
+        fh.write(f"ply\nformat ascii 1.0\nelement vertex {len(v)}\nproperty float x\nproperty float y\nproperty float z\nelement face {len(f)}\nproperty list uchar int vertex_indices\nend_header\n")
+        for a in v:
+            fh.write(f"{float(a[0])!r} {float(a[1])!r} {float(a[2])!r}\n")
+        for t in f:
+            fh.write(f"3 {t[0]} {t[1]} {t[2]}\n")
+    v4, f4 = meshio.read_mesh(asc)
+    assert np.array_equal(v4, v) and np.array_equal(f4, f)
+
+
+@pytest.mark.gpu
+def test_exporter_cli_matches_direct_build(tmp_path, gpu_ctx):
+    import sdflib_amd as S
+    from sdflib_amd import exporter, meshio
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    v, f = bumpy_icosphere(2)
+    ply = str(tmp_path / "m.ply"); out = str(tmp_path / "o.bin")
+    meshio.write_ply(ply, v, f)
+    assert exporter.main([ply, out, "-d", "5", "--start_depth", "2", "--algorithm", "continuity"]) == 0
+    t = S.load_from_file(out, gpu_ctx)
+    ref = S.OctreeSdf(S.Mesh(v, f, gpu_ctx), box_with_margin(v), 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=1)
+    assert np.array_equal(t.get_octree_data(), ref.get_octree_data())
+    assert exporter.main([ply, out, "--sdf_format", "exact_octree", "-d", "5", "--min_triangles_per_node", "16"]) == 0
+    e = S.load_from_file(out, gpu_ctx)
+    assert isinstance(e, S.ExactOctreeSdf) and e.info.max_depth == 5
