@@ -104,6 +104,18 @@ __global__ void k_vertex_normal_apply(const uint32_t* __restrict__ idx, uint32_t
     T[28 + 3 * k] = r.x; T[29 + 3 * k] = r.y; T[30 + 3 * k] = r.z;
 }
 
+__global__ void k_pack_frames(const float* __restrict__ td, uint32_t n, float* __restrict__ frames) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gid / 20u, k = gid - 20u * t;
+    if (t >= n) return;
+    frames[gid] = (k < 19u) ? td[(size_t)TD_FLOATS * t + k] : 0.f;
+}
+int packFrames(hipStream_t st, const float* td, uint32_t numTriangles, float* frames) {
+    k_pack_frames<<<gridFor(20ull * numTriangles, 256), 256, 0, st>>>(td, numTriangles, frames);
+    SDF_HIP_CHECK(hipGetLastError());
+    return SDFHIP_OK;
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -161,10 +173,11 @@ int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uin
     const uint32_t nhe = 3 * nt;
     int rc = SDFHIP_OK;
     auto fail = [&](int code) { delete m; return code; };
-    if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt))) return fail(rc);
+    if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt)) || (rc = m->dFrames.reserve((size_t)FRAME_FLOATS * nt))) return fail(rc);
     SDF_HIP_CHECK(hipMemcpyAsync(m->dVerts.p, xyz, sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(m->dIdx.p, indices, sizeof(uint32_t) * nhe, hipMemcpyHostToDevice, st));
     k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
+    if ((rc = packFrames(st, m->dTri.p, nt, m->dFrames.p))) return fail(rc);
 
     DevBuf<uint64_t> eKey, eKeyS; DevBuf<uint32_t> vKey, vKeyS, val, valS, valS2, counter; DevBuf<float> vnormal; DevBuf<unsigned char> tmp;
     if ((rc = eKey.reserve(nhe)) || (rc = eKeyS.reserve(nhe)) || (rc = vKey.reserve(nhe)) || (rc = vKeyS.reserve(nhe)) ||

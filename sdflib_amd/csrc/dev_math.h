@@ -74,6 +74,18 @@ SDF_HD void loadFrame(const float* __restrict__ td, TriFrame& f) {
     f.v2 = td[16]; f.v3 = F2{td[17], td[18]};
 }
 
+// Packed copy of the 19 frame floats (+1 pad) = 80 B = 5 aligned dwordx4 per triangle: what the brute-force distance
+// loops gather, instead of 19 scalar loads out of the 148-B TriangleData records.
+constexpr int FRAME_FLOATS = 20;
+SDF_DEV void loadFramePacked(const float* __restrict__ frames, uint32_t t, TriFrame& f) {
+    const float4* p = reinterpret_cast<const float4*>(frames) + 5 * (size_t)t;
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    f.origin = F3{a.x, a.y, a.z};
+    f.m[0] = a.w; f.m[1] = b.x; f.m[2] = b.y; f.m[3] = b.z; f.m[4] = b.w; f.m[5] = c.x; f.m[6] = c.y; f.m[7] = c.z; f.m[8] = c.w;
+    f.b = F2{d.x, d.y}; f.c = F2{d.z, d.w};
+    f.v2 = e.x; f.v3 = F2{e.y, e.z};
+}
+
 // Build the frame of a triangle (TriangleData ctor, TriangleUtils.h:23-42); writes td[0..18] and the default
 // pseudonormals (0,0,1) into td[19..36].
 SDF_HD void makeTriangleData(F3 p1, F3 p2, F3 p3, float* td) {

@@ -30,7 +30,7 @@ namespace sdfhip {
 constexpr uint32_t CHUNK = 1024;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-struct ExMesh { const float* verts; const uint32_t* idx; const float* td; };
+struct ExMesh { const float* verts; const uint32_t* idx; const float* td; const float* frames; };
 
 SDF_DEV F3 ldv(const float* __restrict__ v, uint32_t i) { return F3{v[3 * i], v[3 * i + 1], v[3 * i + 2]}; }
 
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(TPB) k_brute_nearest(ExMesh m, const float* __
     float best = INFINITY; uint32_t bestPos = NONE;
     for (uint32_t k = threadIdx.x; k < len; k += TPB) {
         const uint32_t t = list[off + k];
-        TriFrame f; loadFrame(m.td + (size_t)TD_FLOATS * t, f);
+        TriFrame f; loadFramePacked(m.frames, t, f);
         const float d = sqDistPointTriangle(p, f);
         if (d < best) { best = d; bestPos = k; }
     }
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_node_regions(ExMesh m, const float* __r
     if (node >= n) return;
     const int i = lane >> 3, c = lane & 7;
     const uint32_t t = cornerTri[8 * (size_t)node + i];
-    TriFrame f; loadFrame(m.td + (size_t)TD_FLOATS * t, f);
+    TriFrame f; loadFramePacked(m.frames, t, f);
     const F3 p = ldv(center, node) + cornerRel(c) * half;
     const float r = sqrtf(sqDistPointTriangle(p, f));
     // min over the 8 lanes of group i in ascending c with glm::min(a,b) = (b<a)?b:a semantics (order-independent for non-NaN)
@@ -469,7 +469,7 @@ int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3
     const uint32_t bitEnc = maxDepth - 2, bits = I.bits_per_index;
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     const uint32_t T = mesh->numTriangles;
-    ExMesh md{mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    ExMesh md{mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p, mesh->dFrames.p};
     ScanHelper scan; scan.st = st;
 
     DevBuf<uint32_t> stats;          // [0] maxLeaf, [1] maxEncoded

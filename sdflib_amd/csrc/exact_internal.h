@@ -28,7 +28,9 @@ struct sdfhip_exact {
     sdfhip_ctx* ctx = nullptr;
     sdfhip_mesh* mesh = nullptr;           // TriangleData lives in the mesh (it must outlive the tree) ...
     sdfhip::DevBuf<float> ownTri;          // ... or in this buffer for trees created by sdfhip_exact_from_data
+    sdfhip::DevBuf<float> ownFrames;
     const float* tri() const { return ownTri.p ? ownTri.p : mesh->dTri.p; }
+    const float* frames() const { return ownFrames.p ? ownFrames.p : mesh->dFrames.p; }
     sdfhip_exact_info info{};
     float cellSize = 0.f;
     sdfhip::DevBuf<uint32_t> nodes;        // 2 words per node

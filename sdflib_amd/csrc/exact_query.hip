@@ -12,7 +12,7 @@
 namespace sdfhip {
 
 struct ExactView {
-    const uint32_t* nodes; const uint32_t* sets; const uint8_t* masks; const float* td;
+    const uint32_t* nodes; const uint32_t* sets; const uint8_t* masks; const float* td; const float* frames;
     float bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, cellSize;
     int G; uint32_t startDepth, bitEnc, bits;
 };
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* _
             if (m2 && !maskBit(m2, k)) continue;
         }
         const uint32_t ti = unpackIndex(set + 1, t * v.bits, v.bits);
-        TriFrame fr; loadFrame(v.td + (size_t)TD_FLOATS * ti, fr);
+        TriFrame fr; loadFramePacked(v.frames, ti, fr);
         const float d = sqDistPointTriangle(p, fr);
         if (d < best) { best = d; bestTri = ti; }
     }
@@ -105,7 +105,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         if (out_grad) SDF_HIP_CHECK(hipMemsetAsync(dg.p, 0, 12 * n, st));
     }
     const sdfhip_exact_info& I = T->info;
-    ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
+    ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), T->frames(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
                 T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
     if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
     else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
@@ -137,6 +137,8 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     if (info->num_set_words) SDF_HIP_CHECK(hipMemcpyAsync(E->sets.p, sets, 4 * info->num_set_words, hipMemcpyHostToDevice, st));
     if (info->num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(E->masks.p, masks, info->num_mask_bytes, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(E->ownTri.p, triangle_data, sizeof(float) * TD_FLOATS * info->num_triangles, hipMemcpyHostToDevice, st));
+    SDF_TRY(E->ownFrames.reserve((size_t)FRAME_FLOATS * info->num_triangles));
+    SDF_TRY(packFrames(st, E->ownTri.p, (uint32_t)info->num_triangles, E->ownFrames.p));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     E->built = true;
     *out = E.release();

@@ -76,6 +76,7 @@ struct sdfhip_mesh {
     sdfhip::DevBuf<float> dVerts;         // 3 floats per vertex
     sdfhip::DevBuf<uint32_t> dIdx;        // 3 per triangle
     sdfhip::DevBuf<float> dTri;           // 37 floats per triangle (TriangleData)
+    sdfhip::DevBuf<float> dFrames;        // 20 floats per triangle: packed frame (dev_math.h loadFramePacked)
     // bounding-sphere BVH (fp64), 10 doubles per node: left sphere (c, r), right sphere (c, r), {left,right} ints, pad
     sdfhip::DevBuf<double> dBvh;
     uint64_t numBvhNodes = 0;
@@ -84,3 +85,4 @@ struct sdfhip_mesh {
 };
 
 int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh);
+namespace sdfhip { int packFrames(hipStream_t st, const float* td, uint32_t numTriangles, float* frames); }
