@@ -7,6 +7,7 @@
 // streams the set through the mask chain with two running rank counters instead, so it needs no scratch at all.
 // Compile with -ffp-contract=off.
 #include "exact_internal.h"
+#include <hipcub/hipcub.hpp>
 #include <memory>
 
 namespace sdfhip {
@@ -81,6 +82,135 @@ __global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* _
     if (tri) tri[i] = bestTri;
 }
 
+
+// ---- leaf-sorted, wave-cooperative path (large batches) ------------------------------------------------------------------
+// k_exact_locate walks every query down to its leaf and records (leaf id, set / mask positions); queries are then
+// radix-sorted by leaf id so that the queries of one leaf sit next to each other.  k_exact_sorted gives each wave 64
+// consecutive sorted queries: for every distinct leaf in them the wave decodes the leaf's triangle list ONCE (bit-packed
+// set filtered through the byte masks with __ballot/popcount ranks), stages the surviving triangles' 80-byte frames in LDS
+// (each triangle fetched once per wave instead of once per query lane) and all lanes of that leaf scan the staged tile
+// in list order — so the first-minimum rule of the reference is preserved.
+constexpr uint32_t QNONE = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
+                                                      uint32_t* __restrict__ tri, uint32_t* __restrict__ key, uint32_t* __restrict__ qidx, uint32_t* __restrict__ qctx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    qidx[i] = (uint32_t)i;
+    const F3 p = F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+    F3 f = F3{(p.x - v.bminx) / v.cellSize, (p.y - v.bminy) / v.cellSize, (p.z - v.bminz) / v.cellSize};
+    const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
+    const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
+    f = F3{f.x - flx, f.y - fly, f.z - flz};
+    if (ix < 0 || ix >= v.G || iy < 0 || iy >= v.G || iz < 0 || iz >= v.G) {
+        const F3 size = F3{v.bmaxx - v.bminx, v.bmaxy - v.bminy, v.bmaxz - v.bminz};
+        const F3 center = F3{v.bminx, v.bminy, v.bminz} + 0.5f * size;
+        const F3 d = p - center;
+        const F3 q = F3{fabsf(d.x), fabsf(d.y), fabsf(d.z)} - 0.5f * size;
+        const F3 qm = F3{gmax(q.x, 0.f), gmax(q.y, 0.f), gmax(q.z, 0.f)};
+        dist[i] = (length(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f)) + sqrtf(3.0f) * size.x;
+        if (tri) tri[i] = 0;
+        key[i] = QNONE;
+        return;
+    }
+    uint32_t node = (uint32_t)((iz * v.G + iy) * v.G + ix);
+    auto isLeaf = [&](uint32_t nd) { return (v.nodes[2 * (size_t)nd] & 0x80000000u) != 0u; };
+    auto descend = [&](uint32_t nd) {
+        const uint32_t c = ((f.z > 0.5f) ? 4u : 0u) + ((f.y > 0.5f) ? 2u : 0u) + ((f.x > 0.5f) ? 1u : 0u);
+        f = F3{gfract(2.0f * f.x), gfract(2.0f * f.y), gfract(2.0f * f.z)};
+        return (v.nodes[2 * (size_t)nd] & 0x7FFFFFFFu) + c;
+    };
+    uint32_t depth = v.startDepth;
+    while (!isLeaf(node) && depth < v.bitEnc) { node = descend(node); depth++; }
+    const uint32_t setIdx = v.nodes[2 * (size_t)node + 1];
+    uint32_t m1 = QNONE, m2 = QNONE;
+    if (!isLeaf(node)) {
+        node = descend(node); m1 = v.nodes[2 * (size_t)node + 1];
+        if (!isLeaf(node)) { node = descend(node); m2 = v.nodes[2 * (size_t)node + 1]; }
+    }
+    key[i] = node;
+    qctx[3 * i] = setIdx; qctx[3 * i + 1] = m1; qctx[3 * i + 2] = m2;
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_exact_sorted(ExactView v, const float* __restrict__ pts, uint64_t n, const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx,
+                                                      const uint32_t* __restrict__ qctx, float* __restrict__ dist, float* __restrict__ grad, uint32_t* __restrict__ tri) {
+    __shared__ float s_frames[4][64 * FRAME_FLOATS];
+    __shared__ uint32_t s_tri[4][64];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t myKey = QNONE, q = 0;
+    if (e < n) { myKey = skey[e]; q = sidx[e]; }
+    const bool active = myKey != QNONE;
+    F3 p = F3{0.f, 0.f, 0.f};
+    uint32_t cSet = 0, cM1 = QNONE, cM2 = QNONE;
+    if (active) { p = F3{pts[3 * (size_t)q], pts[3 * (size_t)q + 1], pts[3 * (size_t)q + 2]}; cSet = qctx[3 * (size_t)q]; cM1 = qctx[3 * (size_t)q + 1]; cM2 = qctx[3 * (size_t)q + 2]; }
+    bool done = !active;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (;;) {
+        const unsigned long long pending = __ballot(!done);
+        if (pending == 0ull) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const uint32_t k = __shfl(myKey, leader);
+        const bool inRun = !done && myKey == k;
+        const uint32_t setIdx = __shfl(cSet, leader), m1i = __shfl(cM1, leader), m2i = __shfl(cM2, leader);
+        const uint32_t* set = v.sets + setIdx;
+        const uint32_t cnt = set[0];
+        const uint8_t* m1 = (m1i != QNONE) ? v.masks + m1i : nullptr;
+        const uint8_t* m2 = (m2i != QNONE) ? v.masks + m2i : nullptr;
+        float best = INFINITY; uint32_t bestTri = 0;
+        uint32_t r1 = 0;
+        for (uint32_t base = 0; base < cnt; base += 64) {
+            const uint32_t t = base + (uint32_t)lane;
+            const bool valid = t < cnt;
+            const bool pass1 = valid && (m1 ? maskBit(m1, t) : true);
+            const unsigned long long b1 = __ballot(pass1);
+            const uint32_t k1 = r1 + (uint32_t)__popcll(b1 & ltMask);
+            const bool pass = pass1 && (m2 ? maskBit(m2, k1) : true);
+            r1 += (uint32_t)__popcll(b1);
+            const unsigned long long b = __ballot(pass);
+            const uint32_t nk = (uint32_t)__popcll(b);
+            if (nk == 0) continue;
+            if (pass) {
+                const uint32_t slot = (uint32_t)__popcll(b & ltMask);
+                const uint32_t ti = unpackIndex(set + 1, t * v.bits, v.bits);
+                s_tri[w][slot] = ti;
+                const float4* src = reinterpret_cast<const float4*>(v.frames) + 5 * (size_t)ti;
+                float4* dst = reinterpret_cast<float4*>(&s_frames[w][slot * FRAME_FLOATS]);
+#pragma unroll
+                for (int c = 0; c < 5; c++) dst[c] = src[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (inRun) {
+                for (uint32_t s = 0; s < nk; s++) {
+                    const float4* fp = reinterpret_cast<const float4*>(&s_frames[w][s * FRAME_FLOATS]);
+                    const float4 a = fp[0], bq = fp[1], c = fp[2], d4 = fp[3], e4 = fp[4];
+                    TriFrame fr;
+                    fr.origin = F3{a.x, a.y, a.z};
+                    fr.m[0] = a.w; fr.m[1] = bq.x; fr.m[2] = bq.y; fr.m[3] = bq.z; fr.m[4] = bq.w; fr.m[5] = c.x; fr.m[6] = c.y; fr.m[7] = c.z; fr.m[8] = c.w;
+                    fr.b = F2{d4.x, d4.y}; fr.c = F2{d4.z, d4.w}; fr.v2 = e4.x; fr.v3 = F2{e4.y, e4.z};
+                    const float d = sqDistPointTriangle(p, fr);
+                    if (d < best) { best = d; bestTri = s_tri[w][s]; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        if (inRun) {
+            if (GRAD) {
+                F3 g;
+                dist[q] = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, g);
+                grad[3 * (size_t)q] = g.x; grad[3 * (size_t)q + 1] = g.y; grad[3 * (size_t)q + 2] = g.z;
+            } else dist[q] = signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
+            if (tri) tri[q] = bestTri;
+            done = true;
+        }
+    }
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -107,8 +237,24 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     const sdfhip_exact_info& I = T->info;
     ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), T->frames(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
                 T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
-    if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
-    else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
+    if (n < 16384 || n > 0xFFFFFFF0ull) {
+        if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
+        else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
+    } else {
+        DevBuf<uint32_t> key, keyS, qi, qiS, qctx; DevBuf<unsigned char> tmp;
+        SDF_TRY(key.reserve(n)); SDF_TRY(keyS.reserve(n)); SDF_TRY(qi.reserve(n)); SDF_TRY(qiS.reserve(n)); SDF_TRY(qctx.reserve(3 * n));
+        k_exact_locate<<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t, key.p, qi.p, qctx.p);
+        int keyBits = 1; while (keyBits < 32 && (1ull << keyBits) <= T->info.num_nodes) keyBits++;
+        size_t tb = 0;
+        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, 32, st));
+        SDF_TRY(tmp.reserve(tb));
+        (void)keyBits;   // outside-the-grid queries carry key 0xFFFFFFFF: sort on all 32 bits so that they end up last
+        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, 32, st));
+        if (g) k_exact_sorted<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, g, t);
+        else k_exact_sorted<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, nullptr, t);
+        SDF_HIP_CHECK(hipGetLastError());
+        SDF_HIP_CHECK(hipStreamSynchronize(st));      // the scratch buffers above die with this scope
+    }
     SDF_HIP_CHECK(hipGetLastError());
     if (where == SDFHIP_HOST) {
         SDF_HIP_CHECK(hipMemcpyAsync(out_dist, d, 4 * n, hipMemcpyDeviceToHost, st));
