@@ -21,8 +21,11 @@ public:
     ExactOctreeSdf(const Mesh& mesh, BoundingBox box, uint32_t maxDepth, uint32_t startDepth = 1, uint32_t minTrianglesPerNode = 128, uint32_t numThreads = 1) {
         (void)numThreads;   // the GPU build always produces the single-thread (correct) array
         sdfhip_ctx* ctx = detail::defaultContext();
-        detail::check(sdfhip_mesh_create(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
-                                         mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3), &mMesh));
+        const BoundingBox& mb = mesh.getBoundingBox();     // only a computed box (file loader / computeBoundingBox) enables seam welding
+        const float mbox[6] = {mb.min.x, mb.min.y, mb.min.z, mb.max.x, mb.max.y, mb.max.z};
+        detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                            mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
+                                            (mb.min.x <= mb.max.x) ? mbox : nullptr, &mMesh));
         const float bmin[3] = {box.min.x, box.min.y, box.min.z}, bmax[3] = {box.max.x, box.max.y, box.max.z};
         detail::check(sdfhip_exact_build(ctx, mMesh, bmin, bmax, maxDepth, startDepth, minTrianglesPerNode, &mTree));
         detail::check(sdfhip_exact_get_info(mTree, &mInfo));

@@ -87,8 +87,11 @@ private:
                InitAlgorithm alg, uint32_t numThreads) {
         sdfhip_ctx* ctx = detail::defaultContext();
         sdfhip_mesh* m = nullptr;
-        detail::check(sdfhip_mesh_create(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
-                                         mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3), &m));
+        const BoundingBox& mb = mesh.getBoundingBox();     // only a computed box (file loader / computeBoundingBox) enables seam welding
+        const float mbox[6] = {mb.min.x, mb.min.y, mb.min.z, mb.max.x, mb.max.y, mb.max.z};
+        detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                            mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
+                                            (mb.min.x <= mb.max.x) ? mbox : nullptr, &m));
         sdfhip_octree_params p{};
         p.box_min[0] = box.min.x; p.box_min[1] = box.min.y; p.box_min[2] = box.min.z;
         p.box_max[0] = box.max.x; p.box_max[1] = box.max.y; p.box_max[2] = box.max.z;

@@ -8,6 +8,7 @@
  *
  * Reference interfaces replaced (file:line in /root/reference):
  *   sdfhip_mesh_create        <- sdflib::Mesh(vec3*, n, u32*, n)                 src/utils/Mesh.cpp:34-42
+ *   sdfhip_mesh_create_ex     <- sdflib::Mesh(path) + computeBoundingBox()       src/utils/Mesh.cpp:44-62, 90-106
  *                                + TriangleUtils::calculateMeshTriangleData       src/utils/TriangleUtils.cpp:7-428
  *                                + ICG(mesh) (tmd::TriangleMeshDistance BVH)      include/SdfLib/TrianglesInfluence.h:886-924
  *   sdfhip_mesh_nearest       <- ICG::getNearestTriangle                          include/SdfLib/TrianglesInfluence.h:898-905
@@ -87,7 +88,16 @@ void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
 /* ---- mesh: vertices (3 floats each), triangle indices (3 u32 each); host pointers, copied ------------- */
 int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
                        uint32_t num_triangles, sdfhip_mesh** out);
+/* Same, with the mesh bounding box [min xyz, max xyz] the reference's file loader computes (src/utils/Mesh.cpp:90-106).
+ * A non-NULL box enables the non-manifold seam welding of calculateMeshTriangleData (src/utils/TriangleUtils.cpp:292-420):
+ * coincident vertices of single-owner edges are merged (threshold 1e-5 / largest extent) and their edge / vertex
+ * pseudonormals summed.  The reference's raw-pointer Mesh constructor leaves the box at (+inf,-inf), i.e. no welding —
+ * that is sdfhip_mesh_create. */
+int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
+                          uint32_t num_triangles, const float* bbox6, sdfhip_mesh** out);
 int sdfhip_mesh_destroy(sdfhip_mesh* mesh);
+/* edges owned by one triangle before welding / half-edges re-paired by the welding (either pointer may be NULL) */
+int sdfhip_mesh_edge_stats(sdfhip_mesh* mesh, uint32_t* unmatched_edges, uint32_t* welded_half_edges);
 /* 37 floats (148 B) per triangle, field order of TriangleUtils::TriangleData (TriangleUtils.h:56-71) */
 int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host);
 /* build (host planner, fp64) + upload the bounding-sphere BVH; implicit on first use. seconds may be NULL */

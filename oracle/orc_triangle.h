@@ -10,14 +10,16 @@
 //   calculateMeshTriangleData (live branches)  src/utils/TriangleUtils.cpp:7-86, 422-427
 // The four point/triangle variants of the reference repeat the same 2-D Voronoi-region tests; here the
 // region is classified once (same comparisons, same operand order) and each variant switches on it.
-// Not restated: the degenerate-triangle branches (disabled in the reference by `if(false && ...)`,
-// TriangleUtils.cpp:45) and the non-manifold seam welding (TriangleUtils.cpp:292-420) — unmatched edges keep
-// the constructor's default edge normal (0,0,1), which is also what the reference leaves when welding fails.
+// Not restated: the degenerate-triangle branches (disabled in the reference by `if(false && ...)`, TriangleUtils.cpp:45).
+// The non-manifold seam welding (TriangleUtils.cpp:292-420) is restated and runs when a mesh bounding box is supplied:
+// the reference reads mesh.getBoundingBox(), which only the file loader computes — a Mesh built from raw pointers
+// (src/utils/Mesh.cpp:34-42) carries (+inf,-inf), which makes the welding threshold 0 and the pass a no-op.
 #pragma once
 #include "orc_math.h"
 #include <vector>
 #include <map>
 #include <utility>
+#include <algorithm>
 
 namespace orc {
 
@@ -192,8 +194,10 @@ static inline float sqDistPointTriangleRaw(V3 p, V3 a, V3 b, V3 c) {
 }
 
 // calculateMeshTriangleData, live branches only (see file header).
+struct MeshBox { V3 min, max; };
+
 static inline std::vector<TriangleData> meshTriangleData(const V3* vertices, uint32_t numVertices,
-                                                         const uint32_t* indices, uint32_t numTriangles) {
+                                                         const uint32_t* indices, uint32_t numTriangles, const MeshBox* meshBox = nullptr) {
     std::vector<TriangleData> tris(numTriangles);
     for (uint32_t t = 0; t < numTriangles; t++)
         tris[t] = makeTriangleData(vertices[indices[3 * t]], vertices[indices[3 * t + 1]], vertices[indices[3 * t + 2]]);
@@ -218,6 +222,61 @@ static inline std::vector<TriangleData> meshTriangleData(const V3* vertices, uin
             V3 add = angle * tris[t].normal();
             vertexNormal[a] = vertexNormal[a] + add;
         }
+    }
+    if (!openEdges.empty() && meshBox) {
+        // seam welding: vertices of single-owner edges that coincide (within 1e-5 / size) are merged, their edges re-paired
+        std::map<uint32_t, uint32_t> vmap;
+        auto parentOf = [&](uint32_t v) { auto it = vmap.find(v); while (it != vmap.end() && it->second != v) { v = it->second; it = vmap.find(v); } return v; };
+        std::vector<uint32_t> nm;
+        for (auto& e : openEdges) { nm.push_back(e.first.first); nm.push_back(e.first.second); }
+        std::sort(nm.begin(), nm.end()); nm.erase(std::unique(nm.begin(), nm.end()), nm.end());
+        const V3 bb = meshBox->max - meshBox->min; const V3 start = meshBox->min;
+        const uint32_t axisRes = 2048;
+        const float big = gmax(bb.x, gmax(bb.y, bb.z));
+        const float gridScale = (float)axisRes / big;
+        const float threshold = (float)(1e-5 / big);
+        const float sqThr = threshold * threshold;
+        std::map<uint64_t, std::vector<uint32_t>> set1, set2;
+        auto cellId = [axisRes](V3 q) -> uint64_t { const int x = (int)q.x, y = (int)q.y, z = (int)q.z; return (uint32_t)((uint32_t)x + (uint32_t)y * axisRes + (uint32_t)z * axisRes * axisRes); };
+        for (uint32_t v : nm) {
+            const V3 p = vertices[v];
+            set1[cellId((p - start) * gridScale)].push_back(v);
+            set2[cellId((p - start) * gridScale + 0.5f)].push_back(v);
+        }
+        std::map<uint64_t, std::vector<uint32_t>>* sets[2] = {&set1, &set2};
+        for (uint32_t v : nm) {
+            float offset = 0.0f;
+            for (auto* ps : sets) {
+                const V3 p = vertices[v];
+                auto it = ps->find(cellId((p - start) * gridScale + offset));
+                if (it != ps->end()) {
+                    for (uint32_t other : it->second) {
+                        const V3 d = p - vertices[other];
+                        if (dot(d, d) < sqThr) {
+                            const uint32_t p1 = parentOf(v), p2 = parentOf(other);
+                            if (v == p1) vmap[p1] = p1;
+                            vmap[p2] = p1;
+                            break;
+                        }
+                    }
+                }
+                offset += 0.5f;
+            }
+        }
+        std::map<std::pair<uint32_t, uint32_t>, uint32_t> repaired;
+        for (auto it = openEdges.begin(); it != openEdges.end(); ++it) {
+            const uint32_t a = parentOf(it->first.first), b = parentOf(it->first.second);
+            auto ins = repaired.insert(std::make_pair(std::make_pair(a < b ? a : b, a < b ? b : a), it->second));
+            if (!ins.second) {
+                const uint32_t t = it->second / 3, t2 = ins.first->second / 3;
+                V3 en = tris[t].normal() + tris[t2].normal();
+                tris[t].edgesNormal[it->second % 3] = mul(tris[t].transform, en);
+                tris[t2].edgesNormal[ins.first->second % 3] = mul(tris[t2].transform, en);
+                repaired.erase(ins.first);
+            }
+        }
+        for (uint32_t v : nm) { const uint32_t p = parentOf(v); if (p != v) vertexNormal[p] = vertexNormal[p] + vertexNormal[v]; }
+        for (uint32_t v : nm) vertexNormal[v] = vertexNormal[parentOf(v)];
     }
     for (uint32_t i = 0; i < 3 * numTriangles; i++)
         tris[i / 3].verticesNormal[i % 3] = mul(tris[i / 3].transform, vertexNormal[indices[i]]);

@@ -31,7 +31,7 @@ def lib():
         L = C.CDLL(so)
         vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int32
         sig = {
-            "orc_mesh_create": (vp, [vp, u32, vp, u32]), "orc_mesh_destroy": (None, [vp]),
+            "orc_mesh_create": (vp, [vp, u32, vp, u32]), "orc_mesh_create_ex": (vp, [vp, u32, vp, u32, vp]), "orc_mesh_destroy": (None, [vp]),
             "orc_mesh_triangle_data": (None, [vp, vp]), "orc_mesh_build_bvh": (C.c_double, [vp]),
             "orc_bvh_num_nodes": (u64, [vp]), "orc_bvh_export": (None, [vp, vp, vp]),
             "orc_bvh_nearest": (None, [vp, vp, u64, vp, vp]),
@@ -69,10 +69,11 @@ def _f32(a):
 
 
 class Mesh:
-    def __init__(self, vertices, triangles):
+    def __init__(self, vertices, triangles, bbox=None):
         self.v = _f32(vertices).reshape(-1, 3)
         self.f = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
-        self.h = lib().orc_mesh_create(_p(self.v), len(self.v), _p(self.f), len(self.f))
+        bb = _f32(bbox) if bbox is not None else None
+        self.h = lib().orc_mesh_create_ex(_p(self.v), len(self.v), _p(self.f), len(self.f), _p(bb))
 
     def __del__(self):
         if getattr(self, "h", None):

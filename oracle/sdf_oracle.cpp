@@ -27,14 +27,16 @@ static inline Box ldbox(const float* b) { return Box{ld3(b), ld3(b + 3)}; }
 
 extern "C" {
 
-orc_mesh* orc_mesh_create(const float* xyz, uint32_t nv, const uint32_t* idx, uint32_t nt) {
+orc_mesh* orc_mesh_create_ex(const float* xyz, uint32_t nv, const uint32_t* idx, uint32_t nt, const float* bbox6) {
     orc_mesh* m = new orc_mesh();
     m->vertices.resize(nv);
     std::memcpy(m->vertices.data(), xyz, sizeof(float) * 3 * (size_t)nv);
     m->indices.assign(idx, idx + 3 * (size_t)nt);
-    m->td = meshTriangleData(m->vertices.data(), nv, m->indices.data(), nt);
+    MeshBox mb; if (bbox6) { mb.min = ld3(bbox6); mb.max = ld3(bbox6 + 3); }
+    m->td = meshTriangleData(m->vertices.data(), nv, m->indices.data(), nt, bbox6 ? &mb : nullptr);
     return m;
 }
+orc_mesh* orc_mesh_create(const float* xyz, uint32_t nv, const uint32_t* idx, uint32_t nt) { return orc_mesh_create_ex(xyz, nv, idx, nt, nullptr); }
 void orc_mesh_destroy(orc_mesh* m) { delete m; }
 void orc_mesh_triangle_data(orc_mesh* m, float* out) { std::memcpy(out, m->td.data(), m->td.size() * sizeof(TriangleData)); }
 double orc_mesh_build_bvh(orc_mesh* m) {

@@ -14,6 +14,8 @@ typedef struct orc_octree orc_octree;
 typedef struct orc_exact orc_exact;
 
 orc_mesh* orc_mesh_create(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles);
+/* bbox6 (nullable) = the mesh bounding box the reference's file loader computes; enables the non-manifold seam welding */
+orc_mesh* orc_mesh_create_ex(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, const float* bbox6);
 void orc_mesh_destroy(orc_mesh*);
 void orc_mesh_triangle_data(orc_mesh*, float* out /* 37 floats per triangle */);
 double orc_mesh_build_bvh(orc_mesh*);  /* returns seconds */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "sdfhip_ctx_synchronize": (_int, [_vp]),
     "sdfhip_ctx_stream": (_vp, [_vp]),
     "sdfhip_mesh_create": (_int, [_vp, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
+    "sdfhip_mesh_create_ex": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(_vp)]),
+    "sdfhip_mesh_edge_stats": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "sdfhip_mesh_destroy": (_int, [_vp]),
     "sdfhip_mesh_triangle_data": (_int, [_vp, _vp]),
     "sdfhip_mesh_build_bvh": (_int, [_vp, C.POINTER(C.c_double)]),

@@ -76,13 +76,29 @@ def default_context(device=0):
 class Mesh:
     """sdflib::Mesh(vertices, indices) + the per-mesh acceleration data (TriangleData, sphere BVH) on the device."""
 
-    def __init__(self, vertices, indices, ctx=None):
+    def __init__(self, vertices, indices, ctx=None, bbox=None):
+        """bbox (6 floats, optional) = the box the reference's file loader computes; it switches on the non-manifold seam
+        welding (TriangleUtils.cpp:292-420).  None = the raw-pointer constructor's behaviour (no welding)."""
         self.ctx = ctx or default_context()
         self.vertices = _np(vertices, np.float32).reshape(-1, 3)
         self.indices = _np(indices, np.uint32).reshape(-1, 3)
+        self.bbox = None if bbox is None else _np(bbox, np.float32).reshape(6)
         h = C.c_void_p()
-        check(lib().sdfhip_mesh_create(self.ctx.h, _ptr(self.vertices), len(self.vertices), _ptr(self.indices), len(self.indices), C.byref(h)))
+        check(lib().sdfhip_mesh_create_ex(self.ctx.h, _ptr(self.vertices), len(self.vertices), _ptr(self.indices), len(self.indices),
+                                          None if self.bbox is None else _ptr(self.bbox), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def from_file(cls, path, ctx=None):
+        """sdflib::Mesh(path) (src/utils/Mesh.cpp:44-62): load + compute the bounding box (=> seam welding enabled)."""
+        from . import meshio
+        v, f = meshio.read_mesh(path)
+        return cls(v, f, ctx=ctx, bbox=np.concatenate([v.min(axis=0), v.max(axis=0)]))
+
+    def edge_stats(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib().sdfhip_mesh_edge_stats(self.h, C.byref(a), C.byref(b)))
+        return {"unmatched_edges": a.value, "welded_half_edges": b.value}
 
     def close(self):
         if getattr(self, "h", None):

@@ -7,12 +7,15 @@
 //                       are paired (1st,2nd),(3rd,4th)... exactly like the map's insert/erase sequence (:63-83)
 //   vertex pseudonormals: (vertex, 3t+k) pairs stable-sorted by vertex, then ONE lane sums a vertex's
 //                       contributions sequentially in ascending 3t+k — the reference's float addition order (:85-86)
-// Not reproduced: degenerate-triangle branches (dead in the reference: `if(false && ...)`, :45) and non-manifold
-// seam welding (:292-420); single-owner edges keep the default (0,0,1) and are counted in mesh->unmatchedEdges.
+// Not reproduced: degenerate-triangle branches (dead in the reference: `if(false && ...)`, :45).  Non-manifold
+// seam welding (:292-420) runs when sdfhip_mesh_create_ex is given the mesh bounding box (host planner weldSeams below);
+// otherwise single-owner edges keep the default (0,0,1).  They are counted in mesh->unmatchedEdges either way.
 #include "sdfhip_internal.h"
 #include "dev_math.h"
 #include <hipcub/hipcub.hpp>
 #include <string.h>
+#include <map>
+#include <algorithm>
 
 namespace sdfhip {
 
@@ -50,27 +53,39 @@ __global__ void k_halfedge_keys(const uint32_t* __restrict__ idx, uint32_t numHa
     value[i] = i;
 }
 
+__device__ inline void writeEdgeNormalPair(float* __restrict__ td, uint32_t later, uint32_t earlier) {
+    const uint32_t t = later / 3, t2 = earlier / 3;
+    const float* A = td + (size_t)TD_FLOATS * t;
+    const float* B = td + (size_t)TD_FLOATS * t2;
+    const F3 en = triNormal(A + 3) + triNormal(B + 3);
+    const F3 ea = mulM(A + 3, en), eb = mulM(B + 3, en);
+    float* da = td + (size_t)TD_FLOATS * t + 19 + 3 * (later % 3);
+    float* db = td + (size_t)TD_FLOATS * t2 + 19 + 3 * (earlier % 3);
+    da[0] = ea.x; da[1] = ea.y; da[2] = ea.z;
+    db[0] = eb.x; db[1] = eb.y; db[2] = eb.z;
+}
+
+// seam welding (TriangleUtils.cpp:392-411): half-edge pairs found by the host planner get their summed normal
+__global__ void k_weld_edges(const uint32_t* __restrict__ pairs, uint32_t n, float* __restrict__ td) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) writeEdgeNormalPair(td, pairs[2 * i], pairs[2 * i + 1]);
+}
+
 __global__ void k_edge_pair(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t n, float* __restrict__ td,
-                            uint32_t* __restrict__ unmatched) {
+                            uint32_t* __restrict__ unmatched, uint64_t* __restrict__ openKey, uint32_t* __restrict__ openHe) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = key[i];
     uint32_t r = 0;                              // position inside the run of equal keys
     while (r < i && key[i - 1 - r] == k) r++;
     if (r & 1u) {
-        const uint32_t later = val[i], earlier = val[i - 1];
-        const uint32_t t = later / 3, t2 = earlier / 3;
-        const float* A = td + (size_t)TD_FLOATS * t;
-        const float* B = td + (size_t)TD_FLOATS * t2;
-        const F3 en = triNormal(A + 3) + triNormal(B + 3);
-        const F3 ea = mulM(A + 3, en), eb = mulM(B + 3, en);
-        float* da = td + (size_t)TD_FLOATS * t + 19 + 3 * (later % 3);
-        float* db = td + (size_t)TD_FLOATS * t2 + 19 + 3 * (earlier % 3);
-        da[0] = ea.x; da[1] = ea.y; da[2] = ea.z;
-        db[0] = eb.x; db[1] = eb.y; db[2] = eb.z;
+        writeEdgeNormalPair(td, val[i], val[i - 1]);
     } else {
         const bool last = (i + 1 == n) || key[i + 1] != k;
-        if (last) atomicAdd(unmatched, 1u);      // odd run: this half-edge has no partner
+        if (last) {                              // odd run: this half-edge has no partner
+            const uint32_t slot = atomicAdd(unmatched, 1u);
+            if (openKey) { openKey[slot] = k; openHe[slot] = val[i]; }
+        }
     }
 }
 
@@ -114,6 +129,70 @@ int packFrames(hipStream_t st, const float* td, uint32_t numTriangles, float* fr
     k_pack_frames<<<gridFor(20ull * numTriangles, 256), 256, 0, st>>>(td, numTriangles, frames);
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
+}
+
+// Host planner of the non-manifold seam welding (reference: src/utils/TriangleUtils.cpp:292-420).  Integer/set logic and
+// the per-vertex normal merge run here (IEEE float adds, no contraction => same bits as the reference's loop); the
+// per-edge normal writes go back to the device (k_weld_edges).  `openKey` = (min vertex << 32 | max vertex) of every
+// single-owner edge, `openHe` its half-edge; `pairs` receives (later, earlier) half-edges whose edges coincide after welding.
+static void weldSeams(const float* verts, const float* bbox6, const std::vector<uint64_t>& openKey, const std::vector<uint32_t>& openHe,
+                      std::vector<uint32_t>& pairs, float* vnormal) {
+    std::vector<uint32_t> order(openKey.size());
+    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return openKey[a] < openKey[b]; });   // the reference's std::map order
+    std::map<uint32_t, uint32_t> parent;
+    auto parentOf = [&](uint32_t v) { auto it = parent.find(v); while (it != parent.end() && it->second != v) { v = it->second; it = parent.find(v); } return v; };
+    std::vector<uint32_t> seam;
+    for (uint64_t k : openKey) { seam.push_back((uint32_t)(k >> 32)); seam.push_back((uint32_t)k); }
+    std::sort(seam.begin(), seam.end()); seam.erase(std::unique(seam.begin(), seam.end()), seam.end());
+    const float sx = bbox6[3] - bbox6[0], sy = bbox6[4] - bbox6[1], sz = bbox6[5] - bbox6[2];
+    const uint32_t axisRes = 2048;
+    const float big = fmaxf(sx, fmaxf(sy, sz));
+    const float gridScale = (float)axisRes / big;
+    const float threshold = (float)(1e-5 / big);
+    const float sqThr = threshold * threshold;
+    auto cellOf = [&](uint32_t v, float offset) -> uint64_t {
+        const int x = (int)((verts[3 * v] - bbox6[0]) * gridScale + offset), y = (int)((verts[3 * v + 1] - bbox6[1]) * gridScale + offset),
+                  z = (int)((verts[3 * v + 2] - bbox6[2]) * gridScale + offset);
+        return (uint32_t)((uint32_t)x + (uint32_t)y * axisRes + (uint32_t)z * axisRes * axisRes);
+    };
+    std::map<uint64_t, std::vector<uint32_t>> grids[2];
+    // (p - start) * scale without the +0 keeps the reference's un-offset expression for the first grid
+    auto cell0 = [&](uint32_t v) -> uint64_t {
+        const int x = (int)((verts[3 * v] - bbox6[0]) * gridScale), y = (int)((verts[3 * v + 1] - bbox6[1]) * gridScale), z = (int)((verts[3 * v + 2] - bbox6[2]) * gridScale);
+        return (uint32_t)((uint32_t)x + (uint32_t)y * axisRes + (uint32_t)z * axisRes * axisRes);
+    };
+    for (uint32_t v : seam) { grids[0][cell0(v)].push_back(v); grids[1][cellOf(v, 0.5f)].push_back(v); }
+    for (uint32_t v : seam) {
+        float offset = 0.0f;
+        for (int g = 0; g < 2; g++) {
+            auto it = grids[g].find(cellOf(v, offset));
+            if (it != grids[g].end()) {
+                for (uint32_t other : it->second) {
+                    const float dx = verts[3 * v] - verts[3 * other], dy = verts[3 * v + 1] - verts[3 * other + 1], dz = verts[3 * v + 2] - verts[3 * other + 2];
+                    if (dx * dx + dy * dy + dz * dz < sqThr) {
+                        const uint32_t p1 = parentOf(v), p2 = parentOf(other);
+                        if (v == p1) parent[p1] = p1;
+                        parent[p2] = p1;
+                        break;
+                    }
+                }
+            }
+            offset += 0.5f;
+        }
+    }
+    std::map<uint64_t, uint32_t> repaired;
+    for (uint32_t i : order) {
+        const uint32_t a = parentOf((uint32_t)(openKey[i] >> 32)), b = parentOf((uint32_t)openKey[i]);
+        const uint64_t k = a < b ? ((uint64_t)a << 32 | b) : ((uint64_t)b << 32 | a);
+        auto ins = repaired.insert(std::make_pair(k, openHe[i]));
+        if (!ins.second) { pairs.push_back(openHe[i]); pairs.push_back(ins.first->second); repaired.erase(ins.first); }
+    }
+    for (uint32_t v : seam) {
+        const uint32_t p = parentOf(v);
+        if (p != v) { vnormal[3 * p] = vnormal[3 * p] + vnormal[3 * v]; vnormal[3 * p + 1] = vnormal[3 * p + 1] + vnormal[3 * v + 1]; vnormal[3 * p + 2] = vnormal[3 * p + 2] + vnormal[3 * v + 2]; }
+    }
+    for (uint32_t v : seam) { const uint32_t p = parentOf(v); vnormal[3 * v] = vnormal[3 * p]; vnormal[3 * v + 1] = vnormal[3 * p + 1]; vnormal[3 * v + 2] = vnormal[3 * p + 2]; }
 }
 
 }  // namespace sdfhip
@@ -160,6 +239,10 @@ int sdfhip_ctx_synchronize(sdfhip_ctx* ctx) {
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, sdfhip_mesh** out) {
+    return sdfhip_mesh_create_ex(ctx, xyz, nv, indices, nt, nullptr, out);
+}
+
+int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, const float* bbox6, sdfhip_mesh** out) {
     SDF_REQUIRE(ctx && xyz && indices && out, "NULL argument");
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
@@ -190,19 +273,49 @@ int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uin
     if ((rc = tmp.reserve(tb1 > tb2 ? tb1 : tb2))) return fail(rc);
     SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (int)nhe, 0, 64, st));
     SDF_HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), st));
-    k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p);
+    DevBuf<uint64_t> openKey; DevBuf<uint32_t> openHe;
+    if (bbox6 && ((rc = openKey.reserve(nhe)) || (rc = openHe.reserve(nhe)))) return fail(rc);
+    k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p, bbox6 ? openKey.p : nullptr, bbox6 ? openHe.p : nullptr);
     SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
     SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
     k_vertex_normal_sum<<<gridFor(nhe, 256), 256, 0, st>>>(vKeyS.p, valS2.p, nhe, m->dVerts.p, m->dIdx.p, m->dTri.p, vnormal.p);
-    k_vertex_normal_apply<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, vnormal.p, m->dTri.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(&m->unmatchedEdges, counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    if (bbox6 && m->unmatchedEdges > 0) {
+        const uint32_t no = m->unmatchedEdges;
+        std::vector<uint64_t> hKey(no); std::vector<uint32_t> hHe(no); std::vector<float> hVn(3ull * nv);
+        SDF_HIP_CHECK(hipMemcpyAsync(hKey.data(), openKey.p, sizeof(uint64_t) * no, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(hHe.data(), openHe.p, sizeof(uint32_t) * no, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(hVn.data(), vnormal.p, sizeof(float) * 3ull * nv, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        std::vector<uint32_t> pairs;
+        weldSeams(m->hVerts.data(), bbox6, hKey, hHe, pairs, hVn.data());
+        m->weldedEdges = (uint32_t)pairs.size();       // half-edges that found a partner = 2 per welded edge
+        if (!pairs.empty()) {
+            DevBuf<uint32_t> dPairs;
+            if ((rc = dPairs.reserve(pairs.size()))) return fail(rc);
+            SDF_HIP_CHECK(hipMemcpyAsync(dPairs.p, pairs.data(), sizeof(uint32_t) * pairs.size(), hipMemcpyHostToDevice, st));
+            k_weld_edges<<<gridFor(pairs.size() / 2, 256), 256, 0, st>>>(dPairs.p, (uint32_t)(pairs.size() / 2), m->dTri.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        SDF_HIP_CHECK(hipMemcpyAsync(vnormal.p, hVn.data(), sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
+    }
+    k_vertex_normal_apply<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, vnormal.p, m->dTri.p);
+    SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     *out = m;
     return SDFHIP_OK;
 }
 
 int sdfhip_mesh_destroy(sdfhip_mesh* mesh) { delete mesh; return SDFHIP_OK; }
+
+int sdfhip_mesh_edge_stats(sdfhip_mesh* mesh, uint32_t* unmatched_edges, uint32_t* welded_half_edges) {
+    SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
+    if (unmatched_edges) *unmatched_edges = mesh->unmatchedEdges;
+    if (welded_half_edges) *welded_half_edges = mesh->weldedEdges;
+    return SDFHIP_OK;
+}
 
 int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host) {
     SDF_REQUIRE(mesh && out_host, "NULL argument");

@@ -82,6 +82,7 @@ struct sdfhip_mesh {
     uint64_t numBvhNodes = 0;
     bool hasBvh = false;
     uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
+    uint32_t weldedEdges = 0;             // of those, half-edges re-paired by the seam welding
 };
 
 int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh);

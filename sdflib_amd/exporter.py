@@ -39,7 +39,7 @@ def main(argv=None):
     margin = np.float32(a.bb_margin / 100.0) * np.float32((hi - lo).max())
     box = np.concatenate([lo - margin, hi + margin]).astype(np.float32)
 
-    mesh = api.Mesh(v, f)
+    mesh = api.Mesh(v, f, bbox=np.concatenate([lo, hi]))   # loader-computed box => seam welding as in the reference tool
     t0 = time.perf_counter()
     if a.sdf_format == "octree":
         alg = {"uniform": api.ALG_UNIFORM, "no_continuity": api.ALG_NO_CONTINUITY, "continuity": api.ALG_CONTINUITY}.get(a.algorithm)

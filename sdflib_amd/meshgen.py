@@ -70,6 +70,14 @@ def cube_mesh():
     return v, f
 
 
+def triangle_soup(vertices, triangles):
+    """Every triangle gets private copies of its three vertices (what an STL-style export produces): all edges become
+    single-owner seams, which the reference's loader path re-pairs by position (TriangleUtils.cpp:292-420)."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32)[np.asarray(triangles).reshape(-1)]
+    f = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+    return v, f
+
+
 def box_with_margin(vertices, margin=0.2):
     """(min xyz, max xyz) float32[6]: mesh bbox grown by margin * largest extent on every side."""
     lo = vertices.min(axis=0).astype(np.float32)

@@ -275,3 +275,28 @@ def test_edge_cases_and_error_codes(small, gpu_ctx):
     bad = small["box"].copy(); bad[3] = bad[0]
     with pytest.raises(S.SdfHipError):
         S.OctreeSdf(small["gm"], bad, 4, 2, 1e-3)                                # empty box
+
+
+def test_seam_welding_matches_oracle(oracle, gpu_ctx):
+    """sdfhip_mesh_create_ex with the loader's box: welded TriangleData equals the oracle's (reference
+    TriangleUtils.cpp:292-420), and an octree built on the welded soup equals the oracle's."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, triangle_soup, box_with_margin
+    v, f = bumpy_icosphere(3)
+    sv, sf = triangle_soup(v, f)
+    bbox = np.concatenate([sv.min(axis=0), sv.max(axis=0)])
+    om, gm = oracle.Mesh(sv, sf, bbox), S.Mesh(sv, sf, gpu_ctx, bbox=bbox)
+    st = gm.edge_stats()
+    assert st["unmatched_edges"] == 3 * len(sf) and st["welded_half_edges"] == 3 * len(sf)
+    a, b = om.triangle_data(), gm.triangle_data()
+    assert np.array_equal(bits(a[:, :28]), bits(b[:, :28]))
+    np.testing.assert_allclose(a[:, 28:], b[:, 28:], rtol=0, atol=1e-5)
+    raw = S.Mesh(sv, sf, gpu_ctx)
+    assert raw.edge_stats() == {"unmatched_edges": 3 * len(sf), "welded_half_edges": 0}
+    assert np.array_equal(bits(raw.triangle_data()[:, :28]), bits(oracle.Mesh(sv, sf).triangle_data()[:, :28]))
+    box = box_with_margin(sv)
+    ot = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    go, oo = gt.get_octree_data(), ot.data()
+    assert go.shape == oo.shape
+    assert np.array_equal(go, oo)

@@ -231,3 +231,29 @@ def test_continuity_builder_reproduces_the_reference_probe_counts(oracle):
     assert len(on.data()) < len(data)
     pts = random_points_in_box(box, 20000, seed=8)
     assert np.abs(oc.query(pts) - on.query(pts)).max() < 1e-2
+
+
+def test_seam_welding_repairs_a_triangle_soup(oracle):
+    """calculateMeshTriangleData's non-manifold pass (TriangleUtils.cpp:292-420): with the loader's bounding box, a
+    soup of disconnected triangles gets the same edge pseudonormals as the indexed mesh and the same vertex
+    pseudonormals up to summation order; without the box (raw-pointer Mesh ctor) seams keep the default (0,0,1)."""
+    from sdflib_amd.meshgen import icosphere, triangle_soup
+    v, f = icosphere(2)
+    sv, sf = triangle_soup(v, f)
+    bbox = np.concatenate([sv.min(axis=0), sv.max(axis=0)])
+    ref = oracle.Mesh(v, f).triangle_data()
+    raw = oracle.Mesh(sv, sf).triangle_data()
+    welded = oracle.Mesh(sv, sf, bbox).triangle_data()
+    assert np.array_equal(raw[:, 19:28], np.tile(np.float32([0, 0, 1]), (len(f), 3)))
+    np.testing.assert_array_equal(welded[:, :19], ref[:, :19])
+    np.testing.assert_allclose(welded[:, 19:28], ref[:, 19:28], rtol=0, atol=1e-6)       # n1+n2 vs n2+n1 is exact; transform identical
+    np.testing.assert_allclose(welded[:, 28:], ref[:, 28:], rtol=0, atol=2e-6)
+    # signed distance through the welded data has the right sign everywhere around the sphere
+    m = oracle.Mesh(sv, sf, bbox)
+    rng = np.random.default_rng(5)
+    pts = ((rng.random((3000, 3), dtype=np.float32) * 2 - 1) * 1.3).astype(np.float32)
+    ids = m.nearest(pts)
+    sd = np.array([m.signed(ids[i], pts[i]) for i in range(len(pts))])
+    r = np.linalg.norm(pts, axis=1)
+    far = np.abs(r - 1.0) > 0.05
+    assert np.array_equal(np.sign(sd[far]), np.sign(r[far] - 1.0))
