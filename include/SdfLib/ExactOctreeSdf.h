@@ -3,8 +3,10 @@
 // the reference (mutable scratch, ExactOctreeSdf.h:178) queries are re-entrant.
 #ifndef SDFLIB_EXACT_OCTREE_SDF_H
 #define SDFLIB_EXACT_OCTREE_SDF_H
+#include <utility>
 #include <vector>
 #include "SdfFunction.h"
+#include "utils/TriangleUtils.h"
 
 namespace sdflib {
 class ExactOctreeSdf : public SdfFunction {
@@ -34,6 +36,15 @@ public:
     ~ExactOctreeSdf() override { if (mTree) sdfhip_exact_destroy(mTree); if (mMesh) sdfhip_mesh_destroy(mMesh); }
     ExactOctreeSdf(const ExactOctreeSdf&) = delete;
     ExactOctreeSdf& operator=(const ExactOctreeSdf&) = delete;
+    ExactOctreeSdf(ExactOctreeSdf&& o) noexcept { *this = std::move(o); }
+    ExactOctreeSdf& operator=(ExactOctreeSdf&& o) noexcept {
+        if (this != &o) {
+            if (mTree) sdfhip_exact_destroy(mTree);
+            if (mMesh) sdfhip_mesh_destroy(mMesh);
+            mTree = o.mTree; o.mTree = nullptr; mMesh = o.mMesh; o.mMesh = nullptr; mInfo = o.mInfo; mBox = o.mBox;
+        }
+        return *this;
+    }
 
     glm::ivec3 getStartGridSize() const { return glm::ivec3(mInfo.start_grid_size, mInfo.start_grid_size, mInfo.start_grid_size); }
     const BoundingBox& getGridBoundingBox() const { return mBox; }
@@ -48,12 +59,55 @@ public:
         detail::check(sdfhip_exact_download(mTree, reinterpret_cast<uint32_t*>(nodes.data()), has.data(), sets.data(), masks.data()));
         return nodes;
     }
+    // host copy of the per-triangle records (ExactOctreeSdf.h:132)
+    std::vector<TriangleUtils::TriangleData> getTrianglesData() const {
+        std::vector<TriangleUtils::TriangleData> td(mInfo.num_triangles);
+        detail::check(sdfhip_exact_triangle_data(mTree, reinterpret_cast<float*>(td.data())));
+        return td;
+    }
     float getDistance(glm::vec3 sample) const override { float d; getDistances(&sample, 1, &d); return d; }
     float getDistance(glm::vec3 sample, glm::vec3& outGradient) const override { float d; getDistances(&sample, 1, &d, &outGradient); return d; }
     void getDistances(const glm::vec3* samples, size_t n, float* outDistances, glm::vec3* outGradients = nullptr) const override {
         detail::check(sdfhip_exact_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), nullptr, SDFHIP_HOST));
     }
     sdfhip_exact* handle() const { return mTree; }
+
+    // archive body of include/SdfLib/ExactOctreeSdf.h:138-165: mBox, mStartGridSize, mStartDepth, mMinTrianglesInLeafs,
+    // mMaxTrianglesInLeafs, mMaxTrianglesEncodedInLeafs, mBitEncodingStartDepth, mBitsPerIndex, mMaxDepth, mOctreeData,
+    // mTrianglesSets, mTrianglesMasks, mTrianglesData
+    bool readPayload(std::istream& is) {
+        float box[6]; sdfhip_exact_info info{};
+        if (!detail::get(is, box) || !detail::get(is, info.start_grid_size) || !detail::get(is, info.start_depth) || !detail::get(is, info.min_triangles_in_leafs) ||
+            !detail::get(is, info.max_triangles_in_leafs) || !detail::get(is, info.max_triangles_encoded_in_leafs) || !detail::get(is, info.bit_encoding_start_depth) ||
+            !detail::get(is, info.bits_per_index) || !detail::get(is, info.max_depth)) return false;
+        std::vector<OctreeNode> nodes; std::vector<uint32_t> sets; std::vector<uint8_t> masks; std::vector<TriangleUtils::TriangleData> td;
+        if (!detail::getVec(is, nodes) || !detail::getVec(is, sets) || !detail::getVec(is, masks) || !detail::getVec(is, td)) return false;
+        for (int a = 0; a < 3; a++) { info.box_min[a] = box[a]; info.box_max[a] = box[3 + a]; }
+        info.num_nodes = nodes.size(); info.num_set_words = sets.size(); info.num_mask_bytes = masks.size(); info.num_triangles = td.size();
+        sets.push_back(0); masks.push_back(0);          // keep data() non-null for empty vectors
+        sdfhip_exact* t = nullptr;
+        detail::check(sdfhip_exact_from_data(detail::defaultContext(), &info, reinterpret_cast<const uint32_t*>(nodes.data()), sets.data(), masks.data(),
+                                             reinterpret_cast<const float*>(td.data()), &t));
+        if (mTree) sdfhip_exact_destroy(mTree);
+        if (mMesh) { sdfhip_mesh_destroy(mMesh); mMesh = nullptr; }
+        mTree = t;
+        detail::check(sdfhip_exact_get_info(mTree, &mInfo));
+        mBox = BoundingBox(glm::vec3(box[0], box[1], box[2]), glm::vec3(box[3], box[4], box[5]));
+        return true;
+    }
+
+protected:
+    void writePayload(std::ostream& os) const override {
+        std::vector<OctreeNode> nodes(mInfo.num_nodes); std::vector<uint8_t> has(mInfo.num_nodes), masks(mInfo.num_mask_bytes + 1); std::vector<uint32_t> sets(mInfo.num_set_words + 1);
+        detail::check(sdfhip_exact_download(mTree, reinterpret_cast<uint32_t*>(nodes.data()), has.data(), sets.data(), masks.data()));
+        const std::vector<TriangleUtils::TriangleData> td = getTrianglesData();
+        const float box[6] = {mBox.min.x, mBox.min.y, mBox.min.z, mBox.max.x, mBox.max.y, mBox.max.z};
+        detail::put(os, box); detail::put(os, (int32_t)mInfo.start_grid_size); detail::put(os, mInfo.start_depth); detail::put(os, mInfo.min_triangles_in_leafs);
+        detail::put(os, mInfo.max_triangles_in_leafs); detail::put(os, mInfo.max_triangles_encoded_in_leafs); detail::put(os, mInfo.bit_encoding_start_depth);
+        detail::put(os, mInfo.bits_per_index); detail::put(os, mInfo.max_depth);
+        detail::putVec(os, nodes.data(), (uint64_t)mInfo.num_nodes); detail::putVec(os, sets.data(), (uint64_t)mInfo.num_set_words);
+        detail::putVec(os, masks.data(), (uint64_t)mInfo.num_mask_bytes); detail::putVec(os, td.data(), (uint64_t)td.size());
+    }
 
 private:
     sdfhip_mesh* mMesh = nullptr;
@@ -62,4 +116,5 @@ private:
     BoundingBox mBox;
 };
 }  // namespace sdflib
+#include "SdfLoad.h"
 #endif

@@ -5,7 +5,10 @@
 #ifndef SDFLIB_OCTREE_SDF_H
 #define SDFLIB_OCTREE_SDF_H
 #include <array>
+#include <cmath>
+#include <cstring>
 #include <optional>
+#include <utility>
 #include <string>
 #include <vector>
 #include "SdfFunction.h"
@@ -82,6 +85,48 @@ public:
     }
     sdfhip_octree* handle() const { return mTree; }
 
+    // src/sdf/OctreeSdf.cpp:231-277: leaves per depth weighted by their volume fraction (8^-d of a start cell... of the root)
+    void getDepthDensity(std::vector<float>& depthsDensity) {
+        depthsDensity.resize(mMaxDepth + 1);
+        std::vector<uint32_t> leavesPerDepth(depthsDensity.size(), 0);
+        const uint32_t startDepth = (uint32_t)std::lround(std::log2((float)mStartGridSize));
+        std::vector<std::pair<uint32_t, uint32_t>> stack;       // (node index, depth); explicit stack instead of std::function recursion
+        for (uint32_t i = 0; i < (uint32_t)(mStartGridXY * mStartGridSize); i++) stack.emplace_back(i, startDepth);
+        while (!stack.empty()) {
+            const auto [idx, depth] = stack.back(); stack.pop_back();
+            OctreeNode& node = mOctreeData[idx];
+            node.childrenIndex &= ~OctreeNode::MARK_MASK;
+            if (node.isLeaf()) { if (depth < leavesPerDepth.size()) leavesPerDepth[depth]++; }
+            else for (uint32_t c = 0; c < 8; c++) stack.emplace_back(node.getChildrenIndex() + c, depth + 1);
+        }
+        float size = 1.0f;
+        for (size_t d = 0; d < depthsDensity.size(); d++) { depthsDensity[d] = size * (float)leavesPerDepth[d]; size *= 0.125f; }
+    }
+
+    // the archive body of include/SdfLib/OctreeSdf.h:222-238 (save: mBox, mStartGridSize, mMaxDepth, mValueRange, mMinBorderValue, mOctreeData)
+    bool readPayload(std::istream& is) {
+        float box[6]; int32_t grid = 0; uint32_t depth = 0; float vr = 0.f, mb = 0.f; std::vector<uint32_t> words;
+        if (!detail::get(is, box) || !detail::get(is, grid) || !detail::get(is, depth) || !detail::get(is, vr) || !detail::get(is, mb) || !detail::getVec(is, words)) return false;
+        if (grid < 1 || words.size() < (uint64_t)grid * grid * grid) return false;
+        sdfhip_octree* t = nullptr;
+        detail::check(sdfhip_octree_from_data(detail::defaultContext(), words.data(), words.size(), SDFHIP_HOST, box, box + 3, grid, depth, vr, mb, &t));
+        if (mTree) sdfhip_octree_destroy(mTree);
+        mTree = t;
+        mBox = BoundingBox(glm::vec3(box[0], box[1], box[2]), glm::vec3(box[3], box[4], box[5]));
+        mValueRange = vr; mMinBorderValue = mb; mStartGridSize = grid; mStartGridXY = grid * grid; mMaxDepth = depth;
+        mStartGridCellSize = (mBox.max.x - mBox.min.x) / static_cast<float>(mStartGridSize);      // load(): OctreeSdf.h:234-236
+        mOctreeData.resize(words.size());
+        std::memcpy(mOctreeData.data(), words.data(), words.size() * sizeof(uint32_t));
+        return true;
+    }
+
+protected:
+    void writePayload(std::ostream& os) const override {
+        const float box[6] = {mBox.min.x, mBox.min.y, mBox.min.z, mBox.max.x, mBox.max.y, mBox.max.z};
+        detail::put(os, box); detail::put(os, (int32_t)mStartGridSize); detail::put(os, (uint32_t)mMaxDepth); detail::put(os, mValueRange); detail::put(os, mMinBorderValue);
+        detail::putVec(os, reinterpret_cast<const uint32_t*>(mOctreeData.data()), (uint64_t)mOctreeData.size());
+    }
+
 private:
     void build(const Mesh& mesh, BoundingBox box, uint32_t depth, uint32_t startDepth, TerminationRule rule, TerminationRuleParams params,
                InitAlgorithm alg, uint32_t numThreads) {
@@ -156,4 +201,5 @@ private:
     std::vector<OctreeNode> mOctreeData;
 };
 }  // namespace sdflib
+#include "SdfLoad.h"
 #endif

@@ -10,6 +10,8 @@
 #define EXPORT extern "C" __attribute__((visibility("default")))
 #endif
 
+EXPORT void saveSdf(sdflib::SdfFunction* sdf, char* path) { sdf->saveToFile(std::string(path)); }
+EXPORT sdflib::SdfFunction* loadSdf(char* path) { return sdflib::SdfFunction::loadFromFile(std::string(path)).release(); }
 EXPORT sdflib::SdfFunction* createExactOctreeSdf(glm::vec3* vertices, uint32_t numVertices, uint32_t* indices, uint32_t numIndices,
                                                  float bbMinX, float bbMinY, float bbMinZ, float bbMaxX, float bbMaxY, float bbMaxZ,
                                                  uint32_t startOctreeDepth, uint32_t maxOctreeDepth, uint32_t minTrianglesPerNode, uint32_t numThreads) {

@@ -190,6 +190,8 @@ int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
 /* nodes: 2 u32 per node {childrenIndex, trianglesArrayIndex}; node_has_tri_idx: 1 where the reference writes
  * trianglesArrayIndex (it leaves the others uninitialised; here they are 0) */
 int sdfhip_exact_download(sdfhip_exact* tree, uint32_t* nodes, uint8_t* node_has_tri_idx, uint32_t* sets, uint8_t* masks);
+/* the TriangleData array the tree queries against (ExactOctreeSdf::getTrianglesData, ExactOctreeSdf.h:132); 37 floats each */
+int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host);
 int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad /* nullable */,
                        uint32_t* out_triangle /* nullable */, int where);
 

@@ -70,6 +70,7 @@ SIGNATURES = {
     "sdfhip_exact_destroy": (_int, [_vp]),
     "sdfhip_exact_get_info": (_int, [_vp, C.POINTER(ExactInfo)]),
     "sdfhip_exact_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdfhip_exact_triangle_data": (_int, [_vp, _vp]),
     "sdfhip_exact_query": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _int]),
     "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
     "sdfhip_is_near_minimize": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),

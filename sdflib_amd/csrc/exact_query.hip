@@ -291,4 +291,11 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     return SDFHIP_OK;
 }
 
+int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host) {
+    SDF_REQUIRE(tree && tree->built && out_host, "NULL argument or tree not built");
+    SDF_HIP_CHECK(hipMemcpyAsync(out_host, tree->tri(), sizeof(float) * TD_FLOATS * tree->info.num_triangles, hipMemcpyDeviceToHost, tree->ctx->stream));
+    SDF_HIP_CHECK(hipStreamSynchronize(tree->ctx->stream));
+    return SDFHIP_OK;
+}
+
 }  // extern "C"

@@ -36,5 +36,26 @@ int main(int argc, char** argv) {
     ex.getDistances(pts, n, de.data());
     std::printf("exact nodes %zu maxleaf %u d0 %.9g scalar %.9g\n", ex.getOctreeData().size(), ex.getMaxTrianglesInLeafs(), de[0], ex.getDistance(pts[0]));
     fo = std::fopen(argv[5], "wb"); std::fwrite(de.data(), 4, n, fo); std::fclose(fo);
-    return mism == 0 ? 0 : 1;
+
+    // saveToFile / loadFromFile round trip (argv[6], argv[7]) + getDepthDensity + getTrianglesData
+    size_t ioMism = 0;
+    if (argc >= 8) {
+        if (!oct.saveToFile(argv[6]) || !ex.saveToFile(argv[7])) { std::printf("save failed\n"); return 1; }
+        std::unique_ptr<sdflib::SdfFunction> lo = sdflib::SdfFunction::loadFromFile(argv[6]), le = sdflib::SdfFunction::loadFromFile(argv[7]);
+        if (!lo || !le || lo->getFormat() != sdflib::SdfFunction::OCTREE || le->getFormat() != sdflib::SdfFunction::EXACT_OCTREE) { std::printf("load failed\n"); return 1; }
+        std::vector<float> d2(n), e2(n); std::vector<glm::vec3> g2(n);
+        lo->getDistances(pts, n, d2.data(), g2.data());
+        le->getDistances(pts, n, e2.data());
+        for (size_t i = 0; i < n; i++) if (d2[i] != d[i] || g2[i].x != g[i].x || e2[i] != de[i] || lo->getDistance(pts[i]) != d[i]) ioMism++;
+        std::printf("reloaded-vs-built mismatches %zu\n", ioMism);
+        if (sdflib::SdfFunction::loadFromFile("/nonexistent/file.bin")) { std::printf("load of a missing file must fail\n"); return 1; }
+        std::vector<float> dens; oct.getDepthDensity(dens);
+        float total = 0.f; for (float v : dens) total += v;
+        std::printf("depth density levels %zu total %.9g\n", dens.size(), total * 1.0f);
+        const auto td = ex.getTrianglesData();
+        std::printf("triangles %zu normal0 %.9g %.9g %.9g\n", td.size(), td[0].getTriangleNormal().x, td[0].getTriangleNormal().y, td[0].getTriangleNormal().z);
+        sdflib::ExactOctreeSdf moved = std::move(ex);
+        std::printf("moved exact scalar %.9g\n", moved.getDistance(pts[0]));
+    }
+    return (mism == 0 && ioMism == 0) ? 0 : 1;
 }

@@ -37,9 +37,12 @@ def test_cpp_api_matches_oracle(tmp_path, oracle):
     pts[:50] *= 3.0
     p = lambda n: os.path.join(tmp_path, n)
     v.tofile(p("v.bin")); f.tofile(p("f.bin")); pts.tofile(p("p.bin"))
-    r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin")], capture_output=True, text=True)
+    r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin"), p("oct.bin"), p("exact.bin")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "mismatches 0" in r.stdout
+    assert "scalar-vs-batched mismatches 0" in r.stdout and "reloaded-vs-built mismatches 0" in r.stdout
+    # a start grid of 4^3 unit cells: the leaf volumes add up to 8^-startDepth * 64 = 1 (OctreeSdf.cpp:270-276 weights from depth 0)
+    total = float(r.stdout.split("depth density levels")[1].split("total")[1].split()[0])
+    assert abs(total - 1.0) < 1e-6
     om = oracle.Mesh(v, f)
     # the C++ test computes its box like SdfExporter: bbox + 20 % of the largest extent
     oc = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
@@ -48,3 +51,12 @@ def test_cpp_api_matches_oracle(tmp_path, oracle):
     ex = oracle.Exact(om, box, 5, 1, 16)
     e = np.fromfile(p("e.bin"), dtype=np.float32)
     assert np.array_equal(bits(e), bits(ex.query(pts)))
+    # the files the C++ classes wrote parse with the Python restatement of the format and hold the oracle's arrays
+    from sdflib_amd import serialization
+    kind, d_oct = serialization.load(p("oct.bin"))
+    assert kind == "octree" and np.array_equal(d_oct["words"], oc.data()) and d_oct["start_grid_size"] == 4 and d_oct["max_depth"] == 5
+    kind, d_ex = serialization.load(p("exact.bin"))
+    nodes, has, sets, masks = ex.data()
+    assert kind == "exact_octree" and np.array_equal(d_ex["sets"], sets) and np.array_equal(d_ex["masks"], masks)
+    assert np.array_equal(d_ex["nodes"][:, 0], nodes[:, 0]) and np.array_equal(d_ex["nodes"][has == 1, 1], nodes[has == 1, 1])
+    assert np.array_equal(bits(d_ex["triangle_data"][:, :28]), bits(om.triangle_data()[:, :28]))
