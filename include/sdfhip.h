@@ -185,6 +185,23 @@ int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3
  * nodes: 2 u32 per node; triangle_data: 37 floats per triangle. */
 int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const uint32_t* nodes, const uint32_t* sets, const uint8_t* masks,
                            const float* triangle_data, sdfhip_exact** out);
+/* Multi-GPU construction (one process per GPU), same decomposition as the reference's OpenMP loop over start cells
+ * (include/SdfLib/ExactOctreeSdfDepthFirst.h:534-622), with the three arrays laid out as its single-thread build does:
+ *   1. build_shard: levels above start_depth are computed by every rank; from start_depth on only the start cells whose position
+ *      in the reference's emission order (children 7..0 at every level) lies in [rank_begin, rank_end).  get_info then reports the
+ *      shard's LOCAL sizes: num_nodes = body nodes (start-grid slots not counted), num_set_words, num_mask_bytes.
+ *   2. host: exclusive prefix sums over ranks -> node_offset (= 8^start_depth + lower ranks' body nodes), set_offset, mask_offset.
+ *   3. emit_shard: writes the shard's start-grid slots (2 u32 per cell, in the order of shard_cells), body nodes, sets, masks with
+ *      ABSOLUTE indices.  4. host: all-gather, scatter the grid slots by cell id, concatenate the rest, sdfhip_exact_from_parts. */
+int sdfhip_exact_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t max_depth,
+                             uint32_t start_depth, uint32_t min_triangles_per_node, uint32_t rank_begin, uint32_t rank_end, sdfhip_exact** out);
+/* z-major ids (x fastest) of the shard's start cells, ascending; rank_end - rank_begin entries */
+int sdfhip_exact_shard_cells(sdfhip_exact* shard, uint32_t* out_cells);
+int sdfhip_exact_emit_shard(sdfhip_exact* shard, uint64_t node_offset, uint64_t set_offset, uint64_t mask_offset, uint32_t* dst_grid_nodes,
+                            uint8_t* dst_grid_has, uint32_t* dst_body_nodes, uint8_t* dst_body_has, uint32_t* dst_sets, uint8_t* dst_masks, int where);
+/* Wrap assembled arrays for queries; TriangleData stays in `mesh` (which must outlive the tree).  has may be NULL (all 1). */
+int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exact_info* info, const uint32_t* nodes, const uint8_t* node_has_tri_idx,
+                            const uint32_t* sets, const uint8_t* masks, int where, sdfhip_exact** out);
 int sdfhip_exact_destroy(sdfhip_exact* tree);
 int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
 /* nodes: 2 u32 per node {childrenIndex, trianglesArrayIndex}; node_has_tri_idx: 1 where the reference writes

@@ -6,7 +6,7 @@ point requires the built library and a HIP device.
 """
 from . import meshgen  # noqa: F401
 from ._lib import SdfHipError, lib, LIB_PATH  # noqa: F401
-from .api import (Context, Mesh, OctreeSdf, OctreeShard, ExactOctreeSdf, default_context, tricubic_fit, load_from_file,  # noqa: F401
+from .api import (Context, Mesh, OctreeSdf, OctreeShard, ExactShard, ExactOctreeSdf, default_context, tricubic_fit, load_from_file,  # noqa: F401
                   string_to_termination_rule, HOST, DEVICE, RULE_NONE, RULE_TRAPEZOIDAL, RULE_SIMPSONS, RULE_BY_DISTANCE,
                   ALG_UNIFORM, ALG_NO_CONTINUITY, ALG_CONTINUITY, LAYOUT_GLOBAL_DFS, LAYOUT_SUBTREES, EVAL_EXACT, EVAL_FAST,
                   FIT_EXACT, FIT_MFMA)

@@ -70,6 +70,10 @@ SIGNATURES = {
     "sdfhip_exact_destroy": (_int, [_vp]),
     "sdfhip_exact_get_info": (_int, [_vp, C.POINTER(ExactInfo)]),
     "sdfhip_exact_download": (_int, [_vp, _vp, _vp, _vp, _vp]),
+    "sdfhip_exact_build_shard": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, C.POINTER(_vp)]),
+    "sdfhip_exact_shard_cells": (_int, [_vp, _vp]),
+    "sdfhip_exact_emit_shard": (_int, [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _int]),
+    "sdfhip_exact_from_parts": (_int, [_vp, _vp, C.POINTER(ExactInfo), _vp, _vp, _vp, _vp, _int, C.POINTER(_vp)]),
     "sdfhip_exact_triangle_data": (_int, [_vp, _vp]),
     "sdfhip_exact_query": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _int]),
     "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),

@@ -303,6 +303,60 @@ class OctreeShard:
             pass
 
 
+class ExactShard:
+    """One rank's part of a multi-GPU ExactOctreeSdf build (sdfhip_exact_build_shard / emit_shard): the start cells whose
+    position in the reference's emission order lies in rank_range."""
+
+    def __init__(self, mesh, box, max_depth, start_depth, min_triangles_per_node, rank_range):
+        self.ctx, self.mesh = mesh.ctx, mesh
+        box = _np(box, np.float32).reshape(6)
+        bmin, bmax = box[:3].copy(), box[3:].copy()
+        h = C.c_void_p()
+        check(lib().sdfhip_exact_build_shard(self.ctx.h, mesh.h, _ptr(bmin), _ptr(bmax), int(max_depth), int(start_depth), int(min_triangles_per_node),
+                                             int(rank_range[0]), int(rank_range[1]), C.byref(h)))
+        self.h = h
+        self.num_cells = int(rank_range[1]) - int(rank_range[0])
+
+    @property
+    def info(self):
+        i = ExactInfo()
+        check(lib().sdfhip_exact_get_info(self.h, C.byref(i)))
+        return i
+
+    def cells(self):
+        out = np.zeros(self.num_cells, dtype=np.uint32)
+        check(lib().sdfhip_exact_shard_cells(self.h, _ptr(out)))
+        return out
+
+    def emit(self, node_offset, set_offset, mask_offset, device=None):
+        """Returns dict(grid_nodes[ncells,2], grid_has, body_nodes[n,2], body_has, sets, masks): numpy arrays, or torch tensors on
+        `device` (int32 / uint8) for the RCCL exchange."""
+        i = self.info
+        nb, ns, nm, nc = int(i.num_nodes), int(i.num_set_words), int(i.num_mask_bytes), self.num_cells
+        if device is None:
+            mk32 = lambda *shape: np.zeros(shape, dtype=np.uint32); mk8 = lambda n: np.zeros(n, dtype=np.uint8)
+            ptr, where = _ptr, HOST
+        else:
+            import torch
+            mk32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device); mk8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=device)
+            ptr, where = (lambda t: C.c_void_p(t.data_ptr())), DEVICE
+        out = dict(grid_nodes=mk32(nc, 2), grid_has=mk8(nc), body_nodes=mk32(max(nb, 1), 2), body_has=mk8(max(nb, 1)), sets=mk32(max(ns, 1)), masks=mk8(max(nm, 1)))
+        check(lib().sdfhip_exact_emit_shard(self.h, int(node_offset), int(set_offset), int(mask_offset), ptr(out["grid_nodes"]), ptr(out["grid_has"]),
+                                            ptr(out["body_nodes"]), ptr(out["body_has"]), ptr(out["sets"]), ptr(out["masks"]), where))
+        out["body_nodes"] = out["body_nodes"][:nb]; out["body_has"] = out["body_has"][:nb]; out["sets"] = out["sets"][:ns]; out["masks"] = out["masks"][:nm]
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sdfhip_exact_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ExactOctreeSdf:
     """sdflib::ExactOctreeSdf(mesh, box, maxDepth, startDepth=1, minTrianglesPerNode=128) on the GPU."""
 
@@ -339,6 +393,17 @@ class ExactOctreeSdf:
         h = C.c_void_p()
         check(lib().sdfhip_exact_from_data(ctx.h, C.byref(i), _ptr(nodes), _ptr(sets), _ptr(masks), _ptr(td), C.byref(h)))
         return cls(_handle=h, _ctx=ctx)
+
+    @classmethod
+    def from_parts(cls, mesh, info, nodes, has, sets, masks, where=HOST):
+        """Assembled arrays (e.g. after the sharded build's all-gather) + the mesh's TriangleData -> queryable tree.
+        Arrays are numpy (where=HOST) or torch device tensors (where=DEVICE); `info` is an ExactInfo with the totals."""
+        h = C.c_void_p()
+        ptr = (lambda a: None if a is None else _ptr(a)) if where == HOST else (lambda a: None if a is None else C.c_void_p(a.data_ptr()))
+        check(lib().sdfhip_exact_from_parts(mesh.ctx.h, mesh.h, C.byref(info), ptr(nodes), ptr(has), ptr(sets), ptr(masks), where, C.byref(h)))
+        t = cls(_handle=h, _ctx=mesh.ctx)
+        t._mesh = mesh              # TriangleData lives in the mesh
+        return t
 
     def save_to_file(self, path, mesh):
         """SdfFunction::saveToFile; `mesh` supplies the TriangleData block the reference stores in the file."""

@@ -240,6 +240,22 @@ __global__ void k_ex_to_cell_order(const float* __restrict__ center, const uint3
     }
 }
 
+// sharded build: keep only the start cells listed in `sel` (z-major cell ids, ascending)
+__global__ void k_ex_select_cells(const float* __restrict__ center, const uint32_t* __restrict__ coord, const uint32_t* __restrict__ cornerTri,
+                                  const uint32_t* __restrict__ pOff, const uint32_t* __restrict__ pLen, const uint32_t* __restrict__ sel, uint32_t nSel,
+                                  float* __restrict__ ocenter, uint32_t* __restrict__ ocoord, uint32_t* __restrict__ ocornerTri, uint32_t* __restrict__ opOff, uint32_t* __restrict__ opLen) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, j = gid & 7u;
+    if (i >= nSel) return;
+    const uint32_t s = sel[i];
+    ocornerTri[8 * (size_t)i + j] = cornerTri[8 * (size_t)s + j];
+    if (j == 0) {
+        ocenter[3 * (size_t)i] = center[3 * (size_t)s]; ocenter[3 * (size_t)i + 1] = center[3 * (size_t)s + 1]; ocenter[3 * (size_t)i + 2] = center[3 * (size_t)s + 2];
+        ocoord[i] = coord[s]; opOff[i] = pOff[s]; opLen[i] = pLen[s];
+    }
+}
+
+
 // ---- merge step ("second visit") ---------------------------------------------------------------------------------
 SDF_DEV bool sortedContains(const uint32_t* __restrict__ l, uint32_t len, uint32_t v) {
     uint32_t lo = 0, hi = len;
@@ -327,17 +343,21 @@ struct OffArgs {
     const uint32_t* pos; const uint32_t* blk; const uint32_t* setPos; const uint32_t* maskPos;
     const uint32_t* cNode; const uint32_t* cSet; const uint32_t* cMask;
     uint32_t* cpos; uint32_t* cblk; uint32_t* csetPos; uint32_t* cmaskPos; uint32_t* cmaskIdx;   // children outputs
-    uint32_t* nodes; uint8_t* hasTri;   // final node array (2 words per node)
+    // final node array (2 words per node).  `self*` receives the writes at `pos` (the node itself), `nodes/hasTri` the writes
+    // at blk+c (its children block).  Stored VALUES are absolute; buffer index = absolute position - bias, so a shard can
+    // emit its part of the array into local buffers (start level: self = the shard's start-grid slots, bias 0).
+    uint32_t* selfNodes; uint8_t* selfHas; uint32_t selfBias;
+    uint32_t* nodes; uint8_t* hasTri; uint32_t bodyBias;
 };
 __global__ void k_ex_offsets(OffArgs a) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid >> 3, c = gid & 7u;
     if (i >= a.n) return;
-    const uint32_t pos = a.pos[i];
+    const uint32_t pos = a.pos[i] - a.selfBias;
     if (a.flag[i]) {
         if (c == 0) {
-            a.nodes[2 * (size_t)pos] = 0xFFFFFFFFu;
-            if (a.depth <= a.bitEnc) { a.nodes[2 * (size_t)pos + 1] = a.setPos[i]; a.hasTri[pos] = 1; }
+            a.selfNodes[2 * (size_t)pos] = 0xFFFFFFFFu;
+            if (a.depth <= a.bitEnc) { a.selfNodes[2 * (size_t)pos + 1] = a.setPos[i]; a.selfHas[pos] = 1; }
         }
         return;
     }
@@ -350,15 +370,15 @@ __global__ void k_ex_offsets(OffArgs a) {
         const uint32_t nbytes = (a.uLen[i] + 7u) / 8u;
         const uint32_t own = a.maskPos[i] + allMask;                 // the node's own 8 masks follow its children's
         a.cmaskIdx[cb + c] = own + c * nbytes;
-        a.nodes[2 * (size_t)(blk + c) + 1] = own + c * nbytes; a.hasTri[blk + c] = 1;
+        a.nodes[2 * (size_t)(blk + c - a.bodyBias) + 1] = own + c * nbytes; a.hasTri[blk + c - a.bodyBias] = 1;
     }
     if (c == 0) {
-        a.nodes[2 * (size_t)pos] = blk & 0x7FFFFFFFu;
-        if (a.depth == a.bitEnc) { a.nodes[2 * (size_t)pos + 1] = a.setPos[i]; a.hasTri[pos] = 1; }
+        a.selfNodes[2 * (size_t)pos] = blk & 0x7FFFFFFFu;
+        if (a.depth == a.bitEnc) { a.selfNodes[2 * (size_t)pos + 1] = a.setPos[i]; a.selfHas[pos] = 1; }
     }
 }
 // bit-packed set of a node: [count][indices, `bits` each, MSB-first across words][spare]; one wave per node
-struct PackArgs { uint32_t n, depth, bitEnc, bits; const uint32_t* flag; const uint32_t* list; const uint32_t* ulist; const uint32_t* listOff; const uint32_t* listLen; const uint32_t* uLen; const uint32_t* setPos; uint32_t* sets; };
+struct PackArgs { uint32_t n, depth, bitEnc, bits; const uint32_t* flag; const uint32_t* list; const uint32_t* ulist; const uint32_t* listOff; const uint32_t* listLen; const uint32_t* uLen; const uint32_t* setPos; uint32_t* sets; uint32_t setBias; };
 __global__ void __launch_bounds__(256) k_ex_pack_sets(PackArgs a) {
     const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -367,7 +387,7 @@ __global__ void __launch_bounds__(256) k_ex_pack_sets(PackArgs a) {
     if (!((leaf && a.depth <= a.bitEnc) || (!leaf && a.depth == a.bitEnc))) return;
     const uint32_t* l = (leaf ? a.list : a.ulist) + a.listOff[node];
     const uint32_t cnt = leaf ? a.listLen[node] : a.uLen[node];
-    uint32_t* dst = a.sets + a.setPos[node];
+    uint32_t* dst = a.sets + (a.setPos[node] - a.setBias);
     if (lane == 0) dst[0] = cnt;
     const uint32_t inv = 32u - a.bits;
     for (uint32_t t = lane; t < cnt; t += 64) {
@@ -379,7 +399,7 @@ __global__ void __launch_bounds__(256) k_ex_pack_sets(PackArgs a) {
 }
 __global__ void __launch_bounds__(256) k_ex_copy_masks(uint32_t n, uint32_t depth, uint32_t bitEnc, const uint32_t* __restrict__ inner, const uint32_t* __restrict__ uLen,
                                                        const uint32_t* __restrict__ maskOff, const uint8_t* __restrict__ masks, const uint32_t* __restrict__ maskPos,
-                                                       const uint32_t* __restrict__ childBase, const uint32_t* __restrict__ cMask, uint8_t* __restrict__ out) {
+                                                       const uint32_t* __restrict__ childBase, const uint32_t* __restrict__ cMask, uint8_t* __restrict__ out, uint32_t maskBias) {
     const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (node >= n || !inner[node] || depth < bitEnc) return;
@@ -387,14 +407,14 @@ __global__ void __launch_bounds__(256) k_ex_copy_masks(uint32_t n, uint32_t dept
     for (uint32_t k = 0; k < 8; k++) allMask += cMask[childBase[node] + k];
     const uint32_t bytes = 8u * ((uLen[node] + 7u) / 8u);
     const uint8_t* src = masks + maskOff[node];
-    uint8_t* dst = out + maskPos[node] + allMask;
+    uint8_t* dst = out + (maskPos[node] + allMask - maskBias);
     for (uint32_t k = lane; k < bytes; k += 64) dst[k] = src[k];
 }
 __global__ void k_ex_init_cells(uint32_t nCells, const uint32_t* __restrict__ blkIn, const uint32_t* __restrict__ setIn, const uint32_t* __restrict__ maskIn,
                                 uint32_t* __restrict__ pos, uint32_t* __restrict__ blk, uint32_t* __restrict__ setPos, uint32_t* __restrict__ maskPos) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nCells) return;
-    pos[i] = i; blk[i] = blkIn[i]; setPos[i] = setIn[i]; maskPos[i] = maskIn[i];
+    pos[i] = i; blk[i] = blkIn[i]; setPos[i] = setIn[i]; maskPos[i] = maskIn[i];      // pos = slot in the (local) start-grid buffer
 }
 __global__ void k_fill_inner(uint32_t n, uint32_t* __restrict__ flag, uint32_t* __restrict__ inner, uint32_t* __restrict__ childBase) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -439,10 +459,50 @@ static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, u
 
 using namespace sdfhip;
 
-extern "C" {
+// Top-down pass: absolute positions of every node / set / mask block, then the payloads.  All pointers are device buffers
+// that the caller zeroed; grid* = the start-grid slots of this build (all cells, or the shard's cells in ascending z-major
+// order), body* = the nodes from absolute position nodeOff on, sets / masks from setOff / maskOff on.
+static int exactEmit(sdfhip_exact* E, uint32_t nodeOff, uint32_t setOff, uint32_t maskOff, uint32_t* gridNodes, uint8_t* gridHas,
+                     uint32_t* bodyNodes, uint8_t* bodyHas, uint32_t* sets, uint8_t* masks) {
+    hipStream_t st = E->ctx->stream;
+    const sdfhip_exact_info& I = E->info;
+    const uint32_t sod = E->sod, startDepth = I.start_depth, maxDepth = I.max_depth, bitEnc = I.bit_encoding_start_depth, bits = I.bits_per_index;
+    std::vector<std::unique_ptr<ExLevel>>& LV = E->levels;
+    ExLevel* S = LV[startDepth - sod].get();
+    const uint32_t nCells = S->n;
+    std::vector<uint32_t> oB(nCells), oS(nCells), oM(nCells);
+    for (uint32_t i = 0; i < nCells; i++) { oB[i] = nodeOff + E->relB[i]; oS[i] = setOff + E->relS[i]; oM[i] = maskOff + E->relM[i]; }
+    DevBuf<uint32_t> dB, dS, dM;
+    SDF_TRY(dB.reserve(nCells)); SDF_TRY(dS.reserve(nCells)); SDF_TRY(dM.reserve(nCells));
+    SDF_HIP_CHECK(hipMemcpyAsync(dB.p, oB.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dS.p, oS.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dM.p, oM.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
+    k_ex_init_cells<<<gridFor(nCells, 256), 256, 0, st>>>(nCells, dB.p, dS.p, dM.p, S->pos.p, S->blk.p, S->setPos.p, S->maskPos.p);
+    for (uint32_t d = startDepth; d <= maxDepth; d++) {
+        ExLevel* L = LV[d - sod].get();
+        if (!L || L->n == 0) break;
+        ExLevel* C = (d < maxDepth) ? LV[d + 1 - sod].get() : nullptr;
+        const bool top = d == startDepth;
+        OffArgs oa{L->n, d, bitEnc, L->flag.p, L->childBase.p, L->uLen.p, L->pos.p, L->blk.p, L->setPos.p, L->maskPos.p,
+                   C ? C->aNode.p : nullptr, C ? C->aSet.p : nullptr, C ? C->aMask.p : nullptr,
+                   C ? C->pos.p : nullptr, C ? C->blk.p : nullptr, C ? C->setPos.p : nullptr, C ? C->maskPos.p : nullptr, C ? C->maskIdx.p : nullptr,
+                   top ? gridNodes : bodyNodes, top ? gridHas : bodyHas, top ? 0u : nodeOff, bodyNodes, bodyHas, nodeOff};
+        k_ex_offsets<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(oa);
+        if (d <= bitEnc) {
+            PackArgs pa{L->n, d, bitEnc, bits, L->flag.p, L->list.p, L->ulist.p, L->listOff.p, L->listLen.p, L->uLen.p, L->setPos.p, sets, setOff};
+            k_ex_pack_sets<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(pa);
+        }
+        if (d >= bitEnc && C && L->numInner > 0)
+            k_ex_copy_masks<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(L->n, d, bitEnc, L->inner.p, L->uLen.p, L->maskOff.p, L->masks.p, L->maskPos.p, L->childBase.p, C->aMask.p, masks, maskOff);
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));      // dB/dS/dM go out of scope
+    return SDFHIP_OK;
+}
 
-int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
-                       uint32_t minTri, sdfhip_exact** out) {
+// rankRange (nullable) = [begin, end) of start cells in the reference's DFS emission order (dfsRank) built by this shard
+static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
+                          uint32_t minTri, const uint32_t* rankRange, sdfhip_exact** out) {
     SDF_REQUIRE(ctx && mesh && box_min && box_max && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
     SDF_REQUIRE(maxDepth >= 2 && maxDepth <= 10, "max_depth must be in [2,10]");
@@ -530,6 +590,25 @@ int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3
             LV[d - sod] = std::move(R);
             L = LV[d - sod].get();
         }
+        if (d == startDepth && rankRange) {      // sharded build: continue with this shard's start cells only (ascending z-major)
+            SDF_REQUIRE(L->n == G3, "internal: start level is not a full grid");
+            std::vector<uint32_t>& sel = E->shardCells;
+            for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++) {
+                const uint32_t r = dfsRank(x, y, z, startDepth);
+                if (r >= rankRange[0] && r < rankRange[1]) sel.push_back(z * G * G + y * G + x);
+            }
+            const uint32_t ns = (uint32_t)sel.size();
+            DevBuf<uint32_t> dSel; SDF_TRY(dSel.reserve(ns));
+            SDF_HIP_CHECK(hipMemcpyAsync(dSel.p, sel.data(), 4ull * ns, hipMemcpyHostToDevice, st));
+            std::unique_ptr<ExLevel> Q(new ExLevel());
+            Q->depth = d; Q->n = ns; Q->half = L->half;
+            SDF_TRY(Q->center.reserve(3ull * ns)); SDF_TRY(Q->coord.reserve(ns)); SDF_TRY(Q->cornerTri.reserve(8ull * ns)); SDF_TRY(Q->pOff.reserve(ns)); SDF_TRY(Q->pLen.reserve(ns));
+            k_ex_select_cells<<<gridFor(8ull * ns, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->cornerTri.p, L->pOff.p, L->pLen.p, dSel.p, ns,
+                                                                       Q->center.p, Q->coord.p, Q->cornerTri.p, Q->pOff.p, Q->pLen.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            LV[d - sod] = std::move(Q);
+            L = LV[d - sod].get();
+        }
         const uint32_t n = L->n;
         // ---- cull the parent lists into this level's lists
         DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp;
@@ -613,59 +692,101 @@ int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3
         cN = L->aNode.p; cS = L->aSet.p; cM = L->aMask.p;
     }
     SDF_HIP_CHECK(hipGetLastError());
-    // ---- cell offsets in the reference's single-thread DFS order
+    // ---- cell offsets (relative to the shard's first body node / set word / mask byte) in the reference's single-thread DFS order
     ExLevel* S = LV[startDepth - sod].get();
-    SDF_REQUIRE(S && S->n == G3, "internal: start level missing");
-    std::vector<uint32_t> hN(G3), hS(G3), hM(G3), oB(G3), oS(G3), oM(G3);
-    SDF_HIP_CHECK(hipMemcpyAsync(hN.data(), S->aNode.p, 4ull * G3, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(hS.data(), S->aSet.p, 4ull * G3, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(hM.data(), S->aMask.p, 4ull * G3, hipMemcpyDeviceToHost, st));
+    const uint32_t nCells = rankRange ? (uint32_t)E->shardCells.size() : G3;
+    SDF_REQUIRE(S && S->n == nCells, "internal: start level missing");
+    std::vector<uint32_t> hN(nCells), hS(nCells), hM(nCells);
+    SDF_HIP_CHECK(hipMemcpyAsync(hN.data(), S->aNode.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hS.data(), S->aSet.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hM.data(), S->aMask.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     {
-        std::vector<uint32_t> cellOfRank(G3);
+        std::vector<uint32_t> cellOfRank(G3), localOfCell(G3, 0xFFFFFFFFu);
         for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++) cellOfRank[dfsRank(x, y, z, startDepth)] = z * G * G + y * G + x;
-        uint64_t b = G3, s = 0, m = 0;
-        for (uint32_t r = 0; r < G3; r++) { const uint32_t c = cellOfRank[r]; oB[c] = (uint32_t)b; oS[c] = (uint32_t)s; oM[c] = (uint32_t)m; b += hN[c]; s += hS[c]; m += hM[c]; }
-        SDF_REQUIRE(b < (1ull << 31) && s < (1ull << 32) && m < (1ull << 32), "structure too large");
-        I.num_nodes = b; I.num_set_words = s; I.num_mask_bytes = m;
-    }
-    SDF_TRY(E->nodes.reserve(2 * I.num_nodes)); SDF_TRY(E->hasTri.reserve(I.num_nodes)); SDF_TRY(E->sets.reserve(I.num_set_words ? I.num_set_words : 1)); SDF_TRY(E->masks.reserve(I.num_mask_bytes ? I.num_mask_bytes : 1));
-    SDF_HIP_CHECK(hipMemsetAsync(E->nodes.p, 0, 8ull * I.num_nodes, st)); SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 0, I.num_nodes, st));
-    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4ull * (I.num_set_words ? I.num_set_words : 1), st));
-    SDF_HIP_CHECK(hipMemsetAsync(E->masks.p, 0, I.num_mask_bytes ? I.num_mask_bytes : 1, st));
-    DevBuf<uint32_t> dB, dS, dM;
-    SDF_TRY(dB.reserve(G3)); SDF_TRY(dS.reserve(G3)); SDF_TRY(dM.reserve(G3));
-    SDF_HIP_CHECK(hipMemcpyAsync(dB.p, oB.data(), 4ull * G3, hipMemcpyHostToDevice, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(dS.p, oS.data(), 4ull * G3, hipMemcpyHostToDevice, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(dM.p, oM.data(), 4ull * G3, hipMemcpyHostToDevice, st));
-    k_ex_init_cells<<<gridFor(G3, 256), 256, 0, st>>>(G3, dB.p, dS.p, dM.p, S->pos.p, S->blk.p, S->setPos.p, S->maskPos.p);
-    // ---- offsets top-down + payloads
-    for (uint32_t d = startDepth; d <= maxDepth; d++) {
-        ExLevel* L = LV[d - sod].get();
-        if (!L || L->n == 0) break;
-        ExLevel* C = (d < maxDepth) ? LV[d + 1 - sod].get() : nullptr;
-        OffArgs oa{L->n, d, bitEnc, L->flag.p, L->childBase.p, L->uLen.p, L->pos.p, L->blk.p, L->setPos.p, L->maskPos.p,
-                   C ? C->aNode.p : nullptr, C ? C->aSet.p : nullptr, C ? C->aMask.p : nullptr,
-                   C ? C->pos.p : nullptr, C ? C->blk.p : nullptr, C ? C->setPos.p : nullptr, C ? C->maskPos.p : nullptr, C ? C->maskIdx.p : nullptr,
-                   E->nodes.p, E->hasTri.p};
-        k_ex_offsets<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(oa);
-        if (d <= bitEnc) {
-            PackArgs pa{L->n, d, bitEnc, bits, L->flag.p, L->list.p, L->ulist.p, L->listOff.p, L->listLen.p, L->uLen.p, L->setPos.p, E->sets.p};
-            k_ex_pack_sets<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(pa);
+        if (rankRange) for (uint32_t i = 0; i < nCells; i++) localOfCell[E->shardCells[i]] = i;
+        else for (uint32_t i = 0; i < G3; i++) localOfCell[i] = i;
+        E->relB.assign(nCells, 0); E->relS.assign(nCells, 0); E->relM.assign(nCells, 0);
+        uint64_t bn = 0, sw = 0, mb = 0;
+        for (uint32_t r = rankRange ? rankRange[0] : 0u; r < (rankRange ? rankRange[1] : G3); r++) {
+            const uint32_t li = localOfCell[cellOfRank[r]];
+            E->relB[li] = (uint32_t)bn; E->relS[li] = (uint32_t)sw; E->relM[li] = (uint32_t)mb; bn += hN[li]; sw += hS[li]; mb += hM[li];
         }
-        if (d >= bitEnc && C && L->numInner > 0)
-            k_ex_copy_masks<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(L->n, d, bitEnc, L->inner.p, L->uLen.p, L->maskOff.p, L->masks.p, L->maskPos.p, L->childBase.p, C->aMask.p, E->masks.p);
+        SDF_REQUIRE(G3 + bn < (1ull << 31) && sw < (1ull << 32) && mb < (1ull << 32), "structure too large");
+        E->bodyNodes = bn;
+        I.num_nodes = rankRange ? bn : G3 + bn; I.num_set_words = sw; I.num_mask_bytes = mb;
     }
-    SDF_HIP_CHECK(hipGetLastError());
     uint32_t hstats[2]; unsigned long long hcull = 0;
     SDF_HIP_CHECK(hipMemcpyAsync(hstats, stats.p, 8, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipMemcpyAsync(&hcull, cullTests.p, 8, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     I.max_triangles_in_leafs = hstats[0]; I.max_triangles_encoded_in_leafs = hstats[1]; I.cull_tests = hcull;
+    E->sod = sod;
+    if (rankRange) {          // the shard keeps its levels until sdfhip_exact_emit_shard is told the absolute offsets
+        E->isShard = true;
+        I.seconds_total = nowSeconds() - tStart;
+        *out = E.release();
+        return SDFHIP_OK;
+    }
+    SDF_TRY(E->nodes.reserve(2 * I.num_nodes)); SDF_TRY(E->hasTri.reserve(I.num_nodes)); SDF_TRY(E->sets.reserve(I.num_set_words ? I.num_set_words : 1)); SDF_TRY(E->masks.reserve(I.num_mask_bytes ? I.num_mask_bytes : 1));
+    SDF_HIP_CHECK(hipMemsetAsync(E->nodes.p, 0, 8ull * I.num_nodes, st)); SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 0, I.num_nodes, st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4ull * (I.num_set_words ? I.num_set_words : 1), st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->masks.p, 0, I.num_mask_bytes ? I.num_mask_bytes : 1, st));
+    SDF_TRY(exactEmit(E.get(), G3, 0u, 0u, E->nodes.p, E->hasTri.p, E->nodes.p + 2ull * G3, E->hasTri.p + G3, E->sets.p, E->masks.p));
     E->levels.clear();
     E->built = true;
     I.seconds_total = nowSeconds() - tStart;
     *out = E.release();
+    return SDFHIP_OK;
+}
+
+extern "C" {
+
+int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
+                       uint32_t minTri, sdfhip_exact** out) {
+    return exactBuildImpl(ctx, mesh, box_min, box_max, maxDepth, startDepth, minTri, nullptr, out);
+}
+
+int sdfhip_exact_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
+                             uint32_t minTri, uint32_t rank_begin, uint32_t rank_end, sdfhip_exact** out) {
+    SDF_REQUIRE(startDepth <= 10 && rank_begin < rank_end && rank_end <= (1u << (3 * startDepth)), "cell rank range must be a non-empty sub-range of [0, 8^start_depth)");
+    const uint32_t range[2] = {rank_begin, rank_end};
+    return exactBuildImpl(ctx, mesh, box_min, box_max, maxDepth, startDepth, minTri, range, out);
+}
+
+int sdfhip_exact_shard_cells(sdfhip_exact* shard, uint32_t* out_cells) {
+    SDF_REQUIRE(shard && shard->isShard && out_cells, "not a shard");
+    memcpy(out_cells, shard->shardCells.data(), 4ull * shard->shardCells.size());
+    return SDFHIP_OK;
+}
+
+int sdfhip_exact_emit_shard(sdfhip_exact* E, uint64_t node_offset, uint64_t set_offset, uint64_t mask_offset, uint32_t* dst_grid_nodes, uint8_t* dst_grid_has,
+                            uint32_t* dst_body_nodes, uint8_t* dst_body_has, uint32_t* dst_sets, uint8_t* dst_masks, int where) {
+    SDF_REQUIRE(E && E->isShard && !E->levels.empty(), "not a shard, or already emitted");
+    SDF_REQUIRE(dst_grid_nodes && dst_grid_has && dst_body_nodes && dst_body_has && dst_sets && dst_masks, "NULL destination");
+    SDF_REQUIRE(node_offset + E->bodyNodes < (1ull << 31) && set_offset + E->info.num_set_words < (1ull << 32) && mask_offset + E->info.num_mask_bytes < (1ull << 32), "structure too large");
+    SDF_HIP_CHECK(hipSetDevice(E->ctx->device));
+    hipStream_t st = E->ctx->stream;
+    const uint64_t nc = E->shardCells.size(), bn = E->bodyNodes, sw = E->info.num_set_words, mb = E->info.num_mask_bytes;
+    DevBuf<uint32_t> tGrid, tBody, tSets; DevBuf<uint8_t> tGridHas, tBodyHas, tMasks;
+    uint32_t* gN = dst_grid_nodes; uint8_t* gH = dst_grid_has; uint32_t* bN = dst_body_nodes; uint8_t* bH = dst_body_has; uint32_t* sS = dst_sets; uint8_t* mM = dst_masks;
+    if (where == SDFHIP_HOST) {
+        SDF_TRY(tGrid.reserve(2 * nc)); SDF_TRY(tGridHas.reserve(nc)); SDF_TRY(tBody.reserve(2 * bn + 1)); SDF_TRY(tBodyHas.reserve(bn + 1)); SDF_TRY(tSets.reserve(sw + 1)); SDF_TRY(tMasks.reserve(mb + 1));
+        gN = tGrid.p; gH = tGridHas.p; bN = tBody.p; bH = tBodyHas.p; sS = tSets.p; mM = tMasks.p;
+    }
+    SDF_HIP_CHECK(hipMemsetAsync(gN, 0, 8 * nc, st)); SDF_HIP_CHECK(hipMemsetAsync(gH, 0, nc, st));
+    if (bn) { SDF_HIP_CHECK(hipMemsetAsync(bN, 0, 8 * bn, st)); SDF_HIP_CHECK(hipMemsetAsync(bH, 0, bn, st)); }
+    if (sw) SDF_HIP_CHECK(hipMemsetAsync(sS, 0, 4 * sw, st));
+    if (mb) SDF_HIP_CHECK(hipMemsetAsync(mM, 0, mb, st));
+    SDF_TRY(exactEmit(E, (uint32_t)node_offset, (uint32_t)set_offset, (uint32_t)mask_offset, gN, gH, bN, bH, sS, mM));
+    if (where == SDFHIP_HOST) {
+        SDF_HIP_CHECK(hipMemcpyAsync(dst_grid_nodes, gN, 8 * nc, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipMemcpyAsync(dst_grid_has, gH, nc, hipMemcpyDeviceToHost, st));
+        if (bn) { SDF_HIP_CHECK(hipMemcpyAsync(dst_body_nodes, bN, 8 * bn, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipMemcpyAsync(dst_body_has, bH, bn, hipMemcpyDeviceToHost, st)); }
+        if (sw) SDF_HIP_CHECK(hipMemcpyAsync(dst_sets, sS, 4 * sw, hipMemcpyDeviceToHost, st));
+        if (mb) SDF_HIP_CHECK(hipMemcpyAsync(dst_masks, mM, mb, hipMemcpyDeviceToHost, st));
+    }
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    E->levels.clear();
     return SDFHIP_OK;
 }
 

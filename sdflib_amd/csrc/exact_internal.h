@@ -39,4 +39,8 @@ struct sdfhip_exact {
     sdfhip::DevBuf<uint8_t> masks;
     std::vector<std::unique_ptr<sdfhip::ExLevel>> levels;
     bool built = false;
+    // emission plan: per start cell (local order) the offset of its body / sets / masks relative to the first one emitted
+    std::vector<uint32_t> relB, relS, relM; uint64_t bodyNodes = 0; uint32_t sod = 0;
+    // sharded build (sdfhip_exact_build_shard): the start cells of this shard (z-major ids, ascending); levels stay alive until emit
+    bool isShard = false; std::vector<uint32_t> shardCells;
 };

@@ -291,6 +291,32 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     return SDFHIP_OK;
 }
 
+int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exact_info* info, const uint32_t* nodes, const uint8_t* has, const uint32_t* sets,
+                            const uint8_t* masks, int where, sdfhip_exact** out) {
+    SDF_REQUIRE(ctx && mesh && info && nodes && sets && masks && out, "NULL argument");
+    SDF_REQUIRE(mesh->ctx == ctx && info->num_triangles == mesh->numTriangles, "mesh does not match the header");
+    SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
+    SDF_REQUIRE(info->bits_per_index >= 1 && info->bits_per_index <= 32, "bad header");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
+    E->ctx = ctx; E->mesh = mesh; E->info = *info;
+    E->cellSize = (info->box_max[0] - info->box_min[0]) / (float)info->start_grid_size;
+    SDF_TRY(E->nodes.reserve(2 * info->num_nodes)); SDF_TRY(E->hasTri.reserve(info->num_nodes));
+    SDF_TRY(E->sets.reserve(info->num_set_words + 2)); SDF_TRY(E->masks.reserve(info->num_mask_bytes + 1));
+    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4 * (info->num_set_words + 2), st));
+    SDF_HIP_CHECK(hipMemcpyAsync(E->nodes.p, nodes, 8 * info->num_nodes, kind, st));
+    if (has) SDF_HIP_CHECK(hipMemcpyAsync(E->hasTri.p, has, info->num_nodes, kind, st));
+    else SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 1, info->num_nodes, st));
+    if (info->num_set_words) SDF_HIP_CHECK(hipMemcpyAsync(E->sets.p, sets, 4 * info->num_set_words, kind, st));
+    if (info->num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(E->masks.p, masks, info->num_mask_bytes, kind, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    E->built = true;
+    *out = E.release();
+    return SDFHIP_OK;
+}
+
 int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host) {
     SDF_REQUIRE(tree && tree->built && out_host, "NULL argument or tree not built");
     SDF_HIP_CHECK(hipMemcpyAsync(out_host, tree->tri(), sizeof(float) * TD_FLOATS * tree->info.num_triangles, hipMemcpyDeviceToHost, tree->ctx->stream));

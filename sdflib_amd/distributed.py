@@ -1,4 +1,4 @@
-"""Sharded OctreeSdf construction: one process per GPU, start-grid cells partitioned across ranks.
+"""Sharded OctreeSdf / ExactOctreeSdf construction: one process per GPU, start-grid cells partitioned across ranks.
 
 The reference's own OpenMP decomposition makes every start-grid cell an independent sub-octree
 (src/sdf/OctreeSdfDepthFirst.h:433-503); here the cells are split into contiguous z-major ranges, every rank
@@ -121,5 +121,96 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
                                    float(stats[0].item()), float(-stats[1].item()), where=api.DEVICE)
     tree._override = {"leaves_per_depth": [int(x) for x in lpd.cpu().tolist()], "num_leaves": int(cnt[0]), "num_nodes": int(cnt[1]),
                       "num_samples": int(cnt[2])}
+    shard.close()
+    return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ExactOctreeSdf: same decomposition (include/SdfLib/ExactOctreeSdfDepthFirst.h:534-622), three arrays to concatenate.
+# Cells are partitioned in the reference's EMISSION order (children 7..0 at every level), so that the concatenation of the
+# ranks' bodies / sets / masks is exactly the single-thread build's layout; the start-grid slots are scattered by cell id.
+
+def exact_emission_rank(start_depth):
+    """rank[cell] for z-major cell ids (x fastest): position of the cell's subtree in the single-thread array."""
+    G = 1 << start_depth
+    z, y, x = np.meshgrid(np.arange(G), np.arange(G), np.arange(G), indexing="ij")
+    r = np.zeros_like(x)
+    for level in range(start_depth):
+        sh = start_depth - 1 - level
+        c = ((x >> sh) & 1) | (((y >> sh) & 1) << 1) | (((z >> sh) & 1) << 2)
+        r = r * 8 + (7 - c)
+    return r.reshape(-1)
+
+
+def assemble_exact(parts, num_cells):
+    """parts: per rank dict(cells, grid_nodes, grid_has, body_nodes, body_has, sets, masks) in rank order (numpy or torch, all the
+    same kind).  Returns (nodes[(num_cells + sum bodies), 2], has, sets, masks)."""
+    cat = np.concatenate if isinstance(parts[0]["sets"], np.ndarray) else __import__("torch").cat
+    first = parts[0]
+    if isinstance(first["sets"], np.ndarray):
+        grid = np.zeros((num_cells, 2), dtype=first["grid_nodes"].dtype); ghas = np.zeros(num_cells, dtype=np.uint8)
+        idx = lambda c: np.asarray(c, dtype=np.int64)
+    else:
+        import torch
+        grid = torch.zeros((num_cells, 2), dtype=first["grid_nodes"].dtype, device=first["grid_nodes"].device)
+        ghas = torch.zeros(num_cells, dtype=torch.uint8, device=grid.device)
+        idx = lambda c: torch.as_tensor(np.asarray(c, dtype=np.int64), device=grid.device)
+    for p in parts:
+        grid[idx(p["cells"])] = p["grid_nodes"]; ghas[idx(p["cells"])] = p["grid_has"]
+    nodes = cat([grid] + [p["body_nodes"] for p in parts]); has = cat([ghas] + [p["body_has"] for p in parts])
+    return nodes, has, cat([p["sets"] for p in parts]), cat([p["masks"] for p in parts])
+
+
+def exact_offsets(sizes, num_cells):
+    """sizes[r] = (body_nodes, set_words, mask_bytes) of every rank -> [(node_offset, set_offset, mask_offset)] per rank."""
+    out, n, s, m = [], num_cells, 0, 0
+    for bn, sw, mb in sizes:
+        out.append((n, s, m)); n += int(bn); s += int(sw); m += int(mb)
+    return out
+
+
+def _all_gather_padded(t, length, group):
+    """all-gather of 1-D / 2-D tensors whose first dimension differs per rank (lengths[r] known on every rank)."""
+    world = dist.get_world_size(group)
+    mx = max(int(max(length)), 1)
+    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device); pad[:t.shape[0]] = t
+    out = torch.empty((world * mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return [out[r * mx: r * mx + int(length[r])] for r in range(world)]
+
+
+def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_node, rank, world, dev, group=None):
+    """Sharded GPU build + one exchange.  Returns (ExactOctreeSdf holding the full arrays on this GPU, timing dict)."""
+    from . import api
+    num_cells = 8 ** start_depth
+    order = np.argsort(exact_emission_rank(start_depth), kind="stable")          # cell id at every emission rank
+    ranges = partition_cells(num_cells, world, cell_weights(mesh.vertices, box, start_depth)[order])
+    t0 = time.perf_counter()
+    shard = api.ExactShard(mesh, box, max_depth, start_depth, min_triangles_per_node, ranges[rank])
+    info = shard.info
+    t1 = time.perf_counter()
+    mine = torch.tensor([info.num_nodes, info.num_set_words, info.num_mask_bytes, info.max_triangles_in_leafs, info.max_triangles_encoded_in_leafs],
+                        dtype=torch.int64, device=dev)
+    meta = [torch.zeros(5, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(meta, mine, group=group)
+    meta = torch.stack(meta).cpu().numpy()
+    offs = exact_offsets(meta[:, :3], num_cells)
+    part = shard.emit(*offs[rank], device=dev)
+    ncell = [b - a for a, b in ranges]
+    gathered = {"grid_nodes": _all_gather_padded(part["grid_nodes"], ncell, group), "grid_has": _all_gather_padded(part["grid_has"], ncell, group),
+                "body_nodes": _all_gather_padded(part["body_nodes"], meta[:, 0], group), "body_has": _all_gather_padded(part["body_has"], meta[:, 0], group),
+                "sets": _all_gather_padded(part["sets"], meta[:, 1], group), "masks": _all_gather_padded(part["masks"], meta[:, 2], group)}
+    parts = []
+    for r in range(world):
+        cells = np.sort(order[ranges[r][0]:ranges[r][1]])                        # shard_cells() order: ascending z-major
+        parts.append(dict(cells=cells, **{k: v[r] for k, v in gathered.items()}))
+    nodes, has, sets, masks = assemble_exact(parts, num_cells)
+    full = api.ExactInfo.from_buffer_copy(info)
+    full.num_nodes, full.num_set_words, full.num_mask_bytes = int(nodes.shape[0]), int(sets.shape[0]), int(masks.shape[0])
+    full.max_triangles_in_leafs, full.max_triangles_encoded_in_leafs = int(meta[:, 3].max()), int(meta[:, 4].max())
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    tree = api.ExactOctreeSdf.from_parts(mesh, full, nodes.contiguous(), has.contiguous(), sets.contiguous() if len(sets) else torch.zeros(1, dtype=torch.int32, device=dev),
+                                         masks.contiguous() if len(masks) else torch.zeros(1, dtype=torch.uint8, device=dev), where=api.DEVICE)
     shard.close()
     return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1}

@@ -80,3 +80,68 @@ def test_two_rank_gloo_reassembly(tmp_path, oracle):
     np.save(os.path.join(tmp_path, "full.npy"), full)
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+# ---- ExactOctreeSdf: partition in emission order, three arrays + scattered start-grid slots --------------------------------
+
+def test_exact_emission_rank_is_the_dfs_order():
+    from sdflib_amd.distributed import exact_emission_rank
+    r = exact_emission_rank(2)                                   # 4^3 cells, z-major ids
+    assert sorted(r.tolist()) == list(range(64))
+    # the reference visits children 7..0: the first emitted cell is the (+x,+y,+z) corner, the last one the origin cell
+    assert r[63] == 0 and r[0] == 63
+    # one level: child c (bit0 = x) has rank 7 - c
+    assert exact_emission_rank(1).tolist() == [7, 6, 5, 4, 3, 2, 1, 0]
+    assert exact_emission_rank(0).tolist() == [0]
+
+
+def _fake_exact_parts(world, num_cells, seed=3):
+    """Synthetic shards with ragged sizes (one of them with empty masks) + the arrays a single build would hold."""
+    from sdflib_amd.distributed import exact_emission_rank
+    rng = np.random.default_rng(seed)
+    order = np.argsort(exact_emission_rank(int(round(np.log2(num_cells) / 3))), kind="stable")
+    ranges = partition_cells(num_cells, world)
+    parts = []
+    for r, (b, e) in enumerate(ranges):
+        nb, ns, nm = int(rng.integers(8, 200)) * 8, int(rng.integers(5, 300)), (0 if r == 0 else int(rng.integers(1, 500)))
+        parts.append(dict(cells=np.sort(order[b:e]), grid_nodes=rng.integers(0, 2**31, (e - b, 2)).astype(np.int32), grid_has=rng.integers(0, 2, e - b).astype(np.uint8),
+                          body_nodes=rng.integers(0, 2**31, (nb, 2)).astype(np.int32), body_has=rng.integers(0, 2, nb).astype(np.uint8),
+                          sets=rng.integers(0, 2**31, ns).astype(np.int32), masks=rng.integers(0, 256, nm).astype(np.uint8)))
+    grid = np.zeros((num_cells, 2), np.int32); ghas = np.zeros(num_cells, np.uint8)
+    for p in parts:
+        grid[p["cells"]] = p["grid_nodes"]; ghas[p["cells"]] = p["grid_has"]
+    expect = (np.concatenate([grid] + [p["body_nodes"] for p in parts]), np.concatenate([ghas] + [p["body_has"] for p in parts]),
+              np.concatenate([p["sets"] for p in parts]), np.concatenate([p["masks"] for p in parts]))
+    return ranges, parts, expect
+
+
+def test_exact_assembly_and_offsets():
+    from sdflib_amd.distributed import assemble_exact, exact_offsets
+    ranges, parts, expect = _fake_exact_parts(3, 64)
+    got = assemble_exact(parts, 64)
+    assert all(np.array_equal(a, b) for a, b in zip(got, expect))
+    sizes = [(len(p["body_nodes"]), len(p["sets"]), len(p["masks"])) for p in parts]
+    offs = exact_offsets(sizes, 64)
+    assert offs[0] == (64, 0, 0) and offs[2] == (64 + sizes[0][0] + sizes[1][0], sizes[0][1] + sizes[1][1], sizes[0][2] + sizes[1][2])
+
+
+def _exact_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from sdflib_amd.distributed import assemble_exact, _all_gather_padded
+    ranges, parts, expect = _fake_exact_parts(world, 64)
+    mine = {k: torch.from_numpy(v) for k, v in parts[rank].items() if k != "cells"}
+    lens = {"grid_nodes": [e - b for b, e in ranges], "grid_has": [e - b for b, e in ranges], "body_nodes": [len(p["body_nodes"]) for p in parts],
+            "body_has": [len(p["body_nodes"]) for p in parts], "sets": [len(p["sets"]) for p in parts], "masks": [len(p["masks"]) for p in parts]}
+    gathered = {k: _all_gather_padded(mine[k], lens[k], None) for k in mine}
+    got = assemble_exact([dict(cells=parts[r]["cells"], **{k: v[r] for k, v in gathered.items()}) for r in range(world)], 64)
+    for a, b in zip(got, expect):
+        assert np.array_equal(a.numpy(), b), f"rank {rank}: assembled ExactOctreeSdf arrays differ"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_exact_exchange():
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_exact_worker, args=(2, port), nprocs=2, join=True)

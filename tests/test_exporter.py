@@ -48,3 +48,39 @@ def test_exporter_cli_matches_direct_build(tmp_path, gpu_ctx):
     assert exporter.main([ply, out, "--sdf_format", "exact_octree", "-d", "5", "--min_triangles_per_node", "16"]) == 0
     e = S.load_from_file(out, gpu_ctx)
     assert isinstance(e, S.ExactOctreeSdf) and e.info.max_depth == 5
+
+
+SDF_ERROR_EXE = "/tmp/sdflib_amd_SdfError"
+
+
+def _compile_sdf_error():
+    import os, subprocess
+    from conftest import ROOT
+    libdir = os.path.join(ROOT, "sdflib_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "SdfError", "main.cpp"), "-L", libdir, "-lsdfhip", f"-Wl,-rpath,{libdir}", "-o", SDF_ERROR_EXE])
+
+
+def test_sdf_error_tool_compiles():
+    _compile_sdf_error()
+
+
+@pytest.mark.gpu
+def test_sdf_error_tool_reports_the_approximation_error(tmp_path):
+    """Exporter (Python) -> .bin files -> SdfError (C++ classes' loadFromFile + batched getDistances): the reference's
+    evaluation loop (src/tools/SdfError/main.cpp:44-95) end to end."""
+    import subprocess
+    from sdflib_amd import exporter, meshio
+    from sdflib_amd.meshgen import bumpy_icosphere
+    _compile_sdf_error()
+    v, f = bumpy_icosphere(3)
+    ply = str(tmp_path / "m.ply"); oct_bin = str(tmp_path / "oct.bin"); ex_bin = str(tmp_path / "ex.bin")
+    meshio.write_ply(ply, v, f)
+    assert exporter.main([ply, oct_bin, "-d", "6", "--start_depth", "2"]) == 0
+    assert exporter.main([ply, ex_bin, "--sdf_format", "exact_octree", "-d", "5", "--min_triangles_per_node", "32"]) == 0
+    r = subprocess.run([SDF_ERROR_EXE, oct_bin, ex_bin, "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    val = lambda key: float(r.stdout.split(key)[1].split()[0])
+    # threshold 1e-3 (RMS over a node): the reference reports max errors of ~5e-3..1e-2 at this setting (SURVEY 8c)
+    assert val("RMSE:") < 2e-3 and val("MAE:") < 1e-3 and val("Max error:") < 3e-2
+    assert val("Sdf us per query:") > 0 and val("Exact Sdf us per query:") > 0

@@ -133,3 +133,50 @@ def test_exact_full_size_properties(gpu_ctx):
             vals.append((two >> (64 - off - bits_per)) & ((1 << bits_per) - 1))
         vals = np.array(vals)
         assert (vals < len(f)).all() and (np.diff(vals) > 0).all()
+
+
+@pytest.mark.parametrize("depth,start,min_tri,cuts", [(5, 2, 16, (0, 20, 21, 64)), (6, 3, 32, (0, 100, 300, 512)), (5, 1, 16, (0, 3, 8)), (4, 0, 8, (0, 1))])
+def test_exact_shards_reassemble_to_the_single_build(small, depth, start, min_tri, cuts):
+    """sdfhip_exact_build_shard / emit_shard: shards over ranges of start cells (emission order), emitted at the offsets the
+    prefix sums give and assembled by sdflib_amd.distributed.assemble_exact, are bit-identical to the one-GPU build."""
+    import sdflib_amd as S
+    from sdflib_amd import distributed as sdist
+    full = S.ExactOctreeSdf(small["gm"], small["box"], depth, start, min_tri)
+    fn, fh, fs, fm = full.download()
+    shards = [S.ExactShard(small["gm"], small["box"], depth, start, min_tri, (a, b)) for a, b in zip(cuts, cuts[1:])]
+    sizes = [(s.info.num_nodes, s.info.num_set_words, s.info.num_mask_bytes) for s in shards]
+    offs = sdist.exact_offsets(sizes, 8 ** start)
+    order = np.argsort(sdist.exact_emission_rank(start), kind="stable")
+    parts = []
+    for s, o, (a, b) in zip(shards, offs, zip(cuts, cuts[1:])):
+        assert np.array_equal(s.cells(), np.sort(order[a:b]))
+        parts.append(dict(cells=s.cells(), **s.emit(*o)))
+    nodes, has, sets, masks = sdist.assemble_exact(parts, 8 ** start)
+    assert np.array_equal(nodes, fn) and np.array_equal(has, fh) and np.array_equal(sets, fs) and np.array_equal(masks, fm)
+    assert max(s.info.max_triangles_in_leafs for s in shards) == full.info.max_triangles_in_leafs
+    assert max(s.info.max_triangles_encoded_in_leafs for s in shards) == full.info.max_triangles_encoded_in_leafs
+
+
+def test_exact_sharded_build_through_rccl_world1(small):
+    """The N>1 path of the Exact build (shard -> all-gather over RCCL -> from_parts) with a 1-rank group, then queries."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import sdflib_amd as S
+    from sdflib_amd import distributed as sdist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29613")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0)); created = True
+    try:
+        dev = torch.device("cuda", 0)
+        tree, _ = sdist.build_exact_sharded(small["gm"], small["box"], 5, 2, 16, 0, 1, dev)
+        full = S.ExactOctreeSdf(small["gm"], small["box"], 5, 2, 16)
+        for a, b in zip(tree.download(), full.download()):
+            assert np.array_equal(a, b)
+        rng = np.random.default_rng(9)
+        pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.5).astype(np.float32)
+        assert np.array_equal(bits(tree.get_distance(pts)), bits(full.get_distance(pts)))
+    finally:
+        if created:
+            dist.destroy_process_group()
