@@ -104,6 +104,8 @@ int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host);
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds);
 /* nearest triangle id per point (fp64 BVH traversal on the device) */
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
+/* development probe: per query [triangle id, inner nodes entered, deferred children popped, triangles evaluated] */
+int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4);
 /* Hermite sample [d, gx, gy, gz, 0,0,0,0] at each point for a given triangle id
  * (TriCubicInterpolation::calculatePointValues, InterpolationMethods.h:273-290) */
 int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t* tri_ids, uint64_t n, float* out8, int where);
@@ -118,7 +120,7 @@ typedef struct sdfhip_octree_info {
     uint64_t num_words;             /* size of the full node array (u32 words) */
     uint64_t num_leaves;
     uint64_t num_nodes;             /* leaves + inner nodes from the start depth down */
-    uint64_t num_samples;           /* nearest-triangle queries issued by the build */
+    uint64_t num_samples;           /* nearest-triangle samples the reference would issue (8 per root corner set, 19 per evaluated node) */
     /* sharded builds: this shard's part of the array */
     uint32_t cell_begin, cell_end;  /* start-grid cells [begin, end) owned (z-major cell index) */
     uint64_t body_words;            /* words in this shard's bodies */
@@ -126,6 +128,7 @@ typedef struct sdfhip_octree_info {
     double seconds_samples, seconds_decide, seconds_total;
     uint64_t leaves_per_depth[16];  /* leaves at each depth (this shard) */
     uint64_t fit_rechecks;          /* FIT_MFMA: nodes whose decision was re-evaluated with the reference-ordered fit */
+    uint64_t num_traversals;        /* BVH traversals actually run (samples sharing a lattice point AND position bits share one) */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {

@@ -21,7 +21,8 @@ namespace sdfhip {
 
 struct HostBvhBuilder {
     const float* verts; const uint32_t* idx;
-    double* nodes;     // 10 doubles per node
+    double* sph;       // 8 doubles per inner node: spheres of the left and of the right child
+    int* kids;         // 2 ints per inner node: child references (>= 0 inner node, < 0 ~triangle)
     std::vector<int> order;
     int maxParallelDepth = 0;
 
@@ -29,21 +30,19 @@ struct HostBvhBuilder {
     D vtx(int t, int k) const { const uint32_t v = idx[3 * (size_t)t + k]; return D{(double)verts[3 * v], (double)verts[3 * v + 1], (double)verts[3 * v + 2]}; }
     static double comp(const D& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
-    // writes the sphere of range [begin,end) into sph[0..3] and plans node `nodeId`
-    void build(int nodeId, double* sph, int begin, int end, int depth) {
-        double* nd = nodes + (size_t)BVH_NODE_DOUBLES * nodeId;
+    // Plans the subtree over order[begin,end): writes its bounding sphere into out[0..3] and returns the reference to it.
+    // `innerId` = pre-order index this subtree's root gets if it is an inner node (n > 1).
+    int build(int innerId, double* out, int begin, int end, int depth) {
         const int n = end - begin;
         if (n == 1) {
             const int t = order[begin];
-            int lr[2] = {-1, t};
-            std::memcpy(nd + 8, lr, 8);
             const D a = vtx(t, 0), b = vtx(t, 1), c = vtx(t, 2);
             const D s = D{(a.x + b.x) + c.x, (a.y + b.y) + c.y, (a.z + b.z) + c.z};
             const D ce = D{s.x / 3.0, s.y / 3.0, s.z / 3.0};
             auto dist = [&](const D& p) { const double dx = p.x - ce.x, dy = p.y - ce.y, dz = p.z - ce.z; return std::sqrt(dx * dx + dy * dy + dz * dz); };
-            sph[0] = ce.x; sph[1] = ce.y; sph[2] = ce.z;
-            sph[3] = std::max(std::max(dist(a), dist(b)), dist(c));
-            return;
+            out[0] = ce.x; out[1] = ce.y; out[2] = ce.z;
+            out[3] = std::max(std::max(dist(a), dist(b)), dist(c));
+            return ~t;
         }
         const double lo = std::numeric_limits<double>::lowest(), hi = std::numeric_limits<double>::max();
         D top{lo, lo, lo}, bot{hi, hi, hi}, ce{0, 0, 0};
@@ -66,7 +65,7 @@ struct HostBvhBuilder {
                 const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
                 r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
             }
-        sph[0] = ce.x; sph[1] = ce.y; sph[2] = ce.z; sph[3] = std::sqrt(r2);
+        out[0] = ce.x; out[1] = ce.y; out[2] = ce.z; out[3] = std::sqrt(r2);
 
         {   // median split: sort the range by the first vertex's coordinate along `dim`
             struct KeyTri { double key; int tri; };
@@ -76,27 +75,45 @@ struct HostBvhBuilder {
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
         }
         const int mid = (int)(0.5 * (begin + end));
-        const int left = nodeId + 1;
-        const int right = nodeId + 2 * (mid - begin);          // left subtree has 2*(mid-begin)-1 nodes
-        int lr[2] = {left, right};
-        std::memcpy(nd + 8, lr, 8);
+        // pre-order numbering of inner nodes: the left subtree holds (mid - begin) - 1 of them
+        const int leftId = innerId + 1, rightId = innerId + (mid - begin);
+        double* nd = sph + 8 * (size_t)innerId;
+        int refs[2];
         if (depth < maxParallelDepth && n > 8192) {
-            std::thread th([&]() { build(left, nd, begin, mid, depth + 1); });
-            build(right, nd + 4, mid, end, depth + 1);
+            std::thread th([&]() { refs[0] = build(leftId, nd, begin, mid, depth + 1); });
+            refs[1] = build(rightId, nd + 4, mid, end, depth + 1);
             th.join();
         } else {
-            build(left, nd, begin, mid, depth + 1);
-            build(right, nd + 4, mid, end, depth + 1);
+            refs[0] = build(leftId, nd, begin, mid, depth + 1);
+            refs[1] = build(rightId, nd + 4, mid, end, depth + 1);
         }
+        kids[2 * (size_t)innerId] = refs[0]; kids[2 * (size_t)innerId + 1] = refs[1];
+        return innerId;
     }
 };
 
-__global__ void __launch_bounds__(128) k_nearest(const double* __restrict__ nodes, const float* __restrict__ verts, const uint32_t* __restrict__ idx,
-                          const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
+__global__ void k_tri_verts(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numTriangles, float* __restrict__ triV) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = gid / 12u, k = gid - 12u * t;
+    if (t >= numTriangles) return;
+    triV[gid] = (k < 9u) ? verts[3 * (size_t)idx[3 * (size_t)t + k / 3u] + (k % 3u)] : 0.f;
+}
+
+__global__ void __launch_bounds__(128) k_nearest(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
     __shared__ uint32_t s_stack[BVH_STACK * 128];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = bvhNearest<128>(nodes, verts, idx, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, s_stack + threadIdx.x);
+    out[i] = bvhNearest<128>(bvh, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, s_stack + threadIdx.x);
+}
+
+// dev probe: traversal statistics per query
+__global__ void __launch_bounds__(128) k_nearest_stats(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out4) {
+    __shared__ uint32_t s_stack[BVH_STACK * 128];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t c[3] = {0, 0, 0};
+    out4[4 * i] = bvhNearest<128, true>(bvh, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, s_stack + threadIdx.x, c);
+    out4[4 * i + 1] = c[0]; out4[4 * i + 2] = c[1]; out4[4 * i + 3] = c[2];
 }
 
 __global__ void k_point_values(const float* __restrict__ verts, const uint32_t* __restrict__ idx, const float* __restrict__ td,
@@ -128,21 +145,37 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
-    const uint64_t nn = 2ull * mesh->numTriangles - 1;
-    std::vector<double> nodes((size_t)BVH_NODE_DOUBLES * nn, 0.0);
+    const uint32_t T = mesh->numTriangles;
+    const uint64_t nn = T - 1;                                   // inner nodes
+    std::vector<double> sph(8 * (size_t)(nn ? nn : 1), 0.0);
+    std::vector<int> kids(2 * (size_t)(nn ? nn : 1), 0);
     HostBvhBuilder b;
-    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.nodes = nodes.data();
-    b.order.resize(mesh->numTriangles);
-    for (uint32_t i = 0; i < mesh->numTriangles; i++) b.order[i] = (int)i;
+    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.data(); b.kids = kids.data();
+    b.order.resize(T);
+    for (uint32_t i = 0; i < T; i++) b.order[i] = (int)i;
     unsigned hc = std::thread::hardware_concurrency();
     int pd = 0; while ((1u << pd) < (hc ? hc : 1u) && pd < 6) pd++;
     b.maxParallelDepth = pd;
     double rootSphere[4];
-    b.build(0, rootSphere, 0, (int)mesh->numTriangles, 0);
+    b.build(0, rootSphere, 0, (int)T, 0);
     SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
-    SDF_TRY(mesh->dBvh.reserve(nodes.size()));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvh.p, nodes.data(), nodes.size() * sizeof(double), hipMemcpyHostToDevice, mesh->ctx->stream));
-    SDF_HIP_CHECK(hipStreamSynchronize(mesh->ctx->stream));
+    hipStream_t st = mesh->ctx->stream;
+    SDF_TRY(mesh->dBvhSph.reserve(sph.size())); SDF_TRY(mesh->dBvhKids.reserve(kids.size())); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph.data(), sph.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids.data(), kids.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    {
+        std::vector<float> s32(sph.size());
+        for (size_t i = 0; i < sph.size(); i++) s32[i] = (float)sph[i];
+        float scale = 0.f;
+        for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
+        mesh->bvhCoordScale = scale;
+        SDF_TRY(mesh->dBvhSph32.reserve(s32.size()));
+        SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph32.p, s32.data(), s32.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
     mesh->numBvhNodes = nn;
     mesh->hasBvh = true;
     if (seconds) *seconds = nowSeconds() - t0;
@@ -162,9 +195,23 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
         SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
         p = dp.p; o = dout.p;
     }
-    k_nearest<<<gridFor(n, 128), 128, 0, st>>>(mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, p, n, o);
+    k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
     SDF_HIP_CHECK(hipGetLastError());
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out_ids, dout.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+}
+
+int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) {
+    SDF_REQUIRE(mesh && xyz && out4, "NULL argument");
+    SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
+    hipStream_t st = mesh->ctx->stream;
+    DevBuf<float> dp; DevBuf<uint32_t> dout;
+    SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dout.reserve(4 * n));
+    SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+    k_nearest_stats<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), dp.p, n, dout.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipMemcpyAsync(out4, dout.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
 }

@@ -25,11 +25,11 @@
 
 namespace sdfhip {
 
-struct MeshDev { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
+struct MeshDev { BvhDev bvh; const float* verts; const uint32_t* idx; const float* td; };
 
-SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4, uint32_t* __restrict__ stk, double bound = BVH_NO_BOUND) {
-    uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk, bound);
-    if (t == 0xFFFFFFFFu) t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);      // bound was not an upper bound: literal traversal
+SDF_DEV F3 cornerRel(uint32_t c) { return F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f}; }
+
+SDF_DEV void valuesAt(const MeshDev& m, F3 p, uint32_t t, float* __restrict__ out4) {
     const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
     F3 g;
     const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t,
@@ -41,40 +41,64 @@ SDF_DEV void sampleAt(const MeshDev& m, F3 p, float* __restrict__ out4, uint32_t
 
 // 8 corners of every node (only the root level evaluates corners; deeper levels inherit them).
 __global__ void __launch_bounds__(128) k_corner_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ corner) {
-    __shared__ uint32_t s_stack[BVH_STACK * 128];
+    extern __shared__ uint32_t s_stack[];        // [stackDepth][128]
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 8u * n) return;
-    const uint32_t node = gid >> 3, c = gid & 7u;
-    const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
-    const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
-    sampleAt(m, ce + rel * half, corner + 4 * (size_t)gid, s_stack + threadIdx.x);
+    const uint32_t node = gid >> 3;
+    const F3 p = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]} + cornerRel(gid & 7u) * half;
+    valuesAt(m, p, bvhNearest<128>(m.bvh, p, s_stack + threadIdx.x), corner + 4 * (size_t)gid);
 }
 
-// 19 mid-points of every node of a level: the build's hot kernel.
-// The node's 8 corner distances are already known, so dist(p) <= |f(corner)| + |p - corner| bounds the search from the
-// start (triangle inequality); see bvhNearest for why the result is unchanged.  The bound is inflated by 1e-4 relative
-// (+ tiny absolute) to stay strictly above the true distance despite the fp32 rounding of |f| and of the offset length.
-__global__ void __launch_bounds__(128) k_level_samples(MeshDev m, const float* __restrict__ center, const float* __restrict__ corner, float half, uint32_t n,
-                                                       float* __restrict__ mid, int useBound) {
-    extern __shared__ uint32_t s_stack[];        // [stackDepth][128], stackDepth = BVH depth + 1 (smaller stack -> more waves per CU)
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 19u * n) return;
-    const uint32_t node = gid / 19u, mi = gid - 19u * node;
-    const F3 ce = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]};
-    const F3 rel = midRel((int)mi);
-    double bound = BVH_NO_BOUND;
-    if (useBound) {
-        float u = INFINITY;
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-            const float f = fabsf(corner[4 * (8 * (size_t)node + c)]);
-            const F3 d = F3{(rel.x - ((c & 1) ? 1.f : -1.f)) * half, (rel.y - ((c & 2) ? 1.f : -1.f)) * half, (rel.z - ((c & 4) ? 1.f : -1.f)) * half};
-            const float cand = f + sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-            u = (cand < u) ? cand : u;
-        }
-        if (u < INFINITY) bound = (double)u * 1.0001 + 1e-30;
+// ---- 19 mid-points of every node of a level: the build's hot path --------------------------------------------------
+// Neighbouring nodes share mid-points (a face centre belongs to 2 nodes, an edge mid-point to up to 4), and the reference
+// answers each of them with the same deterministic query.  The samples of a level are therefore grouped by lattice point
+// (radix sort of a 36-bit key), one traversal is run per group of samples whose fp32 POSITION BITS are identical — the
+// positions come from different node centres, and only equal bits guarantee the same answer — and every sample then
+// computes its Hermite datum from the shared nearest-triangle id.  About 1.6x fewer traversals, issued in lattice order.
+SDF_DEV F3 midPosition(const float* __restrict__ center, float half, uint32_t q) {
+    const uint32_t node = q / 19u;
+    return F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]} + midRel((int)(q - 19u * node)) * half;
+}
+__global__ void k_mid_keys(const uint32_t* __restrict__ coord, uint32_t n, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 19u * n) return;
+    const uint32_t node = q / 19u, co = coord[node];
+    const F3 r = midRel((int)(q - 19u * node));
+    const uint64_t lx = 2u * (co & 1023u) + (uint32_t)(r.x + 1.f), ly = 2u * ((co >> 10) & 1023u) + (uint32_t)(r.y + 1.f), lz = 2u * (co >> 20) + (uint32_t)(r.z + 1.f);
+    key[q] = lx | (ly << 12) | (lz << 24);
+    val[q] = q;
+}
+// sorted entry j starts a new traversal unless it is the same lattice point AND the same position bits as entry j-1
+__global__ void k_mid_mark(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, const float* __restrict__ center, float half, uint32_t total,
+                           uint32_t* __restrict__ isRep) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    bool rep = true;
+    if (j > 0 && key[j] == key[j - 1]) {
+        const F3 a = midPosition(center, half, val[j]), b = midPosition(center, half, val[j - 1]);
+        rep = !(__float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) && __float_as_uint(a.z) == __float_as_uint(b.z));
     }
-    sampleAt(m, ce + rel * half, mid + 4 * (size_t)gid, s_stack + threadIdx.x, bound);
+    isRep[j] = rep ? 1u : 0u;
+}
+__global__ void k_mid_rep_list(const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ val, uint32_t total,
+                               uint32_t* __restrict__ repSample) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < total && isRep[j]) repSample[scan[j]] = val[j];
+}
+__global__ void __launch_bounds__(128) k_mid_nearest(BvhDev b, const float* __restrict__ center, float half, const uint32_t* __restrict__ repSample, uint32_t numReps,
+                                                     uint32_t* __restrict__ repTri) {
+    extern __shared__ uint32_t s_stack[];        // [stackDepth][128], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= numReps) return;
+    repTri[r] = bvhNearest<128>(b, midPosition(center, half, repSample[r]), s_stack + threadIdx.x);
+}
+__global__ void k_mid_values(MeshDev m, const float* __restrict__ center, float half, const uint32_t* __restrict__ val, const uint32_t* __restrict__ isRep,
+                             const uint32_t* __restrict__ scan, const uint32_t* __restrict__ repTri, uint32_t total, float* __restrict__ mid) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    const uint32_t q = val[j];
+    const uint32_t slot = scan[j] + isRep[j] - 1u;          // exclusive scan: the group's representative is the last flagged entry at or before j
+    valuesAt(m, midPosition(center, half, q), repTri[slot], mid + 4 * (size_t)q);
 }
 
 SDF_DEV uint32_t floatOrderKey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
@@ -273,6 +297,37 @@ __global__ void k_init_start_pos(uint32_t n, uint32_t cellBegin, const uint32_t*
 
 int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, sdfhip_octree** out);   // octree_continuity.hip
 
+// scratch of the mid-point sampler, reused across levels (grows only)
+struct SampleScratch {
+    DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
+};
+static int sampleMidPoints(hipStream_t st, const MeshDev& md, BuildLevel& L, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
+    const uint32_t total = 19u * L.n;
+    SDF_TRY(S.key.reserve(total)); SDF_TRY(S.keyS.reserve(total)); SDF_TRY(S.val.reserve(total)); SDF_TRY(S.valS.reserve(total));
+    SDF_TRY(S.isRep.reserve(total)); SDF_TRY(S.scan.reserve(total));
+    k_mid_keys<<<gridFor(total, 256), 256, 0, st>>>(L.coord.p, L.n, S.key.p, S.val.p);
+    size_t b1 = 0, b2 = 0;
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 36, st));
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, S.isRep.p, S.scan.p, (int)total, st));
+    const size_t need = b1 > b2 ? b1 : b2;
+    if (need > S.tmpBytes) { SDF_TRY(S.tmp.reserve(need)); S.tmpBytes = need; }
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 36, st));
+    k_mid_mark<<<gridFor(total, 256), 256, 0, st>>>(S.keyS.p, S.valS.p, L.center.p, L.half, total, S.isRep.p);
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, b2, S.isRep.p, S.scan.p, (int)total, st));
+    uint32_t lastScan = 0, lastFlag = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&lastScan, S.scan.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&lastFlag, S.isRep.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    const uint32_t numReps = lastScan + lastFlag;
+    SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repTri.reserve(numReps));
+    k_mid_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
+    k_mid_nearest<<<gridFor(numReps, 128), 128, stackBytes, st>>>(md.bvh, L.center.p, L.half, S.repSample.p, numReps, S.repTri.p);
+    k_mid_values<<<gridFor(total, 256), 256, 0, st>>>(md, L.center.p, L.half, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p, total, L.mid.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    traversals += numReps;
+    return SDFHIP_OK;
+}
+
 static int allocLevelCommon(BuildLevel& L) {
     SDF_TRY(L.center.reserve(3ull * L.n));
     SDF_TRY(L.coord.reserve(L.n));
@@ -332,11 +387,14 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     T->startOctreeDepth = sod;
 
-    MeshDev md{mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    MeshDev md{meshBvh(mesh), mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
     DevBuf<uint32_t> stats;            // [0] valueRange bits, [1] minBorder key, [2] MFMA re-checks
     SDF_TRY(stats.reserve(3));
     { const uint32_t init[3] = {0u, 0xFFFFFFFFu, 0u}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 12, hipMemcpyHostToDevice, st)); }
     DevBuf<unsigned char> scanTmp; size_t scanTmpBytes = 0;
+
+    size_t stackBytes;          // LDS traversal stack of a 128-lane block: BVH depth + 2 entries per lane
+    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; stackBytes = (size_t)(depth + 2) * 128 * sizeof(uint32_t); }
 
     // root level
     T->levels.resize(maxDepth - sod + 1);
@@ -356,15 +414,14 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         }
         SDF_HIP_CHECK(hipMemcpyAsync(L->center.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->coord.p, hco.data(), hco.size() * 4, hipMemcpyHostToDevice, st));
-        k_corner_samples<<<gridFor(8ull * L->n, 128), 128, 0, st>>>(md, L->center.p, L->half, L->n, L->corner.p);
+        k_corner_samples<<<gridFor(8ull * L->n, 128), 128, stackBytes, st>>>(md, L->center.p, L->half, L->n, L->corner.p);
         SDF_HIP_CHECK(hipStreamSynchronize(st));   // hc/hco go out of scope
-        T->info.num_samples += 8ull * L->n;
+        T->info.num_samples += 8ull * L->n; T->info.num_traversals += 8ull * L->n;
         T->levels[0] = std::move(L);
     }
 
     double tSamples = 0, tDecide = 0;
-    size_t stackBytes;
-    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; stackBytes = (size_t)(depth + 2) * 128 * sizeof(uint32_t); }
+    SampleScratch SS;
     for (uint32_t d = sod; d <= maxDepth; d++) {
         BuildLevel* L = T->levels[d - sod].get();
         if (!L || L->n == 0) break;
@@ -381,7 +438,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         if (d < maxDepth) {
             SDF_TRY(L->mid.reserve(76ull * L->n));
             const double t0 = nowSeconds();
-            k_level_samples<<<gridFor(19ull * L->n, 128), 128, stackBytes, st>>>(md, L->center.p, L->corner.p, L->half, L->n, L->mid.p, 1);
+            SDF_TRY(sampleMidPoints(st, md, *L, SS, stackBytes, T->info.num_traversals));
             SDF_HIP_CHECK(hipStreamSynchronize(st));
             tSamples += nowSeconds() - t0;
             T->info.num_samples += 19ull * L->n;

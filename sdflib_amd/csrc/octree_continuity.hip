@@ -33,7 +33,7 @@ namespace sdfhip {
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t B31 = 1u << 31, B30 = 1u << 30;
 
-struct CMesh { const double* bvh; const float* verts; const uint32_t* idx; const float* td; };
+struct CMesh { BvhDev bvh; const float* verts; const uint32_t* idx; const float* td; };
 
 // mask of mid-points (bit 18-i) on the face / edge in direction dir (axis bits) with side code sign
 SDF_HD uint32_t neighbourMask(uint32_t dir, uint32_t sign) {
@@ -105,26 +105,13 @@ SDF_DEV void vertexValuesExact(CF c, F3 f, float nodeSize, float* __restrict__ o
 }
 SDF_DEV F3 midFrac(int i) { const F3 r = midRel(i); return F3{0.5f * r.x + 0.5f, 0.5f * r.y + 0.5f, 0.5f * r.z + 0.5f}; }
 
-SDF_DEV void exactSample(const CMesh& m, F3 p, float* __restrict__ out8, uint32_t* __restrict__ stk, double bound) {
-    uint32_t t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk, bound);
-    if (t == NONE32) t = bvhNearest<128>(m.bvh, m.verts, m.idx, p, stk);
+SDF_DEV void exactSample(const CMesh& m, F3 p, float* __restrict__ out8, uint32_t* __restrict__ stk) {
+    const uint32_t t = bvhNearest<128>(m.bvh, p, stk);
     const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
     F3 g;
     const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t, F3{m.verts[3 * a], m.verts[3 * a + 1], m.verts[3 * a + 2]},
                                                 F3{m.verts[3 * b], m.verts[3 * b + 1], m.verts[3 * b + 2]}, F3{m.verts[3 * c], m.verts[3 * c + 1], m.verts[3 * c + 2]}, g);
     out8[0] = d; out8[1] = g.x; out8[2] = g.y; out8[3] = g.z; out8[4] = 0.f; out8[5] = 0.f; out8[6] = 0.f; out8[7] = 0.f;
-}
-// upper bound of dist(p) from the 8 corner values (which may be interpolated: off by at most thr)
-SDF_DEV double cornerBound(const float* __restrict__ vv, F3 rel, float half, float thr) {
-    float u = INFINITY;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-        const float f = fabsf(vv[8 * c]);
-        const F3 d = F3{(rel.x - ((c & 1) ? 1.f : -1.f)) * half, (rel.y - ((c & 2) ? 1.f : -1.f)) * half, (rel.z - ((c & 4) ? 1.f : -1.f)) * half};
-        const float cand = f + sqrtf(d.x * d.x + d.y * d.y + d.z * d.z);
-        u = (cand < u) ? cand : u;
-    }
-    return (u < INFINITY) ? ((double)u + (double)thr) * 1.0001 + 1e-30 : BVH_NO_BOUND;
 }
 
 // ---- level state (structure of arrays) --------------------------------------------------------------------------------
@@ -142,7 +129,7 @@ __global__ void kc_root_corners(CMesh m, CLevelDev L) {
     const uint32_t node = gid >> 3, c = gid & 7u;
     const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
     const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
-    exactSample(m, ce + rel * L.half, L.vv + 64 * (size_t)node + 8 * c, s_stack + threadIdx.x, BVH_NO_BOUND);
+    exactSample(m, ce + rel * L.half, L.vv + 64 * (size_t)node + 8 * c, s_stack + threadIdx.x);
 }
 
 // Iter 1a: refresh the six outward neighbour words (OctreeSdfBreadthFirstNoDelay.h:295-330)
@@ -178,7 +165,7 @@ __global__ void __launch_bounds__(128) kc_samples(CMesh m, CLevelDev L, float th
     const uint32_t node = gid / 19u, mi = gid - 19u * node;
     const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
     const F3 rel = midRel((int)mi);
-    exactSample(m, ce + rel * L.half, L.mid + 152 * (size_t)node + 8 * mi, s_stack + threadIdx.x, cornerBound(L.vv + 64 * (size_t)node, rel, L.half, thr));
+    exactSample(m, ce + rel * L.half, L.mid + 152 * (size_t)node + 8 * mi, s_stack + threadIdx.x);
 }
 
 // Iter 1c: fit (8 slots), termination rule, provisional node word
@@ -402,7 +389,7 @@ __global__ void __launch_bounds__(128) kc_pp_mid(CMesh m, const OpDev* __restric
         const float* src = LT.lv[op.srcLevel].mid + 152 * (size_t)op.srcSlot + 8 * mi;
         for (int k = 0; k < 8; k++) md[k] = src[k];
     } else if (masked) vertexValuesExact(cf, f, 2.0f * half, md);
-    else exactSample(m, ce + midRel((int)mi) * half, md, s_stack + threadIdx.x, cornerBound(vv, midRel((int)mi), half, thr));
+    else exactSample(m, ce + midRel((int)mi) * half, md, s_stack + threadIdx.x);
     if (!masked) {
         const float iv = tricubicValueExact(cf, f);
         const float e = md[0] - iv;
@@ -555,7 +542,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     T->info.start_grid_size = G; T->info.max_depth = maxDepth; T->cellSize = maxSize / (float)G;
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     const float thr = P->rule_params[0], sqThr = thr * thr, param1 = P->rule_params[1];
-    CMesh md{mesh->dBvh.p, mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
+    CMesh md{meshBvh(mesh), mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};
     size_t stackBytes; { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; stackBytes = (size_t)(depth + 2) * 128 * sizeof(uint32_t); }
     DevBuf<unsigned char> scanTmp; size_t scanTmpBytes = 0;
     DevBuf<uint32_t> stats; SDF_TRY(stats.reserve(2));

@@ -77,9 +77,13 @@ struct sdfhip_mesh {
     sdfhip::DevBuf<uint32_t> dIdx;        // 3 per triangle
     sdfhip::DevBuf<float> dTri;           // 37 floats per triangle (TriangleData)
     sdfhip::DevBuf<float> dFrames;        // 20 floats per triangle: packed frame (dev_math.h loadFramePacked)
-    // bounding-sphere BVH (fp64), 10 doubles per node: left sphere (c, r), right sphere (c, r), {left,right} ints, pad
-    sdfhip::DevBuf<double> dBvh;
-    uint64_t numBvhNodes = 0;
+    // bounding-sphere BVH (fp64), see dev_bvh.h: 8 doubles + one int2 per inner node, 12 floats per triangle
+    sdfhip::DevBuf<double> dBvhSph;
+    sdfhip::DevBuf<int> dBvhKids;
+    sdfhip::DevBuf<float> dBvhSph32;      // fp32 copy of the spheres (8 floats per inner node), see dev_bvh.h
+    float bvhCoordScale = 0.f;            // max |coordinate| of the mesh: bounds the fp32 rounding of the sphere centres
+    sdfhip::DevBuf<float> dTriVerts;
+    uint64_t numBvhNodes = 0;             // inner nodes (= numTriangles - 1)
     bool hasBvh = false;
     uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
     uint32_t weldedEdges = 0;             // of those, half-edges re-paired by the seam welding
