@@ -104,6 +104,8 @@ int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host);
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds);
 /* nearest triangle id per point (fp64 BVH traversal on the device) */
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
+/* test hook, host only: mismatches between the BVH planner's threaded restatement of std::sort and std::sort itself on n keys */
+int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads);
 /* development probe: per query [triangle id, inner nodes entered, deferred children popped, triangles evaluated] */
 int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4);
 /* Hermite sample [d, gx, gy, gz, 0,0,0,0] at each point for a given triangle id

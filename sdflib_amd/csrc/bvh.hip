@@ -9,6 +9,14 @@
 // known up front and the two halves of a range can be planned by different host threads without changing a bit
 // of the result.  The sort works on {key, triangle} pairs instead of the reference's 80-byte structs: std::sort's
 // permutation depends only on comparison outcomes, which are the same.
+//
+// The keys are full of ties (triangles sharing their first vertex), std::sort is not stable, and the permutation it leaves
+// decides which triangles fall on which side of every median — so the planner has to end with libstdc++'s permutation,
+// not just with a sorted range.  introsortLike() below restates that algorithm (introsort: median-of-3 to the front,
+// unguarded Hoare partition, recurse right / loop left, 16-element threshold, 2*floor(log2 n) depth limit with heap sort
+// fallback, final insertion sort) so that the independent sub-ranges a partition leaves behind can be handed to other host
+// threads: same comparisons on the same data in each sub-range, same result, critical path O(n) instead of O(n log n).
+// sdfhip_test_sort_matches_std() (tests/test_abi.py) compares it with std::sort on tie-heavy inputs.
 #include "sdfhip_internal.h"
 #include "dev_bvh.h"
 #include <algorithm>
@@ -16,8 +24,90 @@
 #include <thread>
 #include <cmath>
 #include <cstring>
+#include <atomic>
+#include <mutex>
+#include <memory>
 
 namespace sdfhip {
+
+// ---- libstdc++'s std::sort, restated so that it can run on several threads --------------------------------------------
+struct KeyTri { double key; int tri; };
+static inline bool keyLess(const KeyTri& a, const KeyTri& b) { return a.key < b.key; }
+
+static std::atomic<int> g_sortThreads{0};      // live helper threads of all sorts in flight (soft cap = hardware threads)
+
+struct IntroSortLike {
+    int maxThreads = 1;
+    size_t minParallel = 1u << 15;             // ranges below this are finished by the calling thread
+    std::mutex cutMutex; std::vector<size_t> cuts; KeyTri* base = nullptr;
+
+    static void moveMedianToFirst(KeyTri* result, KeyTri* a, KeyTri* b, KeyTri* c) {
+        if (keyLess(*a, *b)) {
+            if (keyLess(*b, *c)) std::iter_swap(result, b);
+            else if (keyLess(*a, *c)) std::iter_swap(result, c);
+            else std::iter_swap(result, a);
+        } else if (keyLess(*a, *c)) std::iter_swap(result, a);
+        else if (keyLess(*b, *c)) std::iter_swap(result, c);
+        else std::iter_swap(result, b);
+    }
+    static KeyTri* unguardedPartition(KeyTri* first, KeyTri* last, KeyTri* pivot) {
+        for (;;) {
+            while (keyLess(*first, *pivot)) ++first;
+            --last;
+            while (keyLess(*pivot, *last)) --last;
+            if (!(first < last)) return first;
+            std::iter_swap(first, last);
+            ++first;
+        }
+    }
+    void loop(KeyTri* first, KeyTri* last, int depthLimit) {
+        std::vector<std::thread> helpers;
+        while (last - first > 16) {
+            if (depthLimit == 0) { std::make_heap(first, last, keyLess); std::sort_heap(first, last, keyLess); break; }
+            --depthLimit;
+            KeyTri* mid = first + (last - first) / 2;
+            moveMedianToFirst(first, first + 1, mid, last - 1);
+            KeyTri* cut = unguardedPartition(first + 1, last, first);
+            bool spawned = false;
+            if ((size_t)(last - cut) >= minParallel && (size_t)(cut - first) >= minParallel) {
+                if (g_sortThreads.fetch_add(1) < maxThreads) {
+                    { std::lock_guard<std::mutex> g(cutMutex); cuts.push_back((size_t)(cut - base)); }
+                    KeyTri* l = last; const int dl = depthLimit;
+                    helpers.emplace_back([this, cut, l, dl]() { loop(cut, l, dl); g_sortThreads.fetch_sub(1); });
+                    spawned = true;
+                } else g_sortThreads.fetch_sub(1);
+            }
+            if (!spawned) loop(cut, last, depthLimit);
+            last = cut;
+        }
+        for (std::thread& t : helpers) t.join();
+    }
+    static void insertionSort(KeyTri* first, KeyTri* last) {       // guarded form; same result as the reference's guarded + unguarded pair
+        if (first == last) return;
+        for (KeyTri* i = first + 1; i != last; ++i) {
+            KeyTri val = *i;
+            if (keyLess(val, *first)) { std::move_backward(first, i, i + 1); *first = val; }
+            else { KeyTri* pos = i; KeyTri* next = i - 1; while (keyLess(val, *next)) { *pos = *next; pos = next; --next; } *pos = val; }
+        }
+    }
+    void sort(KeyTri* first, KeyTri* last) {
+        if (first == last) return;
+        base = first; cuts.clear();
+        int lg = 0; for (size_t n = (size_t)(last - first); n > 1; n >>= 1) lg++;
+        loop(first, last, 2 * lg);
+        // final insertion sort: elements never cross a partition cut, so the ranges between recorded cuts are independent
+        std::sort(cuts.begin(), cuts.end());
+        std::vector<std::thread> helpers;
+        size_t begin = 0;
+        for (size_t k = 0; k <= cuts.size(); k++) {
+            const size_t end = (k < cuts.size()) ? cuts[k] : (size_t)(last - first);
+            if (k < cuts.size()) helpers.emplace_back([this, begin, end]() { insertionSort(base + begin, base + end); });
+            else insertionSort(base + begin, base + end);
+            begin = end;
+        }
+        for (std::thread& t : helpers) t.join();
+    }
+};
 
 struct HostBvhBuilder {
     const float* verts; const uint32_t* idx;
@@ -27,7 +117,9 @@ struct HostBvhBuilder {
     int maxParallelDepth = 0;
 
     struct D { double x, y, z; };
-    D vtx(int t, int k) const { const uint32_t v = idx[3 * (size_t)t + k]; return D{(double)verts[3 * v], (double)verts[3 * v + 1], (double)verts[3 * v + 2]}; }
+    const float* triV = nullptr;       // 9 floats per triangle, gathered once (the planner reads every vertex ~2 log2(T) times)
+    int sortThreads = 1;
+    D vtx(int t, int k) const { const float* q = triV + 9 * (size_t)t + 3 * k; return D{(double)q[0], (double)q[1], (double)q[2]}; }
     static double comp(const D& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
     // Plans the subtree over order[begin,end): writes its bounding sphere into out[0..3] and returns the reference to it.
@@ -68,10 +160,10 @@ struct HostBvhBuilder {
         out[0] = ce.x; out[1] = ce.y; out[2] = ce.z; out[3] = std::sqrt(r2);
 
         {   // median split: sort the range by the first vertex's coordinate along `dim`
-            struct KeyTri { double key; int tri; };
             std::vector<KeyTri> tmp((size_t)n);
             for (int i = 0; i < n; i++) { const int t = order[begin + i]; tmp[i] = KeyTri{comp(vtx(t, 0), dim), t}; }
-            std::sort(tmp.begin(), tmp.end(), [](const KeyTri& a, const KeyTri& b) { return a.key < b.key; });
+            IntroSortLike sorter; sorter.maxThreads = sortThreads;
+            sorter.sort(tmp.data(), tmp.data() + n);
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
         }
         const int mid = (int)(0.5 * (begin + end));
@@ -79,7 +171,7 @@ struct HostBvhBuilder {
         const int leftId = innerId + 1, rightId = innerId + (mid - begin);
         double* nd = sph + 8 * (size_t)innerId;
         int refs[2];
-        if (depth < maxParallelDepth && n > 8192) {
+        if (depth < maxParallelDepth && n > 4096) {
             std::thread th([&]() { refs[0] = build(leftId, nd, begin, mid, depth + 1); });
             refs[1] = build(rightId, nd + 4, mid, end, depth + 1);
             th.join();
@@ -91,6 +183,11 @@ struct HostBvhBuilder {
         return innerId;
     }
 };
+
+__global__ void k_sph32(const double* __restrict__ sph, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)sph[i];            // round to nearest: the bracket in dev_bvh.h assumes |c32 - c| <= 2^-24 |c|
+}
 
 __global__ void k_tri_verts(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numTriangles, float* __restrict__ triV) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,31 +244,37 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     const double t0 = nowSeconds();
     const uint32_t T = mesh->numTriangles;
     const uint64_t nn = T - 1;                                   // inner nodes
-    std::vector<double> sph(8 * (size_t)(nn ? nn : 1), 0.0);
-    std::vector<int> kids(2 * (size_t)(nn ? nn : 1), 0);
+    // uninitialised on purpose: every slot is written by the planner thread that owns it (first touch happens there, in parallel)
+    const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
+    std::unique_ptr<double[]> sph(new double[nSph]);
+    std::unique_ptr<int[]> kids(new int[nKids]);
+    if (nn == 0) { for (size_t i = 0; i < nSph; i++) sph[i] = 0.0; kids[0] = kids[1] = ~0; }
+    std::vector<float> htv(9 * (size_t)T);
+    for (size_t t = 0; t < T; t++) for (int k = 0; k < 3; k++) {
+        const uint32_t v = mesh->hIdx[3 * t + k];
+        htv[9 * t + 3 * k] = mesh->hVerts[3 * (size_t)v]; htv[9 * t + 3 * k + 1] = mesh->hVerts[3 * (size_t)v + 1]; htv[9 * t + 3 * k + 2] = mesh->hVerts[3 * (size_t)v + 2];
+    }
     HostBvhBuilder b;
-    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.data(); b.kids = kids.data();
+    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.get(); b.kids = kids.get(); b.triV = htv.data();
     b.order.resize(T);
     for (uint32_t i = 0; i < T; i++) b.order[i] = (int)i;
     unsigned hc = std::thread::hardware_concurrency();
-    int pd = 0; while ((1u << pd) < (hc ? hc : 1u) && pd < 6) pd++;
+    int pd = 0; while ((1u << pd) < (hc ? hc : 1u) && pd < 8) pd++;
     b.maxParallelDepth = pd;
+    b.sortThreads = (int)(hc ? hc : 1u);
     double rootSphere[4];
     b.build(0, rootSphere, 0, (int)T, 0);
     SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
     hipStream_t st = mesh->ctx->stream;
-    SDF_TRY(mesh->dBvhSph.reserve(sph.size())); SDF_TRY(mesh->dBvhKids.reserve(kids.size())); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph.data(), sph.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids.data(), kids.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph.get(), nSph * sizeof(double), hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids.get(), nKids * sizeof(int), hipMemcpyHostToDevice, st));
     {
-        std::vector<float> s32(sph.size());
-        for (size_t i = 0; i < sph.size(); i++) s32[i] = (float)sph[i];
         float scale = 0.f;
         for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
         mesh->bvhCoordScale = scale;
-        SDF_TRY(mesh->dBvhSph32.reserve(s32.size()));
-        SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph32.p, s32.data(), s32.size() * sizeof(float), hipMemcpyHostToDevice, st));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_TRY(mesh->dBvhSph32.reserve(nSph));
+        k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
     k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
     SDF_HIP_CHECK(hipGetLastError());
@@ -200,6 +303,20 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out_ids, dout.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+}
+
+// Test hook (no GPU needed): sorts n {key, id} pairs with the planner's multi-threaded introsort and with std::sort and
+// returns the number of positions where the two permutations differ (0 = identical).
+int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
+    if (!keys) return -1;
+    std::vector<KeyTri> a(n), b(n);
+    for (uint64_t i = 0; i < n; i++) a[i] = b[i] = KeyTri{keys[i], (int)i};
+    IntroSortLike s; s.maxThreads = threads; s.minParallel = 64;          // small threshold: exercise the threaded paths
+    s.sort(a.data(), a.data() + n);
+    std::sort(b.begin(), b.end(), keyLess);
+    int diff = 0;
+    for (uint64_t i = 0; i < n; i++) diff += (a[i].tri != b[i].tri || a[i].key != b[i].key) ? 1 : 0;
+    return diff;
 }
 
 int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) {

@@ -71,3 +71,20 @@ def test_struct_sizes_match_the_header(built_lib):
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
     a, b, c = (int(x) for x in subprocess.check_output([exe]).split())
     assert (ctypes.sizeof(OctreeInfo), ctypes.sizeof(OctreeParams), ctypes.sizeof(ExactInfo)) == (a, b, c)
+
+
+def test_planner_sort_equals_std_sort():
+    """The BVH planner's multi-threaded restatement of libstdc++'s introsort must leave the SAME permutation as std::sort
+    (ties decide which triangles fall on which side of a median split, hence the tree, hence nearest-triangle ties)."""
+    import ctypes as C
+    import numpy as np
+    from sdflib_amd._lib import lib
+    rng = np.random.default_rng(0)
+    for n in (0, 1, 2, 16, 17, 100, 4097, 70001, 400000):
+        inputs = [rng.random(n), rng.integers(0, max(1, n // 6 + 1), n).astype(np.float64), np.sort(rng.random(n)),
+                  np.sort(rng.integers(0, 50, n).astype(np.float64))[::-1].copy(), np.repeat(rng.random(max(1, n // 3 + 1)), 3)[:n].copy(),
+                  np.zeros(n)]
+        for keys in inputs:
+            keys = np.ascontiguousarray(keys, dtype=np.float64)
+            for threads in (1, 6):
+                assert lib().sdfhip_test_sort_matches_std(keys.ctypes.data_as(C.c_void_p), n, threads) == 0
