@@ -23,6 +23,7 @@
 #include "octree_internal.h"
 #include "dev_bvh.h"
 #include "dev_tricubic.h"
+#include "octree_sampler.h"
 #include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <cstring>
@@ -33,7 +34,7 @@ namespace sdfhip {
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr uint32_t B31 = 1u << 31, B30 = 1u << 30;
 
-struct CMesh { BvhDev bvh; const float* verts; const uint32_t* idx; const float* td; };
+using CMesh = MeshDev;
 
 // mask of mid-points (bit 18-i) on the face / edge in direction dir (axis bits) with side code sign
 SDF_HD uint32_t neighbourMask(uint32_t dir, uint32_t sign) {
@@ -157,16 +158,7 @@ __global__ void kc_refresh(CLevelDev L, uint32_t cd, const uint32_t* __restrict_
     }
 }
 
-// Iter 1b: 19 exact mid-point samples per node
-__global__ void __launch_bounds__(128) kc_samples(CMesh m, CLevelDev L, float thr) {
-    extern __shared__ uint32_t s_stack[];
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 19u * L.n) return;
-    const uint32_t node = gid / 19u, mi = gid - 19u * node;
-    const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
-    const F3 rel = midRel((int)mi);
-    exactSample(m, ce + rel * L.half, L.mid + 152 * (size_t)node + 8 * mi, s_stack + threadIdx.x);
-}
+// Iter 1b: the 19 exact mid-point samples per node come from sampleMidPoints (octree_sampler.h)
 
 // Iter 1c: fit (8 slots), termination rule, provisional node word
 __global__ void __launch_bounds__(128) kc_fit_rule(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t maxDepth, int rule, float sqThr, float param1, uint32_t* __restrict__ oc) {
@@ -463,6 +455,7 @@ __global__ void kc_final_walk(const uint32_t* __restrict__ oc, int G, uint32_t s
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
 struct CLevelHost {
+    bool sampled = false;      // the 19 exact mid-point samples were already enqueued (overlapped with the previous level's post-pass)
     uint32_t depth = 0, n = 0; float half = 0.f;
     DevBuf<float> center, vv, coeff, mid; DevBuf<uint32_t> coord, pci, nIdx, word, cand, allocSize, allocOff, inner, childSlot; DevBuf<uint8_t> path, nDepth, terminal;
     // host mirrors of the integer state (the post-pass planner reads them)
@@ -482,9 +475,32 @@ struct CLevelHost {
 struct PNode { uint32_t path, pci, nIdx[6]; uint8_t nDepth[6]; uint32_t coord, depth; bool ignore; uint32_t srcLevel, srcSlot; };
 struct LeafRef { uint32_t level, slot; };        // level == NONE32 -> pool slot
 
+// word -> node table of the post-pass (insert-if-absent + lookup): open addressing, power-of-two capacity, load <= 1/2
+struct LeafMap {
+    std::vector<uint32_t> keys; std::vector<LeafRef> vals; size_t count = 0, mask = 0;
+    LeafMap() { rehash(1u << 16); }
+    static size_t mix(uint32_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return (size_t)(x >> 20); }
+    void rehash(size_t cap) {
+        std::vector<uint32_t> ok; std::vector<LeafRef> ov; ok.swap(keys); ov.swap(vals);
+        keys.assign(cap, NONE32); vals.resize(cap); mask = cap - 1; count = 0;
+        for (size_t i = 0; i < ok.size(); i++) if (ok[i] != NONE32) emplace(ok[i], ov[i]);
+    }
+    void emplace(uint32_t k, LeafRef v) {
+        if (2 * (count + 1) > keys.size()) rehash(keys.size() * 2);
+        size_t i = mix(k) & mask;
+        while (keys[i] != NONE32) { if (keys[i] == k) return; i = (i + 1) & mask; }
+        keys[i] = k; vals[i] = v; count++;
+    }
+    const LeafRef* find(uint32_t k) const {
+        size_t i = mix(k) & mask;
+        while (keys[i] != NONE32) { if (keys[i] == k) return &vals[i]; i = (i + 1) & mask; }
+        return nullptr;
+    }
+};
+
 struct Planner {
     std::vector<uint32_t> hoc;                    // host mirror of the node words (payload regions are don't-care)
-    std::unordered_map<uint32_t, LeafRef> leaves; // octree word -> node (first registration wins, like std::map::insert)
+    LeafMap leaves;                               // octree word -> node (first registration wins, like std::map::insert)
     std::vector<PNode> pool;                      // nodes created by the post-pass
     std::vector<std::pair<uint32_t, uint32_t>> patches;   // (index, value) for words that existed before this post-pass
     std::vector<uint32_t> marked;
@@ -610,6 +626,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     }
 
     uint64_t numRescheduled = 0;
+    SampleScratch SS;
+    double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
+    auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
     for (uint32_t cd = sod; cd <= maxDepth; cd++) {
         CLevelHost* L = LV[cd].get();
         if (!L || L->n == 0) continue;
@@ -618,7 +637,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         // ---------------- Iter 1
         if (cd < maxDepth) {
             if (cd > startDepth) kc_refresh<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, oc.p);
-            kc_samples<<<gridFor(19ull * n, 128), 128, stackBytes, st>>>(md, Ld, thr);
+            if (!L->sampled) SDF_TRY(sampleMidPoints(st, md, L->coord.p, L->center.p, L->half, n, L->mid.p, 8, SS, stackBytes, T->info.num_traversals));
             T->info.num_samples += 19ull * n;
         }
         kc_fit_rule<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, P->rule, sqThr, param1, oc.p);
@@ -653,6 +672,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         SDF_HIP_CHECK(hipGetLastError());
         ocSize += allocTotal;
+        SDF_HIP_CHECK(hipStreamSynchronize(st)); lap(tIter);
         // ---------------- mirrors for the planner: integer node state of this level + the words written so far
         L->hCoord.resize(n); L->hPci.resize(n); L->hNIdx.resize(6ull * n); L->hWord.resize(n); L->hPath.resize(n); L->hNDepth.resize(6ull * n); L->hTerminal.resize(n);
         SDF_HIP_CHECK(hipMemcpyAsync(L->hCoord.data(), L->coord.p, 4ull * n, hipMemcpyDeviceToHost, st));
@@ -672,10 +692,19 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_HIP_CHECK(hipMemcpyAsync(pl.hoc.data() + lo, oc.p + lo, 4ull * (ocSize - lo), hipMemcpyDeviceToHost, st));
             SDF_HIP_CHECK(hipStreamSynchronize(st));
         }
+        lap(tMirror);
+        // The exact samples of the NEXT level depend only on its node centres, not on the post-pass below: enqueue them now so
+        // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).
+        if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0) {
+            CLevelHost* N = LV[cd + 1].get();
+            SDF_TRY(sampleMidPoints(st, md, N->coord.p, N->center.p, N->half, N->n, N->mid.p, 8, SS, stackBytes, T->info.num_traversals));
+            N->sampled = true;
+        }
         for (uint32_t i = 0; i < n; i++) {
             const bool leaf = (cd >= maxDepth) || L->hTerminal[i];
             if (leaf) pl.leaves.emplace(L->hWord[i], LeafRef{cd, i});
         }
+        lap(tLeafMap);
         numRescheduled += numCand;
         if (numCand == 0) continue;
 
@@ -685,16 +714,17 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         std::vector<std::vector<OpDev>> gens;
         auto addOp = [&](uint32_t gen, const OpDev& op) { if (gens.size() <= gen) gens.resize(gen + 1); gens[gen].push_back(op); };
         for (uint32_t si = 0; si < numCand; si++) {
-            auto it = pl.leaves.find(toSubdivide[si]);
-            if (it == pl.leaves.end()) continue;
+            const LeafRef* it = pl.leaves.find(toSubdivide[si]);
+            if (!it) continue;
+            const LeafRef found = *it;             // the table may grow below
             // materialise the integer state of the scheduled leaf
             PNode root;
-            if (it->second.level != NONE32) {
-                CLevelHost* S = LV[it->second.level].get(); const uint32_t s = it->second.slot;
-                root.path = S->hPath[s]; root.pci = S->hPci[s]; root.coord = S->hCoord[s]; root.depth = it->second.level; root.ignore = false;
+            if (found.level != NONE32) {
+                CLevelHost* S = LV[found.level].get(); const uint32_t s = found.slot;
+                root.path = S->hPath[s]; root.pci = S->hPci[s]; root.coord = S->hCoord[s]; root.depth = found.level; root.ignore = false;
                 for (int k = 0; k < 6; k++) { root.nIdx[k] = S->hNIdx[6ull * s + k]; root.nDepth[k] = S->hNDepth[6ull * s + k]; }
-                root.srcLevel = it->second.level; root.srcSlot = s;
-            } else { root = pl.pool[it->second.slot]; }
+                root.srcLevel = found.level; root.srcSlot = s;
+            } else { root = pl.pool[found.slot]; }
             uint32_t pword;
             if (root.depth > startDepth) pword = root.pci + (root.path & 7u);
             else pword = (root.coord >> 20) * G * G + ((root.coord >> 10) & 1023u) * G + (root.coord & 1023u);
@@ -790,7 +820,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     else {
                         // a level leaf re-finalised in place: the reference pushes an `ignore` copy that is only reachable if its
                         // key was free; that happens at the start depth, where the key wraps to pci + childId
-                        if (pl.leaves.find(key) == pl.leaves.end()) {
+                        if (!pl.leaves.find(key)) {
                             PNode copy = node; copy.srcLevel = node.srcLevel; copy.srcSlot = node.srcSlot;
                             pl.pool.push_back(copy);
                             pl.leaves.emplace(key, LeafRef{NONE32, (uint32_t)pl.pool.size() - 1});
@@ -800,6 +830,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                 first = false;
             }
         }
+        lap(tPlan);
         SDF_REQUIRE(pl.hoc.size() < (size_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
         // ---------------- upload the integer result, then run the float part generation by generation
         SDF_TRY(ensureOc(pl.hoc.size()));
@@ -834,7 +865,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_HIP_CHECK(hipStreamSynchronize(st));
             T->info.num_samples += 19ull * no;
         }
+        lap(tOps);
     }
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, mirrors %.3f s, leaf map %.3f s, post-pass planner %.3f s, post-pass device ops %.3f s\n", tIter, tMirror, tLeafMap, tPlan, tOps);
     // clear the mark bits (OctreeSdfBreadthFirstNoDelay.h:1191-1217)
     if (!pl.marked.empty()) {
         std::vector<uint32_t> pi(pl.marked), pv(pl.marked.size());
