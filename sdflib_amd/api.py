@@ -429,11 +429,11 @@ class ExactOctreeSdf:
         check(lib().sdfhip_exact_download(self.h, _ptr(nodes), _ptr(has), _ptr(sets), _ptr(masks)))
         return nodes, has, sets, masks[:i.num_mask_bytes]
 
-    def get_distance(self, points, gradient=False, triangle=False):
+    def get_distance(self, points, gradient=False, triangle=False, out=None):
         if _is_torch(points):
             import torch
             pts = points.contiguous(); n = pts.numel() // 3
-            d = torch.empty(n, dtype=torch.float32, device=pts.device)
+            d = out if out is not None else torch.empty(n, dtype=torch.float32, device=pts.device)
             g = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if gradient else None
             t = torch.empty(n, dtype=torch.int32, device=pts.device) if triangle else None
             check(lib().sdfhip_exact_query(self.h, C.c_void_p(pts.data_ptr()), n, C.c_void_p(d.data_ptr()),

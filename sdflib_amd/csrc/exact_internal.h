@@ -4,6 +4,7 @@
 #include "dev_math.h"
 #include "dev_tricubic.h"   // stencil tables (child corner sources, mid-point positions)
 #include <memory>
+#include <mutex>
 
 namespace sdfhip {
 
@@ -24,7 +25,13 @@ struct ExLevel {
 
 }  // namespace sdfhip
 
+// scratch of the leaf-sorted batched query, kept with the tree (grow-only) so that a call costs no hipMalloc / hipFree
+struct sdfhip_exact_scratch {
+    sdfhip::DevBuf<uint32_t> key, keyS, qi, qiS, qctx; sdfhip::DevBuf<unsigned char> tmp; std::mutex lock;
+};
+
 struct sdfhip_exact {
+    sdfhip_exact_scratch scratch;
     sdfhip_ctx* ctx = nullptr;
     sdfhip_mesh* mesh = nullptr;           // TriangleData lives in the mesh (it must outlive the tree) ...
     sdfhip::DevBuf<float> ownTri;          // ... or in this buffer for trees created by sdfhip_exact_from_data

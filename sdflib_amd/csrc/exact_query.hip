@@ -241,7 +241,12 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
         else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
     } else {
-        DevBuf<uint32_t> key, keyS, qi, qiS, qctx; DevBuf<unsigned char> tmp;
+        // the tree's own scratch if no other host thread is using it (all work is ordered on the context's stream, so it can be
+        // handed on as soon as this call has enqueued its kernels); a private one otherwise
+        std::unique_lock<std::mutex> own(T->scratch.lock, std::try_to_lock);
+        sdfhip_exact_scratch priv;
+        sdfhip_exact_scratch& S = own.owns_lock() ? T->scratch : priv;
+        DevBuf<uint32_t>&key = S.key, &keyS = S.keyS, &qi = S.qi, &qiS = S.qiS, &qctx = S.qctx; DevBuf<unsigned char>& tmp = S.tmp;
         SDF_TRY(key.reserve(n)); SDF_TRY(keyS.reserve(n)); SDF_TRY(qi.reserve(n)); SDF_TRY(qiS.reserve(n)); SDF_TRY(qctx.reserve(3 * n));
         k_exact_locate<<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t, key.p, qi.p, qctx.p);
         int keyBits = 1; while (keyBits < 32 && (1ull << keyBits) <= T->info.num_nodes) keyBits++;
@@ -253,7 +258,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         if (g) k_exact_sorted<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, g, t);
         else k_exact_sorted<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, nullptr, t);
         SDF_HIP_CHECK(hipGetLastError());
-        SDF_HIP_CHECK(hipStreamSynchronize(st));      // the scratch buffers above die with this scope
+        if (!own.owns_lock()) SDF_HIP_CHECK(hipStreamSynchronize(st));      // the private scratch dies with this scope
     }
     SDF_HIP_CHECK(hipGetLastError());
     if (where == SDFHIP_HOST) {

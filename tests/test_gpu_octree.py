@@ -300,3 +300,22 @@ def test_seam_welding_matches_oracle(oracle, gpu_ctx):
     go, oo = gt.get_octree_data(), ot.data()
     assert go.shape == oo.shape
     assert np.array_equal(go, oo)
+
+
+@pytest.mark.parametrize("ntri", [1, 2, 3])
+def test_tiny_open_meshes(oracle, gpu_ctx, ntri):
+    """One, two and three triangles (open surfaces: every edge single-owner): the BVH degenerates to a leaf root / one inner
+    node; nearest ids, samples and the built array still equal the oracle's."""
+    import sdflib_amd as S
+    v = np.array([[0, 0, 0], [1, 0, 0.1], [0.2, 1, 0], [1.1, 1.2, 0.3], [-0.5, 0.8, 0.6]], np.float32)
+    f = np.array([[0, 1, 2], [1, 3, 2], [0, 2, 4]], np.uint32)[:ntri]
+    box = np.array([-1, -1, -1, 2, 2, 2], np.float32)
+    om, gm = oracle.Mesh(v, f), S.Mesh(v, f, gpu_ctx)
+    rng = np.random.default_rng(3)
+    pts = (rng.random((5000, 3), dtype=np.float32) * 3 - 1).astype(np.float32)
+    assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts))
+    for alg, cont in ((S.ALG_NO_CONTINUITY, False), (S.ALG_CONTINUITY, True)):
+        ot = oracle.Octree(om, box, 4, 1, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_GLOBAL_DFS, continuity=cont)
+        gt = S.OctreeSdf(gm, box, 4, 1, 1e-3, init_algorithm=alg, num_threads=1)
+        assert np.array_equal(ot.data(), gt.get_octree_data())
+        assert np.array_equal(bits(ot.query(pts)), bits(gt.get_distance(pts)))

@@ -11,6 +11,7 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     name = name.replace("void ", "")
     if "rocprim" in name:
