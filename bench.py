@@ -27,6 +27,26 @@ from sdflib_amd import distributed as sdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 
 
+def _pmc_traffic(args):
+    """HBM-side bytes per launch of the timed kernel from the committed rocprofv3 --pmc summary of this same command
+    (profiles/rNN_bench_pmc.csv, written by tools/profile_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950; both are reported in KB.  None if no summary for
+    this configuration is available (a bench run cannot collect counters itself)."""
+    import csv, glob
+    if args.queries != 10_000_000 or args.subdiv != 7 or args.depth != 8 or args.gradient or args.eval != "exact":
+        return None, None
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_pmc.csv")))
+    for path in reversed(files):
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["kernel"].replace(" ", "") == "sdfhip::k_octree_query<0,false>" and row["FETCH_SIZE_avg_per_dispatch"] and row["WRITE_SIZE_avg_per_dispatch"]:
+                    fetch_kb, write_kb = float(row["FETCH_SIZE_avg_per_dispatch"]), float(row["WRITE_SIZE_avg_per_dispatch"])
+                    return int(2 * fetch_kb * 1024 + write_kb * 1024), os.path.join("profiles", os.path.basename(path)) + " (FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+        except Exception:
+            continue
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +134,7 @@ def main():
     total_queries = args.queries * world * args.steps
     value = total_queries / elapsed / 1e6
 
+    traffic, traffic_src = _pmc_traffic(args)
     result = {
         "metric": "Mqueries/sec getDistance() (OctreeSdf, whole job)", "value": round(value, 2), "unit": "Mqueries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -124,7 +145,8 @@ def main():
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
         "roofline": {"bound": "hbm", "kernel": "k_octree_query", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": int(round(bytes_per_query * args.queries)),
                      "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
                      "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
         "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), **{k: round(v, 4) for k, v in binfo.items()}},

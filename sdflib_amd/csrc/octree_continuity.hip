@@ -415,42 +415,46 @@ __global__ void __launch_bounds__(256) kc_pp_children(const OpDev* __restrict__ 
     }
 }
 
-// final walk: leaf histogram + min border value (computeMinBorderValue, OctreeSdf.cpp:155-230); one lane per start cell
-__global__ void kc_final_walk(const uint32_t* __restrict__ oc, int G, uint32_t startDepth, unsigned long long* __restrict__ leavesPerDepth, uint32_t* __restrict__ minBorderKey) {
+// final walk: leaf histogram + min border value (computeMinBorderValue, OctreeSdf.cpp:155-230).  Level-synchronous: one lane
+// per node of the current frontier; inner nodes append their 8 children to the next frontier.
+__global__ void kc_walk_init(int G, uint32_t* __restrict__ at, uint32_t* __restrict__ co) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t G3 = (uint32_t)(G * G * G);
-    if (cell >= G3) return;
-    uint32_t stackAt[80], stackCo[80], stackD[80];
-    int sp = 0;
-    stackAt[0] = cell; stackCo[0] = (cell % G) | (((cell / G) % G) << 10) | ((cell / (G * G)) << 20); stackD[0] = startDepth; sp = 1;
-    while (sp > 0) {
-        sp--;
-        const uint32_t at = stackAt[sp], co = stackCo[sp], d = stackD[sp];
-        const uint32_t w = oc[at];
-        const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
-        if (!(w & LEAF_BIT)) {
-            for (uint32_t c = 0; c < 8; c++) {
-                stackAt[sp] = (w & INDEX_MASK) + c; stackD[sp] = d + 1;
-                stackCo[sp] = (2 * x + (c & 1u)) | ((2 * y + ((c >> 1) & 1u)) << 10) | ((2 * z + (c >> 2)) << 20);
-                sp++;
-            }
-            continue;
+    if (cell >= (uint32_t)(G * G * G)) return;
+    at[cell] = cell; co[cell] = (cell % G) | (((cell / G) % G) << 10) | ((cell / (G * G)) << 20);
+}
+__global__ void kc_walk_level(const uint32_t* __restrict__ oc, const uint32_t* __restrict__ at, const uint32_t* __restrict__ coIn, uint32_t n, uint32_t d,
+                              uint32_t* __restrict__ nextAt, uint32_t* __restrict__ nextCo, uint32_t* __restrict__ nextCount,
+                              unsigned long long* __restrict__ leavesPerDepth, uint32_t* __restrict__ minBorderKey) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t w = valid ? oc[at[i]] : 0u;
+    const uint32_t co = valid ? coIn[i] : 0u;
+    const bool leaf = valid && (w & LEAF_BIT);
+    const unsigned long long leafMask = __ballot(leaf);
+    if (leafMask != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)leafMask) - 1)) atomicAdd(&leavesPerDepth[d], (unsigned long long)__popcll(leafMask));
+    if (!valid) return;
+    const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
+    if (!leaf) {
+        const uint32_t base = atomicAdd(nextCount, 8u);
+        for (uint32_t c = 0; c < 8; c++) {
+            nextAt[base + c] = (w & INDEX_MASK) + c;
+            nextCo[base + c] = (2 * x + (c & 1u)) | ((2 * y + ((c >> 1) & 1u)) << 10) | ((2 * z + (c >> 2)) << 20);
         }
-        atomicAdd(&leavesPerDepth[d], 1ull);
-        const uint32_t last = (1u << d) - 1u;
-        if (!(x == 0 || y == 0 || z == 0 || x == last || y == last || z == last)) continue;
-        const uint32_t* cw = oc + (w & INDEX_MASK);
-        auto cf = [&](int n) { return __uint_as_float(cw[n]); };
-        float mn = INFINITY;
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t bx = k & 1u, by = (k >> 1) & 1u, bz = k >> 2;
-            const bool onBorder = (x + bx == 0) || (y + by == 0) || (z + bz == 0) || (x + bx == last + 1) || (y + by == last + 1) || (z + bz == last + 1);
-            if (!onBorder) continue;
-            const float v = tricubicValueExact(cf, F3{(float)bx, (float)by, (float)bz});
-            mn = gmin(mn, v);
-        }
-        if (mn < INFINITY) { const uint32_t b = __float_as_uint(mn); atomicMin(minBorderKey, (b & 0x80000000u) ? ~b : (b | 0x80000000u)); }
+        return;
     }
+    const uint32_t last = (1u << d) - 1u;
+    if (!(x == 0 || y == 0 || z == 0 || x == last || y == last || z == last)) return;
+    const uint32_t* cw = oc + (w & INDEX_MASK);
+    auto cf = [&](int k) { return __uint_as_float(cw[k]); };
+    float mn = INFINITY;
+    for (uint32_t k = 0; k < 8; k++) {
+        const uint32_t bx = k & 1u, by = (k >> 1) & 1u, bz = k >> 2;
+        const bool onBorder = (x + bx == 0) || (y + by == 0) || (z + bz == 0) || (x + bx == last + 1) || (y + by == last + 1) || (z + bz == last + 1);
+        if (!onBorder) continue;
+        const float v = tricubicValueExact(cf, F3{(float)bx, (float)by, (float)bz});
+        mn = gmin(mn, v);
+    }
+    if (mn < INFINITY) { const uint32_t b = __float_as_uint(mn); atomicMin(minBorderKey, (b & 0x80000000u) ? ~b : (b | 0x80000000u)); }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -491,6 +495,7 @@ struct LeafMap {
         while (keys[i] != NONE32) { if (keys[i] == k) return; i = (i + 1) & mask; }
         keys[i] = k; vals[i] = v; count++;
     }
+    void prefetch(uint32_t k) const { const size_t i = mix(k) & mask; __builtin_prefetch(&keys[i]); __builtin_prefetch(&vals[i]); }
     const LeafRef* find(uint32_t k) const {
         size_t i = mix(k) & mask;
         while (keys[i] != NONE32) { if (keys[i] == k) return &vals[i]; i = (i + 1) & mask; }
@@ -625,7 +630,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         LV[sod] = std::move(L);
     }
 
-    uint64_t numRescheduled = 0;
+    uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
     double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
     auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
@@ -713,7 +718,19 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         pl.patches.clear();
         std::vector<std::vector<OpDev>> gens;
         auto addOp = [&](uint32_t gen, const OpDev& op) { if (gens.size() <= gen) gens.resize(gen + 1); gens[gen].push_back(op); };
+        std::vector<PNode> cache; std::vector<uint32_t> genOf;      // work list of one scheduled leaf, reused
         for (uint32_t si = 0; si < numCand; si++) {
+            // the planner is bound by host cache misses (random reads of the leaf table, the level mirrors and the word mirror):
+            // run two prefetch stages ahead of the candidate being processed
+            if (si + 16 < numCand) pl.leaves.prefetch(toSubdivide[si + 16]);
+            if (si + 8 < numCand) {
+                const LeafRef* nx = pl.leaves.find(toSubdivide[si + 8]);
+                if (nx && nx->level != NONE32) {
+                    const CLevelHost* S = LV[nx->level].get(); const uint32_t q = nx->slot;
+                    __builtin_prefetch(&S->hPath[q]); __builtin_prefetch(&S->hPci[q]); __builtin_prefetch(&S->hCoord[q]);
+                    __builtin_prefetch(&S->hNIdx[6ull * q]); __builtin_prefetch(&S->hNIdx[6ull * q + 5]); __builtin_prefetch(&S->hNDepth[6ull * q]);
+                } else if (nx) __builtin_prefetch(&pl.pool[nx->slot]);
+            }
             const LeafRef* it = pl.leaves.find(toSubdivide[si]);
             if (!it) continue;
             const LeafRef found = *it;             // the table may grow below
@@ -729,13 +746,14 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             if (root.depth > startDepth) pword = root.pci + (root.path & 7u);
             else pword = (root.coord >> 20) * G * G + ((root.coord >> 10) & 1023u) * G + (root.coord & 1023u);
             if (!pl.isLeaf(pword)) continue;
+            ppRoots++;
             bool recycled = false; const uint32_t oldCoeffIndex = pl.childrenIndex(pword);
             bool first = true;
-            std::vector<PNode> cache; std::vector<uint32_t> genOf;
+            cache.clear(); genOf.clear();
             cache.push_back(root); genOf.push_back(0);
             size_t ci = 0;
             while (ci < cache.size()) {
-                PNode node = cache[ci]; const uint32_t gen = genOf[ci]; ci++;
+                PNode node = cache[ci]; const uint32_t gen = genOf[ci]; ci++; ppNodes++;
                 const uint32_t depthN = node.depth, c = node.path & 7u;
                 const int gx = (int)(node.coord & 1023u), gy = (int)((node.coord >> 10) & 1023u), gz = (int)(node.coord >> 20);
                 uint32_t word = NONE32;
@@ -788,6 +806,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                 }
                 OpDev op{}; op.srcLevel = node.srcLevel; op.srcSlot = node.srcSlot;
                 if (cd >= depthN && samplesMask != 0xFFFFFFFFu) {
+                    ppSplits++;
                     op.kind = 0; op.samplesMask = samplesMask; op.recycle = (first && !node.ignore) ? 1u : 0u;
                     const uint32_t childIndex = (uint32_t)pl.hoc.size();
                     pl.setWord(word, (childIndex & INDEX_MASK) | MARK_BIT, sizeBefore);
@@ -867,7 +886,8 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         lap(tOps);
     }
-    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, mirrors %.3f s, leaf map %.3f s, post-pass planner %.3f s, post-pass device ops %.3f s\n", tIter, tMirror, tLeafMap, tPlan, tOps);
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, mirrors %.3f s, leaf map %.3f s, post-pass planner %.3f s, post-pass device ops %.3f s; post-pass: %llu scheduled, %llu still leaves, %llu nodes visited, %llu splits\n", tIter, tMirror, tLeafMap, tPlan, tOps,
+                                            (unsigned long long)numRescheduled, (unsigned long long)ppRoots, (unsigned long long)ppNodes, (unsigned long long)ppSplits);
     // clear the mark bits (OctreeSdfBreadthFirstNoDelay.h:1191-1217)
     if (!pl.marked.empty()) {
         std::vector<uint32_t> pi(pl.marked), pv(pl.marked.size());
@@ -881,7 +901,21 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     // final statistics on the device
     DevBuf<unsigned long long> lpd; SDF_TRY(lpd.reserve(16));
     SDF_HIP_CHECK(hipMemsetAsync(lpd.p, 0, 128, st));
-    kc_final_walk<<<gridFor(G3, 64), 64, 0, st>>>(oc.p, G, startDepth, lpd.p, stats.p + 1);
+    {
+        DevBuf<uint32_t> fa[2], fc[2], cnt; SDF_TRY(cnt.reserve(1));
+        uint32_t n = G3, cur = 0;
+        SDF_TRY(fa[0].reserve(n)); SDF_TRY(fc[0].reserve(n));
+        kc_walk_init<<<gridFor(G3, 256), 256, 0, st>>>(G, fa[0].p, fc[0].p);
+        for (uint32_t d = startDepth; d <= maxDepth && n > 0; d++) {
+            const uint64_t cap = 8ull * n;
+            SDF_TRY(fa[cur ^ 1].reserve(cap)); SDF_TRY(fc[cur ^ 1].reserve(cap));
+            SDF_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, st));
+            kc_walk_level<<<gridFor(n, 256), 256, 0, st>>>(oc.p, fa[cur].p, fc[cur].p, n, d, fa[cur ^ 1].p, fc[cur ^ 1].p, cnt.p, lpd.p, stats.p + 1);
+            SDF_HIP_CHECK(hipMemcpyAsync(&n, cnt.p, 4, hipMemcpyDeviceToHost, st));
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            cur ^= 1;
+        }
+    }
     unsigned long long hl[16]; uint32_t hs[2];
     SDF_HIP_CHECK(hipMemcpyAsync(hl, lpd.p, 128, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipMemcpyAsync(hs, stats.p, 8, hipMemcpyDeviceToHost, st));
