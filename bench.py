@@ -234,6 +234,14 @@ def extras(tree, mesh, box, pts, out, dev, rank):
     ms = _time_ms(lambda: ct.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out))
     r["continuity_octree"] = {"build_s": round(dt, 4), "words": int(ci.num_words), "leaves": int(ci.num_leaves), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
     ct.close()
+    # the 64x64 fit on the matrix cores (SDFHIP_FIT_MFMA): same topology, coefficients within the reference's own rounding noise
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mt = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, fit_mode=S.FIT_MFMA)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    mi = mt.info
+    r["fit_mfma_build"] = {"build_s": round(dt, 4), "words": int(mi.num_words), "same_size_as_exact_fit": bool(int(mi.num_words) == int(tree.info.num_words)),
+                           "decisions_rechecked_with_exact_fit": int(mi.fit_rechecks), "nodes": int(mi.num_nodes)}
+    mt.close()
     return r
 
 

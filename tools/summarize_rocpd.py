@@ -36,7 +36,8 @@ def main(src, prefix):
         for k, (n, s, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             w.writerow([k, n, int(s), int(s / n), int(mn), int(mx), f"{100 * s / tot:.3f}"])
     out = {}
-    for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"])):
+    SQ = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]
+    for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]), ("pmc_sq", SQ)):
         p = os.path.join(src, sub, "bench_results.db")
         if not os.path.exists(p):
             continue
@@ -53,6 +54,13 @@ def main(src, prefix):
                 continue
             n = max(x[0] for x in v.values())
             w.writerow([k, n] + [f"{v[c][1]:.3f}" if c in v else "" for c in cols] + ["FETCH/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE under-reports wide streaming reads by 2x)"])
+    with open(prefix + "_pmc_sq.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "dispatches"] + [c + "_avg_per_dispatch" for c in SQ])
+        for k, v in sorted(out.items()):
+            if k.startswith("sdfhip") and any(c in v for c in SQ):
+                n = max(v[c][0] for c in SQ if c in v)
+                w.writerow([k, n] + [f"{v[c][1]:.6g}" if c in v else "" for c in SQ])
     print(open(prefix + "_kernel_stats.csv").read()[:3000])
     print(open(prefix + "_pmc.csv").read())
 
