@@ -117,10 +117,21 @@ struct HostBvhBuilder {
     int maxParallelDepth = 0;
 
     struct D { double x, y, z; };
+    KeyTri* scratchKeys = nullptr; float* scratchLoc = nullptr;      // T entries / 9 T floats, uninitialised, sliced by range
     const float* triV = nullptr;       // 9 floats per triangle, gathered once (the planner reads every vertex ~2 log2(T) times)
     int sortThreads = 1;
     D vtx(int t, int k) const { const float* q = triV + 9 * (size_t)t + 3 * k; return D{(double)q[0], (double)q[1], (double)q[2]}; }
     static double comp(const D& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+    static constexpr int kWideRange = 1 << 16;
+    // chunks of [0,n) on helper threads (at most 16, at least 32k items each); fn(i0, i1)
+    template <typename F> static void parallelFor(int n, F fn) {
+        int parts = n / 32768; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
+        std::vector<std::thread> th;
+        for (int p = 1; p < parts; p++) { const int i0 = (int)((long long)n * p / parts), i1 = (int)((long long)n * (p + 1) / parts); th.emplace_back([=]() { fn(i0, i1); }); }
+        fn(0, (int)((long long)n / parts));
+        for (std::thread& t : th) t.join();
+    }
 
     // Plans the subtree over order[begin,end): writes its bounding sphere into out[0..3] and returns the reference to it.
     // `innerId` = pre-order index this subtree's root gets if it is an inner node (n > 1).
@@ -138,34 +149,64 @@ struct HostBvhBuilder {
         }
         const double lo = std::numeric_limits<double>::lowest(), hi = std::numeric_limits<double>::max();
         D top{lo, lo, lo}, bot{hi, hi, hi}, ce{0, 0, 0};
-        for (int i = begin; i < end; i++)
-            for (int k = 0; k < 3; k++) {
-                const D p = vtx(order[i], k);
-                ce.x += p.x; ce.y += p.y; ce.z += p.z;
-                top.x = std::max(top.x, p.x); bot.x = std::min(bot.x, p.x);
-                top.y = std::max(top.y, p.y); bot.y = std::min(bot.y, p.y);
-                top.z = std::max(top.z, p.z); bot.z = std::min(bot.z, p.z);
-            }
-        const double cnt = (double)(3 * n);
-        ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
-        const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
-        const int dim = (int)(std::max_element(diag, diag + 3) - diag);
         double r2 = 0.0;
-        for (int i = begin; i < end; i++)
-            for (int k = 0; k < 3; k++) {
-                const D p = vtx(order[i], k);
-                const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
-                r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-            }
-        out[0] = ce.x; out[1] = ce.y; out[2] = ce.z; out[3] = std::sqrt(r2);
-
-        {   // median split: sort the range by the first vertex's coordinate along `dim`
-            std::vector<KeyTri> tmp((size_t)n);
+        int dim = 0;
+        if (n >= kWideRange) {
+            // Large ranges (the top of the tree = the planner's critical path): only the centre sum depends on the order of its
+            // operands; the gather of the range's vertices, the AABB, the radius (max of identical expressions), the keys and
+            // the write-back are order independent and run on helper threads over a contiguous copy of the range.
+            float* loc = scratchLoc + 9 * (size_t)begin;      // this node's slice of the planner-wide scratch (ranges in flight are disjoint)
+            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) std::memcpy(&loc[9 * (size_t)i], triV + 9 * (size_t)order[begin + i], 36); });
+            for (size_t j = 0; j < 3 * (size_t)n; j++) { ce.x += (double)loc[3 * j]; ce.y += (double)loc[3 * j + 1]; ce.z += (double)loc[3 * j + 2]; }
+            const double cnt = (double)(3 * n);
+            ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
+            std::mutex m;
+            parallelFor(n, [&](int i0, int i1) {
+                D t{lo, lo, lo}, bt{hi, hi, hi}; double rr = 0.0;
+                for (size_t j = 3 * (size_t)i0; j < 3 * (size_t)i1; j++) {
+                    const D p{(double)loc[3 * j], (double)loc[3 * j + 1], (double)loc[3 * j + 2]};
+                    t.x = std::max(t.x, p.x); bt.x = std::min(bt.x, p.x); t.y = std::max(t.y, p.y); bt.y = std::min(bt.y, p.y); t.z = std::max(t.z, p.z); bt.z = std::min(bt.z, p.z);
+                    const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
+                    rr = std::max(rr, dx * dx + dy * dy + dz * dz);
+                }
+                std::lock_guard<std::mutex> g(m);
+                top.x = std::max(top.x, t.x); top.y = std::max(top.y, t.y); top.z = std::max(top.z, t.z);
+                bot.x = std::min(bot.x, bt.x); bot.y = std::min(bot.y, bt.y); bot.z = std::min(bot.z, bt.z); r2 = std::max(r2, rr);
+            });
+            const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
+            dim = (int)(std::max_element(diag, diag + 3) - diag);
+            KeyTri* tmp = scratchKeys + begin;
+            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) tmp[i] = KeyTri{(double)loc[9 * (size_t)i + dim], order[begin + i]}; });
+            IntroSortLike sorter; sorter.maxThreads = sortThreads;
+            sorter.sort(tmp, tmp + n);
+            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) order[begin + i] = tmp[i].tri; });
+        } else {
+            for (int i = begin; i < end; i++)
+                for (int k = 0; k < 3; k++) {
+                    const D p = vtx(order[i], k);
+                    ce.x += p.x; ce.y += p.y; ce.z += p.z;
+                    top.x = std::max(top.x, p.x); bot.x = std::min(bot.x, p.x);
+                    top.y = std::max(top.y, p.y); bot.y = std::min(bot.y, p.y);
+                    top.z = std::max(top.z, p.z); bot.z = std::min(bot.z, p.z);
+                }
+            const double cnt = (double)(3 * n);
+            ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
+            const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
+            dim = (int)(std::max_element(diag, diag + 3) - diag);
+            for (int i = begin; i < end; i++)
+                for (int k = 0; k < 3; k++) {
+                    const D p = vtx(order[i], k);
+                    const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
+                    r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
+                }
+            // median split: sort the range by the first vertex's coordinate along `dim`
+            KeyTri* tmp = scratchKeys + begin;
             for (int i = 0; i < n; i++) { const int t = order[begin + i]; tmp[i] = KeyTri{comp(vtx(t, 0), dim), t}; }
             IntroSortLike sorter; sorter.maxThreads = sortThreads;
-            sorter.sort(tmp.data(), tmp.data() + n);
+            sorter.sort(tmp, tmp + n);
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
         }
+        out[0] = ce.x; out[1] = ce.y; out[2] = ce.z; out[3] = std::sqrt(r2);
         const int mid = (int)(0.5 * (begin + end));
         // pre-order numbering of inner nodes: the left subtree holds (mid - begin) - 1 of them
         const int leftId = innerId + 1, rightId = innerId + (mid - begin);
@@ -249,13 +290,19 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     std::unique_ptr<double[]> sph(new double[nSph]);
     std::unique_ptr<int[]> kids(new int[nKids]);
     if (nn == 0) { for (size_t i = 0; i < nSph; i++) sph[i] = 0.0; kids[0] = kids[1] = ~0; }
-    std::vector<float> htv(9 * (size_t)T);
-    for (size_t t = 0; t < T; t++) for (int k = 0; k < 3; k++) {
-        const uint32_t v = mesh->hIdx[3 * t + k];
-        htv[9 * t + 3 * k] = mesh->hVerts[3 * (size_t)v]; htv[9 * t + 3 * k + 1] = mesh->hVerts[3 * (size_t)v + 1]; htv[9 * t + 3 * k + 2] = mesh->hVerts[3 * (size_t)v + 2];
-    }
+    std::unique_ptr<float[]> htvBuf(new float[9 * (size_t)T]);
+    float* htv = htvBuf.get();
+    HostBvhBuilder::parallelFor((int)T, [&](int t0, int t1) {
+        for (size_t t = (size_t)t0; t < (size_t)t1; t++) for (int k = 0; k < 3; k++) {
+            const uint32_t v = mesh->hIdx[3 * t + k];
+            htv[9 * t + 3 * k] = mesh->hVerts[3 * (size_t)v]; htv[9 * t + 3 * k + 1] = mesh->hVerts[3 * (size_t)v + 1]; htv[9 * t + 3 * k + 2] = mesh->hVerts[3 * (size_t)v + 2];
+        }
+    });
+    const double tGather = nowSeconds();
     HostBvhBuilder b;
-    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.get(); b.kids = kids.get(); b.triV = htv.data();
+    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.get(); b.kids = kids.get(); b.triV = htv;
+    std::unique_ptr<KeyTri[]> sk(new KeyTri[T]); std::unique_ptr<float[]> sl(new float[9 * (size_t)T]);
+    b.scratchKeys = sk.get(); b.scratchLoc = sl.get();
     b.order.resize(T);
     for (uint32_t i = 0; i < T; i++) b.order[i] = (int)i;
     unsigned hc = std::thread::hardware_concurrency();
@@ -264,6 +311,7 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     b.sortThreads = (int)(hc ? hc : 1u);
     double rootSphere[4];
     b.build(0, rootSphere, 0, (int)T, 0);
+    const double tPlanned = nowSeconds();
     SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
     hipStream_t st = mesh->ctx->stream;
     SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
@@ -280,6 +328,7 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     mesh->numBvhNodes = nn;
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", tGather - t0, tPlanned - tGather, b.sortThreads, b.maxParallelDepth, nowSeconds() - tPlanned);
     mesh->hasBvh = true;
     if (seconds) *seconds = nowSeconds() - t0;
     return SDFHIP_OK;
