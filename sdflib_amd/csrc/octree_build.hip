@@ -7,7 +7,8 @@
 //
 // MI355X formulation.  The reference walks the tree depth-first, one node at a time; here the tree is grown
 // LEVEL-SYNCHRONOUSLY (all nodes of a depth at once = 10^2..10^5.5 nodes x 19 samples of parallelism):
-//   k_corner_samples / k_level_samples : one lane per sample point: fp64 BVH nearest triangle + fp32 Hermite datum
+//   sampleBatch (octree_sampler.h)     : exact samples of whole levels: dedup by lattice point, fp64 BVH nearest triangle per
+//                                        unique point (dev_bvh.h), fp32 Hermite datum per sample
 //   k_decide          : one lane per node: 64x64 fit (reference summation order), 19-point error rule, leaf/inner
 //   hipcub ExclusiveSum + k_scatter_children : child slots; the 27-point stencil is handed down to the 8 children
 // and afterwards the breadth-first arrays are relabelled into the reference's array layout:
@@ -26,16 +27,6 @@
 
 namespace sdfhip {
 
-
-// 8 corners of every node (only the root level evaluates corners; deeper levels inherit them).
-__global__ void __launch_bounds__(128) k_corner_samples(MeshDev m, const float* __restrict__ center, float half, uint32_t n, float* __restrict__ corner) {
-    extern __shared__ uint32_t s_stack[];        // [stackDepth][128]
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 8u * n) return;
-    const uint32_t node = gid >> 3;
-    const F3 p = F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]} + cornerRel(gid & 7u) * half;
-    valuesAt(m, p, bvhNearest<128>(m.bvh, p, s_stack + threadIdx.x), corner + 4 * (size_t)gid);
-}
 
 SDF_DEV uint32_t floatOrderKey(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 SDF_HD float floatFromOrderKey(uint32_t k) { const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); return f; }
@@ -137,6 +128,21 @@ __global__ void k_scale8(uint32_t n, uint32_t* __restrict__ v) {
     if (i < n) v[i] *= 8u;
 }
 
+// Geometry of ALL children of a level (levels above the start depth subdivide unconditionally): child c of node i is 8 i + c.
+__global__ void k_expand_geometry(const float* __restrict__ center, const uint32_t* __restrict__ coord, float half, uint32_t n,
+                                  float* __restrict__ ncenter, uint32_t* __restrict__ ncoord) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, c = gid & 7u;
+    if (i >= n) return;
+    const float ns = 0.5f * half;
+    ncenter[3 * (size_t)gid] = center[3 * (size_t)i] + ((c & 1u) ? ns : -ns);
+    ncenter[3 * (size_t)gid + 1] = center[3 * (size_t)i + 1] + ((c & 2u) ? ns : -ns);
+    ncenter[3 * (size_t)gid + 2] = center[3 * (size_t)i + 2] + ((c & 4u) ? ns : -ns);
+    const uint32_t co = coord[i];
+    const uint32_t x = 2u * (co & 1023u) + (c & 1u), y = 2u * ((co >> 10) & 1023u) + ((c >> 1) & 1u), z = 2u * (co >> 20) + (c >> 2);
+    ncoord[gid] = x | (y << 10) | (z << 20);
+}
+
 struct ScatterArgs {
     const float* center; const uint32_t* coord; const float* corner; const float* mid; const uint32_t* inner; const uint32_t* childBase;
     uint32_t n; float half;
@@ -167,7 +173,8 @@ __global__ void __launch_bounds__(256) k_scatter_children(ScatterArgs a) {
 
 // Move the start-depth level into start-grid cell order (z-major) and keep only cells [cellBegin, cellEnd).
 __global__ void k_to_cell_order(const float* __restrict__ center, const uint32_t* __restrict__ coord, const float* __restrict__ corner, uint32_t n,
-                                uint32_t G, uint32_t cellBegin, uint32_t cellEnd, float* __restrict__ ocenter, uint32_t* __restrict__ ocoord, float* __restrict__ ocorner) {
+                                uint32_t G, uint32_t cellBegin, uint32_t cellEnd, float* __restrict__ ocenter, uint32_t* __restrict__ ocoord, float* __restrict__ ocorner,
+                                const float* __restrict__ mid, float* __restrict__ omid) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid >> 3, j = gid & 7u;
     if (i >= n) return;
@@ -176,6 +183,7 @@ __global__ void k_to_cell_order(const float* __restrict__ center, const uint32_t
     if (cell < cellBegin || cell >= cellEnd) return;
     const uint32_t d = cell - cellBegin;
     reinterpret_cast<float4*>(ocorner)[8 * (size_t)d + j] = reinterpret_cast<const float4*>(corner)[8 * (size_t)i + j];
+    if (mid) for (uint32_t m = j; m < 19u; m += 8u) reinterpret_cast<float4*>(omid)[19 * (size_t)d + m] = reinterpret_cast<const float4*>(mid)[19 * (size_t)i + m];
     if (j == 0) {
         ocenter[3 * (size_t)d] = center[3 * (size_t)i]; ocenter[3 * (size_t)d + 1] = center[3 * (size_t)i + 1]; ocenter[3 * (size_t)d + 2] = center[3 * (size_t)i + 2];
         ocoord[d] = co;
@@ -319,28 +327,56 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         }
         SDF_HIP_CHECK(hipMemcpyAsync(L->center.p, hc.data(), hc.size() * 4, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->coord.p, hco.data(), hco.size() * 4, hipMemcpyHostToDevice, st));
-        k_corner_samples<<<gridFor(8ull * L->n, 128), 128, stackBytes, st>>>(md, L->center.p, L->half, L->n, L->corner.p);
         SDF_HIP_CHECK(hipStreamSynchronize(st));   // hc/hco go out of scope
-        T->info.num_samples += 8ull * L->n; T->info.num_traversals += 8ull * L->n;
         T->levels[0] = std::move(L);
     }
 
     double tSamples = 0, tDecide = 0;
     SampleScratch SS;
+    {   // Levels down to the start depth exist a priori: create their geometry now and take ALL their samples (the 8 corners of the
+        // root level, 19 mid-points per node of every level) in one deduplicated batch instead of one latency-bound launch each.
+        const double t0 = nowSeconds();
+        SampleBatch B;
+        BuildLevel* R0 = T->levels[0].get();
+        B.add(R0->center.p, R0->coord.p, R0->half, R0->n, 8, R0->corner.p, 4);
+        T->info.num_samples += 8ull * R0->n;
+        for (uint32_t d = sod; d <= startDepth && d <= maxDepth; d++) {
+            BuildLevel* L = T->levels[d - sod].get();
+            if (d < maxDepth) {
+                SDF_TRY(L->mid.reserve(76ull * L->n));
+                B.add(L->center.p, L->coord.p, L->half, L->n, 19, L->mid.p, 4);
+                T->info.num_samples += 19ull * L->n;
+                L->presampled = true;
+            }
+            if (d < startDepth && d < maxDepth) {
+                std::unique_ptr<BuildLevel> N(new BuildLevel());
+                N->depth = d + 1; N->n = 8u * L->n; N->half = 0.5f * L->half;
+                SDF_TRY(allocLevelCommon(*N));
+                k_expand_geometry<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->half, L->n, N->center.p, N->coord.p);
+                T->levels[d + 1 - sod] = std::move(N);
+            }
+        }
+        SDF_TRY(sampleBatch(st, md, B, SS, stackBytes, T->info.num_traversals));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        tSamples += nowSeconds() - t0;
+    }
     for (uint32_t d = sod; d <= maxDepth; d++) {
         BuildLevel* L = T->levels[d - sod].get();
         if (!L || L->n == 0) break;
         if (d == startDepth) {
             // bring the level into cell order and restrict it to this shard's cells
             std::unique_ptr<BuildLevel> R(new BuildLevel());
-            R->depth = d; R->n = cellEnd - cellBegin; R->half = L->half;
+            R->depth = d; R->n = cellEnd - cellBegin; R->half = L->half; R->presampled = L->presampled;
             SDF_TRY(allocLevelCommon(*R));
-            k_to_cell_order<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->corner.p, L->n, G, cellBegin, cellEnd, R->center.p, R->coord.p, R->corner.p);
+            if (L->presampled) SDF_TRY(R->mid.reserve(76ull * R->n));
+            k_to_cell_order<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->corner.p, L->n, G, cellBegin, cellEnd, R->center.p, R->coord.p, R->corner.p,
+                                                                        L->presampled ? L->mid.p : nullptr, L->presampled ? R->mid.p : nullptr);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));      // the unordered level is released by the assignment below
             T->levels[d - sod] = std::move(R);
             L = T->levels[d - sod].get();
         }
         SDF_TRY(L->flag.reserve(L->n)); SDF_TRY(L->inner.reserve(L->n)); SDF_TRY(L->childBase.reserve(L->n));
-        if (d < maxDepth) {
+        if (d < maxDepth && !L->presampled) {
             SDF_TRY(L->mid.reserve(76ull * L->n));
             const double t0 = nowSeconds();
             SDF_TRY(sampleMidPoints(st, md, L->coord.p, L->center.p, L->half, L->n, L->mid.p, 4, SS, stackBytes, T->info.num_traversals));
@@ -379,13 +415,19 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         if (d >= startDepth) { T->info.num_nodes += L->n; T->info.num_leaves += L->numLeaves; T->info.leaves_per_depth[d] = L->numLeaves; }
         if (d < maxDepth && L->numInner > 0) {
             SDF_REQUIRE(L->numInner <= (1u << 24), "level too large");
-            std::unique_ptr<BuildLevel> N(new BuildLevel());
-            N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
-            SDF_TRY(allocLevelCommon(*N));
+            const bool precreated = T->levels[d + 1 - sod] != nullptr;      // levels down to the start depth already have their geometry (same values)
+            std::unique_ptr<BuildLevel> fresh;
+            if (!precreated) {
+                fresh.reset(new BuildLevel());
+                fresh->depth = d + 1; fresh->n = 8u * L->numInner; fresh->half = 0.5f * L->half;
+                SDF_TRY(allocLevelCommon(*fresh));
+            }
+            BuildLevel* N = precreated ? T->levels[d + 1 - sod].get() : fresh.get();
+            SDF_REQUIRE(N->n == 8u * L->numInner, "internal: pre-created level has the wrong size");
             ScatterArgs sa{L->center.p, L->coord.p, L->corner.p, L->mid.p, L->inner.p, L->childBase.p, L->n, L->half, N->center.p, N->coord.p, N->corner.p};
             k_scatter_children<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(sa);
             SDF_HIP_CHECK(hipGetLastError());
-            T->levels[d + 1 - sod] = std::move(N);
+            if (!precreated) T->levels[d + 1 - sod] = std::move(fresh);
         }
         // this level's mid-points are no longer needed once the children exist
         SDF_HIP_CHECK(hipStreamSynchronize(st));

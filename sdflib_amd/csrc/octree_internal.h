@@ -25,6 +25,7 @@ struct BuildLevel {
     DevBuf<uint32_t> alloc;         // n : words of the node's block + all descendants' blocks
     DevBuf<uint32_t> pos, blk;      // n : absolute position of the node word / of its block
     uint32_t numInner = 0, numLeaves = 0;
+    bool presampled = false;        // created and sampled up front (levels down to the start depth exist a priori)
 };
 
 }  // namespace sdfhip

@@ -22,77 +22,99 @@ SDF_DEV void valuesAt(const MeshDev& m, F3 p, uint32_t t, float* __restrict__ ou
     *reinterpret_cast<float4*>(out4) = make_float4(d, g.x, g.y, g.z);
 }
 
-// ---- 19 mid-points of every node of a level: the build's hot path --------------------------------------------------
+// ---- exact samples of whole levels: the build's hot path -------------------------------------------------------------
 // Neighbouring nodes share mid-points (a face centre belongs to 2 nodes, an edge mid-point to up to 4), and the reference
-// answers each of them with the same deterministic query.  The samples of a level are therefore grouped by lattice point
-// (radix sort of a 36-bit key), one traversal is run per group of samples whose fp32 POSITION BITS are identical — the
+// answers each of them with the same deterministic query.  The samples of a batch are therefore grouped by lattice point
+// (radix sort of a 39-bit key), one traversal is run per group of samples whose fp32 POSITION BITS are identical — the
 // positions come from different node centres, and only equal bits guarantee the same answer — and every sample then
 // computes its Hermite datum from the shared nearest-triangle id.  About 1.6x fewer traversals, issued in lattice order.
-SDF_DEV F3 midPosition(const float* __restrict__ center, float half, uint32_t q) {
-    const uint32_t node = q / 19u;
-    return F3{center[3 * node], center[3 * node + 1], center[3 * node + 2]} + midRel((int)(q - 19u * node)) * half;
+// A batch is up to MAX_SEGS segments = (level, kind) pairs: the 19 mid-points or the 8 corners of every node of a level.
+// Levels whose nodes are known a priori (everything above the start depth subdivides) go into ONE batch: their traversals
+// are few and long (points far from the surface), i.e. latency bound, and gain nothing from being launched one after another.
+constexpr int MAX_SEGS = 8;
+struct SampleSeg { const float* center; const uint32_t* coord; float* out; float half; uint32_t n, begin; int points, stride; };
+struct SampleBatch {
+    SampleSeg seg[MAX_SEGS]; int count = 0; uint32_t total = 0;
+    void add(const float* center, const uint32_t* coord, float half, uint32_t n, int points, float* out, int stride) {
+        seg[count] = SampleSeg{center, coord, out, half, n, total, points, stride}; count++; total += (uint32_t)points * n;
+    }
+};
+struct SampleRef { int seg; uint32_t node, k; };
+SDF_DEV SampleRef sampleRef(const SampleBatch& B, uint32_t q) {
+    int s = 0;
+    for (int i = 1; i < B.count; i++) s = (q >= B.seg[i].begin) ? i : s;
+    const uint32_t local = q - B.seg[s].begin, pts = (uint32_t)B.seg[s].points;
+    return SampleRef{s, local / pts, local % pts};
 }
-__global__ void k_mid_keys(const uint32_t* __restrict__ coord, uint32_t n, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
+SDF_DEV F3 sampleRel(const SampleBatch& B, const SampleRef& r) { return B.seg[r.seg].points == 8 ? cornerRel(r.k) : midRel((int)r.k); }
+SDF_DEV F3 samplePosition(const SampleBatch& B, uint32_t q) {
+    const SampleRef r = sampleRef(B, q);
+    const float* c = B.seg[r.seg].center + 3 * (size_t)r.node;
+    return F3{c[0], c[1], c[2]} + sampleRel(B, r) * B.seg[r.seg].half;
+}
+__global__ void k_sample_keys(SampleBatch B, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= 19u * n) return;
-    const uint32_t node = q / 19u, co = coord[node];
-    const F3 r = midRel((int)(q - 19u * node));
-    const uint64_t lx = 2u * (co & 1023u) + (uint32_t)(r.x + 1.f), ly = 2u * ((co >> 10) & 1023u) + (uint32_t)(r.y + 1.f), lz = 2u * (co >> 20) + (uint32_t)(r.z + 1.f);
-    key[q] = lx | (ly << 12) | (lz << 24);
+    if (q >= B.total) return;
+    const SampleRef r = sampleRef(B, q);
+    const uint32_t co = B.seg[r.seg].coord[r.node];
+    const F3 rel = sampleRel(B, r);
+    const uint64_t lx = 2u * (co & 1023u) + (uint32_t)(rel.x + 1.f), ly = 2u * ((co >> 10) & 1023u) + (uint32_t)(rel.y + 1.f), lz = 2u * (co >> 20) + (uint32_t)(rel.z + 1.f);
+    key[q] = lx | (ly << 12) | (lz << 24) | ((uint64_t)r.seg << 36);
     val[q] = q;
 }
 // sorted entry j starts a new traversal unless it is the same lattice point AND the same position bits as entry j-1
-__global__ void k_mid_mark(const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, const float* __restrict__ center, float half, uint32_t total,
-                           uint32_t* __restrict__ isRep) {
+__global__ void k_sample_mark(SampleBatch B, const uint64_t* __restrict__ key, const uint32_t* __restrict__ val, uint32_t* __restrict__ isRep) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
+    if (j >= B.total) return;
     bool rep = true;
     if (j > 0 && key[j] == key[j - 1]) {
-        const F3 a = midPosition(center, half, val[j]), b = midPosition(center, half, val[j - 1]);
+        const F3 a = samplePosition(B, val[j]), b = samplePosition(B, val[j - 1]);
         rep = !(__float_as_uint(a.x) == __float_as_uint(b.x) && __float_as_uint(a.y) == __float_as_uint(b.y) && __float_as_uint(a.z) == __float_as_uint(b.z));
     }
     isRep[j] = rep ? 1u : 0u;
 }
-__global__ void k_mid_rep_list(const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ val, uint32_t total,
-                               uint32_t* __restrict__ repSample) {
+__global__ void k_sample_rep_list(const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ val, uint32_t total,
+                                  uint32_t* __restrict__ repSample) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < total && isRep[j]) repSample[scan[j]] = val[j];
 }
-__global__ void __launch_bounds__(128) k_mid_nearest(BvhDev b, const float* __restrict__ center, float half, const uint32_t* __restrict__ repSample, uint32_t numReps,
-                                                     uint32_t* __restrict__ repTri) {
+__global__ void __launch_bounds__(128) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri) {
     extern __shared__ uint32_t s_stack[];        // [stackDepth][128], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= numReps) return;
-    repTri[r] = bvhNearest<128>(b, midPosition(center, half, repSample[r]), s_stack + threadIdx.x);
+    repTri[r] = bvhNearest<128>(b, samplePosition(B, repSample[r]), s_stack + threadIdx.x);
 }
-// stride = floats per sample in `mid`: 4 ([f, fx, fy, fz]) or 8 (the CONTINUITY builder's Hermite slots, mixed derivatives 0)
-__global__ void k_mid_values(MeshDev m, const float* __restrict__ center, float half, const uint32_t* __restrict__ val, const uint32_t* __restrict__ isRep,
-                             const uint32_t* __restrict__ scan, const uint32_t* __restrict__ repTri, uint32_t total, float* __restrict__ mid, int stride) {
+// stride = floats per sample in the segment's output: 4 ([f, fx, fy, fz]) or 8 (the CONTINUITY builder's Hermite slots, mixed derivatives 0)
+__global__ void k_sample_values(MeshDev m, SampleBatch B, const uint32_t* __restrict__ val, const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan,
+                                const uint32_t* __restrict__ repTri) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= total) return;
+    if (j >= B.total) return;
     const uint32_t q = val[j];
     const uint32_t slot = scan[j] + isRep[j] - 1u;          // exclusive scan: the group's representative is the last flagged entry at or before j
-    valuesAt(m, midPosition(center, half, q), repTri[slot], mid + (size_t)stride * q);
-    if (stride == 8) *reinterpret_cast<float4*>(mid + 8 * (size_t)q + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    const SampleRef r = sampleRef(B, q);
+    const SampleSeg& S = B.seg[r.seg];
+    float* out = S.out + (size_t)S.stride * ((size_t)S.points * r.node + r.k);
+    valuesAt(m, samplePosition(B, q), repTri[slot], out);
+    if (S.stride == 8) *reinterpret_cast<float4*>(out + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// scratch of the mid-point sampler, reused across levels (grows only)
+// scratch of the sampler, reused across levels (grows only)
 struct SampleScratch {
     DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
 };
-static int sampleMidPoints(hipStream_t st, const MeshDev& md, const uint32_t* coord, const float* center, float half, uint32_t n, float* mid, int stride,
-                           SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
-    const uint32_t total = 19u * n;
+static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
+    const uint32_t total = B.total;
+    if (total == 0) return SDFHIP_OK;
     SDF_TRY(S.key.reserve(total)); SDF_TRY(S.keyS.reserve(total)); SDF_TRY(S.val.reserve(total)); SDF_TRY(S.valS.reserve(total));
     SDF_TRY(S.isRep.reserve(total)); SDF_TRY(S.scan.reserve(total));
-    k_mid_keys<<<gridFor(total, 256), 256, 0, st>>>(coord, n, S.key.p, S.val.p);
+    k_sample_keys<<<gridFor(total, 256), 256, 0, st>>>(B, S.key.p, S.val.p);
     size_t b1 = 0, b2 = 0;
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 36, st));
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 39, st));
     SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, S.isRep.p, S.scan.p, (int)total, st));
     const size_t need = b1 > b2 ? b1 : b2;
     if (need > S.tmpBytes) { SDF_TRY(S.tmp.reserve(need)); S.tmpBytes = need; }
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 36, st));
-    k_mid_mark<<<gridFor(total, 256), 256, 0, st>>>(S.keyS.p, S.valS.p, center, half, total, S.isRep.p);
+    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 39, st));
+    k_sample_mark<<<gridFor(total, 256), 256, 0, st>>>(B, S.keyS.p, S.valS.p, S.isRep.p);
     SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, b2, S.isRep.p, S.scan.p, (int)total, st));
     uint32_t lastScan = 0, lastFlag = 0;
     SDF_HIP_CHECK(hipMemcpyAsync(&lastScan, S.scan.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
@@ -100,14 +122,20 @@ static int sampleMidPoints(hipStream_t st, const MeshDev& md, const uint32_t* co
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const uint32_t numReps = lastScan + lastFlag;
     SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repTri.reserve(numReps));
-    k_mid_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
-    k_mid_nearest<<<gridFor(numReps, 128), 128, stackBytes, st>>>(md.bvh, center, half, S.repSample.p, numReps, S.repTri.p);
-    k_mid_values<<<gridFor(total, 256), 256, 0, st>>>(md, center, half, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p, total, mid, stride);
+    k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
+    k_sample_nearest<<<gridFor(numReps, 128), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);
+    k_sample_values<<<gridFor(total, 256), 256, 0, st>>>(md, B, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p);
     SDF_HIP_CHECK(hipGetLastError());
     traversals += numReps;
     return SDFHIP_OK;
 }
-
+// the 19 mid-points of one level
+static int sampleMidPoints(hipStream_t st, const MeshDev& md, const uint32_t* coord, const float* center, float half, uint32_t n, float* mid, int stride,
+                           SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
+    SampleBatch B;
+    B.add(center, coord, half, n, 19, mid, stride);
+    return sampleBatch(st, md, B, S, stackBytes, traversals);
+}
 
 }  // namespace
 }  // namespace sdfhip

@@ -16,6 +16,7 @@ for p in glob.glob(os.path.join(out, "t", "**", "*.db"), recursive=True):
     cols = [r[1] for r in d.execute("pragma table_info(kernels)")]
     agg = {}
     for row in d.execute("select name, duration, grid_x, workgroup_x from kernels order by start").fetchall():
+        row = (row[0].replace("(anonymous namespace)::", "").replace("void ", ""),) + tuple(row[1:])
         if ksub in row[0]:
             if os.environ.get("TRACE_AGG"):
                 k = row[0].split("(")[0]; a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += row[1] / 1e6; a[2] = max(a[2], row[1] / 1e6)
