@@ -143,6 +143,22 @@ __global__ void k_expand_geometry(const float* __restrict__ center, const uint32
     ncoord[gid] = x | (y << 10) | (z << 20);
 }
 
+// Index of a node in a COMPLETE level built by repeated k_expand_geometry from the root level: one octal digit per depth, most
+// significant first, digit = x_bit | y_bit << 1 | z_bit << 2 (the root level itself is stored in that order).
+SDF_DEV uint32_t completeLevelIndex(uint32_t co, uint32_t depth) {
+    const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
+    uint32_t idx = 0;
+    for (int b = (int)depth - 1; b >= 0; b--) idx = (idx << 3) | ((x >> b) & 1u) | (((y >> b) & 1u) << 1) | (((z >> b) & 1u) << 2);
+    return idx;
+}
+// mid-points of the nodes that turned out to exist, taken from the speculatively sampled complete level
+__global__ void k_gather_spec_mids(const uint32_t* __restrict__ coord, uint32_t n, uint32_t depth, const float* __restrict__ specMid, float* __restrict__ mid) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid / 19u, m = gid - 19u * i;
+    if (i >= n) return;
+    reinterpret_cast<float4*>(mid)[gid] = reinterpret_cast<const float4*>(specMid)[19 * (size_t)completeLevelIndex(coord[i], depth) + m];
+}
+
 struct ScatterArgs {
     const float* center; const uint32_t* coord; const float* corner; const float* mid; const uint32_t* inner; const uint32_t* childBase;
     uint32_t n; float half;
@@ -333,6 +349,8 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
 
     double tSamples = 0, tDecide = 0;
     SampleScratch SS;
+    std::unique_ptr<BuildLevel> spec[2];            // complete levels startDepth+1 and +2, sampled speculatively (may stay empty)
+    const uint64_t SPEC_SAMPLE_LIMIT = 1500000;
     {   // Levels down to the start depth exist a priori: create their geometry now and take ALL their samples (the 8 corners of the
         // root level, 19 mid-points per node of every level) in one deduplicated batch instead of one latency-bound launch each.
         const double t0 = nowSeconds();
@@ -355,6 +373,20 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
                 k_expand_geometry<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->half, L->n, N->center.p, N->coord.p);
                 T->levels[d + 1 - sod] = std::move(N);
             }
+        }
+        // Speculation: the next two levels are sampled as COMPLETE levels too while that costs no extra latency (few, long
+        // traversals: the batch is latency bound up to ~1e6 samples); the nodes that really exist pick their samples out of them
+        // (k_gather_spec_mids) and two more dependent launches disappear from the critical path.  Identical values: a sample
+        // depends only on its position, and the complete level computes the node centres with the same operations.
+        for (uint32_t d = startDepth + 1; d <= startDepth + 2 && d < maxDepth; d++) {
+            const BuildLevel* prev = (d == startDepth + 1) ? T->levels[startDepth - sod].get() : spec[d - startDepth - 2].get();
+            if (!prev || 19ull * 8ull * prev->n > SPEC_SAMPLE_LIMIT) break;
+            std::unique_ptr<BuildLevel> N(new BuildLevel());
+            N->depth = d; N->n = 8u * prev->n; N->half = 0.5f * prev->half;
+            SDF_TRY(N->center.reserve(3ull * N->n)); SDF_TRY(N->coord.reserve(N->n)); SDF_TRY(N->mid.reserve(76ull * N->n));
+            k_expand_geometry<<<gridFor(8ull * prev->n, 256), 256, 0, st>>>(prev->center.p, prev->coord.p, prev->half, prev->n, N->center.p, N->coord.p);
+            B.add(N->center.p, N->coord.p, N->half, N->n, 19, N->mid.p, 4);
+            spec[d - startDepth - 1] = std::move(N);
         }
         SDF_TRY(sampleBatch(st, md, B, SS, stackBytes, T->info.num_traversals));
         SDF_HIP_CHECK(hipStreamSynchronize(st));
@@ -427,7 +459,17 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
             ScatterArgs sa{L->center.p, L->coord.p, L->corner.p, L->mid.p, L->inner.p, L->childBase.p, L->n, L->half, N->center.p, N->coord.p, N->corner.p};
             k_scatter_children<<<gridFor(64ull * L->n, 256), 256, 0, st>>>(sa);
             SDF_HIP_CHECK(hipGetLastError());
-            if (!precreated) T->levels[d + 1 - sod] = std::move(fresh);
+            if (!precreated) {
+                const uint32_t si = d + 1 - startDepth - 1;      // 0 or 1 for the two speculative levels
+                if (d + 1 > startDepth && si < 2 && spec[si] && d + 1 < maxDepth) {
+                    SDF_TRY(fresh->mid.reserve(76ull * fresh->n));
+                    k_gather_spec_mids<<<gridFor(19ull * fresh->n, 256), 256, 0, st>>>(fresh->coord.p, fresh->n, d + 1, spec[si]->mid.p, fresh->mid.p);
+                    SDF_HIP_CHECK(hipGetLastError());
+                    fresh->presampled = true;
+                    T->info.num_samples += 19ull * fresh->n;
+                }
+                T->levels[d + 1 - sod] = std::move(fresh);
+            }
         }
         // this level's mid-points are no longer needed once the children exist
         SDF_HIP_CHECK(hipStreamSynchronize(st));

@@ -52,14 +52,22 @@ SDF_DEV F3 samplePosition(const SampleBatch& B, uint32_t q) {
     const float* c = B.seg[r.seg].center + 3 * (size_t)r.node;
     return F3{c[0], c[1], c[2]} + sampleRel(B, r) * B.seg[r.seg].half;
 }
+// 12-bit coordinate -> every third bit (Morton / Z-order): the sorted order then walks the lattice in small cubes, so the 64
+// traversals of a wave start from neighbouring points and visit largely the same BVH nodes
+SDF_DEV uint64_t spreadBits3(uint32_t v) {
+    uint64_t r = 0;
+#pragma unroll
+    for (int b = 0; b < 12; b++) r |= (uint64_t)((v >> b) & 1u) << (3 * b);
+    return r;
+}
 __global__ void k_sample_keys(SampleBatch B, uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= B.total) return;
     const SampleRef r = sampleRef(B, q);
     const uint32_t co = B.seg[r.seg].coord[r.node];
     const F3 rel = sampleRel(B, r);
-    const uint64_t lx = 2u * (co & 1023u) + (uint32_t)(rel.x + 1.f), ly = 2u * ((co >> 10) & 1023u) + (uint32_t)(rel.y + 1.f), lz = 2u * (co >> 20) + (uint32_t)(rel.z + 1.f);
-    key[q] = lx | (ly << 12) | (lz << 24) | ((uint64_t)r.seg << 36);
+    const uint32_t lx = 2u * (co & 1023u) + (uint32_t)(rel.x + 1.f), ly = 2u * ((co >> 10) & 1023u) + (uint32_t)(rel.y + 1.f), lz = 2u * (co >> 20) + (uint32_t)(rel.z + 1.f);
+    key[q] = spreadBits3(lx) | (spreadBits3(ly) << 1) | (spreadBits3(lz) << 2) | ((uint64_t)r.seg << 36);
     val[q] = q;
 }
 // sorted entry j starts a new traversal unless it is the same lattice point AND the same position bits as entry j-1
