@@ -28,6 +28,8 @@
 #include <cmath>
 #include <cstring>
 #include <unordered_map>
+#include <algorithm>
+#include <cstdlib>
 
 namespace sdfhip {
 
@@ -503,8 +505,34 @@ struct LeafMap {
     }
 };
 
+// Host mirror of the node array: grows by realloc (mremap for large blocks: no copy) and never touches the 64-word payload
+// regions it merely reserves, so appending ~100 MB of leaf blocks during a post-pass costs neither page faults nor an upload.
+struct HostWords {
+    uint32_t* p = nullptr; size_t n = 0, cap = 0;
+    HostWords() = default;
+    HostWords(const HostWords&) = delete;
+    HostWords& operator=(const HostWords&) = delete;
+    ~HostWords() { std::free(p); }
+    size_t size() const { return n; }
+    uint32_t* data() { return p; }
+    uint32_t& operator[](size_t i) { return p[i]; }
+    const uint32_t& operator[](size_t i) const { return p[i]; }
+    bool grow(size_t newSize) {                   // contents of the new part are unspecified
+        if (newSize > cap) {
+            size_t c = cap ? cap : (size_t)1 << 22;
+            while (c < newSize) c *= 2;
+            uint32_t* q = (uint32_t*)std::realloc(p, c * sizeof(uint32_t));
+            if (!q) return false;
+            p = q; cap = c;
+        }
+        n = newSize;
+        return true;
+    }
+};
+
 struct Planner {
-    std::vector<uint32_t> hoc;                    // host mirror of the node words (payload regions are don't-care)
+    HostWords hoc;                                // host mirror of the node words (payload regions are don't-care)
+    std::vector<uint32_t> newBlocks;              // child blocks (8 words) appended by the current post-pass
     LeafMap leaves;                               // octree word -> node (first registration wins, like std::map::insert)
     std::vector<PNode> pool;                      // nodes created by the post-pass
     std::vector<std::pair<uint32_t, uint32_t>> patches;   // (index, value) for words that existed before this post-pass
@@ -583,7 +611,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     };
     SDF_TRY(ensureOc(G3));
     SDF_HIP_CHECK(hipMemsetAsync(oc.p, 0, 4ull * G3, st));
-    Planner pl; pl.startDepth = startDepth; pl.G = G; pl.NM = makeMaskTable(); pl.hoc.assign(G3, 0u);
+    Planner pl; pl.startDepth = startDepth; pl.G = G; pl.NM = makeMaskTable();
+    SDF_REQUIRE(pl.hoc.grow(G3), "out of host memory");
+    for (uint32_t i = 0; i < G3; i++) pl.hoc[i] = 0u;
     // pool of post-pass nodes on the device
     DevBuf<float> pCenter, pHalf, pVv; size_t poolCap = 0;
     auto ensurePool = [&](size_t need) -> int {
@@ -688,7 +718,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         SDF_HIP_CHECK(hipMemcpyAsync(L->hNDepth.data(), L->nDepth.p, 6ull * n, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->hTerminal.data(), L->terminal.p, n, hipMemcpyDeviceToHost, st));
         const size_t mirroredFrom = pl.hoc.size();
-        pl.hoc.resize(ocSize);
+        SDF_REQUIRE(pl.hoc.grow(ocSize), "out of host memory");
         // words of this level's nodes live in blocks appended by the previous level (or in the grid): re-read from there on
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         {
@@ -730,6 +760,14 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     __builtin_prefetch(&S->hPath[q]); __builtin_prefetch(&S->hPci[q]); __builtin_prefetch(&S->hCoord[q]);
                     __builtin_prefetch(&S->hNIdx[6ull * q]); __builtin_prefetch(&S->hNIdx[6ull * q + 5]); __builtin_prefetch(&S->hNDepth[6ull * q]);
                 } else if (nx) __builtin_prefetch(&pl.pool[nx->slot]);
+            }
+            if (si + 4 < numCand) {       // third stage: the neighbour words of the candidate four ahead (its mirrors are cached by now)
+                const LeafRef* nx = pl.leaves.find(toSubdivide[si + 4]);
+                if (nx && nx->level != NONE32) {
+                    const CLevelHost* S = LV[nx->level].get(); const uint32_t q = nx->slot;
+                    for (int k = 0; k < 6; k++) { const uint32_t ix = S->hNIdx[6ull * q + k] & INDEX_MASK; if (ix < pl.hoc.size()) __builtin_prefetch(&pl.hoc[ix]); }
+                    if (S->hPci[q] != NONE32 && (size_t)S->hPci[q] + 8 <= pl.hoc.size()) __builtin_prefetch(&pl.hoc[S->hPci[q]]);
+                }
             }
             const LeafRef* it = pl.leaves.find(toSubdivide[si]);
             if (!it) continue;
@@ -811,7 +849,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     const uint32_t childIndex = (uint32_t)pl.hoc.size();
                     pl.setWord(word, (childIndex & INDEX_MASK) | MARK_BIT, sizeBefore);
                     pl.marked.push_back(word);
-                    pl.hoc.resize(pl.hoc.size() + 8, LEAF_BIT);
+                    SDF_REQUIRE(pl.hoc.grow(pl.hoc.size() + 8), "out of host memory");
+                    for (uint32_t q8 = 0; q8 < 8; q8++) pl.hoc[childIndex + q8] = LEAF_BIT;
+                    pl.newBlocks.push_back(childIndex);
                     op.childPool = (uint32_t)pl.pool.size();
                     for (uint32_t ch = 0; ch < 8; ch++) {
                         PNode k{};
@@ -822,12 +862,13 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                         k.srcLevel = NONE32; k.srcSlot = (uint32_t)pl.pool.size();
                         pl.pool.push_back(k);
                         cache.push_back(k); genOf.push_back(gen + 1);
+                        for (int q = 0; q < 6; q++) { const uint32_t ix = k.nIdx[q] & INDEX_MASK; if (ix < pl.hoc.size()) __builtin_prefetch(&pl.hoc[ix]); }
                     }
                     addOp(gen, op);
                 } else {
                     op.kind = 1;
                     uint32_t at = (uint32_t)pl.hoc.size();
-                    if (recycled) { pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); pl.hoc.resize(pl.hoc.size() + 64, 0u); }
+                    if (recycled) { pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); SDF_REQUIRE(pl.hoc.grow(pl.hoc.size() + 64), "out of host memory"); }
                     else { at = oldCoeffIndex; pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); recycled = true; }
                     op.coeffIndex = at;
                     addOp(gen, op);
@@ -853,12 +894,18 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         SDF_REQUIRE(pl.hoc.size() < (size_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
         // ---------------- upload the integer result, then run the float part generation by generation
         SDF_TRY(ensureOc(pl.hoc.size()));
-        if (pl.hoc.size() > sizeBefore)
-            SDF_HIP_CHECK(hipMemcpyAsync(oc.p + sizeBefore, pl.hoc.data() + sizeBefore, 4ull * (pl.hoc.size() - sizeBefore), hipMemcpyHostToDevice, st));
+        // only the appended child blocks carry information (their final words go up as patches); the appended 64-word leaf blocks
+        // are written by the device ops below
+        for (uint32_t b : pl.newBlocks) for (uint32_t q8 = 0; q8 < 8; q8++) pl.patches.push_back(std::make_pair(b + q8, pl.hoc[b + q8]));
+        pl.newBlocks.clear();
         ocSize = (uint32_t)pl.hoc.size();
         if (!pl.patches.empty()) {
-            std::vector<uint32_t> pi(pl.patches.size()), pv(pl.patches.size());
-            for (size_t k = 0; k < pl.patches.size(); k++) { pi[k] = pl.patches[k].first; pv[k] = pl.patches[k].second; }
+            // one patch per word, carrying its FINAL value (a word can be rewritten within a post-pass; the patch kernel is parallel)
+            std::vector<uint32_t> pi(pl.patches.size());
+            for (size_t k = 0; k < pl.patches.size(); k++) pi[k] = pl.patches[k].first;
+            std::sort(pi.begin(), pi.end()); pi.erase(std::unique(pi.begin(), pi.end()), pi.end());
+            std::vector<uint32_t> pv(pi.size());
+            for (size_t k = 0; k < pi.size(); k++) pv[k] = pl.hoc[pi[k]];
             DevBuf<uint32_t> dpi, dpv; SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
             SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
