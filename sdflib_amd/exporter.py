@@ -33,8 +33,9 @@ def main(argv=None):
     lo, hi = v.min(axis=0).astype(np.float32), v.max(axis=0).astype(np.float32)
     if a.normalize:                                   # scale the largest extent to 2 and centre (main.cpp:83-90)
         size = np.float32((hi - lo).max())
-        centre = lo + np.float32(0.5) * (hi - lo)
-        v = ((v - centre) * (np.float32(2.0) / size)).astype(np.float32)
+        centre = (lo + np.float32(0.5) * (hi - lo)).astype(np.float32)
+        s = np.float32(2.0) / size                        # scale(mat4(1), 2/size) * translate(mat4(1), -centre) applied as mat4 * vec4:
+        v = ((s * v).astype(np.float32) + (s * -centre).astype(np.float32)).astype(np.float32)      # fl(fl(s x) + fl(s (-c))), Mesh.cpp:131-139
         lo, hi = v.min(axis=0).astype(np.float32), v.max(axis=0).astype(np.float32)
     margin = np.float32(a.bb_margin / 100.0) * np.float32((hi - lo).max())
     box = np.concatenate([lo - margin, hi + margin]).astype(np.float32)
