@@ -86,11 +86,12 @@ __global__ void k_sample_rep_list(const uint32_t* __restrict__ isRep, const uint
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < total && isRep[j]) repSample[scan[j]] = val[j];
 }
-__global__ void __launch_bounds__(128) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri) {
-    extern __shared__ uint32_t s_stack[];        // [stackDepth][128], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri) {
+    extern __shared__ uint32_t s_stack[];        // [stackDepth][BLOCK], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= numReps) return;
-    repTri[r] = bvhNearest<128>(b, samplePosition(B, repSample[r]), s_stack + threadIdx.x);
+    repTri[r] = bvhNearest<BLOCK>(b, samplePosition(B, repSample[r]), s_stack + threadIdx.x);
 }
 // stride = floats per sample in the segment's output: 4 ([f, fx, fy, fz]) or 8 (the CONTINUITY builder's Hermite slots, mixed derivatives 0)
 __global__ void k_sample_values(MeshDev m, SampleBatch B, const uint32_t* __restrict__ val, const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan,
@@ -131,7 +132,7 @@ static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, 
     const uint32_t numReps = lastScan + lastFlag;
     SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repTri.reserve(numReps));
     k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
-    k_sample_nearest<<<gridFor(numReps, 128), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);
+    k_sample_nearest<128><<<gridFor(numReps, 128), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);   // 64 / 256 lanes per block measured the same
     k_sample_values<<<gridFor(total, 256), 256, 0, st>>>(md, B, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p);
     SDF_HIP_CHECK(hipGetLastError());
     traversals += numReps;
