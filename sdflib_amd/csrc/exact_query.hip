@@ -224,7 +224,11 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf<float> dp, dd, dg; DevBuf<uint32_t> dt;
+    std::unique_lock<std::mutex> stageLock(ctx->stage.lock, std::defer_lock);
+    if (where == SDFHIP_HOST && 12 * n <= sdfhip_stage::kStageKeepBytes) stageLock.try_lock();
+    DevBuf<float> pp, pd, pg; DevBuf<uint32_t> pt;
+    DevBuf<float>& dp = stageLock.owns_lock() ? ctx->stage.pts : pp; DevBuf<float>& dd = stageLock.owns_lock() ? ctx->stage.dist : pd;
+    DevBuf<float>& dg = stageLock.owns_lock() ? ctx->stage.grad : pg; DevBuf<uint32_t>& dt = stageLock.owns_lock() ? ctx->stage.ids : pt;
     const float* p = xyz; float* d = out_dist; float* g = out_grad; uint32_t* t = out_tri;
     if (where == SDFHIP_HOST) {
         SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dd.reserve(n));

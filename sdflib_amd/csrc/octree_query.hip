@@ -140,7 +140,10 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    DevBuf<float> dp, dd, dg;
+    std::unique_lock<std::mutex> own(ctx->stage.lock, std::defer_lock);
+    if (where == SDFHIP_HOST && 12 * n <= sdfhip_stage::kStageKeepBytes) own.try_lock();
+    DevBuf<float> pp, pd, pg;
+    DevBuf<float>& dp = own.owns_lock() ? ctx->stage.pts : pp; DevBuf<float>& dd = own.owns_lock() ? ctx->stage.dist : pd; DevBuf<float>& dg = own.owns_lock() ? ctx->stage.grad : pg;
     const float* p = xyz; float* d = out_dist; float* g = out_grad;
     if (where == SDFHIP_HOST) {
         SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dd.reserve(n));

@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <mutex>
 #include "../../include/sdfhip.h"
 
 namespace sdfhip {
@@ -61,7 +62,16 @@ static inline unsigned gridFor(uint64_t work, unsigned block) { return (unsigned
 
 }  // namespace sdfhip
 
+// Device-side staging of the host-pointer entry points (points in, distances / gradients / ids out), kept with the context
+// (grow-only, up to kStageKeepBytes per buffer) so that small calls — the C++ classes' scalar getDistance among them — cost no
+// hipMalloc / hipFree.  Guarded by a try-lock: a second host thread simply allocates privately.
+struct sdfhip_stage {
+    sdfhip::DevBuf<float> pts, dist, grad; sdfhip::DevBuf<uint32_t> ids; std::mutex lock;
+    static constexpr size_t kStageKeepBytes = 64u << 20;
+};
+
 struct sdfhip_ctx {
+    sdfhip_stage stage;
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownsStream = false;
