@@ -67,9 +67,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook: several ranks on ONE device with gloo collectives (the real launch is one rank per GPU over RCCL)
+    one_device = os.environ.get("SDFHIP_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -77,7 +84,7 @@ def main():
     # ---- setup (untimed): mesh, context on torch's stream, tree -------------------------------------------
     v, f = bumpy_icosphere(args.subdiv)
     box = box_with_margin(v)
-    ctx = S.Context(local_rank, use_torch_stream=True)
+    ctx = S.Context(dev.index, use_torch_stream=True)
     mesh = S.Mesh(v, f, ctx)
     bvh_s = mesh.build_bvh()
     torch.cuda.synchronize()
@@ -119,7 +126,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if one_device else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))

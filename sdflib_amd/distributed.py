@@ -55,6 +55,12 @@ def cell_weights(vertices, box6, start_depth):
     return acc.reshape(-1) + 1.0
 
 
+def _collective_device(dev, group=None):
+    """Device the collectives run on: the GPU with RCCL ('nccl'); host memory with gloo (CPU tests, and 2-rank tests that
+    share one GPU), in which case shard outputs are staged through the host."""
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
+
+
 def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, group=None):
     """Collective part: returns the full node array (int32 view of the u32 words) on every rank.
 
@@ -104,16 +110,17 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
     shard = api.OctreeShard(mesh, box, depth, start_depth, max_error, cells=ranges[rank])
     info = shard.info
     t1 = time.perf_counter()
-    offset, _ = body_offset_for_rank(info.body_words, num_cells, group, dev)
+    offset, _ = body_offset_for_rank(info.body_words, num_cells, group, _collective_device(dev, group))
     ncell = ranges[rank][1] - ranges[rank][0]
     grid_local = torch.empty(ncell, dtype=torch.int32, device=dev)
     body_local = torch.empty(max(int(info.body_words), 1), dtype=torch.int32, device=dev)
     shard.emit(offset, grid_local, body_local)
-    full = exchange_and_assemble(grid_local, body_local, info.body_words, ranges[rank], num_cells, group)
-    stats = torch.tensor([info.value_range, -info.min_border_value], dtype=torch.float32, device=dev)
+    cdev = _collective_device(dev, group)
+    full = exchange_and_assemble(grid_local.to(cdev), body_local.to(cdev), info.body_words, ranges[rank], num_cells, group).to(dev)
+    stats = torch.tensor([info.value_range, -info.min_border_value], dtype=torch.float32, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX, group=group)
-    lpd = torch.tensor(list(info.leaves_per_depth), dtype=torch.int64, device=dev)
-    cnt = torch.tensor([info.num_leaves, info.num_nodes, info.num_samples], dtype=torch.int64, device=dev)
+    lpd = torch.tensor(list(info.leaves_per_depth), dtype=torch.int64, device=cdev)
+    cnt = torch.tensor([info.num_leaves, info.num_nodes, info.num_samples], dtype=torch.int64, device=cdev)
     dist.all_reduce(lpd, group=group); dist.all_reduce(cnt, group=group)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -189,13 +196,14 @@ def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_nod
     shard = api.ExactShard(mesh, box, max_depth, start_depth, min_triangles_per_node, ranges[rank])
     info = shard.info
     t1 = time.perf_counter()
+    cdev = _collective_device(dev, group)
     mine = torch.tensor([info.num_nodes, info.num_set_words, info.num_mask_bytes, info.max_triangles_in_leafs, info.max_triangles_encoded_in_leafs],
-                        dtype=torch.int64, device=dev)
-    meta = [torch.zeros(5, dtype=torch.int64, device=dev) for _ in range(world)]
+                        dtype=torch.int64, device=cdev)
+    meta = [torch.zeros(5, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(meta, mine, group=group)
     meta = torch.stack(meta).cpu().numpy()
     offs = exact_offsets(meta[:, :3], num_cells)
-    part = shard.emit(*offs[rank], device=dev)
+    part = {k: v.to(cdev) for k, v in shard.emit(*offs[rank], device=dev).items()}
     ncell = [b - a for a, b in ranges]
     gathered = {"grid_nodes": _all_gather_padded(part["grid_nodes"], ncell, group), "grid_has": _all_gather_padded(part["grid_has"], ncell, group),
                 "body_nodes": _all_gather_padded(part["body_nodes"], meta[:, 0], group), "body_has": _all_gather_padded(part["body_has"], meta[:, 0], group),
@@ -204,7 +212,7 @@ def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_nod
     for r in range(world):
         cells = np.sort(order[ranges[r][0]:ranges[r][1]])                        # shard_cells() order: ascending z-major
         parts.append(dict(cells=cells, **{k: v[r] for k, v in gathered.items()}))
-    nodes, has, sets, masks = assemble_exact(parts, num_cells)
+    nodes, has, sets, masks = (t.to(dev) for t in assemble_exact(parts, num_cells))
     full = api.ExactInfo.from_buffer_copy(info)
     full.num_nodes, full.num_set_words, full.num_mask_bytes = int(nodes.shape[0]), int(sets.shape[0]), int(masks.shape[0])
     full.max_triangles_in_leafs, full.max_triangles_encoded_in_leafs = int(meta[:, 3].max()), int(meta[:, 4].max())

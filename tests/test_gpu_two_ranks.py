@@ -1,0 +1,84 @@
+"""Two ranks on ONE GPU (gloo for the collectives, both processes on cuda:0): the complete N>1 build path — shard build on the
+device, offset exchange, emit with absolute indices, all-gather, reassembly — against the single-process build."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, ROOT)
+        import sdflib_amd as S
+        from sdflib_amd import distributed as sdist
+        from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        ctx = S.Context(0, use_torch_stream=True)
+        v, f = bumpy_icosphere(4)
+        box = box_with_margin(v)
+        mesh = S.Mesh(v, f, ctx)
+        tree, _ = sdist.build_octree_sharded(mesh, box, 6, 3, 1e-3, rank, world, dev)
+        single = S.OctreeSdf(mesh, box, 6, 3, 1e-3)
+        assert np.array_equal(tree.get_octree_data(), single.get_octree_data()), "sharded OctreeSdf differs from the single build"
+        assert tree.info.value_range == single.info.value_range and tree.info.min_border_value == single.info.min_border_value
+        assert list(tree.info.leaves_per_depth) == list(single.info.leaves_per_depth)
+        ex, _ = sdist.build_exact_sharded(mesh, box, 5, 2, 16, rank, world, dev)
+        ex1 = S.ExactOctreeSdf(mesh, box, 5, 2, 16)
+        for a, b in zip(ex.download(), ex1.download()):
+            assert np.array_equal(a, b), "sharded ExactOctreeSdf differs from the single build"
+        assert ex.info.max_triangles_in_leafs == ex1.info.max_triangles_in_leafs
+        rng = np.random.default_rng(rank)
+        pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
+        assert np.array_equal(tree.get_distance(pts).view(np.uint32), single.get_distance(pts).view(np.uint32))
+        assert np.array_equal(ex.get_distance(pts).view(np.uint32), ex1.get_distance(pts).view(np.uint32))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:       # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_builds_with_several_ranks_on_one_gpu(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 32500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(msg == "ok" for _, msg in results), "\n".join(str(m) for _, m in results)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path (rendezvous from the environment, sharded build, barrier-bracketed timing, MAX over ranks, one JSON
+    line from rank 0) with two ranks sharing the GPU through the gloo test hook."""
+    import json
+    import subprocess
+    env = dict(os.environ, SDFHIP_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(33500 + os.getpid() % 2000),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--subdiv", "5", "--depth", "6", "--queries", "1000000",
+           "--no-cpu-baseline", "--no-extras", "--no-build-1m"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * d["per_gpu_mqueries_s"]) < 1e-6 * d["value"] + 0.02
+    assert d["roofline"]["frac"] > 0 and d["build"]["exchange_s"] >= 0
