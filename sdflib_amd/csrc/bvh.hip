@@ -155,9 +155,13 @@ struct HostBvhBuilder {
             // Large ranges (the top of the tree = the planner's critical path): only the centre sum depends on the order of its
             // operands; the gather of the range's vertices, the AABB, the radius (max of identical expressions), the keys and
             // the write-back are order independent and run on helper threads over a contiguous copy of the range.
+            const bool trace = depth == 0 && getenv("SDFHIP_TIMING"); double tq = nowSeconds();
+            auto lapq = [&](const char* what) { if (trace) { const double now = nowSeconds(); fprintf(stderr, "[sdfhip] bvh root: %s %.4f s\n", what, now - tq); tq = now; } };
             float* loc = scratchLoc + 9 * (size_t)begin;      // this node's slice of the planner-wide scratch (ranges in flight are disjoint)
             parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) std::memcpy(&loc[9 * (size_t)i], triV + 9 * (size_t)order[begin + i], 36); });
+            lapq("gather");
             for (size_t j = 0; j < 3 * (size_t)n; j++) { ce.x += (double)loc[3 * j]; ce.y += (double)loc[3 * j + 1]; ce.z += (double)loc[3 * j + 2]; }
+            lapq("centre sum");
             const double cnt = (double)(3 * n);
             ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
             std::mutex m;
@@ -173,13 +177,17 @@ struct HostBvhBuilder {
                 top.x = std::max(top.x, t.x); top.y = std::max(top.y, t.y); top.z = std::max(top.z, t.z);
                 bot.x = std::min(bot.x, bt.x); bot.y = std::min(bot.y, bt.y); bot.z = std::min(bot.z, bt.z); r2 = std::max(r2, rr);
             });
+            lapq("aabb + radius");
             const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
             dim = (int)(std::max_element(diag, diag + 3) - diag);
             KeyTri* tmp = scratchKeys + begin;
             parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) tmp[i] = KeyTri{(double)loc[9 * (size_t)i + dim], order[begin + i]}; });
             IntroSortLike sorter; sorter.maxThreads = sortThreads;
+            lapq("keys");
             sorter.sort(tmp, tmp + n);
+            lapq("sort");
             parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) order[begin + i] = tmp[i].tri; });
+            lapq("write back");
         } else {
             for (int i = begin; i < end; i++)
                 for (int k = 0; k < 3; k++) {
@@ -309,6 +317,8 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     int pd = 0; while ((1u << pd) < (hc ? hc : 1u) && pd < 8) pd++;
     b.maxParallelDepth = pd;
     b.sortThreads = (int)(hc ? hc : 1u);
+    if (getenv("SDFHIP_BVH_PAR_DEPTH")) b.maxParallelDepth = atoi(getenv("SDFHIP_BVH_PAR_DEPTH"));
+    if (getenv("SDFHIP_BVH_SORT_THREADS")) b.sortThreads = atoi(getenv("SDFHIP_BVH_SORT_THREADS"));
     double rootSphere[4];
     b.build(0, rootSphere, 0, (int)T, 0);
     const double tPlanned = nowSeconds();
