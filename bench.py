@@ -222,7 +222,11 @@ def extras(tree, mesh, box, pts, out, dev, rank):
     ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_EXACT, device_out=True))
     words = int(tree.info.num_words)
     gbytes = 256 ** 3 * 16 + words * 4          # SURVEY 8(d) "G": 16 B written per point + the tree read once
-    r["grid256_value_and_gradient"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1)}
+    r["grid256_value_and_gradient"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
+                                       "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "note": "reference-order polynomial (~1100 flop/point): ALU bound, not HBM bound"}
+    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_FAST, device_out=True))
+    r["grid256_value_and_gradient_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
+                                                 "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
     # ExactOctreeSdf (BASELINE configs[2]): depth 7, start 3, min_triangles_per_node 128
     torch.cuda.synchronize(); t0 = time.perf_counter()
     ex = S.ExactOctreeSdf(mesh, box, 7, 3, 128)

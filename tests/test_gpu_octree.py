@@ -356,3 +356,25 @@ def test_one_million_triangle_build_properties(gpu_ctx):
     assert np.all(d[r > 1.15] > 0) and np.all(d[r < 0.85] < 0)
     assert np.all(np.abs(d) <= np.abs(r - 1.0) + 0.11)
     assert ids.max() < len(f)
+
+
+@pytest.mark.parametrize("scale,offset", [(1e-3, (0.0, 0.0, 0.0)), (1.0, (1000.0, -2000.0, 500.0)), (250.0, (-5000.0, 0.0, 12345.0)), (1e3, (0.0, 0.0, 0.0))])
+def test_nearest_triangle_far_from_the_origin_and_at_other_scales(oracle, gpu_ctx, scale, offset):
+    """The fp32 sphere bracket of the BVH search scales its slack with the mesh's coordinate magnitude; meshes that are tiny,
+    huge or far from the origin (fp32 spacing up to 1e-3 there) must still give the oracle's ids and the oracle's tree."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere
+    v, f = bumpy_icosphere(3)
+    v = (v * np.float32(scale) + np.float32(offset)).astype(np.float32)
+    lo, hi = v.min(axis=0), v.max(axis=0)
+    m = np.float32(0.2) * (hi - lo).max()
+    box = np.concatenate([lo - m, hi + m]).astype(np.float32)
+    om, gm = oracle.Mesh(v, f), S.Mesh(v, f, gpu_ctx)
+    rng = np.random.default_rng(11)
+    pts = (lo - m + rng.random((30000, 3), dtype=np.float32) * (hi - lo + 2 * m)).astype(np.float32)
+    near = (v[rng.integers(0, len(v), 10000)] * (1 + rng.normal(0, 1e-4, (10000, 1)))).astype(np.float32)     # on top of the surface: tie-heavy
+    pts = np.concatenate([pts, near])
+    assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts))
+    ot = oracle.Octree(om, box, 5, 2, 1e-3 * scale, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3 * scale)
+    assert np.array_equal(ot.data(), gt.get_octree_data())
