@@ -378,3 +378,28 @@ def test_nearest_triangle_far_from_the_origin_and_at_other_scales(oracle, gpu_ct
     ot = oracle.Octree(om, box, 5, 2, 1e-3 * scale, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
     gt = S.OctreeSdf(gm, box, 5, 2, 1e-3 * scale)
     assert np.array_equal(ot.data(), gt.get_octree_data())
+
+
+def test_degenerate_triangles_behave_like_the_reference(oracle, gpu_ctx):
+    """Zero-area triangles (repeated vertices, a collinear sliver): the reference's degenerate branch is disabled
+    (`if(false && ...)`, TriangleUtils.cpp:45), so their frames are NaN, their neighbours' pseudonormals inherit NaNs, and the
+    fp64 search never adopts them (NaN distances fail every '<').  Same NaN pattern, same ids, same tree."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import icosphere, box_with_margin
+    v, f = icosphere(2)
+    mid = ((v[3] + v[7]) * np.float32(0.5)).astype(np.float32)
+    v = np.concatenate([v, mid[None]])
+    f = np.concatenate([f, np.array([[0, 0, 5], [1, 2, 2], [3, 7, len(v) - 1]], np.uint32)])
+    box = box_with_margin(v)
+    om, gm = oracle.Mesh(v, f), S.Mesh(v, f, gpu_ctx)
+    a, b = om.triangle_data(), gm.triangle_data()
+    assert np.isnan(a).any() and np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(a[:, :28], b[:, :28], equal_nan=True)
+    rng = np.random.default_rng(0)
+    pts = ((rng.random((50000, 3), dtype=np.float32) * 2 - 1) * 1.3).astype(np.float32)
+    ids = gm.nearest_triangle(pts)
+    assert np.array_equal(om.nearest(pts), ids) and ids.max() < len(f) - 3
+    ot = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    assert np.array_equal(ot.data(), gt.get_octree_data())
+    assert np.array_equal(ot.query(pts), gt.get_distance(pts), equal_nan=True)
