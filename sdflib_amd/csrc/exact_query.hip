@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* _
 // consecutive sorted queries: for every distinct leaf in them the wave decodes the leaf's triangle list ONCE (bit-packed
 // set filtered through the byte masks with __ballot/popcount ranks), stages the surviving triangles' 80-byte frames in LDS
 // (each triangle fetched once per wave instead of once per query lane) and all lanes of that leaf scan the staged tile
-// in list order — so the first-minimum rule of the reference is preserved.
+// in list order — so the first-minimum rule of the reference is preserved.  The lanes of the wave that do not hold a query of
+// the current leaf help with its triangles (see the comment in the kernel).
 constexpr uint32_t QNONE = 0xFFFFFFFFu;
 
 __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
@@ -158,8 +159,16 @@ __global__ void __launch_bounds__(256) k_exact_sorted(ExactView v, const float* 
         const uint32_t cnt = set[0];
         const uint8_t* m1 = (m1i != QNONE) ? v.masks + m1i : nullptr;
         const uint8_t* m2 = (m2i != QNONE) ? v.masks + m2i : nullptr;
-        float best = INFINITY; uint32_t bestTri = 0;
-        uint32_t r1 = 0;
+        // The run's queries sit in consecutive lanes [leader, leader + r).  Runs are short (about 10 queries per leaf at 10 M
+        // queries), so the (query, triangle) pairs of a tile are spread over the WHOLE wave: lane j works for the query of lane
+        // leader + j % r on the staged triangles g, g + G, ... with g = j / r, G = 64 / r, and the partial minima are merged
+        // afterwards by (distance, list position) — the first minimum in list order wins, exactly like the sequential scan.
+        const uint32_t r = (uint32_t)__popcll(__ballot(inRun));
+        const uint32_t G = 64u / r, g = (uint32_t)lane / r;
+        const int owner = leader + (int)((uint32_t)lane % r);
+        const F3 po = F3{__shfl(p.x, owner), __shfl(p.y, owner), __shfl(p.z, owner)};
+        float best = INFINITY; uint32_t bestTri = 0, bestPos = 0xFFFFFFFFu;
+        uint32_t r1 = 0, staged = 0;
         for (uint32_t base = 0; base < cnt; base += 64) {
             const uint32_t t = base + (uint32_t)lane;
             const bool valid = t < cnt;
@@ -183,21 +192,32 @@ __global__ void __launch_bounds__(256) k_exact_sorted(ExactView v, const float* 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (inRun) {
-                for (uint32_t s = 0; s < nk; s++) {
-                    const float4* fp = reinterpret_cast<const float4*>(&s_frames[w][s * FRAME_FLOATS]);
+            if (g < G) {
+                for (uint32_t sIdx = g; sIdx < nk; sIdx += G) {
+                    const float4* fp = reinterpret_cast<const float4*>(&s_frames[w][sIdx * FRAME_FLOATS]);
                     const float4 a = fp[0], bq = fp[1], c = fp[2], d4 = fp[3], e4 = fp[4];
                     TriFrame fr;
                     fr.origin = F3{a.x, a.y, a.z};
                     fr.m[0] = a.w; fr.m[1] = bq.x; fr.m[2] = bq.y; fr.m[3] = bq.z; fr.m[4] = bq.w; fr.m[5] = c.x; fr.m[6] = c.y; fr.m[7] = c.z; fr.m[8] = c.w;
                     fr.b = F2{d4.x, d4.y}; fr.c = F2{d4.z, d4.w}; fr.v2 = e4.x; fr.v3 = F2{e4.y, e4.z};
-                    const float d = sqDistPointTriangle(p, fr);
-                    if (d < best) { best = d; bestTri = s_tri[w][s]; }
+                    const float d = sqDistPointTriangle(po, fr);
+                    if (d < best) { best = d; bestTri = s_tri[w][sIdx]; bestPos = staged + sIdx; }
                 }
             }
+            staged += nk;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        {   // merge the G partial results of every query into its own lane
+            const uint32_t i = inRun ? (uint32_t)(lane - leader) : 0u;
+            float mb = INFINITY; uint32_t mt = 0, mp = 0xFFFFFFFFu;
+            for (uint32_t gg = 0; gg < G; gg++) {
+                const int src = (int)(i + r * gg);
+                const float cd = __shfl(best, src); const uint32_t ct = __shfl(bestTri, src), cp = __shfl(bestPos, src);
+                if (cd < mb || (cd == mb && cp < mp)) { mb = cd; mt = ct; mp = cp; }
+            }
+            best = mb; bestTri = mt;
         }
         if (inRun) {
             if (GRAD) {
