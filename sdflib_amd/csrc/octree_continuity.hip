@@ -662,6 +662,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
 
     uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
+    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist;      // post-pass device buffers, grow-only
     double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
     auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
     for (uint32_t cd = sod; cd <= maxDepth; cd++) {
@@ -694,7 +695,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             LV[cd + 1] = std::move(N);
         }
         // candidates of the post-pass, in node order then slot order
-        DevBuf<uint32_t> cflag, cscan, clist; uint32_t numCand = 0;
+        uint32_t numCand = 0;
         SDF_TRY(cflag.reserve(24ull * n)); SDF_TRY(cscan.reserve(24ull * n));
         kc_flag_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, 24 * n, cflag.p);
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, cflag.p, cscan.p, 24 * n));
@@ -906,7 +907,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             std::sort(pi.begin(), pi.end()); pi.erase(std::unique(pi.begin(), pi.end()), pi.end());
             std::vector<uint32_t> pv(pi.size());
             for (size_t k = 0; k < pi.size(); k++) pv[k] = pl.hoc[pi[k]];
-            DevBuf<uint32_t> dpi, dpv; SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
+            SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
             SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
             kc_patch<<<gridFor(pi.size(), 256), 256, 0, st>>>(dpi.p, dpv.p, (uint32_t)pi.size(), oc.p);
@@ -920,7 +921,6 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             std::vector<OpDev>& ops = gens[g];
             if (ops.empty()) continue;
             for (size_t k = 0; k < ops.size(); k++) ops[k].scratch = (uint32_t)k;
-            DevBuf<OpDev> dops; DevBuf<float> scratch;
             SDF_TRY(dops.reserve(ops.size())); SDF_TRY(scratch.reserve(216 * ops.size()));
             SDF_HIP_CHECK(hipMemcpyAsync(dops.p, ops.data(), sizeof(OpDev) * ops.size(), hipMemcpyHostToDevice, st));
             const uint32_t no = (uint32_t)ops.size();
