@@ -73,6 +73,8 @@ typedef struct sdfhip_exact sdfhip_exact;
 
 const char* sdfhip_last_error(void);
 const char* sdfhip_version(void);
+/* sizeof(sdfhip_octree_info), sizeof(sdfhip_octree_params), sizeof(sdfhip_exact_info): lets a binding verify its struct mirrors */
+void sdfhip_abi_sizes(uint64_t out[3]);
 
 /* One context per (process, device).
  * stream_mode SDFHIP_STREAM_PRIVATE: the context creates its own non-blocking stream (`stream` ignored).
@@ -131,6 +133,7 @@ typedef struct sdfhip_octree_info {
     uint64_t leaves_per_depth[16];  /* leaves at each depth (this shard) */
     uint64_t fit_rechecks;          /* FIT_MFMA: nodes whose decision was re-evaluated with the reference-ordered fit */
     uint64_t num_traversals;        /* BVH traversals actually run (samples sharing a lattice point AND position bits share one) */
+    uint64_t post_pass_scheduled;   /* CONTINUITY: leaves Iter 2 scheduled for re-subdivision (OctreeSdfBreadthFirstNoDelay.h:506-512) */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {

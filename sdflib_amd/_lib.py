@@ -21,7 +21,8 @@ class OctreeInfo(C.Structure):
                 ("value_range", C.c_float), ("min_border_value", C.c_float), ("num_words", C.c_uint64), ("num_leaves", C.c_uint64),
                 ("num_nodes", C.c_uint64), ("num_samples", C.c_uint64), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32),
                 ("body_words", C.c_uint64), ("body_offset", C.c_uint64), ("seconds_samples", C.c_double), ("seconds_decide", C.c_double),
-                ("seconds_total", C.c_double), ("leaves_per_depth", C.c_uint64 * 16), ("fit_rechecks", C.c_uint64), ("num_traversals", C.c_uint64)]
+                ("seconds_total", C.c_double), ("leaves_per_depth", C.c_uint64 * 16), ("fit_rechecks", C.c_uint64), ("num_traversals", C.c_uint64),
+                ("post_pass_scheduled", C.c_uint64)]
 
 
 class OctreeParams(C.Structure):
@@ -54,6 +55,7 @@ SIGNATURES = {
     "sdfhip_mesh_triangle_data": (_int, [_vp, _vp]),
     "sdfhip_mesh_build_bvh": (_int, [_vp, C.POINTER(C.c_double)]),
     "sdfhip_mesh_nearest": (_int, [_vp, _vp, _u64, _vp, _int]),
+    "sdfhip_abi_sizes": (None, [_vp]),
     "sdfhip_test_sort_matches_std": (_int, [_vp, _u64, _int]),
     "sdfhip_mesh_nearest_stats": (_int, [_vp, _vp, _u64, _vp]),
     "sdfhip_mesh_point_values": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),

@@ -203,6 +203,7 @@ extern "C" {
 
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
 const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
+void sdfhip_abi_sizes(uint64_t out[3]) { out[0] = sizeof(sdfhip_octree_info); out[1] = sizeof(sdfhip_octree_params); out[2] = sizeof(sdfhip_exact_info); }
 
 int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx** out) {
     SDF_REQUIRE(out != nullptr, "out is NULL");

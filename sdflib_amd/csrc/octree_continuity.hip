@@ -971,7 +971,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     memcpy(&T->info.value_range, &hs[0], 4);
     { const uint32_t k = hs[1]; const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); T->info.min_border_value = (k == 0xFFFFFFFFu) ? INFINITY : f; }
     T->info.num_words = ocSize; T->info.cell_end = G3; T->info.body_words = ocSize - G3; T->info.body_offset = G3;
-    T->info.fit_rechecks = numRescheduled;      // (re-used field: leaves scheduled for re-subdivision by Iter 2)
+    T->info.post_pass_scheduled = numRescheduled;
     // shrink to fit
     SDF_TRY(T->data.reserve(ocSize));
     SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));

@@ -88,3 +88,11 @@ def test_planner_sort_equals_std_sort():
             keys = np.ascontiguousarray(keys, dtype=np.float64)
             for threads in (1, 6):
                 assert lib().sdfhip_test_sort_matches_std(keys.ctypes.data_as(C.c_void_p), n, threads) == 0
+
+
+def test_ctypes_struct_mirrors_have_the_c_sizes():
+    import ctypes as C
+    from sdflib_amd._lib import lib, OctreeInfo, OctreeParams, ExactInfo
+    out = (C.c_uint64 * 3)()
+    lib().sdfhip_abi_sizes(out)
+    assert [int(x) for x in out] == [C.sizeof(OctreeInfo), C.sizeof(OctreeParams), C.sizeof(ExactInfo)]

@@ -11,5 +11,5 @@ m = S.Mesh(v, f); m.build_bvh()
 for it in range(2):
     t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY); dt = time.time() - t
     i = oc.info
-    print(f"continuity build {dt:.3f}s words={i.num_words} leaves={i.num_leaves} samples={i.num_samples} rescheduled={i.fit_rechecks}")
+    print(f"continuity build {dt:.3f}s words={i.num_words} leaves={i.num_leaves} samples={i.num_samples} rescheduled={i.post_pass_scheduled}")
     del oc
