@@ -403,3 +403,39 @@ def test_degenerate_triangles_behave_like_the_reference(oracle, gpu_ctx):
     gt = S.OctreeSdf(gm, box, 5, 2, 1e-3)
     assert np.array_equal(ot.data(), gt.get_octree_data())
     assert np.array_equal(ot.query(pts), gt.get_distance(pts), equal_nan=True)
+
+
+def _assorted_meshes():
+    from sdflib_amd.meshgen import cube_mesh, icosphere
+    v, f = cube_mesh()
+    yield "cube", v, f
+    a, fa = icosphere(2)
+    two = np.concatenate([a * np.float32(0.5) + np.float32([-0.6, 0, 0]), a * np.float32(0.3) + np.float32([0.7, 0.1, 0])]).astype(np.float32)
+    yield "two spheres", two, np.concatenate([fa, fa + len(a)]).astype(np.uint32)
+    keep = fa[(a[fa].mean(axis=1)[:, 2] > -0.1)]                       # open hemisphere: boundary edges have one owner
+    yield "open hemisphere", a, keep.astype(np.uint32)
+
+
+@pytest.mark.parametrize("name,v,f", list(_assorted_meshes()), ids=lambda x: x if isinstance(x, str) else None)
+def test_assorted_meshes_both_builders_and_exact(oracle, gpu_ctx, name, v, f):
+    """Flat faces and symmetric sample points (exact distance ties everywhere: the BVH's visiting order decides), disjoint
+    components, and an open surface, through the three structures."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import box_with_margin
+    box = box_with_margin(v)
+    om, gm = oracle.Mesh(v, f), S.Mesh(v, f, gpu_ctx)
+    g = np.linspace(box[0], box[3], 33, dtype=np.float32)                # symmetric lattice incl. the mesh's symmetry planes
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3).astype(np.float32)
+    assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts))
+    for cont in (False, True):
+        ot = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_GLOBAL_DFS, continuity=cont)
+        gt = S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY if cont else S.ALG_NO_CONTINUITY, num_threads=1)
+        assert np.array_equal(ot.data(), gt.get_octree_data()), f"{name}: continuity={cont}"
+        assert np.array_equal(bits(ot.query(pts)), bits(gt.get_distance(pts)))
+    oe = oracle.Exact(om, box, 4, 1, 4)
+    ge = S.ExactOctreeSdf(gm, box, 4, 1, 4)
+    on, oh, osets, omasks = oe.data(); gn, gh, gsets, gmasks = ge.download()
+    assert np.array_equal(on[:, 0], gn[:, 0]) and np.array_equal(osets, gsets) and np.array_equal(omasks, gmasks)
+    d, t = ge.get_distance(pts, triangle=True)
+    do, to = oe.query(pts, tri=True)
+    assert np.array_equal(bits(do), bits(d)) and np.array_equal(to, t.astype(np.uint32))
