@@ -14,11 +14,17 @@
  *   sdfhip_mesh_nearest       <- ICG::getNearestTriangle                          include/SdfLib/TrianglesInfluence.h:898-905
  *   sdfhip_octree_build*      <- OctreeSdf::OctreeSdf / buildOctree / initOctree  include/SdfLib/OctreeSdf.h:156-172,
  *                                                                                 src/sdf/OctreeSdf.cpp:17-86, src/sdf/OctreeSdfDepthFirst.h:32-558
+ *                                (algorithm CONTINUITY: initOctreeWithContinuityNoDelay  src/sdf/OctreeSdfBreadthFirstNoDelay.h:84-1224)
+ *   sdfhip_octree_build_shard / _emit_shard  <- the OpenMP loop over start cells + merge/rebase   src/sdf/OctreeSdfDepthFirst.h:433-503
+ *   sdfhip_octree_from_data   <- SdfFunction::loadFromFile (OCTREE payload)       src/sdf/SdfFunction.cpp:43-79, include/SdfLib/OctreeSdf.h:222-238
  *   sdfhip_octree_query       <- OctreeSdf::getDistance (both overloads)          src/sdf/OctreeSdf.cpp:93-152
  *   sdfhip_octree_query_grid  <- the per-pixel/lattice loops of the tools         src/tools/SdfError/main.cpp:60-66
  *   sdfhip_octree_download    <- OctreeSdf::getOctreeData / getters               include/SdfLib/OctreeSdf.h:177-219
  *   sdfhip_exact_build        <- ExactOctreeSdf::ExactOctreeSdf / initOctree      src/sdf/ExactOctreeSdf.cpp:7-31,
  *                                                                                 include/SdfLib/ExactOctreeSdfDepthFirst.h:28-681
+ *   sdfhip_exact_build_shard / _emit_shard / _from_parts  <- its OpenMP loop over start cells + merge   include/SdfLib/ExactOctreeSdfDepthFirst.h:534-622
+ *   sdfhip_exact_from_data    <- SdfFunction::loadFromFile (EXACT_OCTREE payload) include/SdfLib/ExactOctreeSdf.h:138-165
+ *   sdfhip_exact_download / _triangle_data  <- getOctreeData / getTrianglesData   include/SdfLib/ExactOctreeSdf.h:99-134
  *   sdfhip_exact_query        <- ExactOctreeSdf::getDistance (both overloads)     src/sdf/ExactOctreeSdf.cpp:38-320
  *   The Unity-style handle API (createOctreeSdf, getDistance, ...) of src/tools/SdfLibUnity/SdfExportFunc.h:16-58
  *   is provided on top of this header by include/SdfLib/SdfExportFunc.h.
@@ -52,7 +58,7 @@ extern "C" {
 /* OctreeSdf::InitAlgorithm (include/SdfLib/OctreeSdf.h:23-28) */
 #define SDFHIP_ALG_UNIFORM 0        /* not provided (test-only in the reference) */
 #define SDFHIP_ALG_NO_CONTINUITY 1
-#define SDFHIP_ALG_CONTINUITY 2     /* SdfExporter / Unity default; single device, FIT_EXACT only */
+#define SDFHIP_ALG_CONTINUITY 2     /* SdfExporter / Unity default; not sharded (replicas), FIT_EXACT only */
 
 /* node-array layout: which reference branch's array is reproduced */
 #define SDFHIP_LAYOUT_GLOBAL_DFS 0  /* numThreads < 2  (src/sdf/OctreeSdfDepthFirst.h:394-416) */
