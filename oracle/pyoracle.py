@@ -115,6 +115,16 @@ class Mesh:
         lib().orc_point_values(self.h, _p(pts), _p(tris), len(pts), _p(out)); return out
 
 
+def triangle_distance_test(seed=2222, n=1000000):
+    """The reference's TriangleDistanceTest loop (glibc srand/rand sample sequence): (violations, max |raw - data|, max |signed^2 - data|, sums)."""
+    f = lib().orc_triangle_distance_test
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint, C.c_uint32] + [C.POINTER(C.c_float)] * 4
+    a, b, c, d = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+    bad = f(seed, n, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    return int(bad), a.value, b.value, c.value, d.value
+
+
 def sqdist_raw(p, a, b, c):
     return lib().orc_sqdist_point_triangle_raw(_p(_f32(p)), _p(_f32(a)), _p(_f32(b)), _p(_f32(c)))
 

@@ -70,6 +70,29 @@ float orc_sqdist_point_triangle_raw(const float p[3], const float a[3], const fl
     return sqDistPointTriangleRaw(ld3(p), ld3(a), ld3(b), ld3(c));
 }
 float orc_signed_dist_point_triangle(orc_mesh* m, uint32_t t, const float p[3]) { return signedDistPointTriangle(ld3(p), m->td[t]); }
+
+// The reference's TriangleDistanceTest as it stands (src/tools/TriangleDistanceTest/main.cpp:12-64): srand(seed), n points of
+// 2*rand()/RAND_MAX-1 per coordinate around the fixed triangle; returns the number of points violating either assert and the
+// largest deviations seen (the two `total` sums it prints are returned too: they differ between its two distance routines
+// only by rounding).
+uint32_t orc_triangle_distance_test(unsigned seed, uint32_t n, float* maxRawVsData, float* maxSignedVsData, float* sumRaw, float* sumData) {
+    std::srand(seed);
+    const V3 v1 = v3(-0.5f, -0.5f, 0.0f), v2 = v3(0.5f, -0.5f, 0.0f), w3 = v3(0.0f, 0.5f, 0.0f);
+    const TriangleData td = makeTriangleData(v1, v2, w3);
+    auto rnd = []() { return 2.0f * (static_cast<float>(std::rand()) / static_cast<float>(RAND_MAX)) - 1.0f; };
+    uint32_t bad = 0; float m1 = 0.f, m2 = 0.f, t1 = 0.f, t2 = 0.f;
+    for (uint32_t i = 0; i < n; i++) {
+        const float x = rnd(), y = rnd(), z = rnd();
+        const V3 s = v3(x, y, z);
+        const float a = sqDistPointTriangleRaw(s, v1, v2, w3), b = sqDistPointTriangle(s, td), sg = signedDistPointTriangle(s, td);
+        t1 += a; t2 += b;
+        const float e1 = std::fabs(a - b), e2 = std::fabs(sg * sg - b);
+        m1 = gmax(m1, e1); m2 = gmax(m2, e2);
+        if (!(e1 < 0.001f) || !(e2 < 0.001f)) bad++;
+    }
+    *maxRawVsData = m1; *maxSignedVsData = m2; *sumRaw = t1; *sumData = t2;
+    return bad;
+}
 float orc_signed_dist_point_triangle_grad(orc_mesh* m, uint32_t t, const float p[3], float g[3]) {
     V3 n;
     const float d = signedDistPointTriangleGrad(ld3(p), m->td[t], m->vertices[m->indices[3 * t]], m->vertices[m->indices[3 * t + 1]], m->vertices[m->indices[3 * t + 2]], n);

@@ -26,6 +26,7 @@ void orc_bvh_nearest(orc_mesh*, const float* pts, uint64_t n, uint32_t* out_ids,
 float orc_sqdist_point_triangle(orc_mesh*, uint32_t tri, const float p[3]);
 float orc_sqdist_point_triangle_raw(const float p[3], const float a[3], const float b[3], const float c[3]);
 float orc_signed_dist_point_triangle(orc_mesh*, uint32_t tri, const float p[3]);
+uint32_t orc_triangle_distance_test(unsigned seed, uint32_t n, float* max_raw_vs_data, float* max_signed_vs_data, float* sum_raw, float* sum_data);
 float orc_signed_dist_point_triangle_grad(orc_mesh*, uint32_t tri, const float p[3], float out_grad[3]);
 float orc_signed_dist_point_triangle_grad_local(orc_mesh*, uint32_t tri, const float p[3], float out_grad[3]);
 void orc_point_values(orc_mesh*, const float* pts, const uint32_t* tris, uint64_t n, float* out8);

@@ -30,6 +30,15 @@ def test_triangle_distance_kat(oracle):
         assert abs(s * s - b) < 1e-3
 
 
+def test_reference_triangle_distance_test_full_run(oracle):
+    """The reference's own TriangleDistanceTest, restated loop for loop: srand(2222), 1 M points from rand(), both asserts
+    (src/tools/TriangleDistanceTest/main.cpp:12-64; the survey ran the real tool: all 1 M points pass)."""
+    bad, max_raw, max_signed, sum_raw, sum_data = oracle.triangle_distance_test(2222, 1000000)
+    assert bad == 0
+    assert max_raw < 1e-5 and max_signed < 1e-5           # far inside the tool's 1e-3 tolerance
+    assert abs(sum_raw - sum_data) < 1e-3 * abs(sum_raw)
+
+
 def test_fit_matrix_is_inverse_of_hermite_constraints(oracle):
     """Derivation check (src/tools/CalculateInterpolationParameters/main.cpp:22-143): M @ C == I where C maps the
     64 monomial coefficients to the 64 Hermite values (value + 7 derivatives at the 8 unit-cube corners)."""
