@@ -48,23 +48,31 @@ SDF_DEV float boxDistanceGrad(const QueryTree& t, F3 p, float* g) {
     return boxDistance(t, p);
 }
 
-template <int EVAL, bool GRAD>
-SDF_DEV float queryOne(const QueryTree& t, F3 p, float* grad) {
-    F3 f = F3{(p.x - t.bminx) / t.cellSize, (p.y - t.bminy) / t.cellSize, (p.z - t.bminz) / t.cellSize};
+// Walk from the start grid to the leaf holding p: index of its 64 coefficients and the local coordinates in [0,1)^3.
+// Returns false for points outside the start grid.
+SDF_DEV bool locateLeaf(const QueryTree& t, F3 p, uint32_t& at, F3& f) {
+    f = F3{(p.x - t.bminx) / t.cellSize, (p.y - t.bminy) / t.cellSize, (p.z - t.bminz) / t.cellSize};
     const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
     const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
     f = F3{f.x - flx, f.y - fly, f.z - flz};
-    if (ix < 0 || ix >= t.G || iy < 0 || iy >= t.G || iz < 0 || iz >= t.G) {
-        if (GRAD) return boxDistanceGrad(t, p, grad) + t.minBorder;
-        return boxDistance(t, p) + t.minBorder;
-    }
+    if (ix < 0 || ix >= t.G || iy < 0 || iy >= t.G || iz < 0 || iz >= t.G) return false;
     uint32_t w = t.data[(iz * t.G + iy) * t.G + ix];
     while (!(w & LEAF_BIT)) {
         const uint32_t child = ((f.z >= 0.5f) ? 4u : 0u) + ((f.y >= 0.5f) ? 2u : 0u) + ((f.x >= 0.5f) ? 1u : 0u);
         w = t.data[(w & INDEX_MASK) + child];
         f = F3{gfract(2.0f * f.x), gfract(2.0f * f.y), gfract(2.0f * f.z)};
     }
-    const uint32_t at = w & INDEX_MASK;
+    at = w & INDEX_MASK;
+    return true;
+}
+
+template <int EVAL, bool GRAD>
+SDF_DEV float queryOne(const QueryTree& t, F3 p, float* grad) {
+    uint32_t at; F3 f;
+    if (!locateLeaf(t, p, at, f)) {
+        if (GRAD) return boxDistanceGrad(t, p, grad) + t.minBorder;
+        return boxDistance(t, p) + t.minBorder;
+    }
     float c[64];
     if ((at & 3u) == 0u) {
         const float4* src = reinterpret_cast<const float4*>(t.data + at);

@@ -124,6 +124,17 @@ def test_grid_query_matches_point_query(small):
     pts = np.stack([origin[0] + i.astype(np.float32) * step[0], origin[1] + j.astype(np.float32) * step[1], origin[2] + k.astype(np.float32) * step[2]], axis=-1).reshape(-1, 3).astype(np.float32)
     d2, g2 = gt.get_distance(pts, gradient=True, eval_mode=S.EVAL_EXACT)
     assert np.array_equal(bits(d), bits(d2)) and np.array_equal(bits(g), bits(g2))
+    # EVAL_FAST on lattices: inside the box, sticking out of it, odd sides
+    for org, stp, dims in ((origin, step, (n, n, n)), (origin - 6 * step, (step * np.float32(1.5)).astype(np.float32), (32, 28, 36)), (origin, step, (31, 30, 29))):
+        df, gf = gt.get_distance_grid(org, stp, dims, gradient=True, eval_mode=S.EVAL_FAST)
+        df_only = gt.get_distance_grid(org, stp, dims, gradient=False, eval_mode=S.EVAL_FAST)
+        kk, jj, ii = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+        q = np.stack([org[0] + ii.astype(np.float32) * stp[0], org[1] + jj.astype(np.float32) * stp[1], org[2] + kk.astype(np.float32) * stp[2]], axis=-1).reshape(-1, 3).astype(np.float32)
+        de, ge = gt.get_distance(q, gradient=True, eval_mode=S.EVAL_EXACT)
+        np.testing.assert_allclose(df, de, rtol=0, atol=1e-5)
+        np.testing.assert_allclose(df_only, de, rtol=0, atol=1e-5)
+        ok = np.isfinite(ge).all(axis=1) & np.isfinite(gf).all(axis=1)
+        np.testing.assert_allclose(gf[ok], ge[ok], rtol=0, atol=2e-4)        # unit gradients: normalisation amplifies the 1e-5 of the components
 
 
 def test_sharded_build_emits_the_same_array(small, oracle):
