@@ -156,7 +156,7 @@ def main():
                      "algorithmic_bytes_per_launch": int(round(bytes_per_query * args.queries)),
                      "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
                      "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
-        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), **{k: round(v, 4) for k, v in binfo.items()}},
+        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **{k: round(v, 4) for k, v in binfo.items()}},
     }
 
     if rank == 0 and not args.no_cpu_baseline:
