@@ -67,6 +67,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # every rank plans the (replicated) BVH on the shared host: split the hardware threads instead of oversubscribing them
+        per_rank = max(4, (os.cpu_count() or 8) // world)
+        os.environ.setdefault("SDFHIP_BVH_SORT_THREADS", str(per_rank))
+        os.environ.setdefault("SDFHIP_BVH_PAR_DEPTH", str(max(2, per_rank.bit_length() - 1)))
     # test hook: several ranks on ONE device with gloo collectives (the real launch is one rank per GPU over RCCL)
     one_device = os.environ.get("SDFHIP_BENCH_ONE_DEVICE") == "1"
     if one_device:
