@@ -12,7 +12,8 @@
 //                     stride the chunk, gather 3 indices + 3 vertices per triangle, run the Frank-Wolfe test, and
 //                     compact the survivors IN ORDER with __ballot + mbcnt prefix (lists stay ascending by id)
 //   hipcub scan + k_compact : chunk counts -> packed per-node lists
-//   k_brute_nearest : wave per (node, sample point): first-minimum nearest triangle over the node's list
+//   k_brute_nearest / k_brute_nearest_mids : first-minimum nearest triangle of a node's sample points over the node's list
+//                     (block per (node, corner) at the root; block per node with LDS-staged frames for the 19 mid-points)
 //   k_merge_*       : the "second visit" of the last two levels: sorted union of the children's lists + per-child
 //                     MSB-first byte masks (ExactOctreeSdfDepthFirst.h:195-259), as binary-search membership tests
 //   k_ex_sizes / k_ex_offsets / k_ex_emit_* : pre/post-order offsets of the reference's three arrays (nodes, bit-packed
@@ -88,6 +89,56 @@ __global__ void __launch_bounds__(TPB) k_brute_nearest(ExMesh m, const float* __
         }
     }
     if (threadIdx.x == 0) outTri[(size_t)node * pointsPerNode + pi] = (bestPos == NONE) ? (len ? list[off] : 0u) : list[off + bestPos];
+}
+
+// The 19 mid-points of a node against the node's own list, ONE block per node: the list's 80-byte frames are staged through LDS
+// once (64 per tile) and shared by the 19 points, instead of 19 blocks each streaming the list from L2 (the first version's
+// profile: 4.9 GB x2 of FETCH per launch).  Thread = (point m, slice s): the tile's triangles s, s + 13, ... ; partial minima
+// are merged by (distance, list position), i.e. the first minimum in list order like the sequential scan.
+constexpr int BN_SLICES = 13;                     // 19 points x 13 slices = 247 of 256 threads
+__global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const float* __restrict__ center, float half, uint32_t n, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
+                                                            const uint32_t* __restrict__ skip, uint32_t* __restrict__ outTri) {
+    __shared__ float4 s_fr[64 * 5];
+    __shared__ float s_d[19 * BN_SLICES]; __shared__ uint32_t s_p[19 * BN_SLICES];
+    const uint32_t node = blockIdx.x;
+    if (node >= n) return;
+    if (skip && skip[node]) return;                                   // whole block
+    const int tid = threadIdx.x;
+    const int mi = tid / BN_SLICES, sl = tid - BN_SLICES * mi;
+    const bool worker = mi < 19;
+    const F3 p = ldv(center, node) + (worker ? midRel(mi) : F3{0.f, 0.f, 0.f}) * half;
+    const uint32_t off = listOff[node], len = listLen[node];
+    float best = INFINITY; uint32_t bestPos = NONE;
+    for (uint32_t base = 0; base < len; base += 64) {
+        const uint32_t cnt = (len - base < 64u) ? len - base : 64u;
+        __syncthreads();                                              // previous tile fully consumed
+        for (uint32_t e = (uint32_t)tid; e < 5u * cnt; e += 256u) {    // 5 x 16 B per triangle, coalesced within a frame
+            const uint32_t k = e / 5u, c = e - 5u * k;
+            s_fr[5 * k + c] = reinterpret_cast<const float4*>(m.frames)[5 * (size_t)list[off + base + k] + c];
+        }
+        __syncthreads();
+        if (worker) {
+            for (uint32_t k = (uint32_t)sl; k < cnt; k += BN_SLICES) {
+                const float4 a = s_fr[5 * k], b = s_fr[5 * k + 1], c = s_fr[5 * k + 2], d4 = s_fr[5 * k + 3], e4 = s_fr[5 * k + 4];
+                TriFrame f;
+                f.origin = F3{a.x, a.y, a.z};
+                f.m[0] = a.w; f.m[1] = b.x; f.m[2] = b.y; f.m[3] = b.z; f.m[4] = b.w; f.m[5] = c.x; f.m[6] = c.y; f.m[7] = c.z; f.m[8] = c.w;
+                f.b = F2{d4.x, d4.y}; f.c = F2{d4.z, d4.w}; f.v2 = e4.x; f.v3 = F2{e4.y, e4.z};
+                const float d = sqDistPointTriangle(p, f);
+                if (d < best) { best = d; bestPos = base + k; }
+            }
+        }
+    }
+    if (worker) { s_d[tid] = best; s_p[tid] = bestPos; }
+    __syncthreads();
+    if (worker && sl == 0) {
+        for (int q = 1; q < BN_SLICES; q++) {
+            const float od = s_d[tid + q]; const uint32_t op = s_p[tid + q];
+            if (od < best || (od == best && op < bestPos)) { best = od; bestPos = op; }
+        }
+        outTri[(size_t)node * 19 + mi] = (bestPos == NONE) ? (len ? list[off] : 0u) : list[off + bestPos];
+    }
 }
 
 // 8x8 corner-sphere radii of a node: lane l = 8*i + c  ->  dist(corner c, nearest triangle of corner i) - min_c
@@ -644,7 +695,10 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         SDF_HIP_CHECK(hipGetLastError());
         if (L->numInner > 0) {
             SDF_TRY(L->midTri.reserve(19ull * n));
-            k_brute_nearest<64><<<19 * n, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
+            // few nodes with long lists near the root: a block per (node, point) keeps the chip busy; many nodes with short lists below:
+            // a block per node shares the staged frames among the 19 points
+            if (n >= 4096) k_brute_nearest_mids<<<n, 256, 0, st>>>(md, L->center.p, L->half, n, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
+            else k_brute_nearest<64><<<19 * n, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
             std::unique_ptr<ExLevel> N(new ExLevel());
             N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
             SDF_TRY(N->center.reserve(3ull * N->n)); SDF_TRY(N->coord.reserve(N->n)); SDF_TRY(N->cornerTri.reserve(8ull * N->n));
