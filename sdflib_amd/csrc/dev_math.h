@@ -14,6 +14,13 @@
 #define SDF_DEV __device__ __forceinline__
 #define SDF_HD __host__ __device__ __forceinline__
 
+// XCD-aware block order.  Workgroups are dealt round-robin to the 8 XCDs of the MI355X (block b -> XCD b % 8), each with a private
+// 4 MB L2.  When consecutive LOGICAL blocks work on neighbouring data (sorted queries, lattice rows, Morton-ordered points),
+// giving XCD x the x-th contiguous eighth of the logical blocks keeps each L2's working set to one region of the data.
+// Launch with xcdGrid(blocks) blocks (a multiple of 8) and guard the tail in the kernel.
+__device__ __forceinline__ unsigned xcdLogicalBlock() { const unsigned per = gridDim.x >> 3; return (blockIdx.x & 7u) * per + (blockIdx.x >> 3); }
+static inline unsigned xcdGrid(unsigned blocks) { return (blocks + 7u) / 8u * 8u; }
+
 namespace sdfhip {
 
 struct F3 { float x, y, z; };

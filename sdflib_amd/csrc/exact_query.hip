@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_exact_sorted(ExactView v, const float* 
     __shared__ float s_frames[4][64 * FRAME_FLOATS];
     __shared__ uint32_t s_tri[4][64];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t e = (uint64_t)xcdLogicalBlock() * blockDim.x + threadIdx.x;       // queries are sorted by leaf: a contiguous range of leaves per XCD
     uint32_t myKey = QNONE, q = 0;
     if (e < n) { myKey = skey[e]; q = sidx[e]; }
     const bool active = myKey != QNONE;
@@ -279,8 +279,8 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         SDF_TRY(tmp.reserve(tb));
         (void)keyBits;   // outside-the-grid queries carry key 0xFFFFFFFF: sort on all 32 bits so that they end up last
         SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, 32, st));
-        if (g) k_exact_sorted<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, g, t);
-        else k_exact_sorted<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, nullptr, t);
+        if (g) k_exact_sorted<true><<<xcdGrid(gridFor(n, 256)), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, g, t);
+        else k_exact_sorted<false><<<xcdGrid(gridFor(n, 256)), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, nullptr, t);
         SDF_HIP_CHECK(hipGetLastError());
         if (!own.owns_lock()) SDF_HIP_CHECK(hipStreamSynchronize(st));      // the private scratch dies with this scope
     }

@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256) k_octree_query(QueryTree t, const float* 
 template <int EVAL, bool GRAD>
 __global__ void __launch_bounds__(256) k_octree_query_grid(QueryTree t, F3 origin, F3 step, uint32_t nx, uint32_t ny, uint32_t nz,
                                                            float* __restrict__ dist, float* __restrict__ grad) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // (an XCD-contiguous slab order was measured: slower here)
     const uint64_t n = (uint64_t)nx * ny * nz;
     if (i >= n) return;
     const uint32_t x = (uint32_t)(i % nx), y = (uint32_t)((i / nx) % ny), z = (uint32_t)(i / ((uint64_t)nx * ny));

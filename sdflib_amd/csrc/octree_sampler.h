@@ -89,11 +89,7 @@ __global__ void k_sample_rep_list(const uint32_t* __restrict__ isRep, const uint
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri) {
     extern __shared__ uint32_t s_stack[];        // [stackDepth][BLOCK], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own 4 MB L2.  The
-    // representatives are in Morton order, so XCD x is given the x-th CONTIGUOUS eighth of them: its L2 then only has to hold the
-    // BVH subtrees of one region of space instead of all of them.
-    const uint32_t per = gridDim.x >> 3;                              // the grid is launched with a multiple of 8 blocks
-    const uint32_t lb = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);  // bijection on [0, gridDim.x)
+    const uint32_t lb = xcdLogicalBlock();            // the representatives are in Morton order: a contiguous eighth of them per XCD
     const uint32_t r = lb * blockDim.x + threadIdx.x;
     if (r >= numReps) return;
     repTri[r] = bvhNearest<BLOCK>(b, samplePosition(B, repSample[r]), s_stack + threadIdx.x);
@@ -137,7 +133,7 @@ static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, 
     const uint32_t numReps = lastScan + lastFlag;
     SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repTri.reserve(numReps));
     k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
-    k_sample_nearest<128><<<(gridFor(numReps, 128) + 7u) / 8u * 8u, 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);   // 64 / 256 lanes per block measured the same
+    k_sample_nearest<128><<<xcdGrid(gridFor(numReps, 128)), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);   // 64 / 256 lanes per block measured the same
     k_sample_values<<<gridFor(total, 256), 256, 0, st>>>(md, B, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p);
     SDF_HIP_CHECK(hipGetLastError());
     traversals += numReps;
