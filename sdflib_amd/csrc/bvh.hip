@@ -324,6 +324,7 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     const double tPlanned = nowSeconds();
     SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
     hipStream_t st = mesh->ctx->stream;
+    AllocScope allocScope(st);
     SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
     SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph.get(), nSph * sizeof(double), hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids.get(), nKids * sizeof(int), hipMemcpyHostToDevice, st));

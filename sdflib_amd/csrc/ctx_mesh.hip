@@ -218,6 +218,10 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
     sdfhip_ctx* c = new sdfhip_ctx();
     c->device = device_id;
     SDF_HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
+    {   // stream-ordered allocations (AllocScope) are served from the device's default pool: keep freed blocks for reuse
+        hipMemPool_t pool = nullptr; uint64_t keep = ~0ull;
+        if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
     if (stream_mode == SDFHIP_STREAM_BORROWED) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
     else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
     *out = c;
@@ -255,6 +259,7 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     m->hIdx.assign(indices, indices + 3ull * nt);
     hipStream_t st = ctx->stream;
     const uint32_t nhe = 3 * nt;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     int rc = SDFHIP_OK;
     auto fail = [&](int code) { delete m; return code; };
     if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt)) || (rc = m->dFrames.reserve((size_t)FRAME_FLOATS * nt))) return fail(rc);

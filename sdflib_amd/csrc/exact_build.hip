@@ -516,6 +516,7 @@ using namespace sdfhip;
 static int exactEmit(sdfhip_exact* E, uint32_t nodeOff, uint32_t setOff, uint32_t maskOff, uint32_t* gridNodes, uint8_t* gridHas,
                      uint32_t* bodyNodes, uint8_t* bodyHas, uint32_t* sets, uint8_t* masks) {
     hipStream_t st = E->ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const sdfhip_exact_info& I = E->info;
     const uint32_t sod = E->sod, startDepth = I.start_depth, maxDepth = I.max_depth, bitEnc = I.bit_encoding_start_depth, bits = I.bits_per_index;
     std::vector<std::unique_ptr<ExLevel>>& LV = E->levels;
@@ -561,6 +562,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     SDF_REQUIRE(mesh->numTriangles >= 2, "at least 2 triangles are needed (bits per index)");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const double tStart = nowSeconds();
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
     E->ctx = ctx; E->mesh = mesh;
@@ -821,6 +823,7 @@ int sdfhip_exact_emit_shard(sdfhip_exact* E, uint64_t node_offset, uint64_t set_
     SDF_REQUIRE(node_offset + E->bodyNodes < (1ull << 31) && set_offset + E->info.num_set_words < (1ull << 32) && mask_offset + E->info.num_mask_bytes < (1ull << 32), "structure too large");
     SDF_HIP_CHECK(hipSetDevice(E->ctx->device));
     hipStream_t st = E->ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const uint64_t nc = E->shardCells.size(), bn = E->bodyNodes, sw = E->info.num_set_words, mb = E->info.num_mask_bytes;
     DevBuf<uint32_t> tGrid, tBody, tSets; DevBuf<uint8_t> tGridHas, tBodyHas, tMasks;
     uint32_t* gN = dst_grid_nodes; uint8_t* gH = dst_grid_has; uint32_t* bN = dst_body_nodes; uint8_t* bH = dst_body_has; uint32_t* sS = dst_sets; uint8_t* mM = dst_masks;

@@ -299,6 +299,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const double tStart = nowSeconds();
 
     std::unique_ptr<sdfhip_octree> T(new sdfhip_octree());
@@ -502,6 +503,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     T->info.min_border_value = (stat[1] == 0xFFFFFFFFu) ? INFINITY : floatFromOrderKey(stat[1]);
     T->info.cell_begin = cellBegin; T->info.cell_end = cellEnd;
     T->info.fit_rechecks = stat[2];
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] octree build: hipMalloc/hipFree so far on this thread: %ld calls, %.4f s\n", g_allocCalls(), g_allocSeconds());
     T->info.body_words = bodyWords;
     T->info.body_offset = G3;     // provisional (single shard); emit_shard overrides it
     T->info.num_words = partial ? 0 : (uint64_t)G3 + bodyWords;
@@ -542,6 +544,7 @@ int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* d
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const uint32_t sod = T->startOctreeDepth, startDepth = T->params.start_depth, maxDepth = T->params.depth;
     const uint32_t G = 1u << startDepth, G3 = G * G * G;
     const uint32_t cellBegin = T->info.cell_begin, cellEnd = T->info.cell_end, nCells = cellEnd - cellBegin;

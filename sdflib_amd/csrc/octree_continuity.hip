@@ -576,6 +576,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const double tStart = nowSeconds();
     const uint32_t maxDepth = P->depth, startDepth = P->start_depth;
     const int G = 1 << startDepth; const uint32_t G3 = (uint32_t)(G * G * G);

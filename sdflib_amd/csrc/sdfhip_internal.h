@@ -34,25 +34,56 @@ static inline double nowSeconds() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// Plain device allocation owned by one object; freed in the destructor.
+// allocation cost accounting (diagnostics under SDFHIP_TIMING)
+inline double& g_allocSeconds() { static thread_local double v = 0; return v; }
+inline long& g_allocCalls() { static thread_local long v = 0; return v; }
+
+// Stream-ordered allocation.  A build creates and drops a few hundred device buffers (hipMalloc / hipFree cost ~40 us each
+// and hipFree synchronises the device: 10 ms of a 60 ms build in the first measurements).  Inside an AllocScope the buffers of
+// the calling thread come from the device's default memory pool on the given stream instead (hipMallocAsync / hipFreeAsync: no
+// synchronisation, freed blocks are reused by later requests on the stream).  Outside a scope DevBuf falls back to hipMalloc /
+// hipFree, which is also how long-lived buffers (trees, meshes) are released later.
+struct AllocState { hipStream_t stream = nullptr; bool active = false; };
+inline AllocState& tlsAlloc() { static thread_local AllocState s; return s; }
+struct AllocScope {
+    AllocState prev;
+    explicit AllocScope(hipStream_t s) { prev = tlsAlloc(); tlsAlloc().stream = s; tlsAlloc().active = true; }
+    ~AllocScope() { tlsAlloc() = prev; }
+    AllocScope(const AllocScope&) = delete;
+    AllocScope& operator=(const AllocScope&) = delete;
+};
+
+// Device allocation owned by one object; freed in the destructor.
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool pooled = false;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), pooled(o.pooled) { o.p = nullptr; o.n = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; n = o.n; pooled = o.pooled; o.p = nullptr; o.n = 0; return *this; }
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void release() {
+        if (!p) return;
+        const double t0 = nowSeconds();
+        if (pooled && tlsAlloc().active) (void)hipFreeAsync(p, tlsAlloc().stream);
+        else (void)hipFree(p);
+        g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
+        p = nullptr; n = 0;
+    }
     // grows only; contents are NOT preserved
     int reserve(size_t count) {
         if (count <= n && p) return SDFHIP_OK;
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; setError("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e)); return SDFHIP_E_HIP; }
+        const double t0 = nowSeconds();
+        hipError_t e;
+        if (tlsAlloc().active) { e = hipMallocAsync((void**)&p, count * sizeof(T), tlsAlloc().stream); pooled = true; }
+        else { e = hipMalloc((void**)&p, count * sizeof(T)); pooled = false; }
+        g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
+        if (e != hipSuccess) { p = nullptr; setError("device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return SDFHIP_E_HIP; }
         n = count;
         return SDFHIP_OK;
     }
