@@ -366,7 +366,6 @@ __global__ void __launch_bounds__(128) kc_pp_fit(const OpDev* __restrict__ ops, 
 }
 // the 19 mid-points of every subdividing op
 __global__ void __launch_bounds__(128) kc_pp_mid(CMesh m, const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ scratch, float thr, float sqThr) {
-    extern __shared__ uint32_t s_stack[];
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= 19u * nOps) return;
     const uint32_t o = gid / 19u, mi = gid - 19u * o;
@@ -383,12 +382,41 @@ __global__ void __launch_bounds__(128) kc_pp_mid(CMesh m, const OpDev* __restric
         const float* src = LT.lv[op.srcLevel].mid + 152 * (size_t)op.srcSlot + 8 * mi;
         for (int k = 0; k < 8; k++) md[k] = src[k];
     } else if (masked) vertexValuesExact(cf, f, 2.0f * half, md);
-    else exactSample(m, ce + midRel((int)mi) * half, md, s_stack + threadIdx.x);
+    // else: md already holds the exact sample (kc_pp_sample_all)
     if (!masked) {
         const float iv = tricubicValueExact(cf, f);
         const float e = md[0] - iv;
         if (e * e < sqThr) vertexValuesExact(cf, f, 2.0f * half, md);
     } else if (op.recycle) vertexValuesExact(cf, f, 2.0f * half, md);
+}
+// geometry of the children of every subdividing op (centres only: lets the exact samples of ALL generations of a post-pass be
+// taken in one launch before the value passes run generation by generation)
+__global__ void kc_pp_geom(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ pcenter, float* __restrict__ phalf) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t o = gid >> 3, c = gid & 7u;
+    if (o >= nOps) return;
+    const OpDev op = ops[o];
+    if (op.kind != 0) return;
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    const uint32_t child = op.childPool + c;
+    const float ns = 0.5f * half;
+    pcenter[3 * (size_t)child] = ce.x + ((c & 1u) ? ns : -ns);
+    pcenter[3 * (size_t)child + 1] = ce.y + ((c & 2u) ? ns : -ns);
+    pcenter[3 * (size_t)child + 2] = ce.z + ((c & 4u) ? ns : -ns);
+    phalf[child] = ns;
+}
+// the exact mid-point samples of every subdividing op of a post-pass (all generations): few, long traversals -> one launch
+__global__ void __launch_bounds__(128) kc_pp_sample_all(CMesh m, const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ scratch) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= 19u * nOps) return;
+    const uint32_t o = gid / 19u, mi = gid - 19u * o;
+    const OpDev op = ops[o];
+    if (op.kind != 0 || op.recycle || (op.samplesMask & (1u << (18 - mi)))) return;
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    exactSample(m, ce + midRel((int)mi) * half, scratch + 216 * (size_t)op.scratch + 64 + 8 * mi, s_stack + threadIdx.x);
 }
 // children of every subdividing op -> pool
 __global__ void __launch_bounds__(256) kc_pp_children(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, const float* __restrict__ scratch,
@@ -918,19 +946,33 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         LevelTable LT{};
         for (uint32_t d = 0; d <= maxDepth && d < 12; d++) if (LV[d]) LT.lv[d] = LevelPtrs{LV[d]->center.p, LV[d]->vv.p, LV[d]->coeff.p, LV[d]->mid.p, LV[d]->half};
         PoolDev PD{pCenter.p, pHalf.p, pVv.p};
-        for (size_t g = 0; g < gens.size(); g++) {
-            std::vector<OpDev>& ops = gens[g];
-            if (ops.empty()) continue;
-            for (size_t k = 0; k < ops.size(); k++) ops[k].scratch = (uint32_t)k;
-            SDF_TRY(dops.reserve(ops.size())); SDF_TRY(scratch.reserve(216 * ops.size()));
-            SDF_HIP_CHECK(hipMemcpyAsync(dops.p, ops.data(), sizeof(OpDev) * ops.size(), hipMemcpyHostToDevice, st));
-            const uint32_t no = (uint32_t)ops.size();
-            kc_pp_fit<<<gridFor(no, 128), 128, 0, st>>>(dops.p, no, LT, PD, scratch.p, oc.p);
-            kc_pp_mid<<<gridFor(19ull * no, 128), 128, stackBytes, st>>>(md, dops.p, no, LT, PD, scratch.p, thr, sqThr);
-            kc_pp_children<<<gridFor(64ull * no, 256), 256, 0, st>>>(dops.p, no, LT, PD, scratch.p, pCenter.p, pHalf.p, pVv.p);
-            SDF_HIP_CHECK(hipGetLastError());
-            SDF_HIP_CHECK(hipStreamSynchronize(st));
-            T->info.num_samples += 19ull * no;
+        {
+            // all generations' ops in one array (scratch slot = global index); geometry first, then ONE launch for every exact
+            // sample of the post-pass, then fit / mid-point / children values generation by generation — no host round trip between
+            std::vector<OpDev> all; std::vector<size_t> gBegin;
+            for (size_t g = 0; g < gens.size(); g++) { gBegin.push_back(all.size()); for (const OpDev& op : gens[g]) { all.push_back(op); all.back().scratch = (uint32_t)(all.size() - 1); } }
+            gBegin.push_back(all.size());
+            if (!all.empty()) {
+                SDF_TRY(dops.reserve(all.size())); SDF_TRY(scratch.reserve(216 * all.size()));
+                SDF_HIP_CHECK(hipMemcpyAsync(dops.p, all.data(), sizeof(OpDev) * all.size(), hipMemcpyHostToDevice, st));
+                for (size_t g = 0; g + 1 < gBegin.size(); g++) {
+                    const uint32_t no = (uint32_t)(gBegin[g + 1] - gBegin[g]);
+                    if (no) kc_pp_geom<<<gridFor(8ull * no, 256), 256, 0, st>>>(dops.p + gBegin[g], no, LT, PD, pCenter.p, pHalf.p);
+                }
+                const uint32_t na = (uint32_t)all.size();
+                kc_pp_sample_all<<<gridFor(19ull * na, 128), 128, stackBytes, st>>>(md, dops.p, na, LT, PD, scratch.p);
+                for (size_t g = 0; g + 1 < gBegin.size(); g++) {
+                    const uint32_t no = (uint32_t)(gBegin[g + 1] - gBegin[g]);
+                    if (!no) continue;
+                    const OpDev* ops = dops.p + gBegin[g];
+                    kc_pp_fit<<<gridFor(no, 128), 128, 0, st>>>(ops, no, LT, PD, scratch.p, oc.p);
+                    kc_pp_mid<<<gridFor(19ull * no, 128), 128, 0, st>>>(md, ops, no, LT, PD, scratch.p, thr, sqThr);
+                    kc_pp_children<<<gridFor(64ull * no, 256), 256, 0, st>>>(ops, no, LT, PD, scratch.p, pCenter.p, pHalf.p, pVv.p);
+                    T->info.num_samples += 19ull * no;
+                }
+                SDF_HIP_CHECK(hipGetLastError());
+                SDF_HIP_CHECK(hipStreamSynchronize(st));      // `all` goes out of scope
+            }
         }
         lap(tOps);
     }
