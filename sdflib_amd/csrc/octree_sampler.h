@@ -36,7 +36,9 @@ struct SampleSeg { const float* center; const uint32_t* coord; float* out; float
 struct SampleBatch {
     SampleSeg seg[MAX_SEGS]; int count = 0; uint32_t total = 0;
     void add(const float* center, const uint32_t* coord, float half, uint32_t n, int points, float* out, int stride) {
-        seg[count] = SampleSeg{center, coord, out, half, n, total, points, stride}; count++; total += (uint32_t)points * n;
+        seg[count] = SampleSeg{center, coord, out, half, n, total, points, stride}; count++;
+        const uint64_t t = (uint64_t)total + (uint64_t)points * n;
+        total = t < 0xFFFFFFFFull ? (uint32_t)t : 0xFFFFFFFFu;      // saturates; sampleBatch rejects anything >= 2^31
     }
 };
 struct SampleRef { int seg; uint32_t node, k; };
@@ -115,6 +117,7 @@ struct SampleScratch {
 static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
     const uint32_t total = B.total;
     if (total == 0) return SDFHIP_OK;
+    SDF_REQUIRE(total < (1u << 31), "level too large for one sample batch (2^31 samples)");
     SDF_TRY(S.key.reserve(total)); SDF_TRY(S.keyS.reserve(total)); SDF_TRY(S.val.reserve(total)); SDF_TRY(S.valS.reserve(total));
     SDF_TRY(S.isRep.reserve(total)); SDF_TRY(S.scan.reserve(total));
     k_sample_keys<<<gridFor(total, 256), 256, 0, st>>>(B, S.key.p, S.val.p);
