@@ -139,6 +139,12 @@ orc_octree* orc_octree_build_continuity(orc_mesh* m, const float box6[6], uint32
     computeMinBorder(o->d);
     return o;
 }
+// the rule-generated stencil tables, for tools/check_ref_expressions.py: 19 x 3 relative positions, 8 x 8 child sources, 19 weights
+void orc_stencil_tables(float* midRel57, int32_t* childSrc64, float* midWeight19) {
+    const Stencil& st = stencil();
+    for (int m = 0; m < 19; m++) { midRel57[3 * m] = st.midRel[m].x; midRel57[3 * m + 1] = st.midRel[m].y; midRel57[3 * m + 2] = st.midRel[m].z; midWeight19[m] = st.midWeight[m]; }
+    for (int c = 0; c < 8; c++) for (int j = 0; j < 8; j++) childSrc64[8 * c + j] = st.childSrc[c][j];
+}
 void orc_neighbour_masks(uint32_t* out24) { const NeighbourMasks& n = neighbourMasks(); for (int i = 0; i < 24; i++) out24[i] = n.m[i]; }
 void orc_octree_destroy(orc_octree* o) { delete o; }
 uint64_t orc_octree_size(orc_octree* o) { return o->d.data.size(); }

@@ -46,6 +46,7 @@ orc_octree* orc_octree_build(orc_mesh*, const float box6[6], uint32_t depth, uin
                              float p0, float p1, int vertex_cache, int layout);
 /* OctreeSdf CONTINUITY builder (canonical mode, single layout) */
 orc_octree* orc_octree_build_continuity(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, int rule, float p0, float p1);
+void orc_stencil_tables(float* mid_rel_57, int32_t* child_src_64, float* mid_weight_19);
 void orc_neighbour_masks(uint32_t* out24);
 void orc_octree_destroy(orc_octree*);
 uint64_t orc_octree_size(orc_octree*);

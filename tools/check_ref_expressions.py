@@ -118,6 +118,48 @@ def main():
     L.orc_neighbour_masks(mine.ctypes.data_as(C.c_void_p))
     assert [int(x) for x in mine] == lits, (list(mine), lits)
     print("neighbour masks: 24 entries identical")
+    # ---- NO_CONTINUITY builder: the 19 sample offsets and the hand-down of the 27-point stencil to the 8 children
+    df = open("/root/reference/src/sdf/OctreeSdfDepthFirst.h").read()
+    blk = df[df.index("nodeSamplePoints ="):]
+    blk = blk[:blk.index("};")]
+    pts = []
+    for mm in re.finditer(r"glm::vec3\(([^)]*)\)", blk):
+        a = [float(x.strip().rstrip("f")) for x in mm.group(1).split(",")]
+        pts.append(a * 3 if len(a) == 1 else a)
+    assert len(pts) == 19
+    L.orc_stencil_tables.restype = None; L.orc_stencil_tables.argtypes = [C.c_void_p] * 3
+    rel = np.zeros((19, 3), np.float32); src = np.zeros((8, 8), np.int32); wt = np.zeros(19, np.float32)
+    L.orc_stencil_tables(rel.ctypes.data_as(C.c_void_p), src.ctypes.data_as(C.c_void_p), wt.ctypes.data_as(C.c_void_p))
+    assert rel.tolist() == pts, (rel.tolist(), pts)
+    print("nodeSamplePoints: 19 offsets identical")
+    body = df[df.index("// Generate new childrens"):]
+    blocks = re.findall(r"nodesStack\.push\(NodeInfo\((.*?)\)\);\s*\{(.*?)\n\t*\s*\}", body, re.S)
+    seen = {}
+    for head, inner in blocks[:8]:
+        sg = re.search(r"glm::vec3\((-?)newSize, (-?)newSize, (-?)newSize\)", head)
+        c = (0 if sg.group(1) else 1) | ((0 if sg.group(2) else 1) << 1) | ((0 if sg.group(3) else 1) << 2)
+        row = [None] * 8
+        for j, kind, idx in re.findall(r"child\.verticesValues\[(\d)\] = (midPointsValues|node\.verticesValues)\[(\d+)\]", inner):
+            row[int(j)] = int(idx) if kind == "midPointsValues" else -int(idx) - 1
+        info = [None] * 8
+        for j, kind, idx in re.findall(r"child\.verticesInfo\[(\d)\] = (pointsInfo|node\.verticesInfo)\[(\d+)\]", inner):
+            info[int(j)] = int(idx) if kind == "pointsInfo" else -int(idx) - 1
+        assert None not in row and row == info, (c, row, info)
+        seen[c] = row
+    assert sorted(seen) == list(range(8))
+    assert [seen[c] for c in range(8)] == src.tolist(), ([seen[c] for c in range(8)], src.tolist())
+    print("child stencil hand-down: 8 x 8 sources identical")
+    # trapezoid rule (OctreeSdfUtils.h:60-85): term m =  w/64 * pow2(middlePoints[m][0] - interpolateValue(coeff, p_m))  in order m = 0..18,
+    # w in {2,4,8}, p_m = the sample offset mapped to [0,1]^3
+    ut = open("/root/reference/include/SdfLib/OctreeSdfUtils.h").read()
+    fn = ut[ut.index("estimateErrorFunctionIntegralByTrapezoidRule"):]
+    fn = fn[fn.index("return"):fn.index(";")]
+    terms = re.findall(r"(\d)\.0f / 64\.0f \* pow2\(middlePoints\[(\d+)\]\[0\] - Inter::interpolateValue\(interpolationCoeff, glm::vec3\(([^)]*)\)\)\)", fn)
+    assert len(terms) == 19 and [int(t[1]) for t in terms] == list(range(19))
+    assert [float(t[0]) for t in terms] == wt.tolist(), ([t[0] for t in terms], wt.tolist())
+    frac = [[float(x.strip().rstrip("f")) for x in t[2].split(",")] for t in terms]
+    assert frac == (0.5 * rel + 0.5).tolist(), (frac, (0.5 * rel + 0.5).tolist())
+    print("trapezoid rule: 19 weights, evaluation points and their order identical")
     return 0
 
 
