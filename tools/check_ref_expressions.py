@@ -160,6 +160,22 @@ def main():
     frac = [[float(x.strip().rstrip("f")) for x in t[2].split(",")] for t in terms]
     assert frac == (0.5 * rel + 0.5).tolist(), (frac, (0.5 * rel + 0.5).tolist())
     print("trapezoid rule: 19 weights, evaluation points and their order identical")
+    # Simpson's rule (OctreeSdfUtils.h:213-238): same points and order, weights (w^2)/216
+    fn = ut[ut.index("estimateErrorFunctionIntegralBySimpsonsRule"):]
+    fn = fn[fn.index("return"):fn.index(";")]
+    terms = re.findall(r"(\d+)\.0f / 216\.0f \* pow2\(middlePoints\[(\d+)\]\[0\] - Inter::interpolateValue\(interpolationCoeff, glm::vec3\(([^)]*)\)\)\)", fn)
+    assert len(terms) == 19 and [int(t[1]) for t in terms] == list(range(19))
+    assert [float(t[0]) for t in terms] == (wt * wt).tolist(), ([t[0] for t in terms], (wt * wt).tolist())
+    assert [[float(x.strip().rstrip("f")) for x in t[2].split(",")] for t in terms] == frac
+    print("Simpson's rule: 19 weights (w^2/216), points and order identical")
+    # by-distance (decay) rule (OctreeSdfUtils.h:87-138): value at p_m, then  w/64 * pow2(max(|mid - value| - decay * |value|, 0))
+    fn = ut[ut.index("estimateDecayErrorFunctionIntegralByTrapezoidRule"):]
+    fn = fn[:fn.index("return error")]
+    pts_d = [[float(x.strip().rstrip("f")) for x in t.split(",")] for t in re.findall(r"value = Inter::interpolateValue\(interpolationCoeff, glm::vec3\(([^)]*)\)\);", fn)]
+    terms = re.findall(r"error \+= (\d)\.0f / 64\.0f \* pow2\(glm::max\(glm::abs\(middlePoints\[(\d+)\]\[0\] - value\) - errorDecayByDistance \* glm::abs\(value\), 0\.0f\)\);", fn)
+    assert len(terms) == 19 and len(pts_d) == 19 and [int(t[1]) for t in terms] == list(range(19))
+    assert [float(t[0]) for t in terms] == wt.tolist() and pts_d == frac
+    print("by-distance rule: 19 weights, points, order and the max(|e| - decay |v|, 0) form identical")
     return 0
 
 
