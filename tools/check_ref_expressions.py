@@ -170,7 +170,7 @@ def main():
     print("Simpson's rule: 19 weights (w^2/216), points and order identical")
     # by-distance (decay) rule (OctreeSdfUtils.h:87-138): value at p_m, then  w/64 * pow2(max(|mid - value| - decay * |value|, 0))
     fn = ut[ut.index("estimateDecayErrorFunctionIntegralByTrapezoidRule"):]
-    fn = fn[:fn.index("return error")]
+    fn = fn[:fn.index("return error;")]
     pts_d = [[float(x.strip().rstrip("f")) for x in t.split(",")] for t in re.findall(r"value = Inter::interpolateValue\(interpolationCoeff, glm::vec3\(([^)]*)\)\);", fn)]
     terms = re.findall(r"error \+= (\d)\.0f / 64\.0f \* pow2\(glm::max\(glm::abs\(middlePoints\[(\d+)\]\[0\] - value\) - errorDecayByDistance \* glm::abs\(value\), 0\.0f\)\);", fn)
     assert len(terms) == 19 and len(pts_d) == 19 and [int(t[1]) for t in terms] == list(range(19))
