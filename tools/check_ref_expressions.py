@@ -172,7 +172,7 @@ def main():
     fn = ut[ut.index("estimateDecayErrorFunctionIntegralByTrapezoidRule"):]
     fn = fn[:fn.index("return error;")]
     pts_d = [[float(x.strip().rstrip("f")) for x in t.split(",")] for t in re.findall(r"value = Inter::interpolateValue\(interpolationCoeff, glm::vec3\(([^)]*)\)\);", fn)]
-    terms = re.findall(r"error \+= (\d)\.0f / 64\.0f \* pow2\(glm::max\(glm::abs\(middlePoints\[(\d+)\]\[0\] - value\) - errorDecayByDistance \* glm::abs\(value\), 0\.0f\)\);", fn)
+    terms = re.findall(r"error \+= (\d)\.0f / 64\.0f \* pow2\(glm::max\(glm::abs\(middlePoints\[(\d+)\]\[0\] ?- ?value\) - errorDecayByDistance \* glm::abs\(value\), 0\.0f\)\);", fn)
     assert len(terms) == 19 and len(pts_d) == 19 and [int(t[1]) for t in terms] == list(range(19))
     assert [float(t[0]) for t in terms] == wt.tolist() and pts_d == frac
     print("by-distance rule: 19 weights, points, order and the max(|e| - decay |v|, 0) form identical")
