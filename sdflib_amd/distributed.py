@@ -222,3 +222,36 @@ def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_nod
                                          masks.contiguous() if len(masks) else torch.zeros(1, dtype=torch.uint8, device=dev), where=api.DEVICE)
     shard.close()
     return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Queries: the tree is replicated, the query array is split by contiguous ranges (first row).  A tree that only
+# one rank holds (built there, or loaded from a .bin file) reaches the others with ONE broadcast of its node array.
+
+def broadcast_octree(tree, ctx, dev, src=0, group=None):
+    """Every rank returns an OctreeSdf holding rank `src`'s node array (rank `src` passes its tree, the others pass None)."""
+    from . import api
+    rank = dist.get_rank(group)
+    cdev = _collective_device(dev, group)
+    head = torch.zeros(12, dtype=torch.float64, device=cdev)
+    if rank == src:
+        i = tree.info
+        head = torch.tensor(list(i.box_min) + list(i.box_max) + [i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, i.num_words, 0],
+                            dtype=torch.float64, device=cdev)
+    dist.broadcast(head, src, group=group)
+    h = head.cpu().tolist()
+    n = int(h[10])
+    if rank == src:
+        words = torch.from_numpy(tree.get_octree_data().view(np.int32)).to(cdev)
+    else:
+        words = torch.empty(n, dtype=torch.int32, device=cdev)
+    dist.broadcast(words, src, group=group)
+    if rank == src:
+        return tree
+    return api.OctreeSdf.from_data(ctx, words.to(dev), np.float32(h[0:3]), np.float32(h[3:6]), int(h[6]), int(h[7]), float(np.float32(h[8])), float(np.float32(h[9])),
+                                   where=api.DEVICE)
+
+
+def query_range(n, rank, world):
+    """Contiguous share [begin, end) of n queries for `rank`."""
+    return (n * rank) // world, (n * (rank + 1)) // world

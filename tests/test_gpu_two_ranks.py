@@ -42,6 +42,11 @@ def _worker(rank, world, port, q):
         pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
         assert np.array_equal(tree.get_distance(pts).view(np.uint32), single.get_distance(pts).view(np.uint32))
         assert np.array_equal(ex.get_distance(pts).view(np.uint32), ex1.get_distance(pts).view(np.uint32))
+        # queries: rank 0's tree reaches the others with one broadcast; each rank answers its contiguous share
+        got = sdist.broadcast_octree(single if rank == 0 else None, ctx, dev, src=0)
+        assert np.array_equal(got.get_octree_data(), single.get_octree_data()) and got.info.min_border_value == single.info.min_border_value
+        b, e = sdist.query_range(len(pts), rank, world)
+        assert np.array_equal(got.get_distance(pts[b:e]).view(np.uint32), single.get_distance(pts)[b:e].view(np.uint32))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
