@@ -128,21 +128,6 @@ __global__ void k_scale8(uint32_t n, uint32_t* __restrict__ v) {
     if (i < n) v[i] *= 8u;
 }
 
-// Geometry of ALL children of a level (levels above the start depth subdivide unconditionally): child c of node i is 8 i + c.
-__global__ void k_expand_geometry(const float* __restrict__ center, const uint32_t* __restrict__ coord, float half, uint32_t n,
-                                  float* __restrict__ ncenter, uint32_t* __restrict__ ncoord) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = gid >> 3, c = gid & 7u;
-    if (i >= n) return;
-    const float ns = 0.5f * half;
-    ncenter[3 * (size_t)gid] = center[3 * (size_t)i] + ((c & 1u) ? ns : -ns);
-    ncenter[3 * (size_t)gid + 1] = center[3 * (size_t)i + 1] + ((c & 2u) ? ns : -ns);
-    ncenter[3 * (size_t)gid + 2] = center[3 * (size_t)i + 2] + ((c & 4u) ? ns : -ns);
-    const uint32_t co = coord[i];
-    const uint32_t x = 2u * (co & 1023u) + (c & 1u), y = 2u * ((co >> 10) & 1023u) + ((c >> 1) & 1u), z = 2u * (co >> 20) + (c >> 2);
-    ncoord[gid] = x | (y << 10) | (z << 20);
-}
-
 // Index of a node in a COMPLETE level built by repeated k_expand_geometry from the root level: one octal digit per depth, most
 // significant first, digit = x_bit | y_bit << 1 | z_bit << 2 (the root level itself is stored in that order).
 SDF_DEV uint32_t completeLevelIndex(uint32_t co, uint32_t depth) {

@@ -125,16 +125,6 @@ struct CLevelDev {
     uint32_t* cand; uint32_t* allocSize; uint32_t* allocOff; uint32_t* inner; uint32_t* childSlot;
 };
 
-__global__ void kc_root_corners(CMesh m, CLevelDev L) {
-    extern __shared__ uint32_t s_stack[];
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= 8u * L.n) return;
-    const uint32_t node = gid >> 3, c = gid & 7u;
-    const F3 ce = F3{L.center[3 * node], L.center[3 * node + 1], L.center[3 * node + 2]};
-    const F3 rel = F3{(c & 1u) ? 1.f : -1.f, (c & 2u) ? 1.f : -1.f, (c & 4u) ? 1.f : -1.f};
-    exactSample(m, ce + rel * L.half, L.vv + 64 * (size_t)node + 8 * c, s_stack + threadIdx.x);
-}
-
 // Iter 1a: refresh the six outward neighbour words (OctreeSdfBreadthFirstNoDelay.h:295-330)
 __global__ void kc_refresh(CLevelDev L, uint32_t cd, const uint32_t* __restrict__ oc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -683,7 +673,6 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         SDF_HIP_CHECK(hipMemcpyAsync(L->path.p, hp.data(), n, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->nDepth.p, hnd.data(), 6 * n, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->terminal.p, ht.data(), n, hipMemcpyHostToDevice, st));
-        kc_root_corners<<<gridFor(8ull * n, 128), 128, stackBytes, st>>>(md, L->dev());
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         T->info.num_samples += 8ull * n;
         LV[sod] = std::move(L);
@@ -692,6 +681,25 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
     DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist;      // post-pass device buffers, grow-only
+    {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
+        // write the same centres / coordinates again together with everything else — and take the root corners and all their
+        // mid-point samples in ONE deduplicated batch instead of one latency-bound launch per level.
+        SampleBatch B;
+        CLevelHost* R0 = LV[sod].get();
+        B.add(R0->center.p, R0->coord.p, R0->half, R0->n, 8, R0->vv.p, 8);
+        for (uint32_t d = sod; d <= startDepth && d < maxDepth; d++) {
+            CLevelHost* L = LV[d].get();
+            B.add(L->center.p, L->coord.p, L->half, L->n, 19, L->mid.p, 8);
+            L->sampled = true;
+            if (d < startDepth && d + 1 <= maxDepth) {
+                std::unique_ptr<CLevelHost> N(new CLevelHost());
+                N->depth = d + 1; N->half = 0.5f * L->half; SDF_TRY(N->alloc(8u * L->n));
+                k_expand_geometry<<<gridFor(8ull * L->n, 256), 256, 0, st>>>(L->center.p, L->coord.p, L->half, L->n, N->center.p, N->coord.p);
+                LV[d + 1] = std::move(N);
+            }
+        }
+        SDF_TRY(sampleBatch(st, md, B, SS, stackBytes, T->info.num_traversals));
+    }
     double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
     auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
     for (uint32_t cd = sod; cd <= maxDepth; cd++) {
@@ -718,10 +726,13 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         uint32_t numInner = 0; SDF_TRY(lastPlus(st, L->childSlot.p, L->inner.p, n, numInner));
         kc_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childSlot.p);
         if (numInner > 0) {
-            std::unique_ptr<CLevelHost> N(new CLevelHost());
-            N->depth = cd + 1; N->half = 0.5f * L->half; SDF_TRY(N->alloc(8u * numInner));
-            kc_children<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, N->dev(), cd, startDepth, base, G);
-            LV[cd + 1] = std::move(N);
+            if (!LV[cd + 1]) {
+                std::unique_ptr<CLevelHost> N(new CLevelHost());
+                N->depth = cd + 1; N->half = 0.5f * L->half; SDF_TRY(N->alloc(8u * numInner));
+                LV[cd + 1] = std::move(N);
+            }
+            SDF_REQUIRE(LV[cd + 1]->n == 8u * numInner, "internal: pre-created level has the wrong size");
+            kc_children<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, LV[cd + 1]->dev(), cd, startDepth, base, G);
         }
         // candidates of the post-pass, in node order then slot order
         uint32_t numCand = 0;
@@ -760,7 +771,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         lap(tMirror);
         // The exact samples of the NEXT level depend only on its node centres, not on the post-pass below: enqueue them now so
         // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).
-        if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0) {
+        if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0 && !LV[cd + 1]->sampled) {
             CLevelHost* N = LV[cd + 1].get();
             SDF_TRY(sampleMidPoints(st, md, N->coord.p, N->center.p, N->half, N->n, N->mid.p, 8, SS, stackBytes, T->info.num_traversals));
             N->sampled = true;
