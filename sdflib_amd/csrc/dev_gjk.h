@@ -48,4 +48,28 @@ SDF_DEV bool isNearMinimize(float half, const float* __restrict__ radius, F3 t0,
     return isNear || iter >= 15u;
 }
 
+// The same test as a resumable state machine (one Frank-Wolfe iteration per step) for kernels that keep a wave busy by giving a
+// lane the next triangle as soon as its current one is decided.  Identical arithmetic and termination logic.
+struct NearMinimizeState {
+    F3 t0, t1, t2, cur; unsigned iter;
+    SDF_DEV void start(F3 a, F3 b, F3 c) { t0 = a; t1 = b; t2 = c; cur = -a; iter = 0; }
+    // returns true when decided; `result` is then the value isNearMinimize would have returned
+    SDF_DEV bool step(float half, const float* __restrict__ radius, float thr, bool& result) {
+        const F3 g = normalize(-cur);
+        const F3 p = furthestOnHull(half, radius, g) - furthestOnTriangle(t0, t1, t2, -g);
+        const float distToP = dot(g, p - cur);
+        const float distToO = dot(g, -cur);
+        const F3 dir = p - cur;
+        const float d = dot(dir, -cur);
+        if ((double)d < 1.0e-5) { result = distToO <= distToP + thr; return true; }
+        cur = cur + dir * gmin(d / dot(dir, dir), 1.0f);
+        const bool isNear = dot(cur, cur) < thr * thr;
+        if (isNear) { result = true; return true; }
+        if (!(distToO <= distToP + thr)) { result = iter >= 15u; return true; }     // (++iter is not evaluated in this case)
+        if (++iter < 15u) return false;
+        result = true;                                                               // isNear || iter >= 15
+        return true;
+    }
+};
+
 }  // namespace sdfhip

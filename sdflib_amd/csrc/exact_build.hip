@@ -183,10 +183,15 @@ struct CullArgs {
 };
 
 // THE hot kernel of the Exact build: one wave per chunk of a node's parent list.
+// The Frank-Wolfe test takes 1..15 iterations depending on the triangle (the first version's counters: 23 % of the lanes busy per
+// VALU instruction), so a lane does not wait for its neighbours: as soon as its triangle is decided it takes the chunk's next
+// undecided entry (rank within the ballot of idle lanes), and every wave-loop iteration is one Frank-Wolfe step for the lanes
+// that hold a triangle.  Decisions land in a per-wave bit mask in LDS; the survivors are then written out in list order.
 __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
     __shared__ float s_region[4][64];
     __shared__ float s_min[4][8];
     __shared__ uint32_t s_corner[4][8];
+    __shared__ uint32_t s_keep[4][CHUNK / 32];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (uint32_t)w;
     if (q >= a.numChunks) return;
@@ -194,28 +199,53 @@ __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
     const uint32_t ck = q - a.chunkBase[node];
     s_region[w][lane] = a.region[64 * (size_t)node + lane];
     if (lane < 8) { s_min[w][lane] = a.minDist[8 * (size_t)node + lane]; s_corner[w][lane] = a.cornerTri[8 * (size_t)node + lane]; }
-    __builtin_amdgcn_wave_barrier();
+    if (lane < (int)(CHUNK / 32)) s_keep[w][lane] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const F3 ce = ldv(a.center, node);
     const uint32_t off = a.pOff[node], len = a.pLen[node];
     const uint32_t begin = ck * CHUNK, end = (begin + CHUNK < len) ? begin + CHUNK : len;
-    uint32_t kept = 0; unsigned long long tests = 0;
-    for (uint32_t base = begin; base < end; base += 64) {
-        const uint32_t k = base + lane;
-        bool keep = false; uint32_t t = 0; bool tested = false;
-        if (k < end) {
-            t = a.plist[off + k];
-            const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
-            const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
-            const F3 pt = 0.3333333f * ((t0 + t1) + t2);
-            const int vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
-            if (s_corner[w][vId] == t) keep = true;
-            else { tested = true; keep = isNearMinimize(a.half, &s_region[w][8 * vId], t0, t1, t2, s_min[w][vId]); }
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t next = begin;                       // wave-uniform: first entry not handed out yet
+    unsigned long long tests = 0;
+    NearMinimizeState fw; int vId = 0; uint32_t myEntry = 0;
+    bool busy = false, retired = false;
+    while (__ballot(!retired) != 0ull) {
+        // idle lanes take the next entries of the chunk
+        const unsigned long long idle = __ballot(!busy && !retired);
+        if (idle != 0ull) {
+            if (!busy && !retired) {
+                const uint32_t k = next + (uint32_t)__popcll(idle & ltMask);
+                if (k < end) {
+                    const uint32_t t = a.plist[off + k];
+                    const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
+                    const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
+                    const F3 pt = 0.3333333f * ((t0 + t1) + t2);
+                    vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
+                    myEntry = k - begin;
+                    if (s_corner[w][vId] == t) atomicOr(&s_keep[w][myEntry >> 5], 1u << (myEntry & 31u));      // the corner's own nearest triangle is always kept
+                    else { fw.start(t0, t1, t2); busy = true; }
+                } else retired = true;
+            }
+            next += (uint32_t)__popcll(idle);
+            tests += (unsigned long long)__popcll(__ballot(busy) & idle);      // entries that entered the Frank-Wolfe test in this round
         }
+        if (busy) {
+            bool keep;
+            if (fw.step(a.half, &s_region[w][8 * vId], s_min[w][vId], keep)) {
+                if (keep) atomicOr(&s_keep[w][myEntry >> 5], 1u << (myEntry & 31u));
+                busy = false;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // survivors in list order
+    uint32_t kept = 0;
+    for (uint32_t base = 0; begin + base < end; base += 64) {
+        const uint32_t e = base + (uint32_t)lane;
+        const bool keep = (begin + e < end) && ((s_keep[w][e >> 5] >> (e & 31u)) & 1u);
         const unsigned long long mask = __ballot(keep);
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (keep) a.tmp[(size_t)q * CHUNK + kept + before] = t;
+        if (keep) a.tmp[(size_t)q * CHUNK + kept + (uint32_t)__popcll(mask & ltMask)] = a.plist[off + begin + e];
         kept += (uint32_t)__popcll(mask);
-        tests += (unsigned long long)__popcll(__ballot(tested));
     }
     if (lane == 0) { a.chunkCount[q] = kept; if (tests) atomicAdd(a.cullTests, tests); }
 }
