@@ -167,7 +167,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
     if not args.no_extras:
-        result["extras"] = extras(tree, mesh, box, pts, out, dev, rank)
+        result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world)
     if not args.no_build_1m:
         result["build_1m"] = build_1m(ctx, rank, world, dev)
     if rank == 0:
@@ -213,7 +213,7 @@ def _time_ms(fn, reps=5):
     return a.elapsed_time(b) / reps
 
 
-def extras(tree, mesh, box, pts, out, dev, rank):
+def extras(tree, mesh, box, pts, out, dev, rank, world=1):
     """Secondary per-GPU measurements (rank-local, untimed region): the other BASELINE.json configs on the same mesh."""
     n = pts.shape[0]
     outg = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -243,12 +243,21 @@ def extras(tree, mesh, box, pts, out, dev, rank):
                                   "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1)}
     ex.close()
     # CONTINUITY builder (SdfExporter's default) on the same mesh / depth
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    ct = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    # (N > 1: every rank builds the whole tree, the BVH traversals of each sample batch are shared out, one all-reduce per batch)
+    cinfo = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        ct, cinfo = sdist.build_continuity_sharded(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, rank, world, dev)
+        cinfo = {"exchange_s": round(cinfo["exchange_s"], 4), "exchange_bytes": int(cinfo["exchange_bytes"]), "ranks_sharing_traversals": world}
+    else:
+        ct = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, init_algorithm=S.ALG_CONTINUITY)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ci = ct.info
     ms = _time_ms(lambda: ct.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out))
-    r["continuity_octree"] = {"build_s": round(dt, 4), "words": int(ci.num_words), "leaves": int(ci.num_leaves), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
+    r["continuity_octree"] = {"build_s": round(dt, 4), "words": int(ci.num_words), "leaves": int(ci.num_leaves), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1), **cinfo}
     ct.close()
     # the 64x64 fit on the matrix cores (SDFHIP_FIT_MFMA): same topology, coefficients within the reference's own rounding noise
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -93,6 +93,24 @@ int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
 
+/* Multi-GPU CONTINUITY build: the breadth-first builder couples neighbouring start cells in its serial
+ * second iteration (src/sdf/OctreeSdfBreadthFirstNoDelay.h:440-482), so its trees are not built per cell.  What shards is the
+ * part that costs the time: the nearest-triangle traversals of a level's sample points.  With an exchange installed every
+ * rank runs the whole build, but of each deduplicated sample batch it traverses only its share (128-sample blocks dealt
+ * round-robin), writes the triangle ids into a zero-filled buffer obtained from `acquire`, and `all_reduce_sum` makes the
+ * buffer complete on every rank (ids of the other ranks' blocks + zeros).  All ranks then hold bit-identical trees.
+ * The library synchronises its stream before calling all_reduce_sum; the callee must return only when the result is visible
+ * to later work on ANY stream of the device (e.g. RCCL all-reduce followed by a device synchronise).
+ * world <= 1 or x == NULL removes the exchange.  Builds with an exchange installed are collective calls: every rank must
+ * run the same builds in the same order.  NO_CONTINUITY / Exact builds shard by start cell instead and ignore it. */
+typedef struct sdfhip_exchange {
+    void* user;
+    uint32_t* (*acquire)(void* user, uint64_t count);        /* device buffer of `count` u32, zero-filled; valid until the next acquire */
+    int (*all_reduce_sum)(void* user, uint64_t count);      /* in place on the acquired buffer; 0 = ok */
+    int32_t rank, world;
+} sdfhip_exchange;
+int sdfhip_ctx_set_exchange(sdfhip_ctx* ctx, const sdfhip_exchange* x);
+
 /* ---- mesh: vertices (3 floats each), triangle indices (3 u32 each); host pointers, copied ------------- */
 int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
                        uint32_t num_triangles, sdfhip_mesh** out);

@@ -39,6 +39,14 @@ class ExactInfo(C.Structure):
                 ("num_mask_bytes", C.c_uint64), ("num_triangles", C.c_uint64), ("cull_tests", C.c_uint64), ("seconds_total", C.c_double)]
 
 
+ACQUIRE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
+
+
+class Exchange(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("acquire", ACQUIRE_FN), ("all_reduce_sum", ALL_REDUCE_FN), ("rank", C.c_int32), ("world", C.c_int32)]
+
+
 # every symbol include/sdfhip.h declares: name -> (restype, argtypes)
 _vp, _u32, _u64, _i32, _f32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_int
 SIGNATURES = {
@@ -48,6 +56,7 @@ SIGNATURES = {
     "sdfhip_ctx_destroy": (_int, [_vp]),
     "sdfhip_ctx_synchronize": (_int, [_vp]),
     "sdfhip_ctx_stream": (_vp, [_vp]),
+    "sdfhip_ctx_set_exchange": (_int, [_vp, C.POINTER(Exchange)]),
     "sdfhip_mesh_create": (_int, [_vp, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
     "sdfhip_mesh_create_ex": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(_vp)]),
     "sdfhip_mesh_edge_stats": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),

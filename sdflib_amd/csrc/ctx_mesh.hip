@@ -243,6 +243,15 @@ int sdfhip_ctx_synchronize(sdfhip_ctx* ctx) {
 
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+int sdfhip_ctx_set_exchange(sdfhip_ctx* ctx, const sdfhip_exchange* x) {
+    SDF_REQUIRE(ctx, "null context");
+    if (!x || x->world <= 1) { ctx->exchange = sdfhip_exchange{}; return SDFHIP_OK; }
+    SDF_REQUIRE(x->acquire && x->all_reduce_sum, "exchange without callbacks");
+    SDF_REQUIRE(x->rank >= 0 && x->rank < x->world, "exchange rank outside [0, world)");
+    ctx->exchange = *x;
+    return SDFHIP_OK;
+}
+
 int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, sdfhip_mesh** out) {
     return sdfhip_mesh_create_ex(ctx, xyz, nv, indices, nt, nullptr, out);
 }

@@ -680,6 +680,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
 
     uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
+    if (ctx->exchange.world > 1) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
     DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
         // write the same centres / coordinates again together with everything else — and take the root corners and all their
@@ -703,6 +704,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
     auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
     for (uint32_t cd = sod; cd <= maxDepth; cd++) {
+        SDF_TRY(sampleBatchEnd(st, md, SS));       // the samples begun during the previous level's planning
         CLevelHost* L = LV[cd].get();
         if (!L || L->n == 0) continue;
         const uint32_t n = L->n;
@@ -773,7 +775,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).
         if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0 && !LV[cd + 1]->sampled) {
             CLevelHost* N = LV[cd + 1].get();
-            SDF_TRY(sampleMidPoints(st, md, N->coord.p, N->center.p, N->half, N->n, N->mid.p, 8, SS, stackBytes, T->info.num_traversals));
+            SampleBatch B;
+            B.add(N->center.p, N->coord.p, N->half, N->n, 19, N->mid.p, 8);
+            SDF_TRY(sampleBatchBegin(st, md, B, SS, stackBytes, T->info.num_traversals));      // ended at the top of the next iteration
             N->sampled = true;
         }
         for (uint32_t i = 0; i < n; i++) {
@@ -987,6 +991,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         lap(tOps);
     }
+    SDF_TRY(sampleBatchEnd(st, md, SS));
     if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, mirrors %.3f s, leaf map %.3f s, post-pass planner %.3f s, post-pass device ops %.3f s; post-pass: %llu scheduled, %llu still leaves, %llu nodes visited, %llu splits\n", tIter, tMirror, tLeafMap, tPlan, tOps,
                                             (unsigned long long)numRescheduled, (unsigned long long)ppRoots, (unsigned long long)ppNodes, (unsigned long long)ppSplits);
     // clear the mark bits (OctreeSdfBreadthFirstNoDelay.h:1191-1217)

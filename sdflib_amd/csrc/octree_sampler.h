@@ -103,11 +103,14 @@ __global__ void k_sample_rep_list(const uint32_t* __restrict__ isRep, const uint
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < total && isRep[j]) repSample[scan[j]] = val[j];
 }
+// With `world` > 1 this launch covers only the 128-representative blocks b with b % world == rank (dealt round-robin so that
+// every rank gets the same mix of short and long traversals); the other blocks' ids arrive through the exchange.
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri) {
+__global__ void __launch_bounds__(BLOCK) k_sample_nearest(BvhDev b, SampleBatch B, const uint32_t* __restrict__ repSample, uint32_t numReps, uint32_t* __restrict__ repTri,
+                                                          uint32_t rank, uint32_t world) {
     extern __shared__ uint32_t s_stack[];        // [stackDepth][BLOCK], stackDepth = BVH depth + 2 (smaller stack -> more waves per CU)
     const uint32_t lb = xcdLogicalBlock();            // the representatives are in Morton order: a contiguous eighth of them per XCD
-    const uint32_t r = lb * blockDim.x + threadIdx.x;
+    const uint64_t r = ((uint64_t)lb * world + rank) * blockDim.x + threadIdx.x;
     if (r >= numReps) return;
     repTri[r] = bvhNearest<BLOCK>(b, samplePosition(B, repSample[r]), s_stack + threadIdx.x);
 }
@@ -128,9 +131,14 @@ __global__ void k_sample_values(MeshDev m, SampleBatch B, const uint32_t* __rest
 // scratch of the sampler, reused across levels (grows only)
 struct SampleScratch {
     DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
+    const sdfhip_exchange* exchange = nullptr;      // set by the CONTINUITY builder when the context has one (world > 1)
+    bool pending = false; SampleBatch pendingBatch; uint32_t pendingReps = 0; uint32_t* pendingTri = nullptr;
 };
-static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
+// A batch runs in two halves so that a caller can put host work between them: Begin enqueues everything up to the traversals,
+// End (the exchange, if any, and) the per-sample Hermite data.  One batch may be pending per scratch.
+static int sampleBatchBegin(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
     const uint32_t total = B.total;
+    SDF_REQUIRE(!S.pending, "internal: sample batch begun while another is pending");
     if (total == 0) return SDFHIP_OK;
     SDF_REQUIRE(total < (1u << 31), "level too large for one sample batch (2^31 samples)");
     SDF_TRY(S.key.reserve(total)); SDF_TRY(S.keyS.reserve(total)); SDF_TRY(S.val.reserve(total)); SDF_TRY(S.valS.reserve(total));
@@ -149,13 +157,40 @@ static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, 
     SDF_HIP_CHECK(hipMemcpyAsync(&lastFlag, S.isRep.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const uint32_t numReps = lastScan + lastFlag;
-    SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repTri.reserve(numReps));
+    SDF_TRY(S.repSample.reserve(numReps));
     k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
-    k_sample_nearest<128><<<xcdGrid(gridFor(numReps, 128)), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.repTri.p);   // 64 / 256 lanes per block measured the same
-    k_sample_values<<<gridFor(total, 256), 256, 0, st>>>(md, B, S.valS.p, S.isRep.p, S.scan.p, S.repTri.p);
+    const uint32_t blocks = gridFor(numReps, 128);
+    if (S.exchange) {
+        const uint32_t rank = (uint32_t)S.exchange->rank, world = (uint32_t)S.exchange->world;
+        S.pendingTri = S.exchange->acquire(S.exchange->user, numReps);
+        SDF_REQUIRE(S.pendingTri, "exchange: acquire failed");
+        const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
+        if (mine) k_sample_nearest<128><<<xcdGrid(mine), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, rank, world);
+    } else {
+        SDF_TRY(S.repTri.reserve(numReps));
+        S.pendingTri = S.repTri.p;
+        k_sample_nearest<128><<<xcdGrid(blocks), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, 0u, 1u);   // 64 / 256 lanes per block measured the same
+    }
     SDF_HIP_CHECK(hipGetLastError());
+    S.pending = true; S.pendingBatch = B; S.pendingReps = numReps;
     traversals += numReps;
     return SDFHIP_OK;
+}
+static int sampleBatchEnd(hipStream_t st, const MeshDev& md, SampleScratch& S) {
+    if (!S.pending) return SDFHIP_OK;
+    S.pending = false;
+    if (S.exchange) {
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_REQUIRE(S.exchange->all_reduce_sum(S.exchange->user, S.pendingReps) == 0, "exchange: all_reduce_sum failed");
+    }
+    const uint32_t total = S.pendingBatch.total;
+    k_sample_values<<<gridFor(total, 256), 256, 0, st>>>(md, S.pendingBatch, S.valS.p, S.isRep.p, S.scan.p, S.pendingTri);
+    SDF_HIP_CHECK(hipGetLastError());
+    return SDFHIP_OK;
+}
+static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
+    SDF_TRY(sampleBatchBegin(st, md, B, S, stackBytes, traversals));
+    return sampleBatchEnd(st, md, S);
 }
 // the 19 mid-points of one level
 static int sampleMidPoints(hipStream_t st, const MeshDev& md, const uint32_t* coord, const float* center, float half, uint32_t n, float* mid, int stride,

@@ -10,11 +10,14 @@ builds its range on its GPU, and ONE exchange reassembles the node array:
 Every rank ends with the full, identical array (queries are then embarrassingly parallel).
 The partition / assembly logic is backend-agnostic torch code so that it is covered by world_size-2 gloo tests.
 """
+import ctypes as C
 import time
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def partition_cells(num_cells, world, weights=None):
@@ -130,6 +133,81 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
                       "num_samples": int(cnt[2])}
     shard.close()
     return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CONTINUITY build: the tree is not separable by start cell (the second iteration couples neighbouring cells,
+# src/sdf/OctreeSdfBreadthFirstNoDelay.h:440-482), so every rank builds the whole tree and only the nearest-triangle
+# traversals of each sample batch are shared out (include/sdfhip.h, sdfhip_exchange): one all-reduce of 4 B per unique
+# sample point and batch (a-priori levels, then one per level).
+
+class SampleExchange:
+    """torch.distributed side of sdfhip_exchange.  Use as a context manager around collective CONTINUITY builds."""
+
+    def __init__(self, ctx, rank, world, dev, group=None):
+        self.ctx, self.rank, self.world, self.dev, self.group = ctx, int(rank), int(world), dev, group
+        self.buf = None
+        self.error = None
+        self.bytes_reduced = 0
+        self.seconds = 0.0
+        self._acq = _lib.ACQUIRE_FN(self._acquire)
+        self._red = _lib.ALL_REDUCE_FN(self._all_reduce)
+        self._x = _lib.Exchange(None, self._acq, self._red, self.rank, self.world)
+
+    def _sync(self):
+        if torch.device(self.dev).type == "cuda":
+            torch.cuda.synchronize(self.dev)
+
+    def _acquire(self, _user, count):
+        try:
+            n = max(int(count), 1)
+            if self.buf is None or self.buf.numel() < n:
+                self.buf = torch.empty(int(n * 1.25) + 1024, dtype=torch.int32, device=self.dev)
+            self.buf[:n].zero_()
+            self._sync()      # the library writes from its own stream
+            return self.buf.data_ptr()
+        except Exception as e:      # never let an exception cross the C boundary
+            self.error = e
+            return None
+
+    def _all_reduce(self, _user, count):
+        try:
+            t0 = time.perf_counter()
+            n = int(count)
+            view = self.buf[:n]
+            if _collective_device(self.dev, self.group).type == "cpu":
+                h = view.cpu()
+                dist.all_reduce(h, group=self.group)
+                view.copy_(h)
+            else:
+                dist.all_reduce(view, group=self.group)
+            self._sync()
+            self.bytes_reduced += 4 * n
+            self.seconds += time.perf_counter() - t0
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
+
+    def __enter__(self):
+        _lib.check(_lib.lib().sdfhip_ctx_set_exchange(self.ctx.h, C.byref(self._x)))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().sdfhip_ctx_set_exchange(self.ctx.h, None)
+        return False
+
+
+def build_continuity_sharded(mesh, box, depth, start_depth, max_error, rank, world, dev, group=None, **kw):
+    """CONTINUITY OctreeSdf on `world` GPUs: identical tree on every rank, traversals shared.  Returns (tree, timing dict)."""
+    from . import api
+    t0 = time.perf_counter()
+    with SampleExchange(mesh.ctx, rank, world, dev, group) as x:
+        try:
+            tree = api.OctreeSdf(mesh, box, depth, start_depth, max_error, init_algorithm=api.ALG_CONTINUITY, **kw)
+        except Exception as e:
+            raise (x.error or e)
+    return tree, {"build_s": time.perf_counter() - t0, "exchange_s": x.seconds, "exchange_bytes": x.bytes_reduced}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

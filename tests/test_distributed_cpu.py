@@ -145,3 +145,31 @@ def _exact_worker(rank, world, port):
 def test_two_rank_gloo_exact_exchange():
     port = 31500 + (os.getpid() % 2000)
     mp.spawn(_exact_worker, args=(2, port), nprocs=2, join=True)
+
+
+def _sample_exchange_worker(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import ctypes
+    from sdflib_amd.distributed import SampleExchange
+    x = SampleExchange(None, rank, world, torch.device("cpu"))
+    for n in (1, 127, 128, 1000, 128 * 7 + 5):
+        ptr = x._acquire(None, n)
+        buf = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_int32)), shape=(n,))
+        assert not buf.any(), "acquire must hand out zeros"
+        ids = (np.arange(n, dtype=np.int64) * 2654435761 % 1000003).astype(np.int32)        # what the traversals would return
+        for b in range(rank, (n + 127) // 128, world):                                       # this rank's 128-sample blocks, dealt round-robin
+            buf[128 * b: 128 * (b + 1)] = ids[128 * b: 128 * (b + 1)]
+        assert x._all_reduce(None, n) == 0, x.error
+        assert np.array_equal(buf, ids), f"rank {rank}: exchange of {n} ids incomplete"
+    assert x.bytes_reduced == 4 * (1 + 127 + 128 + 1000 + 128 * 7 + 5)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sample_exchange():
+    """The torch.distributed side of sdfhip_exchange (CONTINUITY build, traversals shared out): zero-filled buffer, every rank
+    fills its round-robin blocks, one all-reduce completes it on both ranks."""
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_sample_exchange_worker, args=(2, port), nprocs=2, join=True)

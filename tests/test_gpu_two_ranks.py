@@ -1,5 +1,6 @@
 """Two ranks on ONE GPU (gloo for the collectives, both processes on cuda:0): the complete N>1 build path — shard build on the
-device, offset exchange, emit with absolute indices, all-gather, reassembly — against the single-process build."""
+device, offset exchange, emit with absolute indices, all-gather, reassembly — against the single-process build; and the
+CONTINUITY build with its traversals shared out through sdfhip_exchange."""
 import os
 import sys
 
@@ -38,6 +39,12 @@ def _worker(rank, world, port, q):
         for a, b in zip(ex.download(), ex1.download()):
             assert np.array_equal(a, b), "sharded ExactOctreeSdf differs from the single build"
         assert ex.info.max_triangles_in_leafs == ex1.info.max_triangles_in_leafs
+        # CONTINUITY: every rank builds the whole tree, the traversals of each sample batch are shared through the exchange
+        ct, tm = sdist.build_continuity_sharded(mesh, box, 6, 3, 1e-3, rank, world, dev)
+        c1 = S.OctreeSdf(mesh, box, 6, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY)      # exchange removed again: a plain local build
+        assert tm["exchange_bytes"] > 0
+        assert np.array_equal(ct.get_octree_data(), c1.get_octree_data()), "CONTINUITY tree built with shared traversals differs from the single build"
+        assert ct.info.value_range == c1.info.value_range and ct.info.min_border_value == c1.info.min_border_value
         rng = np.random.default_rng(rank)
         pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
         assert np.array_equal(tree.get_distance(pts).view(np.uint32), single.get_distance(pts).view(np.uint32))
@@ -78,7 +85,7 @@ def test_bench_two_ranks_on_one_gpu():
     env = dict(os.environ, SDFHIP_BENCH_ONE_DEVICE="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(33500 + os.getpid() % 2000),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--subdiv", "5", "--depth", "6", "--queries", "1000000",
-           "--no-cpu-baseline", "--no-extras", "--no-build-1m"]
+           "--no-cpu-baseline", "--no-build-1m"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -87,3 +94,5 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * d["per_gpu_mqueries_s"]) < 1e-6 * d["value"] + 0.02
     assert d["roofline"]["frac"] > 0 and d["build"]["exchange_s"] >= 0
+    c = d["extras"]["continuity_octree"]
+    assert c["ranks_sharing_traversals"] == 2 and c["exchange_bytes"] > 0 and c["words"] > 0
