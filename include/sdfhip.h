@@ -101,7 +101,8 @@ void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
  * buffer complete on every rank (ids of the other ranks' blocks + zeros).  All ranks then hold bit-identical trees.
  * The library synchronises its stream before calling all_reduce_sum; the callee must return only when the result is visible
  * to later work on ANY stream of the device (e.g. RCCL all-reduce followed by a device synchronise).
- * world <= 1 or x == NULL removes the exchange.  Builds with an exchange installed are collective calls: every rank must
+ * x == NULL (or world < 1) removes the exchange; world == 1 is allowed (the all-reduce is then an identity: used to test a
+ * host's callbacks on one device).  Builds with an exchange installed are collective calls: every rank must
  * run the same builds in the same order.  NO_CONTINUITY / Exact builds shard by start cell instead and ignore it. */
 typedef struct sdfhip_exchange {
     void* user;

@@ -245,7 +245,7 @@ void* sdfhip_ctx_stream(sdfhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nul
 
 int sdfhip_ctx_set_exchange(sdfhip_ctx* ctx, const sdfhip_exchange* x) {
     SDF_REQUIRE(ctx, "null context");
-    if (!x || x->world <= 1) { ctx->exchange = sdfhip_exchange{}; return SDFHIP_OK; }
+    if (!x || x->world < 1) { ctx->exchange = sdfhip_exchange{}; return SDFHIP_OK; }
     SDF_REQUIRE(x->acquire && x->all_reduce_sum, "exchange without callbacks");
     SDF_REQUIRE(x->rank >= 0 && x->rank < x->world, "exchange rank outside [0, world)");
     ctx->exchange = *x;

@@ -107,7 +107,7 @@ struct sdfhip_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hipDeviceProp_t prop;
-    sdfhip_exchange exchange{};           // world > 1: the CONTINUITY build shards its traversals (sdfhip.h)
+    sdfhip_exchange exchange{};           // world >= 1: the CONTINUITY build shares out its traversals (sdfhip.h)
 };
 
 struct sdfhip_mesh {

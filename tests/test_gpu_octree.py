@@ -250,6 +250,10 @@ def test_sharded_build_through_rccl_world1(small):
         assert np.array_equal(tree.get_octree_data(), full.get_octree_data())
         assert tree.info.value_range == full.info.value_range and tree.info.min_border_value == full.info.min_border_value
         assert list(tree.info.leaves_per_depth) == list(full.info.leaves_per_depth)
+        # CONTINUITY: the traversal exchange (acquire / all-reduce callbacks) over RCCL
+        ct, tm = sdist.build_continuity_sharded(small["gm"], small["box"], 5, 2, 1e-3, 0, 1, dev)
+        c1 = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+        assert tm["exchange_bytes"] > 0 and np.array_equal(ct.get_octree_data(), c1.get_octree_data())
     finally:
         if created:
             dist.destroy_process_group()
