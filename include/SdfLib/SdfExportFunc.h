@@ -1,7 +1,8 @@
 // Handle-style C interface of the reference's Unity plugin (src/tools/SdfLibUnity/SdfExportFunc.h:16-58), implemented on
 // top of the C++ classes above.  createOctreeSdf uses the CONTINUITY builder like the reference (SdfExportFunc.cpp:84-113).
 // One difference, on purpose: deleteSdf frees every format (the reference leaks OCTREE objects, SdfExportFunc.cpp:170-182).
-// Include in exactly one translation unit of the plugin.
+// Include in exactly one translation unit of the plugin (tools/SdfLibUnity/SdfExportFunc.cpp -> libSdfLibUnity.so).
+// getDistances (batched) is an addition: one device launch instead of one per point.
 #ifndef SDFLIB_EXPORT_FUNC_H
 #define SDFLIB_EXPORT_FUNC_H
 #include "OctreeSdf.h"
@@ -31,10 +32,9 @@ EXPORT float getDistanceAndGradient(sdflib::SdfFunction* sdf, float x, float y, 
 EXPORT void getDistances(sdflib::SdfFunction* sdf, const glm::vec3* points, uint64_t n, float* outDistances, glm::vec3* outGradients) { sdf->getDistances(points, n, outDistances, outGradients); }
 EXPORT glm::vec3 getBBMinPoint(sdflib::SdfFunction* sdf) { return sdf->getSampleArea().min; }
 EXPORT glm::vec3 getBBSize(sdflib::SdfFunction* sdf) { return sdf->getSampleArea().getSize(); }
-EXPORT glm::ivec3 getStartGridSize(sdflib::SdfFunction* sdf) {
-    if (sdf->getFormat() == sdflib::SdfFunction::OCTREE) return static_cast<sdflib::OctreeSdf*>(sdf)->getStartGridSize();
-    if (sdf->getFormat() == sdflib::SdfFunction::EXACT_OCTREE) return static_cast<sdflib::ExactOctreeSdf*>(sdf)->getStartGridSize();
-    return glm::ivec3(0, 0, 0);
+// OctreeSdf only, x component, 0 for every other format — as the reference (SdfExportFunc.cpp:140-145)
+EXPORT uint32_t getStartGridSize(sdflib::SdfFunction* sdf) {
+    return sdf->getFormat() == sdflib::SdfFunction::OCTREE ? (uint32_t)static_cast<sdflib::OctreeSdf*>(sdf)->getStartGridSize().x : 0u;
 }
 EXPORT uint32_t getOctreeDataSize(sdflib::SdfFunction* sdf) {
     return sdf->getFormat() == sdflib::SdfFunction::OCTREE ? (uint32_t)static_cast<sdflib::OctreeSdf*>(sdf)->getOctreeData().size() : 0u;
