@@ -467,3 +467,35 @@ def test_deep_tree_depth_9_matches_oracle(oracle, gpu_ctx):
     assert gt.info.num_words > 400_000_000 and gt.info.num_traversals < gt.info.num_samples
     ot = oracle.Octree(oracle.Mesh(v, f), box, 9, 3, 2e-4, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
     assert np.array_equal(ot.data(), gt.get_octree_data())
+
+
+def test_concurrent_host_threads_query_one_tree(small):
+    """queries are pure reads and may come from several host threads at once (the reference's OctreeSdf is
+    re-entrant; its ExactOctreeSdf is not — ours is).  Four threads query the same OctreeSdf and ExactOctreeSdf with host
+    buffers of different sizes, repeatedly; every answer must equal the single-threaded one."""
+    import threading
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    tree = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3)
+    exact = S.ExactOctreeSdf(small["gm"], small["box"], 5, 2, 16)
+    sets = [random_points_in_box(small["box"], n, seed=40 + i) for i, n in enumerate((1, 777, 30000, 200000))]
+    want = [(tree.get_distance(p, gradient=True), exact.get_distance(p)) for p in sets]
+    errors = []
+
+    def work(i):
+        try:
+            for _ in range(12):
+                d, g = tree.get_distance(sets[i], gradient=True)
+                e = exact.get_distance(sets[i])
+                if not (np.array_equal(bits(d), bits(want[i][0][0])) and np.array_equal(bits(g), bits(want[i][0][1])) and np.array_equal(bits(e), bits(want[i][1]))):
+                    errors.append(f"thread {i}: result differs from the single-threaded query")
+                    return
+        except Exception as ex:      # noqa: BLE001
+            errors.append(f"thread {i}: {ex!r}")
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(sets))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
