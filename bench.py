@@ -233,14 +233,22 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1):
     r["grid256_value_and_gradient_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
                                                  "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
     # ExactOctreeSdf (BASELINE configs[2]): depth 7, start 3, min_triangles_per_node 128
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    ex = S.ExactOctreeSdf(mesh, box, 7, 3, 128)
+    einfo = {}
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:       # start cells sharded over the ranks, one exchange (distributed.build_exact_sharded)
+        ex, einfo = sdist.build_exact_sharded(mesh, box, 7, 3, 128, rank, world, dev)
+        einfo = {k: round(v, 4) for k, v in einfo.items()}
+    else:
+        ex = S.ExactOctreeSdf(mesh, box, 7, 3, 128)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     i = ex.info
     q = pts
     ms = _time_ms(lambda: ex.get_distance(q, out=out), reps=3)
     r["exact_octree_d7_min128"] = {"build_s": round(dt, 4), "nodes": int(i.num_nodes), "cull_tests": int(i.cull_tests), "max_triangles_in_leafs": int(i.max_triangles_in_leafs),
-                                  "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1)}
+                                  "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1), **einfo}
     ex.close()
     # CONTINUITY builder (SdfExporter's default) on the same mesh / depth
     # (N > 1: every rank builds the whole tree, the BVH traversals of each sample batch are shared out, one all-reduce per batch)

@@ -275,9 +275,9 @@ def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_nod
     info = shard.info
     t1 = time.perf_counter()
     cdev = _collective_device(dev, group)
-    mine = torch.tensor([info.num_nodes, info.num_set_words, info.num_mask_bytes, info.max_triangles_in_leafs, info.max_triangles_encoded_in_leafs],
-                        dtype=torch.int64, device=cdev)
-    meta = [torch.zeros(5, dtype=torch.int64, device=cdev) for _ in range(world)]
+    mine = torch.tensor([info.num_nodes, info.num_set_words, info.num_mask_bytes, info.max_triangles_in_leafs, info.max_triangles_encoded_in_leafs,
+                         info.cull_tests], dtype=torch.int64, device=cdev)
+    meta = [torch.zeros(6, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(meta, mine, group=group)
     meta = torch.stack(meta).cpu().numpy()
     offs = exact_offsets(meta[:, :3], num_cells)
@@ -294,6 +294,7 @@ def build_exact_sharded(mesh, box, max_depth, start_depth, min_triangles_per_nod
     full = api.ExactInfo.from_buffer_copy(info)
     full.num_nodes, full.num_set_words, full.num_mask_bytes = int(nodes.shape[0]), int(sets.shape[0]), int(masks.shape[0])
     full.max_triangles_in_leafs, full.max_triangles_encoded_in_leafs = int(meta[:, 3].max()), int(meta[:, 4].max())
+    full.cull_tests = int(meta[:, 5].sum())          # whole job (levels above the start depth are tested by every rank)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     tree = api.ExactOctreeSdf.from_parts(mesh, full, nodes.contiguous(), has.contiguous(), sets.contiguous() if len(sets) else torch.zeros(1, dtype=torch.int32, device=dev),
