@@ -190,7 +190,7 @@ struct TraversalLane {
 };
 
 // Nearest triangle id for a float point (widened to double).  STRIDE = LDS stride between the lane's stack entries.
-// counts[0..2] (optional, dev probe): inner nodes entered, deferred children popped, triangles evaluated.
+// counts[0..2] (optional, dev probe): inner nodes entered, iterations of the WAVE's loop while this lane was in it, triangles evaluated.
 template <int STRIDE, bool STATS = false>
 SDF_DEV uint32_t bvhNearest(const BvhDev& b, F3 pf, uint32_t* __restrict__ stk, uint32_t* counts = nullptr) {
     TraversalLane L;
@@ -198,9 +198,9 @@ SDF_DEV uint32_t bvhNearest(const BvhDev& b, F3 pf, uint32_t* __restrict__ stk, 
     // wave-synchronous form: every iteration runs the pop step, then the enter / triangle step, for the lanes that need them
     bool alive = true;
     while (__ballot(alive) != 0ull) {
+        if (STATS) counts[1]++;
         if (alive && !L.haveRef) {
             if (L.template popStep<STRIDE>(b, stk)) alive = false;
-            else if (STATS) counts[1]++;
         }
         if (alive && L.haveRef && L.ref >= 0) { L.template enterStep<STRIDE>(b, stk); if (STATS) counts[0]++; }
         if (alive && L.haveRef && L.ref < 0) { L.triStep(b); if (STATS) counts[2]++; }

@@ -16,4 +16,4 @@ for scale in (0.005, 0.02, 0.08, 0.3):
     pts = (base * (1.0 + rng.normal(0, scale, (n, 1)))).astype(np.float32)
     out = np.zeros((n, 4), np.uint32)
     check(lib().sdfhip_mesh_nearest_stats(m.h, pts.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
-    print(f"T={len(f)} offset~{scale}: inner {out[:,1].mean():.1f} (max {out[:,1].max()}) pops {out[:,2].mean():.1f} tris {out[:,3].mean():.1f} (max {out[:,3].max()})")
+    print(f"T={len(f)} offset~{scale}: inner {out[:,1].mean():.1f} (max {out[:,1].max()}) wave iterations {out[:,2].mean():.1f} tris {out[:,3].mean():.1f} (max {out[:,3].max()})")
