@@ -49,6 +49,22 @@ class Context:
         h = C.c_void_p()
         check(lib().sdfhip_ctx_create(int(device), C.c_void_p(stream) if stream else None, 1 if borrowed else 0, C.byref(h)))
         self.h, self.device = h, int(device)
+        self.stream = int(stream) if (borrowed and stream) else (0 if borrowed else None)      # None: a private stream of the library
+
+    # torch tensors in / out: the engine is asynchronous on ITS stream.  When that is torch's current stream nothing is needed;
+    # otherwise the call is fenced on both sides so that results are never read (or inputs written) across streams.
+    def _shares_torch_stream(self):
+        import torch
+        return self.stream is not None and self.stream == int(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _torch_inputs_ready(self):
+        if not self._shares_torch_stream():
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def _torch_outputs_ready(self):
+        if not self._shares_torch_stream():
+            self.synchronize()
 
     def synchronize(self):
         check(lib().sdfhip_ctx_synchronize(self.h))
@@ -175,8 +191,10 @@ class OctreeSdf:
             words = _np(words, np.uint32); ptr, n = _ptr(words), len(words)
         else:
             ptr, n = C.c_void_p(words.data_ptr()), words.numel()
+            ctx._torch_inputs_ready()
         check(lib().sdfhip_octree_from_data(ctx.h, ptr, n, where, _ptr(bmin), _ptr(bmax), int(start_grid_size), int(max_depth),
                                             float(value_range), float(min_border_value), C.byref(h)))
+        if where != HOST: ctx._torch_outputs_ready()       # the words are copied on the engine's stream
         return cls(_handle=h, _ctx=ctx)
 
     def close(self):
@@ -231,8 +249,10 @@ class OctreeSdf:
             n = pts.numel() // 3
             d = out if out is not None else torch.empty(n, dtype=torch.float32, device=pts.device)
             g = (out_grad if out_grad is not None else torch.empty((n, 3), dtype=torch.float32, device=pts.device)) if gradient else None
+            self.ctx._torch_inputs_ready()
             check(lib().sdfhip_octree_query(self.h, C.c_void_p(pts.data_ptr()), n, C.c_void_p(d.data_ptr()),
                                             C.c_void_p(g.data_ptr()) if gradient else None, DEVICE, eval_mode))
+            self.ctx._torch_outputs_ready()
             return (d, g) if gradient else d
         pts = _np(points, np.float32).reshape(-1, 3)
         d = np.empty(len(pts), dtype=np.float32)
@@ -250,8 +270,10 @@ class OctreeSdf:
             dev = torch.device("cuda", self.ctx.device)
             d = torch.empty(n, dtype=torch.float32, device=dev)
             g = torch.empty((n, 3), dtype=torch.float32, device=dev) if gradient else None
+            self.ctx._torch_inputs_ready()
             check(lib().sdfhip_octree_query_grid(self.h, _ptr(o), _ptr(s), nx, ny, nz, C.c_void_p(d.data_ptr()),
                                                  C.c_void_p(g.data_ptr()) if gradient else None, DEVICE, eval_mode))
+            self.ctx._torch_outputs_ready()
             return (d, g) if gradient else d
         d = np.empty(n, dtype=np.float32)
         g = np.zeros((n, 3), dtype=np.float32) if gradient else None
@@ -289,7 +311,9 @@ class OctreeShard:
     def emit(self, body_offset, dst_grid, dst_body):
         """Write this shard's start-grid words and bodies (absolute indices) into numpy arrays or torch CUDA tensors."""
         if _is_torch(dst_grid):
+            self.ctx._torch_inputs_ready()
             check(lib().sdfhip_octree_emit_shard(self.h, int(body_offset), C.c_void_p(dst_grid.data_ptr()), C.c_void_p(dst_body.data_ptr()), DEVICE))
+            self.ctx._torch_outputs_ready()
         else:
             check(lib().sdfhip_octree_emit_shard(self.h, int(body_offset), _ptr(dst_grid), _ptr(dst_body), HOST))
 
@@ -342,8 +366,10 @@ class ExactShard:
             mk32 = lambda *shape: torch.zeros(shape, dtype=torch.int32, device=device); mk8 = lambda n: torch.zeros(n, dtype=torch.uint8, device=device)
             ptr, where = (lambda t: C.c_void_p(t.data_ptr())), DEVICE
         out = dict(grid_nodes=mk32(nc, 2), grid_has=mk8(nc), body_nodes=mk32(max(nb, 1), 2), body_has=mk8(max(nb, 1)), sets=mk32(max(ns, 1)), masks=mk8(max(nm, 1)))
+        if where == DEVICE: self.ctx._torch_inputs_ready()
         check(lib().sdfhip_exact_emit_shard(self.h, int(node_offset), int(set_offset), int(mask_offset), ptr(out["grid_nodes"]), ptr(out["grid_has"]),
                                             ptr(out["body_nodes"]), ptr(out["body_has"]), ptr(out["sets"]), ptr(out["masks"]), where))
+        if where == DEVICE: self.ctx._torch_outputs_ready()
         out["body_nodes"] = out["body_nodes"][:nb]; out["body_has"] = out["body_has"][:nb]; out["sets"] = out["sets"][:ns]; out["masks"] = out["masks"][:nm]
         return out
 
@@ -401,7 +427,9 @@ class ExactOctreeSdf:
         Arrays are numpy (where=HOST) or torch device tensors (where=DEVICE); `info` is an ExactInfo with the totals."""
         h = C.c_void_p()
         ptr = (lambda a: None if a is None else _ptr(a)) if where == HOST else (lambda a: None if a is None else C.c_void_p(a.data_ptr()))
+        if where == DEVICE: mesh.ctx._torch_inputs_ready()
         check(lib().sdfhip_exact_from_parts(mesh.ctx.h, mesh.h, C.byref(info), ptr(nodes), ptr(has), ptr(sets), ptr(masks), where, C.byref(h)))
+        if where == DEVICE: mesh.ctx._torch_outputs_ready()       # the arrays are copied on the engine's stream: keep them alive / unchanged until then
         t = cls(_handle=h, _ctx=mesh.ctx)
         t._mesh = mesh              # TriangleData lives in the mesh
         return t
@@ -437,8 +465,10 @@ class ExactOctreeSdf:
             d = out if out is not None else torch.empty(n, dtype=torch.float32, device=pts.device)
             g = torch.empty((n, 3), dtype=torch.float32, device=pts.device) if gradient else None
             t = torch.empty(n, dtype=torch.int32, device=pts.device) if triangle else None
+            self.ctx._torch_inputs_ready()
             check(lib().sdfhip_exact_query(self.h, C.c_void_p(pts.data_ptr()), n, C.c_void_p(d.data_ptr()),
                                            C.c_void_p(g.data_ptr()) if gradient else None, C.c_void_p(t.data_ptr()) if triangle else None, DEVICE))
+            self.ctx._torch_outputs_ready()
         else:
             pts = _np(points, np.float32).reshape(-1, 3)
             d = np.empty(len(pts), dtype=np.float32)

@@ -241,6 +241,14 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     SDF_REQUIRE(T && xyz && out_dist, "NULL argument");
     SDF_REQUIRE(T->built, "tree is not built");
     if (n == 0) return SDFHIP_OK;
+    const uint64_t chunk = queryChunk(where == SDFHIP_HOST);
+    if (n > chunk) {
+        for (uint64_t off = 0; off < n; off += chunk) {
+            const uint64_t m = n - off < chunk ? n - off : chunk;
+            SDF_TRY(sdfhip_exact_query(T, xyz + 3 * off, m, out_dist + off, out_grad ? out_grad + 3 * off : nullptr, out_tri ? out_tri + off : nullptr, where));
+        }
+        return SDFHIP_OK;
+    }
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -261,7 +269,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     const sdfhip_exact_info& I = T->info;
     ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), T->frames(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
                 T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
-    if (n < 16384 || n > 0xFFFFFFF0ull) {
+    if (n < 16384) {
         if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
         else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
     } else {

@@ -145,6 +145,14 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     SDF_REQUIRE(T->hasData, "tree has no assembled node array");
     SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
     if (n == 0) return SDFHIP_OK;
+    const uint64_t chunk = queryChunk(where == SDFHIP_HOST);
+    if (n > chunk) {
+        for (uint64_t off = 0; off < n; off += chunk) {
+            const uint64_t m = n - off < chunk ? n - off : chunk;
+            SDF_TRY(sdfhip_octree_query(T, xyz + 3 * off, m, out_dist + off, out_grad ? out_grad + 3 * off : nullptr, where, eval_mode));
+        }
+        return SDFHIP_OK;
+    }
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -184,6 +192,7 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
     SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
     const uint64_t n = (uint64_t)nx * ny * nz;
     if (n == 0) return SDFHIP_OK;
+    SDF_REQUIRE((double)nx * ny * nz <= (double)(1ull << 38), "lattice larger than 2^38 points");
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;

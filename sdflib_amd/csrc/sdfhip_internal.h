@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string>
@@ -90,6 +91,14 @@ struct DevBuf {
 };
 
 static inline unsigned gridFor(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
+
+// Point queries are answered in chunks of at most this many points (grid dimensions and the sort's element count are 32-bit;
+// host arrays are staged chunk by chunk).  SDFHIP_QUERY_CHUNK overrides it (tests run the chunk loop on small inputs).
+static inline uint64_t queryChunk(bool hostBuffers) {
+    static const uint64_t forced = getenv("SDFHIP_QUERY_CHUNK") ? strtoull(getenv("SDFHIP_QUERY_CHUNK"), nullptr, 10) : 0;
+    if (forced) return forced;
+    return hostBuffers ? (1ull << 27) : (1ull << 30);
+}
 
 }  // namespace sdfhip
 

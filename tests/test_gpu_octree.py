@@ -499,3 +499,39 @@ def test_concurrent_host_threads_query_one_tree(small):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_large_query_arrays_are_answered_in_chunks():
+    """Point queries run in chunks (32-bit grid dimensions / sort sizes; host arrays staged chunk by chunk).  The chunk loop is
+    exercised on a small input by forcing the chunk size down (read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import sdflib_amd as S
+from oracle import pyoracle as O
+from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+v, f = bumpy_icosphere(2); box = box_with_margin(v)
+m = S.Mesh(v, f)
+t = S.OctreeSdf(m, box, 5, 2, 1e-3); e = S.ExactOctreeSdf(m, box, 4, 1, 8)
+om = O.Mesh(v, f); ot = O.Octree(om, box, 5, 2, 1e-3); oe = O.Exact(om, box, 4, 1, 8)
+pts = random_points_in_box(box, 40001, seed=3); pts[::97] *= 3.0
+d0, g0 = ot.query(pts, grad=True); e0 = oe.query(pts)
+b = lambda a: np.ascontiguousarray(a).view(np.uint32)
+d, g = t.get_distance(pts, gradient=True)                        # host arrays
+assert np.array_equal(b(d), b(d0)) and np.array_equal(b(g), b(g0))
+assert np.array_equal(b(e.get_distance(pts)), b(e0))
+tp = torch.from_numpy(pts).cuda()                                # device arrays; the default context has its OWN stream: the calls are fenced
+assert np.array_equal(b(t.get_distance(tp).cpu().numpy()), b(d0))
+assert np.array_equal(b(e.get_distance(tp).cpu().numpy()), b(e0))
+ctx2 = S.Context(0, use_torch_stream=True)                       # engine on torch's stream: no fences, plain stream order
+m2 = S.Mesh(v, f, ctx2); e2 = S.ExactOctreeSdf(m2, box, 4, 1, 8)
+assert np.array_equal(b(e2.get_distance(tp).cpu().numpy()), b(e0))
+print("chunks ok")
+''' % ROOT
+    env = dict(os.environ, SDFHIP_QUERY_CHUNK="16411")          # 3 chunks, the last one ragged; >= 16384 so the sorted exact path runs too
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
