@@ -45,7 +45,11 @@ extern "C" {
 #define SDFHIP_E_TOO_LARGE (-4)   /* structure exceeds the 30-bit node index of the reference layout */
 #define SDFHIP_E_UNSUPPORTED (-5)
 
-/* where a caller-supplied buffer lives */
+/* where a caller-supplied buffer lives.
+ * SDFHIP_HOST:   the call returns when the host buffers hold the results (blocking, like the reference's CPU calls).
+ * SDFHIP_DEVICE: the work is ENQUEUED on the context's stream and the call returns at once; inputs must be ready in that
+ *                stream's order and outputs are valid in that stream's order (sdfhip_ctx_synchronize, or share the stream:
+ *                SDFHIP_STREAM_BORROWED).  Point queries of any size are accepted (processed in chunks). */
 #define SDFHIP_HOST 0
 #define SDFHIP_DEVICE 1
 
