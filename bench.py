@@ -147,6 +147,7 @@ def main():
     value = total_queries / elapsed / 1e6
 
     traffic, traffic_src = _pmc_traffic(args)
+    copy_gbs = measured_copy_gbs(dev)
     result = {
         "metric": "Mqueries/sec getDistance() (OctreeSdf, whole job)", "value": round(value, 2), "unit": "Mqueries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -160,6 +161,7 @@ def main():
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(round(bytes_per_query * args.queries)),
                      "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
+                     "copy_bw_measured_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved_gbs / copy_gbs, 4),
                      "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
         "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **{k: round(v, 4) for k, v in binfo.items()}},
     }
@@ -175,6 +177,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_copy_gbs(dev):
+    """The practical HBM ceiling next to the datasheet one: device-to-device copy of 1 GiB, read + write bytes
+    over the best of 5 timings (HIP events)."""
+    n = 256 << 20
+    a = torch.empty(n, dtype=torch.float32, device=dev).fill_(1.0); b = torch.empty_like(a)
+    best = 1e30
+    for _ in range(6):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del a, b
+    return 2 * 4 * n / (best * 1e-3) / 1e9
 
 
 def cpu_baseline(v, f, box, args, pts):
