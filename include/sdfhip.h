@@ -44,6 +44,7 @@ extern "C" {
 #define SDFHIP_E_NO_DEVICE (-3)   /* no usable gfx950 device: there is no CPU fallback */
 #define SDFHIP_E_TOO_LARGE (-4)   /* structure exceeds the 30-bit node index of the reference layout */
 #define SDFHIP_E_UNSUPPORTED (-5)
+#define SDFHIP_E_HOST (-6)        /* host-side failure (out of memory, thread creation ...): reported, never thrown */
 
 /* where a caller-supplied buffer lives.
  * SDFHIP_HOST:   the call returns when the host buffers hold the results (blocking, like the reference's CPU calls).

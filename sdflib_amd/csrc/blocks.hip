@@ -33,6 +33,7 @@ using namespace sdfhip;
 extern "C" {
 
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && values_8x8 && node_sizes && out64, "NULL argument");
     SDF_REQUIRE(fit_mode == SDFHIP_FIT_EXACT || fit_mode == SDFHIP_FIT_MFMA, "unknown fit_mode");
     if (n == 0) return SDFHIP_OK;
@@ -48,9 +49,11 @@ int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* n
     SDF_HIP_CHECK(hipMemcpyAsync(out64, dout.p, 256 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr, uint64_t n, uint8_t* out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && half && radius8 && tri9 && thr && out, "NULL argument");
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
@@ -66,6 +69,7 @@ int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* rad
     SDF_HIP_CHECK(hipMemcpyAsync(out, dout.p, n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

@@ -281,13 +281,16 @@ __global__ void k_point_values(const float* __restrict__ verts, const uint32_t* 
 using namespace sdfhip;
 
 int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh) {
+    SDF_API_BEGIN
     if (mesh->hasBvh) return SDFHIP_OK;
     return sdfhip_mesh_build_bvh(mesh, nullptr);
+    SDF_API_END
 }
 
 extern "C" {
 
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
@@ -343,9 +346,11 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     mesh->hasBvh = true;
     if (seconds) *seconds = nowSeconds() - t0;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh && xyz && out_ids, "NULL argument");
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
     if (n == 0) return SDFHIP_OK;
@@ -363,11 +368,13 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out_ids, dout.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 // Test hook (no GPU needed): sorts n {key, id} pairs with the planner's multi-threaded introsort and with std::sort and
 // returns the number of positions where the two permutations differ (0 = identical).
 int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
+    SDF_API_BEGIN
     if (!keys) return -1;
     std::vector<KeyTri> a(n), b(n);
     for (uint64_t i = 0; i < n; i++) a[i] = b[i] = KeyTri{keys[i], (int)i};
@@ -377,9 +384,11 @@ int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
     int diff = 0;
     for (uint64_t i = 0; i < n; i++) diff += (a[i].tri != b[i].tri || a[i].key != b[i].key) ? 1 : 0;
     return diff;
+    SDF_API_END
 }
 
 int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh && xyz && out4, "NULL argument");
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
     hipStream_t st = mesh->ctx->stream;
@@ -391,9 +400,11 @@ int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, u
     SDF_HIP_CHECK(hipMemcpyAsync(out4, dout.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t* tri_ids, uint64_t n, float* out8, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh && xyz && tri_ids && out8, "NULL argument");
     if (n == 0) return SDFHIP_OK;
     hipStream_t st = mesh->ctx->stream;
@@ -411,6 +422,7 @@ int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out8, dout.p, sizeof(float) * 8 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

@@ -206,6 +206,7 @@ const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
 void sdfhip_abi_sizes(uint64_t out[3]) { out[0] = sizeof(sdfhip_octree_info); out[1] = sizeof(sdfhip_octree_params); out[2] = sizeof(sdfhip_exact_info); }
 
 int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(out != nullptr, "out is NULL");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -226,37 +227,47 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
     else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
     *out = c;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
+    SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
     if (ctx->ownsStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx != nullptr, "ctx is NULL");
     SDF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int sdfhip_ctx_set_exchange(sdfhip_ctx* ctx, const sdfhip_exchange* x) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx, "null context");
     if (!x || x->world < 1) { ctx->exchange = sdfhip_exchange{}; return SDFHIP_OK; }
     SDF_REQUIRE(x->acquire && x->all_reduce_sum, "exchange without callbacks");
     SDF_REQUIRE(x->rank >= 0 && x->rank < x->world, "exchange rank outside [0, world)");
     ctx->exchange = *x;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, sdfhip_mesh** out) {
+    SDF_API_BEGIN
     return sdfhip_mesh_create_ex(ctx, xyz, nv, indices, nt, nullptr, out);
+    SDF_API_END
 }
 
 int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, const float* bbox6, sdfhip_mesh** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && xyz && indices && out, "NULL argument");
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
@@ -321,22 +332,27 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     *out = m;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_mesh_destroy(sdfhip_mesh* mesh) { delete mesh; return SDFHIP_OK; }
 
 int sdfhip_mesh_edge_stats(sdfhip_mesh* mesh, uint32_t* unmatched_edges, uint32_t* welded_half_edges) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
     if (unmatched_edges) *unmatched_edges = mesh->unmatchedEdges;
     if (welded_half_edges) *welded_half_edges = mesh->weldedEdges;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host) {
+    SDF_API_BEGIN
     SDF_REQUIRE(mesh && out_host, "NULL argument");
     SDF_HIP_CHECK(hipMemcpyAsync(out_host, mesh->dTri.p, sizeof(float) * TD_FLOATS * (size_t)mesh->numTriangles, hipMemcpyDeviceToHost, mesh->ctx->stream));
     SDF_HIP_CHECK(hipStreamSynchronize(mesh->ctx->stream));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

@@ -830,24 +830,31 @@ extern "C" {
 
 int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
                        uint32_t minTri, sdfhip_exact** out) {
+    SDF_API_BEGIN
     return exactBuildImpl(ctx, mesh, box_min, box_max, maxDepth, startDepth, minTri, nullptr, out);
+    SDF_API_END
 }
 
 int sdfhip_exact_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t maxDepth, uint32_t startDepth,
                              uint32_t minTri, uint32_t rank_begin, uint32_t rank_end, sdfhip_exact** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(startDepth <= 10 && rank_begin < rank_end && rank_end <= (1u << (3 * startDepth)), "cell rank range must be a non-empty sub-range of [0, 8^start_depth)");
     const uint32_t range[2] = {rank_begin, rank_end};
     return exactBuildImpl(ctx, mesh, box_min, box_max, maxDepth, startDepth, minTri, range, out);
+    SDF_API_END
 }
 
 int sdfhip_exact_shard_cells(sdfhip_exact* shard, uint32_t* out_cells) {
+    SDF_API_BEGIN
     SDF_REQUIRE(shard && shard->isShard && out_cells, "not a shard");
     memcpy(out_cells, shard->shardCells.data(), 4ull * shard->shardCells.size());
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_emit_shard(sdfhip_exact* E, uint64_t node_offset, uint64_t set_offset, uint64_t mask_offset, uint32_t* dst_grid_nodes, uint8_t* dst_grid_has,
                             uint32_t* dst_body_nodes, uint8_t* dst_body_has, uint32_t* dst_sets, uint8_t* dst_masks, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(E && E->isShard && !E->levels.empty(), "not a shard, or already emitted");
     SDF_REQUIRE(dst_grid_nodes && dst_grid_has && dst_body_nodes && dst_body_has && dst_sets && dst_masks, "NULL destination");
     SDF_REQUIRE(node_offset + E->bodyNodes < (1ull << 31) && set_offset + E->info.num_set_words < (1ull << 32) && mask_offset + E->info.num_mask_bytes < (1ull << 32), "structure too large");
@@ -875,17 +882,21 @@ int sdfhip_exact_emit_shard(sdfhip_exact* E, uint64_t node_offset, uint64_t set_
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     E->levels.clear();
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_destroy(sdfhip_exact* tree) { delete tree; return SDFHIP_OK; }
 
 int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(tree && out, "NULL argument");
     *out = tree->info;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_download(sdfhip_exact* T, uint32_t* nodes, uint8_t* has, uint32_t* sets, uint8_t* masks) {
+    SDF_API_BEGIN
     SDF_REQUIRE(T && nodes && has && sets && masks, "NULL argument");
     hipStream_t st = T->ctx->stream;
     SDF_HIP_CHECK(hipMemcpyAsync(nodes, T->nodes.p, 8ull * T->info.num_nodes, hipMemcpyDeviceToHost, st));
@@ -894,6 +905,7 @@ int sdfhip_exact_download(sdfhip_exact* T, uint32_t* nodes, uint8_t* has, uint32
     if (T->info.num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(masks, T->masks.p, T->info.num_mask_bytes, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

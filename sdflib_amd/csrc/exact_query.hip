@@ -238,6 +238,7 @@ using namespace sdfhip;
 extern "C" {
 
 int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out_dist, float* out_grad, uint32_t* out_tri, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(T && xyz && out_dist, "NULL argument");
     SDF_REQUIRE(T->built, "tree is not built");
     if (n == 0) return SDFHIP_OK;
@@ -300,10 +301,12 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const uint32_t* nodes, const uint32_t* sets, const uint8_t* masks,
                            const float* triangle_data, sdfhip_exact** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && info && nodes && sets && masks && triangle_data && out, "NULL argument");
     SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
     SDF_REQUIRE(info->bits_per_index >= 1 && info->bits_per_index <= 32 && info->num_triangles >= 1, "bad header");
@@ -326,10 +329,12 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     E->built = true;
     *out = E.release();
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exact_info* info, const uint32_t* nodes, const uint8_t* has, const uint32_t* sets,
                             const uint8_t* masks, int where, sdfhip_exact** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && mesh && info && nodes && sets && masks && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx && info->num_triangles == mesh->numTriangles, "mesh does not match the header");
     SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
@@ -352,13 +357,16 @@ int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exa
     E->built = true;
     *out = E.release();
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host) {
+    SDF_API_BEGIN
     SDF_REQUIRE(tree && tree->built && out_host, "NULL argument or tree not built");
     SDF_HIP_CHECK(hipMemcpyAsync(out_host, tree->tri(), sizeof(float) * TD_FLOATS * tree->info.num_triangles, hipMemcpyDeviceToHost, tree->ctx->stream));
     SDF_HIP_CHECK(hipStreamSynchronize(tree->ctx->stream));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

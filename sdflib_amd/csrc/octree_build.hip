@@ -514,16 +514,21 @@ using namespace sdfhip;
 extern "C" {
 
 int sdfhip_octree_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(params != nullptr, "params is NULL");
     SDF_REQUIRE(params->cell_begin == 0 && (params->cell_end == 0 || params->cell_end == (1u << (3 * params->start_depth))), "sdfhip_octree_build builds all cells; use sdfhip_octree_build_shard");
     return buildImpl(ctx, mesh, params, false, out);
+    SDF_API_END
 }
 
 int sdfhip_octree_build_shard(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* params, sdfhip_octree** out) {
+    SDF_API_BEGIN
     return buildImpl(ctx, mesh, params, true, out);
+    SDF_API_END
 }
 
 int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* dst_grid, uint32_t* dst_body, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(T && dst_grid && dst_body, "NULL argument");
     SDF_REQUIRE(T->built && !T->levels.empty(), "construction state is no longer available");
     sdfhip_ctx* ctx = T->ctx;
@@ -578,10 +583,12 @@ int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* d
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     T->info.body_offset = body_offset;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num_words, int where, const float box_min[3], const float box_max[3],
                             int32_t start_grid_size, uint32_t max_depth, float value_range, float min_border_value, sdfhip_octree** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && words && box_min && box_max && out, "NULL argument");
     SDF_REQUIRE(start_grid_size >= 1 && (uint64_t)start_grid_size * start_grid_size * start_grid_size <= num_words, "start grid does not fit");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
@@ -597,22 +604,27 @@ int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num
     T->hasData = true;
     *out = T.release();
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_octree_destroy(sdfhip_octree* tree) { delete tree; return SDFHIP_OK; }
 
 int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(tree && out, "NULL argument");
     *out = tree->info;
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where) {
+    SDF_API_BEGIN
     SDF_REQUIRE(tree && out_words, "NULL argument");
     SDF_REQUIRE(tree->hasData, "tree has no assembled node array (sharded build: emit + from_data first)");
     SDF_HIP_CHECK(hipMemcpyAsync(out_words, tree->data.p, 4ull * tree->info.num_words, where == SDFHIP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, tree->ctx->stream));
     SDF_HIP_CHECK(hipStreamSynchronize(tree->ctx->stream));
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) { return (tree && tree->hasData) ? tree->data.p : nullptr; }

@@ -141,6 +141,7 @@ using namespace sdfhip;
 extern "C" {
 
 int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int where, int eval_mode) {
+    SDF_API_BEGIN
     SDF_REQUIRE(T && xyz && out_dist, "NULL argument");
     SDF_REQUIRE(T->hasData, "tree has no assembled node array");
     SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
@@ -183,10 +184,12 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const float step[3], uint32_t nx, uint32_t ny, uint32_t nz,
                              float* out_dist, float* out_grad, int where, int eval_mode) {
+    SDF_API_BEGIN
     SDF_REQUIRE(T && origin && step && out_dist, "NULL argument");
     SDF_REQUIRE(T->hasData, "tree has no assembled node array");
     SDF_REQUIRE(eval_mode == SDFHIP_EVAL_EXACT || eval_mode == SDFHIP_EVAL_FAST, "unknown eval_mode");
@@ -220,6 +223,7 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
     return SDFHIP_OK;
+    SDF_API_END
 }
 
 }  // extern "C"

@@ -6,6 +6,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string>
+#include <new>
+#include <exception>
 #include <vector>
 #include <chrono>
 #include <mutex>
@@ -23,6 +25,13 @@ void setError(const char* fmt, ...);
             return SDFHIP_E_HIP;                                                                   \
         }                                                                                          \
     } while (0)
+
+// Every int-returning entry point runs between these two: no C++ exception crosses the C boundary (include/sdfhip.h).
+#define SDF_API_BEGIN try {
+#define SDF_API_END                                                                                   \
+    } catch (const std::bad_alloc&) { sdfhip::setError("out of host memory"); return SDFHIP_E_HOST; }  \
+    catch (const std::exception& e) { sdfhip::setError("host-side failure: %s", e.what()); return SDFHIP_E_HOST; } \
+    catch (...) { sdfhip::setError("host-side failure (unknown exception)"); return SDFHIP_E_HOST; }
 
 #define SDF_REQUIRE(cond, msg)                                                  \
     do {                                                                        \
