@@ -1,0 +1,91 @@
+"""Differential fuzzing on the GPU box: random meshes / boxes / parameters, GPU (through the C ABI) against the CPU oracle, bit for
+bit — TriangleData, nearest-triangle ids, both OctreeSdf builders (all rules, both layouts), ExactOctreeSdf arrays, queries with
+gradients.  Usage: tools/gpu_fuzz.py [iterations] [first seed].  Prints one line per case and a summary; exit code 1 on mismatch."""
+import sys, os, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import sdflib_amd as S
+from oracle import pyoracle as O
+from sdflib_amd.meshgen import icosphere, bumpy_icosphere, cube_mesh, box_with_margin
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+ctx = S.Context(0)
+
+
+def random_mesh(rng):
+    kind = rng.integers(0, 5)
+    if kind == 0: v, f = icosphere(int(rng.integers(0, 4)))
+    elif kind == 1: v, f = bumpy_icosphere(int(rng.integers(1, 4)))
+    elif kind == 2: v, f = cube_mesh()
+    elif kind == 3:                                  # two components, one inside the other or apart
+        a, fa = icosphere(int(rng.integers(1, 3)))
+        off = rng.normal(0, 0.6, 3).astype(np.float32)
+        v = np.concatenate([a, a * np.float32(rng.uniform(0.2, 0.8)) + off]).astype(np.float32); f = np.concatenate([fa, fa + len(a)]).astype(np.uint32)
+    else:                                            # random soup of a few triangles
+        n = int(rng.integers(1, 30))
+        v = rng.normal(0, 1, (3 * n, 3)).astype(np.float32); f = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    v = v.astype(np.float32).copy(); f = f.astype(np.uint32).copy()
+    if rng.random() < 0.5:                           # anisotropic scale, rotation, translation
+        A = np.linalg.qr(rng.normal(0, 1, (3, 3)))[0] * rng.uniform(0.3, 3.0, 3)[None, :]
+        v = (v @ A.T.astype(np.float32) + rng.normal(0, 2.0, 3).astype(np.float32)).astype(np.float32)
+    if rng.random() < 0.3: v = (v + rng.normal(0, 0.01, v.shape).astype(np.float32)).astype(np.float32)
+    if rng.random() < 0.3 and len(f) > 4: f = f[rng.random(len(f)) > 0.2]                        # holes
+    if rng.random() < 0.2 and len(f) > 2: f = np.concatenate([f, f[rng.integers(0, len(f), 2)]])  # coincident duplicates
+    if rng.random() < 0.2: f = f[:, [0, 2, 1]]                                                    # flipped winding
+    return np.ascontiguousarray(v), np.ascontiguousarray(f.astype(np.uint32))
+
+
+def one(seed):
+    rng = np.random.default_rng(seed)
+    if os.environ.get("FUZZ_VERBOSE"): print(f"  seed {seed} start", flush=True)
+    v, f = random_mesh(rng)
+    if len(f) < 1: return "skip"
+    box = np.asarray(box_with_margin(v, margin=float(rng.uniform(0.05, 0.5))), dtype=np.float32)
+    if rng.random() < 0.4: box[3:] += rng.uniform(0, 0.5, 3).astype(np.float32) * (box[3:] - box[:3])      # non-cubic input box
+    use_bbox = rng.random() < 0.3
+    bbox = np.concatenate([v.min(0), v.max(0)]).astype(np.float32) if use_bbox else None
+    om = O.Mesh(v, f, bbox=bbox) if use_bbox else O.Mesh(v, f)
+    gm = S.Mesh(v, f, ctx, bbox=bbox) if use_bbox else S.Mesh(v, f, ctx)
+    a, b = om.triangle_data(), gm.triangle_data()
+    assert np.array_equal(bits(a[:, :28]), bits(b[:, :28])) or np.array_equal(a[:, :28], b[:, :28], equal_nan=True), "TriangleData frames / edge normals"
+    assert np.allclose(a[:, 28:], b[:, 28:], rtol=0, atol=1e-5, equal_nan=True), "TriangleData vertex normals"      # acosf: glibc vs ocml, last ulp
+    size = float((box[3:] - box[:3]).max())
+    pts = (box[:3] + rng.random((20000, 3), dtype=np.float32) * size * np.float32(1.2) - np.float32(0.1 * size)).astype(np.float32)
+    assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts)), "nearest ids"
+    depth = int(rng.integers(2, 7)); start = int(rng.integers(0, min(depth, 3) + 1))
+    rule = int(rng.choice([S.RULE_TRAPEZOIDAL, S.RULE_TRAPEZOIDAL, S.RULE_SIMPSONS, S.RULE_BY_DISTANCE, S.RULE_NONE]))
+    if rule == S.RULE_NONE: depth = min(depth, 4)
+    thr = float(10 ** rng.uniform(-4, -2)); decay = float(rng.uniform(0.0, 0.2))
+    cont = rng.random() < 0.4
+    layout1 = rng.random() < 0.5
+    ot = O.Octree(om, box, depth, start, thr, rule=rule, param1=decay, vertex_cache=False, layout=O.LAYOUT_GLOBAL_DFS if layout1 else O.LAYOUT_SUBTREES, continuity=cont)
+    gt = S.OctreeSdf(gm, box, depth, start, thr, init_algorithm=S.ALG_CONTINUITY if cont else S.ALG_NO_CONTINUITY, num_threads=1 if layout1 else 2,
+                     termination_rule=rule, rule_params=(thr, decay))
+    assert np.array_equal(ot.data(), gt.get_octree_data()), f"octree array (cont={cont} rule={rule} depth={depth} start={start} thr={thr:g})"
+    assert np.float32(ot.value_range) == np.float32(gt.info.value_range) and (np.float32(ot.min_border) == np.float32(gt.info.min_border_value) or np.isnan(ot.min_border)), "range/border"
+    d0, g0 = ot.query(pts, grad=True); d1, g1 = gt.get_distance(pts, gradient=True)
+    assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(bits(g0), bits(g1)), "octree queries"
+    if len(f) < 2: return f"T={len(f)} octree only (ExactOctreeSdf needs 2 triangles: bits per index)"
+    edepth = int(rng.integers(2, 6)); estart = int(rng.integers(0, min(edepth - 2, 2) + 1)); mint = int(rng.choice([1, 2, 8, 32, 128]))
+    oe = O.Exact(om, box, edepth, estart, mint); ge = S.ExactOctreeSdf(gm, box, edepth, estart, mint)
+    for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
+        if name == "nodes": x, y = x[:, 0], y[:, 0]
+        if name == "has": continue
+        assert x.shape == y.shape and np.array_equal(x, y), f"exact {name} (depth={edepth} start={estart} min={mint})"
+    e0, t0 = oe.query(pts, tri=True); e1, t1 = ge.get_distance(pts, triangle=True)
+    assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0, t1.astype(np.uint32)), "exact queries"
+    return f"T={len(f)} cont={int(cont)} rule={rule} d={depth}/{start} words={len(ot.data())} exact d={edepth}/{estart} min={mint}"
+
+
+fails = 0; t00 = time.time()
+for s in range(seed0, seed0 + iters):
+    try:
+        print(f"seed {s}: {one(s)}", flush=True)
+    except AssertionError as e:
+        fails += 1; print(f"seed {s}: MISMATCH {e}", flush=True)
+    except Exception as e:      # noqa: BLE001
+        fails += 1; print(f"seed {s}: ERROR {type(e).__name__}: {e}", flush=True)
+print(f"{iters} cases, {fails} failures, {time.time() - t00:.0f} s")
+sys.exit(1 if fails else 0)
