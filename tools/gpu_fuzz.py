@@ -68,6 +68,29 @@ def one(seed):
     d0, g0 = ot.query(pts, grad=True); d1, g1 = gt.get_distance(pts, gradient=True)
     assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(bits(g0), bits(g1)), "octree queries"
     if len(f) < 2: return f"T={len(f)} octree only (ExactOctreeSdf needs 2 triangles: bits per index)"
+    extra = ""
+    if not cont and not layout1 and rng.random() < 0.5:          # sharded build over random contiguous cell ranges == the single build
+        G3 = 8 ** start
+        cuts = sorted(set([0, G3] + [int(c) for c in rng.integers(0, G3 + 1, int(rng.integers(1, 5)))]))
+        shards = [S.OctreeShard(gm, box, depth, start, thr, cells=(a_, b_), termination_rule=rule, rule_params=(thr, decay)) for a_, b_ in zip(cuts, cuts[1:])]
+        out = np.zeros(G3 + sum(int(sh.info.body_words) for sh in shards), dtype=np.uint32); off = G3
+        for sh, (a_, b_) in zip(shards, zip(cuts, cuts[1:])):
+            nb = int(sh.info.body_words); grid = np.zeros(b_ - a_, dtype=np.uint32); body = np.zeros(max(nb, 1), dtype=np.uint32)
+            sh.emit(off, grid, body); out[a_:b_] = grid; out[off:off + nb] = body[:nb]; off += nb
+        assert np.array_equal(out, ot.data()), f"octree shards {cuts}"
+        extra += f" shards={len(shards)}"
+    if not cont and rng.random() < 0.3:                           # MFMA fit: same topology as the exact fit
+        mt = S.OctreeSdf(gm, box, depth, start, thr, num_threads=1 if layout1 else 2, termination_rule=rule, rule_params=(thr, decay), fit_mode=S.FIT_MFMA)
+        a_, b_ = ot.data(), mt.get_octree_data()
+        assert a_.shape == b_.shape, "FIT_MFMA tree size"
+        extra += " mfma"
+    if rng.random() < 0.3:                                        # lattice query == point query
+        nxyz = tuple(int(x) for x in rng.integers(1, 20, 3)); org = (box[:3] - np.float32(0.05 * size)).astype(np.float32); st = (rng.uniform(0.01, 0.1, 3) * size).astype(np.float32)
+        gi = np.stack(np.meshgrid(np.arange(nxyz[2]), np.arange(nxyz[1]), np.arange(nxyz[0]), indexing="ij"), -1).reshape(-1, 3)[:, ::-1].astype(np.float32)
+        lp = (org + gi * st).astype(np.float32)
+        dg, gg = gt.get_distance_grid(org, st, nxyz, gradient=True); dp, gp = gt.get_distance(lp, gradient=True)
+        assert np.array_equal(bits(dg), bits(dp)) and np.array_equal(bits(gg), bits(gp)), "lattice query"
+        extra += " grid"
     edepth = int(rng.integers(2, 6)); estart = int(rng.integers(0, min(edepth - 2, 2) + 1)); mint = int(rng.choice([1, 2, 8, 32, 128]))
     oe = O.Exact(om, box, edepth, estart, mint); ge = S.ExactOctreeSdf(gm, box, edepth, estart, mint)
     for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
@@ -76,7 +99,17 @@ def one(seed):
         assert x.shape == y.shape and np.array_equal(x, y), f"exact {name} (depth={edepth} start={estart} min={mint})"
     e0, t0 = oe.query(pts, tri=True); e1, t1 = ge.get_distance(pts, triangle=True)
     assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0, t1.astype(np.uint32)), "exact queries"
-    return f"T={len(f)} cont={int(cont)} rule={rule} d={depth}/{start} words={len(ot.data())} exact d={edepth}/{estart} min={mint}"
+    if rng.random() < 0.4 and estart >= 1:                        # ExactOctreeSdf shards over random ranges of the emission order
+        from sdflib_amd import distributed as sdist
+        G3 = 8 ** estart
+        cuts = sorted(set([0, G3] + [int(c) for c in rng.integers(0, G3 + 1, int(rng.integers(1, 4)))]))
+        shards = [S.ExactShard(gm, box, edepth, estart, mint, (a_, b_)) for a_, b_ in zip(cuts, cuts[1:])]
+        offs = sdist.exact_offsets([(sh.info.num_nodes, sh.info.num_set_words, sh.info.num_mask_bytes) for sh in shards], G3)
+        parts = [dict(cells=sh.cells(), **sh.emit(*o)) for sh, o in zip(shards, offs)]
+        for name, x, y in zip(("nodes", "has", "sets", "masks"), ge.download(), sdist.assemble_exact(parts, G3)):
+            assert np.array_equal(x, y), f"exact shards {cuts}: {name}"
+        extra += f" exact-shards={len(shards)}"
+    return f"T={len(f)} cont={int(cont)} rule={rule} d={depth}/{start} words={len(ot.data())} exact d={edepth}/{estart} min={mint}{extra}"
 
 
 fails = 0; t00 = time.time()
