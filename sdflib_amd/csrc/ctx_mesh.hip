@@ -11,6 +11,8 @@
 // seam welding (:292-420) runs when sdfhip_mesh_create_ex is given the mesh bounding box (host planner weldSeams below);
 // otherwise single-owner edges keep the default (0,0,1).  They are counted in mesh->unmatchedEdges either way.
 #include "sdfhip_internal.h"
+#include <thread>
+#include <cmath>
 #include "dev_math.h"
 #include <hipcub/hipcub.hpp>
 #include <string.h>
@@ -89,23 +91,33 @@ __global__ void k_edge_pair(const uint64_t* __restrict__ key, const uint32_t* __
     }
 }
 
+// cosine of the corner angle of half-edge he = 3 t + k (corner k of triangle t), clamped: the argument of the reference's acos
+// (TriangleUtils.cpp:85-86).  The arc cosine itself is taken on the HOST, by the platform's libm — the very function the
+// reference calls: libm's acosf is not correctly rounded, so no device implementation can promise its bits (ocml's differs in
+// the last ulp for some arguments), and one ulp in a vertex pseudonormal flips the sign of a sample that lies in the plane
+// spanned by it.  12 B per triangle each way; the host works while the device sorts the half-edges.
+__global__ void k_corner_cos(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numHalfEdges, float* __restrict__ cs) {
+    const uint32_t he = blockIdx.x * blockDim.x + threadIdx.x;
+    if (he >= numHalfEdges) return;
+    const uint32_t t = he / 3, k = he - 3 * t;
+    const uint32_t a = idx[he], b = idx[3 * t + (k + 1) % 3], c = idx[3 * t + (k + 2) % 3];
+    const F3 pa = F3{verts[3 * a], verts[3 * a + 1], verts[3 * a + 2]};
+    const F3 pb = F3{verts[3 * b], verts[3 * b + 1], verts[3 * b + 2]};
+    const F3 pc = F3{verts[3 * c], verts[3 * c + 1], verts[3 * c + 2]};
+    cs[he] = gclamp(dot(normalize(pb - pa), normalize(pc - pa)), -1.0f, 1.0f);
+}
+
 __global__ void k_vertex_normal_sum(const uint32_t* __restrict__ vkey, const uint32_t* __restrict__ val, uint32_t n,
-                                    const float* __restrict__ verts, const uint32_t* __restrict__ idx, const float* __restrict__ td,
+                                    const float* __restrict__ angle, const float* __restrict__ td,
                                     float* __restrict__ vnormal) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t v = vkey[i];
     if (i > 0 && vkey[i - 1] == v) return;       // only the head of a run works
     F3 acc = F3{0.f, 0.f, 0.f};
-    const F3 pa = F3{verts[3 * v], verts[3 * v + 1], verts[3 * v + 2]};
     for (uint32_t j = i; j < n && vkey[j] == v; j++) {
-        const uint32_t he = val[j], t = he / 3, k = he - 3 * t;
-        const uint32_t b = idx[3 * t + (k + 1) % 3], c = idx[3 * t + (k + 2) % 3];
-        const F3 pb = F3{verts[3 * b], verts[3 * b + 1], verts[3 * b + 2]};
-        const F3 pc = F3{verts[3 * c], verts[3 * c + 1], verts[3 * c + 2]};
-        const float cs = gclamp(dot(normalize(pb - pa), normalize(pc - pa)), -1.0f, 1.0f);
-        const float angle = acosf(cs);
-        acc = acc + angle * triNormal(td + (size_t)TD_FLOATS * t + 3);
+        const uint32_t he = val[j], t = he / 3;
+        acc = acc + angle[he] * triNormal(td + (size_t)TD_FLOATS * t + 3);
     }
     vnormal[3 * v] = acc.x; vnormal[3 * v + 1] = acc.y; vnormal[3 * v + 2] = acc.z;
 }
@@ -286,6 +298,12 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     SDF_HIP_CHECK(hipMemcpyAsync(m->dVerts.p, xyz, sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(m->dIdx.p, indices, sizeof(uint32_t) * nhe, hipMemcpyHostToDevice, st));
     k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
+    DevBuf<float> cornerAngle;
+    if ((rc = cornerAngle.reserve(nhe))) return fail(rc);
+    k_corner_cos<<<gridFor(nhe, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nhe, cornerAngle.p);
+    std::vector<float> hAngle(nhe);
+    SDF_HIP_CHECK(hipMemcpyAsync(hAngle.data(), cornerAngle.p, sizeof(float) * nhe, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
     if ((rc = packFrames(st, m->dTri.p, nt, m->dFrames.p))) return fail(rc);
 
     DevBuf<uint64_t> eKey, eKeyS; DevBuf<uint32_t> vKey, vKeyS, val, valS, valS2, counter; DevBuf<float> vnormal; DevBuf<unsigned char> tmp;
@@ -304,7 +322,20 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p, bbox6 ? openKey.p : nullptr, bbox6 ? openHe.p : nullptr);
     SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
     SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
-    k_vertex_normal_sum<<<gridFor(nhe, 256), 256, 0, st>>>(vKeyS.p, valS2.p, nhe, m->dVerts.p, m->dIdx.p, m->dTri.p, vnormal.p);
+    {   // the arc cosines, on host threads, while the device sorts (see k_corner_cos)
+        unsigned parts = (unsigned)(nhe / 65536u); const unsigned hc = std::thread::hardware_concurrency();
+        if (parts > (hc ? hc : 1u)) parts = hc ? hc : 1u;
+        if (parts > 64u) parts = 64u;
+        if (parts < 1u) parts = 1u;
+        float* a = hAngle.data();
+        auto work = [a](uint64_t i0, uint64_t i1) { for (uint64_t i = i0; i < i1; i++) a[i] = std::acos(a[i]); };
+        std::vector<std::thread> th;
+        for (unsigned q = 1; q < parts; q++) th.emplace_back(work, (uint64_t)nhe * q / parts, (uint64_t)nhe * (q + 1) / parts);
+        work(0, (uint64_t)nhe / parts);
+        for (std::thread& t : th) t.join();
+    }
+    SDF_HIP_CHECK(hipMemcpyAsync(cornerAngle.p, hAngle.data(), sizeof(float) * nhe, hipMemcpyHostToDevice, st));
+    k_vertex_normal_sum<<<gridFor(nhe, 256), 256, 0, st>>>(vKeyS.p, valS2.p, nhe, cornerAngle.p, m->dTri.p, vnormal.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(&m->unmatchedEdges, counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));

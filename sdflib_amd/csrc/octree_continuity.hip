@@ -298,6 +298,11 @@ __global__ void kc_compact_cand(const uint32_t* __restrict__ cand, const uint32_
     if (i < n && flag[i]) out[scan[i]] = cand[i];
 }
 __global__ void kc_mul8(uint32_t n, uint32_t* __restrict__ v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] *= 8u; }
+// the planner's mirror needs the WORDS of a level's nodes (8 topology words per 64-word payload block: 2 % of the array)
+__global__ void kc_gather_words(const uint32_t* __restrict__ idx, uint32_t n, const uint32_t* __restrict__ oc, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (idx[i] != NONE32) ? oc[idx[i]] : 0u;
+}
 __global__ void kc_patch(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t n, uint32_t* __restrict__ oc) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) oc[idx[i]] = val[i];
@@ -681,7 +686,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
     if (ctx->exchange.world >= 1 && ctx->exchange.acquire) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
-    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist;      // post-pass device buffers, grow-only
+    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist, wordVals; std::vector<uint32_t> hWordVals;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
         // write the same centres / coordinates again together with everything else — and take the root corners and all their
         // mid-point samples in ONE deduplicated batch instead of one latency-bound launch per level.
@@ -760,16 +765,19 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         SDF_HIP_CHECK(hipMemcpyAsync(L->hPath.data(), L->path.p, n, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->hNDepth.data(), L->nDepth.p, 6ull * n, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->hTerminal.data(), L->terminal.p, n, hipMemcpyDeviceToHost, st));
-        const size_t mirroredFrom = pl.hoc.size();
         SDF_REQUIRE(pl.hoc.grow(ocSize), "out of host memory");
-        // words of this level's nodes live in blocks appended by the previous level (or in the grid): re-read from there on
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
-        {
-            uint32_t lo = (uint32_t)mirroredFrom;
-            if (cd >= startDepth) for (uint32_t i = 0; i < n; i++) if (L->hWord[i] != NONE32 && L->hWord[i] < lo) lo = L->hWord[i];
-            SDF_HIP_CHECK(hipMemcpyAsync(pl.hoc.data() + lo, oc.p + lo, 4ull * (ocSize - lo), hipMemcpyDeviceToHost, st));
-            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        // The planner reads node WORDS only (leaf / mark bits, child indices) and only of nodes down to this level; the words of
+        // this level's nodes — written by kc_iter2_write into blocks appended by the previous level, or into the grid — are all
+        // that has changed on the device since the last mirror (the post-pass's own words are the host's: it uploads them as
+        // patches).  Gather them instead of copying the array region, 98 % of which is coefficient payload.
+        if (cd >= startDepth) {
+            SDF_TRY(wordVals.reserve(n));
+            kc_gather_words<<<gridFor(n, 256), 256, 0, st>>>(L->word.p, n, oc.p, wordVals.p);
+            hWordVals.resize(n);
+            SDF_HIP_CHECK(hipMemcpyAsync(hWordVals.data(), wordVals.p, 4ull * n, hipMemcpyDeviceToHost, st));
         }
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        if (cd >= startDepth) for (uint32_t i = 0; i < n; i++) if (L->hWord[i] != NONE32) pl.hoc[L->hWord[i]] = hWordVals[i];
         lap(tMirror);
         // The exact samples of the NEXT level depend only on its node centres, not on the post-pass below: enqueue them now so
         // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).

@@ -23,10 +23,8 @@ def small(oracle, gpu_ctx):
 def test_triangle_data_matches_oracle(small):
     a = small["om"].triangle_data()
     b = small["gm"].triangle_data()
-    # frames and edge pseudonormals: bit-exact
-    assert np.array_equal(bits(a[:, :28]), bits(b[:, :28]))
-    # vertex pseudonormals go through acosf (glibc vs ocml may differ in the last ulp): tolerance 1e-5
-    np.testing.assert_allclose(a[:, 28:], b[:, 28:], rtol=0, atol=1e-5)
+    # frames, edge pseudonormals AND vertex pseudonormals: bit-exact (the corner angles' acosf is the host libm's, as in the reference)
+    assert np.array_equal(bits(a), bits(b))
 
 
 def test_nearest_triangle_ids_bit_exact(small, oracle):
@@ -43,9 +41,7 @@ def test_point_values_match(small):
     ids = small["om"].nearest(pts)
     a = small["om"].point_values(pts, ids)
     b = small["gm"].point_values(pts, ids)
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
-    # everything except a possible sign decision through the vertex pseudonormal is bit-exact
-    assert (bits(a) == bits(b)).mean() > 0.999
+    assert np.array_equal(bits(a), bits(b))
 
 
 def test_tricubic_fit_bit_exact(oracle, gpu_ctx):
