@@ -78,7 +78,8 @@ struct ExactBuilder {
     V3 coordToId, minPoint;
     uint64_t cullTests = 0;
 
-    ExactBuilder(const MeshView& m, ExactOctreeData& o) : mesh(m), out(o) {}
+    const std::vector<TriangleData>* meshTd = nullptr;      // the mesh's TriangleData (calculateMeshTriangleData(mesh): welded when the mesh carries its box)
+    ExactBuilder(const MeshView& m, ExactOctreeData& o, const std::vector<TriangleData>* td = nullptr) : mesh(m), out(o), meshTd(td) {}
 
     struct Node { uint32_t nodeIndex; uint32_t depth; V3 center; float size; uint32_t vi[8]; };
 
@@ -215,7 +216,8 @@ struct ExactBuilder {
         out.box.max = inBox.center() + 0.5f * maxSize;
         out.startGridSize = 1 << startDepth; out.startGridXY = out.startGridSize * out.startGridSize; out.startDepth = startDepth;
         out.startGridCellSize = maxSize / (float)out.startGridSize;
-        out.triangles = meshTriangleData(mesh.vertices, mesh.numVertices, mesh.indices, mesh.numTriangles);
+        // ExactOctreeSdf.cpp:25: calculateMeshTriangleData(mesh) — the same call OctreeSdf makes, seam welding included
+        out.triangles = meshTd ? *meshTd : meshTriangleData(mesh.vertices, mesh.numVertices, mesh.indices, mesh.numTriangles);
         out.minTrianglesInLeafs = minTri;
         const uint32_t sod = startDepth < 1u ? startDepth : 1u;
         out.bitEncodingStartDepth = depth - 2;

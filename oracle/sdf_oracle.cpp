@@ -178,7 +178,7 @@ void orc_octree_query_raw(const uint32_t* data, uint64_t size, const float box6[
 
 orc_exact* orc_exact_build(orc_mesh* m, const float box6[6], uint32_t depth, uint32_t startDepth, uint32_t minTri, int cache) {
     orc_exact* e = new orc_exact();
-    ExactBuilder b(m->view(), e->d);
+    ExactBuilder b(m->view(), e->d, &m->td);
     b.run(ldbox(box6), depth, startDepth, minTri, cache != 0);
     e->cullTests = b.cullTests;
     return e;

@@ -16,8 +16,9 @@ ctx = S.Context(0)
 
 def random_mesh(rng):
     kind = rng.integers(0, 5)
-    if kind == 0: v, f = icosphere(int(rng.integers(0, 4)))
-    elif kind == 1: v, f = bumpy_icosphere(int(rng.integers(1, 4)))
+    big = rng.random() < 0.08
+    if kind == 0: v, f = icosphere(int(rng.integers(0, 4)) + (2 if big else 0))
+    elif kind == 1: v, f = bumpy_icosphere(int(rng.integers(1, 4)) + (2 if big else 0))
     elif kind == 2: v, f = cube_mesh()
     elif kind == 3:                                  # two components, one inside the other or apart
         a, fa = icosphere(int(rng.integers(1, 3)))
@@ -34,6 +35,10 @@ def random_mesh(rng):
     if rng.random() < 0.3 and len(f) > 4: f = f[rng.random(len(f)) > 0.2]                        # holes
     if rng.random() < 0.2 and len(f) > 2: f = np.concatenate([f, f[rng.integers(0, len(f), 2)]])  # coincident duplicates
     if rng.random() < 0.2: f = f[:, [0, 2, 1]]                                                    # flipped winding
+    if rng.random() < 0.1 and len(f) > 3:                                                         # degenerate triangles (repeated index / zero area)
+        bad = f[rng.integers(0, len(f), 2)].copy(); bad[:, 2] = bad[:, 1]; f = np.concatenate([f, bad])
+    if rng.random() < 0.3:                                                                        # extreme scales, far from the origin
+        sc = np.float32(10.0 ** rng.uniform(-3, 3)); v = (v * sc + sc * rng.normal(0, 1, 3).astype(np.float32) * np.float32(10.0 ** rng.uniform(0, 2.5))).astype(np.float32)
     return np.ascontiguousarray(v), np.ascontiguousarray(f.astype(np.uint32))
 
 
