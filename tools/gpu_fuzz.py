@@ -8,6 +8,7 @@ import sdflib_amd as S
 from oracle import pyoracle as O
 from sdflib_amd.meshgen import icosphere, bumpy_icosphere, cube_mesh, box_with_margin
 
+MODE = os.environ.get("FUZZ_MODE", "")      # "continuity": always the CONTINUITY builder, deeper trees; "exact": deeper ExactOctreeSdf; "big": larger meshes
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
@@ -16,7 +17,7 @@ ctx = S.Context(0)
 
 def random_mesh(rng):
     kind = rng.integers(0, 5)
-    big = rng.random() < 0.08
+    big = rng.random() < (0.5 if MODE == "big" else 0.08)
     if kind == 0: v, f = icosphere(int(rng.integers(0, 4)) + (2 if big else 0))
     elif kind == 1: v, f = bumpy_icosphere(int(rng.integers(1, 4)) + (2 if big else 0))
     elif kind == 2: v, f = cube_mesh()
@@ -58,11 +59,12 @@ def one(seed):
     size = float((box[3:] - box[:3]).max())
     pts = (box[:3] + rng.random((20000, 3), dtype=np.float32) * size * np.float32(1.2) - np.float32(0.1 * size)).astype(np.float32)
     assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts)), "nearest ids"
-    depth = int(rng.integers(2, 7)); start = int(rng.integers(0, min(depth, 3) + 1))
+    depth = int(rng.integers(4, 8) if MODE in ("continuity", "big") else rng.integers(2, 7)); start = int(rng.integers(0, min(depth, 3) + 1))
     rule = int(rng.choice([S.RULE_TRAPEZOIDAL, S.RULE_TRAPEZOIDAL, S.RULE_SIMPSONS, S.RULE_BY_DISTANCE, S.RULE_NONE]))
     if rule == S.RULE_NONE: depth = min(depth, 4)
     thr = float(10 ** rng.uniform(-4, -2)); decay = float(rng.uniform(0.0, 0.2))
-    cont = rng.random() < 0.4
+    cont = rng.random() < (1.0 if MODE == "continuity" else 0.4)
+    if depth == 7: thr = max(thr, 1e-3)           # keeps the single-threaded oracle build within seconds
     layout1 = rng.random() < 0.5
     ot = O.Octree(om, box, depth, start, thr, rule=rule, param1=decay, vertex_cache=False, layout=O.LAYOUT_GLOBAL_DFS if layout1 else O.LAYOUT_SUBTREES, continuity=cont)
     gt = S.OctreeSdf(gm, box, depth, start, thr, init_algorithm=S.ALG_CONTINUITY if cont else S.ALG_NO_CONTINUITY, num_threads=1 if layout1 else 2,
@@ -95,7 +97,7 @@ def one(seed):
         dg, gg = gt.get_distance_grid(org, st, nxyz, gradient=True); dp, gp = gt.get_distance(lp, gradient=True)
         assert np.array_equal(bits(dg), bits(dp)) and np.array_equal(bits(gg), bits(gp)), "lattice query"
         extra += " grid"
-    edepth = int(rng.integers(2, 6)); estart = int(rng.integers(0, min(edepth - 2, 2) + 1)); mint = int(rng.choice([1, 2, 8, 32, 128]))
+    edepth = int(rng.integers(4, 8) if MODE == "exact" else rng.integers(2, 6)); estart = int(rng.integers(0, min(edepth - 2, 2) + 1)); mint = int(rng.choice([1, 2, 8, 32, 128]))
     oe = O.Exact(om, box, edepth, estart, mint); ge = S.ExactOctreeSdf(gm, box, edepth, estart, mint)
     for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
         if name == "nodes": x, y = x[:, 0], y[:, 0]
