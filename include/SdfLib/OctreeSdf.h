@@ -150,7 +150,7 @@ private:
         mBox = BoundingBox(glm::vec3(info.box_min[0], info.box_min[1], info.box_min[2]), glm::vec3(info.box_max[0], info.box_max[1], info.box_max[2]));
         mValueRange = info.value_range; mMinBorderValue = info.min_border_value; mStartGridSize = info.start_grid_size;
         mStartGridXY = mStartGridSize * mStartGridSize; mMaxDepth = info.max_depth;
-        mStartGridCellSize = (mBox.max.x - mBox.min.x) / static_cast<float>(mStartGridSize);
+        mStartGridCellSize = info.start_grid_cell_size;      // built: largest extent of the INPUT box / grid size (OctreeSdf.cpp:43-52), not the stored box's
         mOctreeData.resize(info.num_words);
         detail::check(sdfhip_octree_download(mTree, reinterpret_cast<uint32_t*>(mOctreeData.data()), SDFHIP_HOST));
     }

@@ -164,6 +164,9 @@ typedef struct sdfhip_octree_info {
     uint64_t fit_rechecks;          /* FIT_MFMA: nodes whose decision was re-evaluated with the reference-ordered fit */
     uint64_t num_traversals;        /* BVH traversals actually run (samples sharing a lattice point AND position bits share one) */
     uint64_t post_pass_scheduled;   /* CONTINUITY: leaves Iter 2 scheduled for re-subdivision (OctreeSdfBreadthFirstNoDelay.h:506-512) */
+    float start_grid_cell_size;     /* mStartGridCellSize: a BUILT tree takes it from the input box's largest extent (OctreeSdf.cpp:43-52),
+                                       a LOADED one from the stored box (OctreeSdf.h:233); far from the origin the two differ in the last bit */
+    float reserved0;
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {
@@ -194,6 +197,9 @@ int sdfhip_octree_emit_shard(sdfhip_octree* tree, uint64_t body_offset, uint32_t
 int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num_words, int where, const float box_min[3],
                             const float box_max[3], int32_t start_grid_size, uint32_t max_depth, float value_range,
                             float min_border_value, sdfhip_octree** out);
+/* A tree reassembled from the shards of a BUILD answers like the built tree only with the build's cell size (info.start_grid_cell_size
+ * of any shard); sdfhip_octree_from_data alone gives it the loaded tree's. */
+int sdfhip_octree_set_start_grid_cell_size(sdfhip_octree* tree, float cell_size);
 int sdfhip_octree_destroy(sdfhip_octree* tree);
 int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out);
 /* copy the node array (getOctreeData(): u32 words, leaf bit31, 64 float coefficients per leaf) */
@@ -215,6 +221,8 @@ typedef struct sdfhip_exact_info {
     uint64_t num_nodes, num_set_words, num_mask_bytes, num_triangles;
     uint64_t cull_tests;            /* IsNearMinimize evaluations during the build */
     double seconds_total;
+    float start_grid_cell_size;     /* as in sdfhip_octree_info; sdfhip_exact_from_parts uses it when > 0, sdfhip_exact_from_data never */
+    float reserved0;
 } sdfhip_exact_info;
 
 int sdfhip_exact_build(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_min[3], const float box_max[3], uint32_t max_depth,

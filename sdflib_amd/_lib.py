@@ -22,7 +22,7 @@ class OctreeInfo(C.Structure):
                 ("num_nodes", C.c_uint64), ("num_samples", C.c_uint64), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32),
                 ("body_words", C.c_uint64), ("body_offset", C.c_uint64), ("seconds_samples", C.c_double), ("seconds_decide", C.c_double),
                 ("seconds_total", C.c_double), ("leaves_per_depth", C.c_uint64 * 16), ("fit_rechecks", C.c_uint64), ("num_traversals", C.c_uint64),
-                ("post_pass_scheduled", C.c_uint64)]
+                ("post_pass_scheduled", C.c_uint64), ("start_grid_cell_size", C.c_float), ("reserved0", C.c_float)]
 
 
 class OctreeParams(C.Structure):
@@ -36,7 +36,8 @@ class ExactInfo(C.Structure):
                 ("max_depth", C.c_uint32), ("bit_encoding_start_depth", C.c_uint32), ("bits_per_index", C.c_uint32),
                 ("min_triangles_in_leafs", C.c_uint32), ("max_triangles_in_leafs", C.c_uint32),
                 ("max_triangles_encoded_in_leafs", C.c_uint32), ("num_nodes", C.c_uint64), ("num_set_words", C.c_uint64),
-                ("num_mask_bytes", C.c_uint64), ("num_triangles", C.c_uint64), ("cull_tests", C.c_uint64), ("seconds_total", C.c_double)]
+                ("num_mask_bytes", C.c_uint64), ("num_triangles", C.c_uint64), ("cull_tests", C.c_uint64), ("seconds_total", C.c_double),
+                ("start_grid_cell_size", C.c_float), ("reserved0", C.c_float)]
 
 
 ACQUIRE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
@@ -72,6 +73,7 @@ SIGNATURES = {
     "sdfhip_octree_build_shard": (_int, [_vp, _vp, C.POINTER(OctreeParams), C.POINTER(_vp)]),
     "sdfhip_octree_emit_shard": (_int, [_vp, _u64, _vp, _vp, _int]),
     "sdfhip_octree_from_data": (_int, [_vp, _vp, _u64, _int, _vp, _vp, _i32, _u32, _f32, _f32, C.POINTER(_vp)]),
+    "sdfhip_octree_set_start_grid_cell_size": (_int, [_vp, _f32]),
     "sdfhip_octree_destroy": (_int, [_vp]),
     "sdfhip_octree_get_info": (_int, [_vp, C.POINTER(OctreeInfo)]),
     "sdfhip_octree_download": (_int, [_vp, _vp, _int]),

@@ -184,7 +184,9 @@ class OctreeSdf:
         self._info = None
 
     @classmethod
-    def from_data(cls, ctx, words, box_min, box_max, start_grid_size, max_depth, value_range, min_border_value, where=HOST):
+    def from_data(cls, ctx, words, box_min, box_max, start_grid_size, max_depth, value_range, min_border_value, where=HOST, cell_size=None):
+        """Wrap a node array.  Without ``cell_size`` the tree behaves like a LOADED one (cell size from the box, OctreeSdf.h:233);
+        reassembled shards of a build pass the build's (info.start_grid_cell_size), see sdfhip.h."""
         h = C.c_void_p()
         bmin, bmax = _np(box_min, np.float32), _np(box_max, np.float32)
         if where == HOST:
@@ -195,6 +197,8 @@ class OctreeSdf:
         check(lib().sdfhip_octree_from_data(ctx.h, ptr, n, where, _ptr(bmin), _ptr(bmax), int(start_grid_size), int(max_depth),
                                             float(value_range), float(min_border_value), C.byref(h)))
         if where != HOST: ctx._torch_outputs_ready()       # the words are copied on the engine's stream
+        if cell_size is not None:
+            check(lib().sdfhip_octree_set_start_grid_cell_size(h, float(cell_size)))
         return cls(_handle=h, _ctx=ctx)
 
     def close(self):

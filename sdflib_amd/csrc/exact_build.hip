@@ -608,7 +608,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     I.start_grid_size = (int32_t)G; I.start_depth = startDepth; I.max_depth = maxDepth;
     I.bit_encoding_start_depth = maxDepth - 2; I.min_triangles_in_leafs = minTri; I.num_triangles = mesh->numTriangles;
     I.bits_per_index = (uint32_t)(int32_t)std::ceil(std::log2((float)mesh->numTriangles));
-    E->cellSize = maxSize / (float)G;
+    E->cellSize = maxSize / (float)G; I.start_grid_cell_size = E->cellSize;
     const uint32_t bitEnc = maxDepth - 2, bits = I.bits_per_index;
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     const uint32_t T = mesh->numTriangles;

@@ -315,6 +315,7 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
     E->ctx = ctx; E->info = *info;
     E->cellSize = (info->box_max[0] - info->box_min[0]) / (float)info->start_grid_size;     // load(): mBox.getSize().x / mStartGridSize
+    E->info.start_grid_cell_size = E->cellSize;
     SDF_TRY(E->nodes.reserve(2 * info->num_nodes)); SDF_TRY(E->hasTri.reserve(info->num_nodes));
     SDF_TRY(E->sets.reserve(info->num_set_words + 2)); SDF_TRY(E->masks.reserve(info->num_mask_bytes + 1)); SDF_TRY(E->ownTri.reserve((size_t)TD_FLOATS * info->num_triangles));
     SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 1, info->num_nodes, st));
@@ -344,7 +345,9 @@ int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exa
     const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
     E->ctx = ctx; E->mesh = mesh; E->info = *info;
-    E->cellSize = (info->box_max[0] - info->box_min[0]) / (float)info->start_grid_size;
+    // parts of a BUILD carry the build's cell size; without it the loaded tree's (ExactOctreeSdf.h load())
+    E->cellSize = info->start_grid_cell_size > 0.f ? info->start_grid_cell_size : (info->box_max[0] - info->box_min[0]) / (float)info->start_grid_size;
+    E->info.start_grid_cell_size = E->cellSize;
     SDF_TRY(E->nodes.reserve(2 * info->num_nodes)); SDF_TRY(E->hasTri.reserve(info->num_nodes));
     SDF_TRY(E->sets.reserve(info->num_set_words + 2)); SDF_TRY(E->masks.reserve(info->num_mask_bytes + 1));
     SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4 * (info->num_set_words + 2), st));

@@ -298,7 +298,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     float bmax[3] = {cx + 0.5f * maxSize, cy + 0.5f * maxSize, cz + 0.5f * maxSize};
     memcpy(T->info.box_min, bmin, 12); memcpy(T->info.box_max, bmax, 12);
     T->info.start_grid_size = (int32_t)G; T->info.max_depth = maxDepth;
-    T->cellSize = maxSize / (float)G;
+    T->cellSize = maxSize / (float)G; T->info.start_grid_cell_size = T->cellSize;
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     T->startOctreeDepth = sod;
 
@@ -598,11 +598,20 @@ int sdfhip_octree_from_data(sdfhip_ctx* ctx, const uint32_t* words, uint64_t num
     T->info.start_grid_size = start_grid_size; T->info.max_depth = max_depth;
     T->info.value_range = value_range; T->info.min_border_value = min_border_value; T->info.num_words = num_words;
     T->cellSize = (box_max[0] - box_min[0]) / (float)start_grid_size;       // load(): mBox.getSize().x / mStartGridSize (OctreeSdf.h:232)
+    T->info.start_grid_cell_size = T->cellSize;
     SDF_TRY(T->data.reserve(num_words));
     SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, words, 4ull * num_words, where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     SDF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     T->hasData = true;
     *out = T.release();
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_octree_set_start_grid_cell_size(sdfhip_octree* tree, float cell_size) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(tree && cell_size > 0.f, "bad argument");
+    tree->cellSize = cell_size; tree->info.start_grid_cell_size = cell_size;
     return SDFHIP_OK;
     SDF_API_END
 }

@@ -612,7 +612,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};
     float bmax[3] = {cx + 0.5f * maxSize, cy + 0.5f * maxSize, cz + 0.5f * maxSize};
     memcpy(T->info.box_min, bmin, 12); memcpy(T->info.box_max, bmax, 12);
-    T->info.start_grid_size = G; T->info.max_depth = maxDepth; T->cellSize = maxSize / (float)G;
+    T->info.start_grid_size = G; T->info.max_depth = maxDepth; T->cellSize = maxSize / (float)G; T->info.start_grid_cell_size = T->cellSize;
     const uint32_t sod = startDepth < 1u ? startDepth : 1u;
     const float thr = P->rule_params[0], sqThr = thr * thr, param1 = P->rule_params[1];
     CMesh md{meshBvh(mesh), mesh->dVerts.p, mesh->dIdx.p, mesh->dTri.p};

@@ -128,7 +128,7 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     tree = api.OctreeSdf.from_data(mesh.ctx, full, info.box_min, info.box_max, info.start_grid_size, info.max_depth,
-                                   float(stats[0].item()), float(-stats[1].item()), where=api.DEVICE)
+                                   float(stats[0].item()), float(-stats[1].item()), where=api.DEVICE, cell_size=info.start_grid_cell_size)
     tree._override = {"leaves_per_depth": [int(x) for x in lpd.cpu().tolist()], "num_leaves": int(cnt[0]), "num_nodes": int(cnt[1]), "num_traversals": int(cnt[3]),
                       "num_samples": int(cnt[2])}
     shard.close()
@@ -315,7 +315,7 @@ def broadcast_octree(tree, ctx, dev, src=0, group=None):
     head = torch.zeros(12, dtype=torch.float64, device=cdev)
     if rank == src:
         i = tree.info
-        head = torch.tensor(list(i.box_min) + list(i.box_max) + [i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, i.num_words, 0],
+        head = torch.tensor(list(i.box_min) + list(i.box_max) + [i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, i.num_words, i.start_grid_cell_size],
                             dtype=torch.float64, device=cdev)
     dist.broadcast(head, src, group=group)
     h = head.cpu().tolist()
@@ -328,7 +328,7 @@ def broadcast_octree(tree, ctx, dev, src=0, group=None):
     if rank == src:
         return tree
     return api.OctreeSdf.from_data(ctx, words.to(dev), np.float32(h[0:3]), np.float32(h[3:6]), int(h[6]), int(h[7]), float(np.float32(h[8])), float(np.float32(h[9])),
-                                   where=api.DEVICE)
+                                   where=api.DEVICE, cell_size=float(np.float32(h[11])))      # answers like rank src's tree, built or loaded
 
 
 def query_range(n, rank, world):

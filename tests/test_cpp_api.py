@@ -79,3 +79,66 @@ def test_cpp_host_drives_the_sharded_build(tmp_path):
         r = subprocess.run([exe, p("v.bin"), p("f.bin"), p("box.bin"), str(ranks)], capture_output=True, text=True)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "sharded-vs-single mismatches 0 value_range_equal 1 min_border_equal 1" in r.stdout and "query_equal 1" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_built_tree_keeps_the_builds_cell_size_far_from_the_origin(tmp_path, oracle):
+    """mStartGridCellSize of a BUILT tree is the input box's largest extent / grid size (OctreeSdf.cpp:43-52); a LOADED tree derives
+    it from the stored box (OctreeSdf.h:233).  Far from the origin the two differ in the last bit.  The C++ class's host-side
+    scalar getDistance, the batched device query, trees reassembled from shards and broadcast trees must all use the build's;
+    a loaded tree the stored box's — as the reference does.  (Found by tools/gpu_fuzz.py.)"""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+    _compile()
+    v0, f = bumpy_icosphere(2)
+    f32 = np.float32
+    rng = np.random.default_rng(4)
+    for _ in range(200):        # an offset for which the cube-ified box's stored extent and the input box's largest extent differ in fp32
+        v = (v0 + (rng.normal(0, 20, 3)).astype(f32)).astype(f32)
+        box = box_with_margin(v)
+        size = (box[3:] - box[:3]).astype(f32); mx = f32(size.max())
+        center = (box[:3] + f32(0.5) * size).astype(f32)
+        lo, hi = (center - f32(0.5) * mx).astype(f32), (center + f32(0.5) * mx).astype(f32)
+        if f32(hi[0] - lo[0]) / f32(4) != mx / f32(4):
+            break
+    gm = S.Mesh(v, f)
+    single = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    i = single.info
+    stored = np.float32(i.box_max[0] - i.box_min[0]) / np.float32(i.start_grid_size)
+    assert np.float32(i.start_grid_cell_size) != stored, "pick an offset where the two cell sizes differ, or this test checks nothing"
+    pts = random_points_in_box(box, 40000, seed=5)
+    d = single.get_distance(pts)
+    om = oracle.Mesh(v, f)
+    assert np.array_equal(bits(d), bits(oracle.Octree(om, box, 5, 2, 1e-3).query(pts)))
+    # shards of the build, reassembled by hand
+    shards = [S.OctreeShard(gm, box, 5, 2, 1e-3, cells=c) for c in ((0, 30), (30, 64))]
+    out = np.zeros(64 + sum(int(s.info.body_words) for s in shards), dtype=np.uint32); off = 64
+    for s, c in zip(shards, ((0, 30), (30, 64))):
+        grid = np.zeros(c[1] - c[0], dtype=np.uint32); body = np.zeros(int(s.info.body_words), dtype=np.uint32)
+        s.emit(off, grid, body); out[c[0]:c[1]] = grid; out[off:off + len(body)] = body; off += len(body)
+    re = S.OctreeSdf.from_data(gm.ctx, out, i.box_min, i.box_max, i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, cell_size=shards[0].info.start_grid_cell_size)
+    assert np.array_equal(bits(re.get_distance(pts)), bits(d))
+    # a loaded tree: the stored box's cell size, like the reference's load()
+    path = os.path.join(tmp_path, "t.bin"); single.save_to_file(path)
+    raw = oracle.octree_query_raw(single.get_octree_data(), single.get_grid_bounding_box(), i.start_grid_size, i.min_border_value, pts)
+    dl = S.load_from_file(path, gm.ctx).get_distance(pts)
+    assert np.array_equal(bits(dl), bits(raw)) and not np.array_equal(bits(dl), bits(d))
+    # ExactOctreeSdf: shards of a build keep the build's cell size through from_parts
+    from sdflib_amd import distributed as sdist
+    ex = S.ExactOctreeSdf(gm, box, 4, 1, 8)
+    es = [S.ExactShard(gm, box, 4, 1, 8, c) for c in ((0, 3), (3, 8))]
+    offs = sdist.exact_offsets([(s.info.num_nodes, s.info.num_set_words, s.info.num_mask_bytes) for s in es], 8)
+    nodes, has, sets, masks = sdist.assemble_exact([dict(cells=s.cells(), **s.emit(*o)) for s, o in zip(es, offs)], 8)
+    full = S.api.ExactInfo.from_buffer_copy(es[0].info)
+    full.num_nodes, full.num_set_words, full.num_mask_bytes = len(nodes), len(sets), len(masks)
+    full.max_triangles_in_leafs = max(s.info.max_triangles_in_leafs for s in es); full.max_triangles_encoded_in_leafs = max(s.info.max_triangles_encoded_in_leafs for s in es)
+    ep = S.ExactOctreeSdf.from_parts(gm, full, nodes, has, sets, masks)
+    assert np.array_equal(bits(ep.get_distance(pts)), bits(ex.get_distance(pts)))
+    assert np.array_equal(bits(ex.get_distance(pts)), bits(oracle.Exact(om, box, 4, 1, 8).query(pts)))
+    # the C++ class: scalar (host) getDistance == batched (device) getDistances on a built object, and the reloaded object differs
+    p = lambda n: os.path.join(tmp_path, n)
+    v.tofile(p("v.bin")); f.tofile(p("f.bin")); pts[:5000].tofile(p("p.bin"))
+    r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin"), p("oct.bin"), p("exact.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "octree scalar-vs-batched mismatches 0" in r.stdout, r.stdout
+    assert "reloaded-vs-built mismatches" in r.stdout and "reloaded-vs-built mismatches 0" not in r.stdout, r.stdout      # loaded != built here, as in the reference

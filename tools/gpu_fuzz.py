@@ -90,6 +90,23 @@ def one(seed):
         a_, b_ = ot.data(), mt.get_octree_data()
         assert a_.shape == b_.shape, "FIT_MFMA tree size"
         extra += " mfma"
+    if rng.random() < 0.3:                                        # separable-Horner evaluation stays within 1e-5 of the literal order (at the tree's scale)
+        df = gt.get_distance(pts, eval_mode=S.EVAL_FAST)
+        scale = max(1.0, float(gt.info.value_range))
+        err = float(np.nanmax(np.abs(df - d1))) if len(d1) else 0.0
+        assert err <= 3e-5 * scale, f"EVAL_FAST error {err:g} at value range {scale:g}"
+        extra += " fast"
+    if rng.random() < 0.15:                                       # the reference's .bin layout: save, load, same words and answers
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmpd:
+            path = os.path.join(tmpd, "t.bin")
+            gt.save_to_file(path)
+            lt = S.load_from_file(path, ctx)
+            # a LOADED tree takes its cell size from the stored box (OctreeSdf.h:233), a built one from the input box's largest extent
+            # (OctreeSdf.cpp:43-50): far from the origin the two differ in the last bit, in the reference as here
+            raw = O.octree_query_raw(gt.get_octree_data(), gt.get_grid_bounding_box(), gt.info.start_grid_size, gt.info.min_border_value, pts)
+            assert np.array_equal(lt.get_octree_data(), gt.get_octree_data()) and np.array_equal(bits(lt.get_distance(pts)), bits(raw)), "octree save/load"
+        extra += " bin"
     if rng.random() < 0.3:                                        # lattice query == point query
         nxyz = tuple(int(x) for x in rng.integers(1, 20, 3)); org = (box[:3] - np.float32(0.05 * size)).astype(np.float32); st = (rng.uniform(0.01, 0.1, 3) * size).astype(np.float32)
         gi = np.stack(np.meshgrid(np.arange(nxyz[2]), np.arange(nxyz[1]), np.arange(nxyz[0]), indexing="ij"), -1).reshape(-1, 3)[:, ::-1].astype(np.float32)
