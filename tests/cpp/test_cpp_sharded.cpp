@@ -57,6 +57,7 @@ int main(int argc, char** argv) {
     }
     sdfhip_octree* tree = nullptr;
     CHECK(sdfhip_octree_from_data(ctx, full.data(), total, SDFHIP_HOST, si.box_min, si.box_max, si.start_grid_size, si.max_depth, valueRange, minBorder, &tree));
+    CHECK(sdfhip_octree_set_start_grid_cell_size(tree, info[0].start_grid_cell_size));      // a BUILT tree's cell size, not a loaded one's (sdfhip.h)
 
     size_t mism = (total != expect.size()) ? (size_t)-1 : 0;
     if (!mism) for (size_t i = 0; i < total; i++) mism += full[i] != expect[i];
