@@ -84,6 +84,9 @@ def one(seed):
             nb = int(sh.info.body_words); grid = np.zeros(b_ - a_, dtype=np.uint32); body = np.zeros(max(nb, 1), dtype=np.uint32)
             sh.emit(off, grid, body); out[a_:b_] = grid; out[off:off + nb] = body[:nb]; off += nb
         assert np.array_equal(out, ot.data()), f"octree shards {cuts}"
+        gi_ = gt.info
+        re_ = S.OctreeSdf.from_data(ctx, out, gi_.box_min, gi_.box_max, gi_.start_grid_size, gi_.max_depth, gi_.value_range, gi_.min_border_value, cell_size=shards[0].info.start_grid_cell_size)
+        assert np.array_equal(bits(re_.get_distance(pts)), bits(d1)), "reassembled shards answer like the built tree"
         extra += f" shards={len(shards)}"
     if not cont and rng.random() < 0.3:                           # MFMA fit: same topology as the exact fit
         mt = S.OctreeSdf(gm, box, depth, start, thr, num_threads=1 if layout1 else 2, termination_rule=rule, rule_params=(thr, decay), fit_mode=S.FIT_MFMA)
@@ -132,6 +135,22 @@ def one(seed):
         for name, x, y in zip(("nodes", "has", "sets", "masks"), ge.download(), sdist.assemble_exact(parts, G3)):
             assert np.array_equal(x, y), f"exact shards {cuts}: {name}"
         extra += f" exact-shards={len(shards)}"
+    if rng.random() < 0.15:                                       # ExactOctreeSdf .bin round trip: arrays kept; answers = the oracle's for the stored box
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmpd:
+            path = os.path.join(tmpd, "e.bin")
+            ge.save_to_file(path, gm)
+            le = S.load_from_file(path, ctx)
+            for name, x, y in zip(("nodes", "has", "sets", "masks"), ge.download(), le.download()):
+                if name == "has": continue
+                if name == "nodes": x, y = x[:, 0], y[:, 0]
+                assert np.array_equal(x, y), f"exact save/load {name}"
+            dl_ = le.get_distance(pts)
+            same = np.array_equal(bits(dl_), bits(e1))
+            gi_ = ge.info
+            stored_cell = np.float32(gi_.box_max[0] - gi_.box_min[0]) / np.float32(gi_.start_grid_size)
+            assert same or stored_cell != np.float32(gi_.start_grid_cell_size), "exact save/load answers"
+        extra += " ebin"
     return f"T={len(f)} cont={int(cont)} rule={rule} d={depth}/{start} words={len(ot.data())} exact d={edepth}/{estart} min={mint}{extra}"
 
 
