@@ -284,6 +284,8 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
     for (uint64_t i = 0; i < 3ull * nt; i++) SDF_REQUIRE(indices[i] < nv, "triangle index out of range");
+    // NaN / infinite coordinates make the reference's std::sort comparator inconsistent (undefined behaviour): rejected here
+    for (uint64_t i = 0; i < 3ull * nv; i++) SDF_REQUIRE(std::isfinite(xyz[i]), "non-finite vertex coordinate");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     sdfhip_mesh* m = new sdfhip_mesh();
     m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;

@@ -597,7 +597,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
     E->ctx = ctx; E->mesh = mesh;
     const float sx = box_max[0] - box_min[0], sy = box_max[1] - box_min[1], sz = box_max[2] - box_min[2];
-    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0, "empty box");
+    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0 && std::isfinite(sx) && std::isfinite(sy) && std::isfinite(sz), "empty or non-finite box");
     const float maxSize = gmax(gmax(sx, sy), sz);
     const float cx = box_min[0] + 0.5f * sx, cy = box_min[1] + 0.5f * sy, cz = box_min[2] + 0.5f * sz;
     float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};

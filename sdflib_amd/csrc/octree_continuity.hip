@@ -606,7 +606,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     std::unique_ptr<sdfhip_octree> T(new sdfhip_octree());
     T->ctx = ctx; T->params = *P;
     const float sx = P->box_max[0] - P->box_min[0], sy = P->box_max[1] - P->box_min[1], sz = P->box_max[2] - P->box_min[2];
-    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0, "empty box");
+    SDF_REQUIRE(sx > 0 && sy > 0 && sz > 0 && std::isfinite(sx) && std::isfinite(sy) && std::isfinite(sz), "empty or non-finite box");
     const float maxSize = gmax(gmax(sx, sy), sz);
     const float cx = P->box_min[0] + 0.5f * sx, cy = P->box_min[1] + 0.5f * sy, cz = P->box_min[2] + 0.5f * sz;
     float bmin[3] = {cx - 0.5f * maxSize, cy - 0.5f * maxSize, cz - 0.5f * maxSize};

@@ -286,6 +286,24 @@ def test_edge_cases_and_error_codes(small, gpu_ctx):
     bad = small["box"].copy(); bad[3] = bad[0]
     with pytest.raises(S.SdfHipError):
         S.OctreeSdf(small["gm"], bad, 4, 2, 1e-3)                                # empty box
+    nanbox = small["box"].copy(); nanbox[1] = np.nan
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], nanbox, 4, 2, 1e-3)                             # NaN box
+    with pytest.raises(S.SdfHipError):
+        S.ExactOctreeSdf(small["gm"], nanbox, 4, 1, 16)
+    vn = small["v"].copy(); vn[3, 1] = np.inf
+    with pytest.raises(S.SdfHipError):
+        S.Mesh(vn, small["f"], gpu_ctx)                                          # non-finite vertex
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3)                      # depth beyond the 10-bit lattice coordinates
+    with pytest.raises(S.SdfHipError):
+        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, termination_rule=7)   # unknown rule
+    # NaN / infinite query points are answered (NaN in, NaN or the box distance out), never a fault
+    q = np.array([[np.nan, 0, 0], [np.inf, 0, 0], [0, -np.inf, 0], [1e30, 1e30, 1e30]], np.float32)
+    out = t.get_distance(q, gradient=True)
+    assert len(out[0]) == 4
+    e = S.ExactOctreeSdf(small["gm"], small["box"], 4, 1, 16)
+    assert len(e.get_distance(q)) == 4
 
 
 def test_seam_welding_matches_oracle(oracle, gpu_ctx):
