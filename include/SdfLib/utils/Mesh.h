@@ -77,12 +77,14 @@ inline bool readPly(std::istream& is, std::vector<glm::vec3>& vertices, std::vec
             ls >> p.name; elements.back().props.push_back(p);
         } else if (tag == "end_header") break;
     }
-    if (format != "ascii" && format != "binary_little_endian") return false;
-    const bool ascii = format == "ascii";
+    if (format != "ascii" && format != "binary_little_endian" && format != "binary_big_endian") return false;
+    const bool ascii = format == "ascii", swapBytes = format == "binary_big_endian";      // hosts are little-endian (x86-64)
     std::vector<char> buf;
     auto readScalar = [&](const std::string& t) -> double {
         if (ascii) { double v = 0; is >> v; return v; }
-        const size_t n = plyTypeSize(t); buf.resize(8); is.read(buf.data(), (std::streamsize)n); return plyScalar(buf.data(), t);
+        const size_t n = plyTypeSize(t); buf.resize(8); is.read(buf.data(), (std::streamsize)n);
+        if (swapBytes) for (size_t a = 0, b = n ? n - 1 : 0; a < b; a++, b--) std::swap(buf[a], buf[b]);
+        return plyScalar(buf.data(), t);
     };
     for (const Element& e : elements) {
         for (size_t i = 0; i < e.count; i++) {
