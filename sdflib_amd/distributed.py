@@ -22,7 +22,9 @@ from . import _lib
 
 def partition_cells(num_cells, world, weights=None):
     """Contiguous ranges [(begin, end)] * world covering [0, num_cells), balanced by `weights` (>= 1 cell each)."""
-    assert 1 <= world <= num_cells
+    if not 1 <= world <= num_cells:
+        raise ValueError(f"{world} ranks cannot share {num_cells} start-grid cells: the build shards by start cell (8^start_depth of them); "
+                         "use a larger start_depth or fewer ranks")
     if weights is None:
         weights = np.ones(num_cells, dtype=np.float64)
     w = np.asarray(weights, dtype=np.float64) + 1e-9

@@ -27,6 +27,13 @@ def test_partition_cells_covers_everything():
     assert max(loads) < 1.6 * (sum(loads) / 4)
 
 
+def test_more_ranks_than_cells_is_a_clear_error():
+    from sdflib_amd.distributed import partition_cells
+    with pytest.raises(ValueError, match="start_depth"):
+        partition_cells(1, 2)
+    assert partition_cells(8, 8) == [(i, i + 1) for i in range(8)]
+
+
 def _subtree_words(data, root_word):
     """number of words of the body hanging under a start-grid word (block + descendants)"""
     if root_word & 0x80000000:
