@@ -87,7 +87,9 @@ const char* sdfhip_version(void);
 /* sizeof(sdfhip_octree_info), sizeof(sdfhip_octree_params), sizeof(sdfhip_exact_info): lets a binding verify its struct mirrors */
 void sdfhip_abi_sizes(uint64_t out[3]);
 
-/* One context per (process, device).
+/* One context per (process, device).  Thread safety: queries on finished trees may come from any number of host threads at once;
+ * builds (mesh preparation, BVH, octrees) issued on one context from several threads are serialised by the context;
+ * sdfhip_last_error() is thread-local.
  * stream_mode SDFHIP_STREAM_PRIVATE: the context creates its own non-blocking stream (`stream` ignored).
  * stream_mode SDFHIP_STREAM_BORROWED: run on the caller's hipStream_t `stream` (e.g. torch's current stream);
  *                                     NULL then means the device's default (null) stream. */

@@ -292,6 +292,8 @@ extern "C" {
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_API_BEGIN
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
+    std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
+    if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
     const uint32_t T = mesh->numTriangles;

@@ -281,6 +281,7 @@ int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uin
 int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, const float* bbox6, sdfhip_mesh** out) {
     SDF_API_BEGIN
     SDF_REQUIRE(ctx && xyz && indices && out, "NULL argument");
+    std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
     for (uint64_t i = 0; i < 3ull * nt; i++) SDF_REQUIRE(indices[i] < nv, "triangle index out of range");

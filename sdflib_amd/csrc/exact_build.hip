@@ -587,6 +587,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
                           uint32_t minTri, const uint32_t* rankRange, sdfhip_exact** out) {
     SDF_REQUIRE(ctx && mesh && box_min && box_max && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
+    std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
     SDF_REQUIRE(maxDepth >= 2 && maxDepth <= 10, "max_depth must be in [2,10]");
     SDF_REQUIRE(startDepth + 2 <= maxDepth, "start_depth must be <= max_depth - 2 (the reference dereferences a null node otherwise)");
     SDF_REQUIRE(mesh->numTriangles >= 2, "at least 2 triangles are needed (bits per index)");

@@ -264,6 +264,7 @@ static uint32_t dfsRankOfCell(uint32_t x, uint32_t y, uint32_t z, uint32_t start
 static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, bool shardOnly, sdfhip_octree** out) {
     SDF_REQUIRE(ctx && mesh && P && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
+    std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
     if (P->algorithm == SDFHIP_ALG_CONTINUITY) {
         SDF_REQUIRE(!shardOnly, "the CONTINUITY builder is not sharded (Iter 2 couples neighbouring start cells)");
         return continuityBuildImpl(ctx, mesh, P, out);

@@ -125,6 +125,9 @@ struct sdfhip_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     hipDeviceProp_t prop;
+    // Builds (mesh preparation, BVH, octrees) on one context run one at a time: they share the stream-ordered allocator's scope and,
+    // with an exchange installed, must stay in collective order.  Queries take no part in this and run concurrently.
+    std::recursive_mutex buildLock;
     sdfhip_exchange exchange{};           // world >= 1: the CONTINUITY build shares out its traversals (sdfhip.h)
 };
 

@@ -554,3 +554,37 @@ print("chunks ok")
     env = dict(os.environ, SDFHIP_QUERY_CHUNK="16411")          # 3 chunks, the last one ragged; >= 16384 so the sorted exact path runs too
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "chunks ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_concurrent_builds_on_one_context_are_serialised(small, oracle):
+    """Three host threads build an OctreeSdf, a CONTINUITY OctreeSdf and an ExactOctreeSdf on the SAME context while a fourth
+    queries an existing tree: builds take the context's build lock one at a time, queries do not wait for it; every result equals
+    the sequential one."""
+    import threading
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gm, box = small["gm"], small["box"]
+    pts = random_points_in_box(box, 50000, seed=2)
+    ref = dict(a=S.OctreeSdf(gm, box, 6, 3, 1e-3).get_octree_data(), b=S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY).get_octree_data(),
+               c=S.ExactOctreeSdf(gm, box, 5, 2, 16).download())
+    live = S.OctreeSdf(gm, box, 5, 2, 1e-3); want = live.get_distance(pts)
+    out, errors = {}, []
+
+    def run(name, fn):
+        try:
+            for _ in range(3):
+                out[name] = fn()
+        except Exception as ex:      # noqa: BLE001
+            errors.append(f"{name}: {ex!r}")
+
+    jobs = [("a", lambda: S.OctreeSdf(gm, box, 6, 3, 1e-3).get_octree_data()),
+            ("b", lambda: S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY).get_octree_data()),
+            ("c", lambda: S.ExactOctreeSdf(gm, box, 5, 2, 16).download()),
+            ("q", lambda: [live.get_distance(pts) for _ in range(10)][-1])]
+    th = [threading.Thread(target=run, args=j) for j in jobs]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
+    assert np.array_equal(out["a"], ref["a"]) and np.array_equal(out["b"], ref["b"])
+    assert all(np.array_equal(x, y) for x, y in zip(out["c"], ref["c"]))
+    assert np.array_equal(bits(out["q"]), bits(want))
