@@ -166,7 +166,7 @@ def main():
         "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **{k: round(v, 4) for k, v in binfo.items()}},
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
     if not args.no_extras:
         result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world)
