@@ -195,6 +195,7 @@ def measured_copy_gbs(dev):
 
 def cpu_baseline(v, f, box, args, pts):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores: bounded sample."""
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # the oracle's idle OpenMP workers must not spin into the GPU measurements that follow
     from oracle import pyoracle as O
     cores = os.cpu_count() or 1
     om = O.Mesh(v, f)
