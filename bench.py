@@ -67,11 +67,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        # every rank plans the (replicated) BVH on the shared host: split the hardware threads instead of oversubscribing them
-        per_rank = max(4, (os.cpu_count() or 8) // world)
-        os.environ.setdefault("SDFHIP_BVH_SORT_THREADS", str(per_rank))
-        os.environ.setdefault("SDFHIP_BVH_PAR_DEPTH", str(max(2, per_rank.bit_length() - 1)))
     # test hook: several ranks on ONE device with gloo collectives (the real launch is one rank per GPU over RCCL)
     one_device = os.environ.get("SDFHIP_BENCH_ONE_DEVICE") == "1"
     if one_device:
@@ -91,7 +86,7 @@ def main():
     box = box_with_margin(v)
     ctx = S.Context(dev.index, use_torch_stream=True)
     mesh = S.Mesh(v, f, ctx)
-    bvh_s = mesh.build_bvh()
+    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: planned once (rank 0, all cores), broadcast
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if world > 1:
@@ -301,7 +296,7 @@ def build_1m(ctx, rank, world, dev):
     t0 = time.perf_counter()
     mesh = S.Mesh(v, f, ctx)
     prep = time.perf_counter() - t0
-    bvh_s = mesh.build_bvh()
+    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: planned once (rank 0, all cores), broadcast
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

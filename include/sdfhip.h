@@ -136,6 +136,12 @@ int sdfhip_mesh_edge_stats(sdfhip_mesh* mesh, uint32_t* unmatched_edges, uint32_
 int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host);
 /* build (host planner, fp64) + upload the bounding-sphere BVH; implicit on first use. seconds may be NULL */
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds);
+/* The planned tree of a mesh with T triangles: 8 doubles (spheres of the two children) and 2 int32 (child references: >= 0 inner node,
+ * < 0 ~triangle) per inner node, T - 1 of them in the reference's pre-order (one dummy node when T == 1).  Multi-GPU hosts plan the
+ * tree ONCE (the planner is host code that wants all the cores: eight ranks planning the same tree at the same time take 5x longer
+ * than one), broadcast the two arrays and import them on the other ranks.  export builds the tree if needed. */
+int sdfhip_mesh_bvh_export(sdfhip_mesh* mesh, double* out_spheres, int32_t* out_children, int where);
+int sdfhip_mesh_bvh_import(sdfhip_mesh* mesh, const double* spheres, const int32_t* children, int where);
 /* nearest triangle id per point (fp64 BVH traversal on the device) */
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
 /* test hook, host only: mismatches between the BVH planner's threaded restatement of std::sort and std::sort itself on n keys */

@@ -64,6 +64,8 @@ SIGNATURES = {
     "sdfhip_mesh_destroy": (_int, [_vp]),
     "sdfhip_mesh_triangle_data": (_int, [_vp, _vp]),
     "sdfhip_mesh_build_bvh": (_int, [_vp, C.POINTER(C.c_double)]),
+    "sdfhip_mesh_bvh_export": (_int, [_vp, _vp, _vp, _int]),
+    "sdfhip_mesh_bvh_import": (_int, [_vp, _vp, _vp, _int]),
     "sdfhip_mesh_nearest": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sdfhip_abi_sizes": (None, [_vp]),
     "sdfhip_test_sort_matches_std": (_int, [_vp, _u64, _int]),

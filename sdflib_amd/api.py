@@ -136,6 +136,28 @@ class Mesh:
         check(lib().sdfhip_mesh_build_bvh(self.h, C.byref(s)))
         return s.value
 
+    def bvh_arrays(self, spheres=None, children=None):
+        """The planned BVH: (float64[8 (T-1)], int32[2 (T-1)]) as numpy arrays, or written into the given torch CUDA tensors."""
+        n = max(len(self.indices) - 1, 1)
+        if spheres is not None and _is_torch(spheres):
+            self.ctx._torch_inputs_ready()
+            check(lib().sdfhip_mesh_bvh_export(self.h, C.c_void_p(spheres.data_ptr()), C.c_void_p(children.data_ptr()), DEVICE))
+            self.ctx._torch_outputs_ready()
+            return spheres, children
+        sph = np.empty(8 * n, dtype=np.float64); kids = np.empty(2 * n, dtype=np.int32)
+        check(lib().sdfhip_mesh_bvh_export(self.h, _ptr(sph), _ptr(kids), HOST))
+        return sph, kids
+
+    def set_bvh(self, spheres, children):
+        """Install a BVH planned elsewhere (another rank) instead of planning it here."""
+        if _is_torch(spheres):
+            self.ctx._torch_inputs_ready()
+            check(lib().sdfhip_mesh_bvh_import(self.h, C.c_void_p(spheres.data_ptr()), C.c_void_p(children.data_ptr()), DEVICE))
+            self.ctx._torch_outputs_ready()
+        else:
+            sph = _np(spheres, np.float64); kids = _np(children, np.int32)
+            check(lib().sdfhip_mesh_bvh_import(self.h, _ptr(sph), _ptr(kids), HOST))
+
     def nearest_triangle(self, points):
         pts = _np(points, np.float32).reshape(-1, 3)
         out = np.empty(len(pts), dtype=np.uint32)

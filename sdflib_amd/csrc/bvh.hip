@@ -287,6 +287,34 @@ int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh) {
     SDF_API_END
 }
 
+// Upload a planned tree (8 doubles + 2 ints per inner node, host or device memory) and derive what the traversal needs besides:
+// the fp32 copy of the spheres, the coordinate scale bounding its rounding, and the per-triangle vertex records.
+static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where) {
+    const uint32_t T = mesh->numTriangles;
+    const uint64_t nn = T - 1;
+    const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
+    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
+    hipStream_t st = mesh->ctx->stream;
+    AllocScope allocScope(st);
+    const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph, nSph * sizeof(double), kind, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids, nKids * sizeof(int), kind, st));
+    {
+        float scale = 0.f;
+        for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
+        mesh->bvhCoordScale = scale;
+        SDF_TRY(mesh->dBvhSph32.reserve(nSph));
+        k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
+    }
+    k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    mesh->numBvhNodes = nn;
+    mesh->hasBvh = true;
+    return SDFHIP_OK;
+}
+
 extern "C" {
 
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
@@ -327,27 +355,35 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     double rootSphere[4];
     b.build(0, rootSphere, 0, (int)T, 0);
     const double tPlanned = nowSeconds();
-    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
-    hipStream_t st = mesh->ctx->stream;
-    AllocScope allocScope(st);
-    SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph.get(), nSph * sizeof(double), hipMemcpyHostToDevice, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids.get(), nKids * sizeof(int), hipMemcpyHostToDevice, st));
-    {
-        float scale = 0.f;
-        for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
-        mesh->bvhCoordScale = scale;
-        SDF_TRY(mesh->dBvhSph32.reserve(nSph));
-        k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
-    }
-    k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
-    SDF_HIP_CHECK(hipGetLastError());
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    mesh->numBvhNodes = nn;
+    SDF_TRY(installBvh(mesh, sph.get(), kids.get(), SDFHIP_HOST));
     if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", tGather - t0, tPlanned - tGather, b.sortThreads, b.maxParallelDepth, nowSeconds() - tPlanned);
-    mesh->hasBvh = true;
     if (seconds) *seconds = nowSeconds() - t0;
     return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_mesh_bvh_export(sdfhip_mesh* mesh, double* out_spheres, int32_t* out_children, int where) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(mesh && out_spheres && out_children, "NULL argument");
+    SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
+    const uint64_t nn = mesh->numTriangles - 1;
+    const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
+    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
+    hipStream_t st = mesh->ctx->stream;
+    const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    SDF_HIP_CHECK(hipMemcpyAsync(out_spheres, mesh->dBvhSph.p, nSph * sizeof(double), kind, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(out_children, mesh->dBvhKids.p, nKids * sizeof(int), kind, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_mesh_bvh_import(sdfhip_mesh* mesh, const double* spheres, const int32_t* children, int where) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(mesh && spheres && children, "NULL argument");
+    std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
+    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
+    return installBvh(mesh, spheres, children, where);
     SDF_API_END
 }
 

@@ -138,6 +138,31 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# The sphere BVH is planned on the host and wants all its cores: planned by every rank at the same time on one node it takes
+# several times longer than planned once.  Rank `src` plans, the two arrays (72 + 8 B per triangle) are broadcast, the others import.
+
+def share_bvh(mesh, rank, world, dev, group=None, src=0):
+    """Collective.  Returns the seconds this rank spent (planning on `src`, waiting + import elsewhere)."""
+    t0 = time.perf_counter()
+    n = max(len(mesh.indices) - 1, 1)
+    cdev = _collective_device(dev, group)
+    sph = torch.empty(8 * n, dtype=torch.float64, device=cdev); kids = torch.empty(2 * n, dtype=torch.int32, device=cdev)
+    if rank == src:
+        mesh.build_bvh()
+        if cdev.type == "cpu":
+            a, b = mesh.bvh_arrays(); sph.copy_(torch.from_numpy(a)); kids.copy_(torch.from_numpy(b))
+        else:
+            mesh.bvh_arrays(sph, kids)
+    dist.broadcast(sph, src, group=group); dist.broadcast(kids, src, group=group)
+    if rank != src:
+        if cdev.type == "cpu":
+            mesh.set_bvh(sph.numpy(), kids.numpy())
+        else:
+            mesh.set_bvh(sph, kids)
+    return time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # CONTINUITY build: the tree is not separable by start cell (the second iteration couples neighbouring cells,
 # src/sdf/OctreeSdfBreadthFirstNoDelay.h:440-482), so every rank builds the whole tree and only the nearest-triangle
 # traversals of each sample batch are shared out (include/sdfhip.h, sdfhip_exchange): one all-reduce of 4 B per unique

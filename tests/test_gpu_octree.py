@@ -588,3 +588,24 @@ def test_concurrent_builds_on_one_context_are_serialised(small, oracle):
     assert np.array_equal(out["a"], ref["a"]) and np.array_equal(out["b"], ref["b"])
     assert all(np.array_equal(x, y) for x, y in zip(out["c"], ref["c"]))
     assert np.array_equal(bits(out["q"]), bits(want))
+
+
+def test_bvh_export_import(small, oracle, gpu_ctx):
+    """sdfhip_mesh_bvh_export / _import: a tree planned on one mesh object (another rank, in the multi-GPU flow) and installed in a
+    second one gives the same nearest triangles and the same octree as planning it there."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    sph, kids = small["gm"].bvh_arrays()
+    assert sph.shape == (8 * (len(small["f"]) - 1),) and kids.shape == (2 * (len(small["f"]) - 1),)
+    other = S.Mesh(small["v"], small["f"], gpu_ctx)
+    other.set_bvh(sph, kids)
+    assert other.build_bvh() == 0.0                                  # nothing left to plan
+    pts = random_points_in_box(small["box"], 50000, seed=12)
+    assert np.array_equal(other.nearest_triangle(pts), small["om"].nearest(pts))
+    assert np.array_equal(S.OctreeSdf(other, small["box"], 5, 2, 1e-3).get_octree_data(), S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3).get_octree_data())
+    a, b = other.bvh_arrays()
+    assert np.array_equal(a.view(np.uint64), sph.view(np.uint64)) and np.array_equal(b, kids)
+    # one-triangle mesh: a single dummy node
+    tiny = S.Mesh(small["v"][:3], np.array([[0, 1, 2]], np.uint32), gpu_ctx)
+    s1, k1 = tiny.bvh_arrays()
+    assert s1.shape == (8,) and k1.shape == (2,)

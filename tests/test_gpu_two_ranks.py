@@ -29,6 +29,11 @@ def _worker(rank, world, port, q):
         v, f = bumpy_icosphere(4)
         box = box_with_margin(v)
         mesh = S.Mesh(v, f, ctx)
+        sdist.share_bvh(mesh, rank, world, dev)                      # planned by rank 0, broadcast, imported by the others
+        assert mesh.build_bvh() == 0.0
+        ref_mesh = S.Mesh(v, f, ctx)                                 # plans its own
+        probe = ((np.random.default_rng(5).random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
+        assert np.array_equal(mesh.nearest_triangle(probe), ref_mesh.nearest_triangle(probe)), "shared BVH differs from a locally planned one"
         tree, _ = sdist.build_octree_sharded(mesh, box, 6, 3, 1e-3, rank, world, dev)
         single = S.OctreeSdf(mesh, box, 6, 3, 1e-3)
         assert np.array_equal(tree.get_octree_data(), single.get_octree_data()), "sharded OctreeSdf differs from the single build"

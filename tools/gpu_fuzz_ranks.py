@@ -56,7 +56,8 @@ if __name__ == "__main__":
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     bad = 0
-    for world in (2, 3, 5):
+    worlds = tuple(int(w) for w in os.environ.get("FUZZ_WORLDS", "2,3,5").split(","))
+    for world in worlds:
         c = mp.get_context("spawn"); q = c.Queue()
         procs = [c.Process(target=worker, args=(r, world, 34000 + world + (os.getpid() % 500), seed0, cases, q)) for r in range(world)]
         for p in procs: p.start()
@@ -64,5 +65,5 @@ if __name__ == "__main__":
         for p in procs: p.join(timeout=60)
         for r, msg in res:
             if msg != "ok": bad += 1; print(f"world {world} rank {r}: {msg}")
-    print(f"{3 * cases} multi-rank cases, {bad} failing ranks")
+    print(f"{len(worlds) * cases} multi-rank cases, {bad} failing ranks")
     sys.exit(1 if bad else 0)
