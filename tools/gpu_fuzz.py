@@ -94,10 +94,12 @@ def one(seed):
         assert a_.shape == b_.shape, "FIT_MFMA tree size"
         extra += " mfma"
     if rng.random() < 0.3:                                        # separable-Horner evaluation stays within 1e-5 of the literal order (at the tree's scale)
-        df = gt.get_distance(pts, eval_mode=S.EVAL_FAST)
+        df, gf = gt.get_distance(pts, gradient=True, eval_mode=S.EVAL_FAST)
         scale = max(1.0, float(gt.info.value_range))
         err = float(np.nanmax(np.abs(df - d1))) if len(d1) else 0.0
         assert err <= 3e-5 * scale, f"EVAL_FAST error {err:g} at value range {scale:g}"
+        ok_ = np.isfinite(gf).all(1) & np.isfinite(g1).all(1)      # unit vectors; where the polynomial's gradient nearly vanishes the direction is ill-conditioned in BOTH orders
+        assert not ok_.any() or float(np.median(np.abs(gf[ok_] - g1[ok_]).max(1))) <= 1e-4, "EVAL_FAST gradients differ from the literal-order ones"
         extra += " fast"
     if rng.random() < 0.15:                                       # the reference's .bin layout: save, load, same words and answers
         import tempfile
@@ -125,6 +127,12 @@ def one(seed):
         assert x.shape == y.shape and np.array_equal(x, y), f"exact {name} (depth={edepth} start={estart} min={mint})"
     e0, t0 = oe.query(pts, tri=True); e1, t1 = ge.get_distance(pts, triangle=True)
     assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0, t1.astype(np.uint32)), "exact queries"
+    if rng.random() < 0.5:                                        # ExactOctreeSdf gradients (TriangleUtils.h:292-376), NaN directions included
+        eg0 = oe.query(pts, grad=True); eg1 = ge.get_distance(pts, gradient=True)
+        assert np.array_equal(bits(eg0[0]), bits(eg1[0])) and (np.array_equal(bits(eg0[1]), bits(eg1[1])) or np.array_equal(eg0[1], eg1[1], equal_nan=True)), "exact gradients"
+    if rng.random() < 0.2:                                        # small batches take the per-lane kernel instead of the leaf-sorted one
+        k_ = int(rng.integers(1, 300))
+        assert np.array_equal(bits(ge.get_distance(pts[:k_])), bits(e0[:k_])), "exact small batch"
     if rng.random() < 0.4 and estart >= 1:                        # ExactOctreeSdf shards over random ranges of the emission order
         from sdflib_amd import distributed as sdist
         G3 = 8 ** estart
