@@ -273,7 +273,7 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1):
         ct, cinfo = sdist.build_continuity_sharded(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, rank, world, dev)
         cinfo = {"exchange_s": round(cinfo["exchange_s"], 4), "exchange_bytes": int(cinfo["exchange_bytes"]), "ranks_sharing_traversals": world}
     else:
-        ct = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, init_algorithm=S.ALG_CONTINUITY)
+        ct = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ci = ct.info
     ms = _time_ms(lambda: ct.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out))
@@ -281,7 +281,7 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1):
     ct.close()
     # the 64x64 fit on the matrix cores (SDFHIP_FIT_MFMA): same topology, coefficients within the reference's own rounding noise
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    mt = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, fit_mode=S.FIT_MFMA)
+    mt = S.OctreeSdf(mesh, box, int(tree.info.max_depth), int(round(np.log2(tree.info.start_grid_size))), 1e-3, fit_mode=S.FIT_MFMA, num_threads=2)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     mi = mt.info
     r["fit_mfma_build"] = {"build_s": round(dt, 4), "words": int(mi.num_words), "same_size_as_exact_fit": bool(int(mi.num_words) == int(tree.info.num_words)),

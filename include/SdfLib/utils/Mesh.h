@@ -129,7 +129,8 @@ public:
         mVertices.resize(numVertices); std::memcpy(mVertices.data(), vertices, sizeof(glm::vec3) * numVertices);
         mIndices.resize(numIndices); std::memcpy(mIndices.data(), indices, sizeof(uint32_t) * numIndices);
     }
-    // The reference's file constructor (src/utils/Mesh.cpp:9-62) goes through assimp (first mesh, faces triangulated); here:
+    // The reference's file constructor (src/utils/Mesh.cpp:9-62) goes through assimp (first aiMesh, faces triangulated); here:
+    // an OBJ file's objects / groups are read as ONE mesh (assimp would split them and the reference keep the first only);
     // OBJ and ASCII / binary-little-endian PLY, polygons fan-triangulated, then the bounding box — which, as in the reference,
     // is what later enables the seam welding of the triangle data.  On failure the mesh stays empty (the reference logs and returns).
     explicit Mesh(const std::string& filePath) {

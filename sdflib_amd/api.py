@@ -192,7 +192,7 @@ class OctreeSdf:
     """
 
     def __init__(self, mesh=None, box=None, depth=None, start_depth=None, max_error=1e-3, init_algorithm=ALG_NO_CONTINUITY,
-                 num_threads=2, termination_rule=RULE_TRAPEZOIDAL, rule_params=None, fit_mode=FIT_EXACT, _handle=None, _ctx=None):
+                 num_threads=1, termination_rule=RULE_TRAPEZOIDAL, rule_params=None, fit_mode=FIT_EXACT, _handle=None, _ctx=None):
         if _handle is not None:
             self.h, self.ctx = _handle, _ctx
         else:
@@ -418,6 +418,7 @@ class ExactOctreeSdf:
             self.h, self.ctx = _handle, _ctx
             return
         self.ctx = mesh.ctx
+        self._mesh = mesh           # the tree queries the mesh's TriangleData (device memory owned by the Mesh): keep it alive
         box = _np(box, np.float32).reshape(6)
         bmin, bmax = box[:3].copy(), box[3:].copy()
         h = C.c_void_p()

@@ -11,6 +11,7 @@
 // seam welding (:292-420) runs when sdfhip_mesh_create_ex is given the mesh bounding box (host planner weldSeams below);
 // otherwise single-owner edges keep the default (0,0,1).  They are counted in mesh->unmatchedEdges either way.
 #include "sdfhip_internal.h"
+#include <memory>
 #include <thread>
 #include <cmath>
 #include "dev_math.h"
@@ -288,7 +289,8 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     // NaN / infinite coordinates make the reference's std::sort comparator inconsistent (undefined behaviour): rejected here
     for (uint64_t i = 0; i < 3ull * nv; i++) SDF_REQUIRE(std::isfinite(xyz[i]), "non-finite vertex coordinate");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
-    sdfhip_mesh* m = new sdfhip_mesh();
+    std::unique_ptr<sdfhip_mesh> owner(new sdfhip_mesh());      // released on success only: every early return below frees it
+    sdfhip_mesh* m = owner.get();
     m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;
     m->hVerts.assign(xyz, xyz + 3ull * nv);
     m->hIdx.assign(indices, indices + 3ull * nt);
@@ -296,7 +298,7 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     const uint32_t nhe = 3 * nt;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     int rc = SDFHIP_OK;
-    auto fail = [&](int code) { delete m; return code; };
+    auto fail = [&](int code) { return code; };
     if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt)) || (rc = m->dFrames.reserve((size_t)FRAME_FLOATS * nt))) return fail(rc);
     SDF_HIP_CHECK(hipMemcpyAsync(m->dVerts.p, xyz, sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(m->dIdx.p, indices, sizeof(uint32_t) * nhe, hipMemcpyHostToDevice, st));
@@ -364,7 +366,7 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     k_vertex_normal_apply<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, vnormal.p, m->dTri.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));
-    *out = m;
+    *out = owner.release();
     return SDFHIP_OK;
     SDF_API_END
 }

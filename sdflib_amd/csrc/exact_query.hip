@@ -310,6 +310,7 @@ int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const
     SDF_REQUIRE(ctx && info && nodes && sets && masks && triangle_data && out, "NULL argument");
     SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
     SDF_REQUIRE(info->bits_per_index >= 1 && info->bits_per_index <= 32 && info->num_triangles >= 1, "bad header");
+    SDF_REQUIRE(info->max_depth >= 2 && info->max_depth - info->bit_encoding_start_depth == 2, "unsupported file: the query decodes exactly two mask levels (bitEncodingStartDepth must be maxDepth - 2)");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
@@ -340,6 +341,7 @@ int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exa
     SDF_REQUIRE(mesh->ctx == ctx && info->num_triangles == mesh->numTriangles, "mesh does not match the header");
     SDF_REQUIRE(info->start_grid_size >= 1 && info->num_nodes >= (uint64_t)info->start_grid_size * info->start_grid_size * info->start_grid_size, "start grid does not fit");
     SDF_REQUIRE(info->bits_per_index >= 1 && info->bits_per_index <= 32, "bad header");
+    SDF_REQUIRE(info->max_depth >= 2 && info->max_depth - info->bit_encoding_start_depth == 2, "unsupported header: the query decodes exactly two mask levels (bitEncodingStartDepth must be maxDepth - 2)");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;

@@ -1,5 +1,7 @@
 """Minimal triangle-mesh readers (OBJ, ASCII / binary PLY) standing in for the reference's assimp loader
-(src/utils/Mesh.cpp:9-88: first mesh of the file, faces triangulated).  Polygons are fan-triangulated.  Host-side IO only."""
+(src/utils/Mesh.cpp:9-88: faces triangulated).  Polygons are fan-triangulated.  Host-side IO only.
+Difference from assimp, on purpose: an OBJ file's objects / groups / materials are read as ONE mesh (all faces of the file);
+assimp splits them into aiMeshes and the reference keeps mMeshes[0] only.  Single-object files behave identically."""
 import numpy as np
 
 
@@ -35,7 +37,7 @@ def read_ply(path):
         data = fh.read()
     end = data.index(b"end_header") + len(b"end_header")
     header = data[:end].decode("ascii", errors="ignore").splitlines()
-    body = data[end:].lstrip(b"\r").lstrip(b"\n") if data[end:end + 2] in (b"\r\n",) else data[end + 1:]
+    body = data[end + 2:] if data[end:end + 2] == b"\r\n" else data[end + 1:]      # exactly ONE line terminator: the binary body may start with 0x0A
     fmt, elements = None, []
     for line in header:
         p = line.split()

@@ -102,7 +102,7 @@ def test_built_tree_keeps_the_builds_cell_size_far_from_the_origin(tmp_path, ora
         if f32(hi[0] - lo[0]) / f32(4) != mx / f32(4):
             break
     gm = S.Mesh(v, f)
-    single = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    single = S.OctreeSdf(gm, box, 5, 2, 1e-3, num_threads=2)
     i = single.info
     stored = np.float32(i.box_max[0] - i.box_min[0]) / np.float32(i.start_grid_size)
     assert np.float32(i.start_grid_cell_size) != stored, "pick an offset where the two cell sizes differ, or this test checks nothing"

@@ -16,7 +16,7 @@ def test_continuity_build_bit_exact(oracle, gpu_ctx, subdiv, depth, start):
     om = oracle.Mesh(v, f)
     oc = oracle.Octree(om, box, depth, start, 1e-3, continuity=True)
     gm = S.Mesh(v, f, gpu_ctx)
-    gt = S.OctreeSdf(gm, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    gt = S.OctreeSdf(gm, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
     a, b = oc.data(), gt.get_octree_data()
     assert a.shape == b.shape
     assert np.array_equal(a, b), f"first mismatch at word {np.flatnonzero(a != b)[:5]} of {len(a)}"
@@ -33,7 +33,7 @@ def test_continuity_larger_mesh_matches_oracle_and_reference_probe_counts(oracle
     from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
     v, f = bumpy_icosphere(5)
     box = box_with_margin(v)
-    gt = S.OctreeSdf(S.Mesh(v, f, gpu_ctx), box, 7, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    gt = S.OctreeSdf(S.Mesh(v, f, gpu_ctx), box, 7, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
     i = gt.info
     assert abs(int(i.num_words) - 32156200) <= 5 * 456 and abs(int(i.num_leaves) - 493627) <= 5 * 7
     oc = oracle.Octree(oracle.Mesh(v, f), box, 7, 3, 1e-3, continuity=True)

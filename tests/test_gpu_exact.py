@@ -180,3 +180,21 @@ def test_exact_sharded_build_through_rccl_world1(small):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_tree_keeps_a_temporary_mesh_alive(gpu_ctx, oracle):
+    """ExactOctreeSdf(Mesh(...), ...) with a temporary Mesh — the tree reads the mesh's TriangleData on the device,
+    so it must hold a reference (the C++ class keeps mMesh, from_parts sets _mesh)."""
+    import gc
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+    v, f = bumpy_icosphere(3)
+    box = box_with_margin(v)
+    t = S.ExactOctreeSdf(S.Mesh(v, f, gpu_ctx), box, 5, 1, 16)
+    gc.collect()
+    junk = [S.Mesh(v * 0.5, f, gpu_ctx) for _ in range(3)]          # would recycle the freed device blocks
+    pts = random_points_in_box(box, 2000, seed=3)
+    want = oracle.Exact(oracle.Mesh(v, f), box, 5, 1, 16).query(pts)
+    assert np.array_equal(bits(t.get_distance(pts)), bits(want))
+    del junk

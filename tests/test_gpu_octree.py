@@ -73,7 +73,7 @@ def test_octree_query_exact_and_fast(small, oracle):
     import sdflib_amd as S
     from sdflib_amd.meshgen import random_points_in_box
     oc = oracle.Octree(small["om"], small["box"], 6, 3, 1e-3)
-    gt = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3)
+    gt = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, num_threads=2)
     pts = random_points_in_box(small["box"], 200000, seed=11)
     # a few points outside the grid as well
     pts[:200] *= 3.0
@@ -99,7 +99,7 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
     td = gm.triangle_data()
     assert np.array_equal(bits(td[:, :28]), bits(g["triangle_data"][:, :28]))
     assert np.array_equal(gm.nearest_triangle(g["points"]), g["nearest_ids"])
-    t = S.OctreeSdf(gm, g["box"], int(g["depth"]), int(g["start_depth"]), 1e-3)
+    t = S.OctreeSdf(gm, g["box"], int(g["depth"]), int(g["start_depth"]), 1e-3, num_threads=2)
     assert np.array_equal(t.get_octree_data(), g["octree_words"])
     assert np.float32(t.info.value_range) == g["octree_value_range"] and np.float32(t.info.min_border_value) == g["octree_min_border"]
     d, gr = t.get_distance(g["points"], gradient=True, eval_mode=S.EVAL_EXACT)
@@ -110,7 +110,7 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
 
 def test_grid_query_matches_point_query(small):
     import sdflib_amd as S
-    gt = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3)
+    gt = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, num_threads=2)
     bb = gt.get_grid_bounding_box()
     size = np.float32(bb[3] - bb[0]); n = 32
     step = np.full(3, size / np.float32(n), dtype=np.float32)
@@ -136,7 +136,7 @@ def test_grid_query_matches_point_query(small):
 def test_sharded_build_emits_the_same_array(small, oracle):
     """Two shards built separately and concatenated by hand == the single-device array (no collective involved)."""
     import sdflib_amd as S
-    full = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3).get_octree_data()
+    full = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, num_threads=2).get_octree_data()
     G3 = 64
     parts = [(0, 23), (23, 64)]
     shards = [S.OctreeShard(small["gm"], small["box"], 5, 2, 1e-3, cells=c) for c in parts]
@@ -149,7 +149,7 @@ def test_sharded_build_emits_the_same_array(small, oracle):
         out[c[0]:c[1]] = grid; out[off:off + n] = body
         off += n
     assert np.array_equal(out, full)
-    assert max(s.info.value_range for s in shards) == S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3).info.value_range
+    assert max(s.info.value_range for s in shards) == S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, num_threads=2).info.value_range
 
 
 def test_mfma_fit_is_the_correctly_rounded_product(oracle, gpu_ctx):
@@ -176,8 +176,8 @@ def test_mfma_fit_is_the_correctly_rounded_product(oracle, gpu_ctx):
 
 def test_mfma_build_has_identical_topology_and_close_coefficients(small):
     import sdflib_amd as S
-    a = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_EXACT)
-    b = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_MFMA)
+    a = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_EXACT, num_threads=2)
+    b = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, fit_mode=S.FIT_MFMA, num_threads=2)
     da, db = a.get_octree_data(), b.get_octree_data()
     assert da.shape == db.shape
     # walk: node words identical (bit-exact topology); leaf payloads agree to the fp32 rounding noise of the 64-term sums
@@ -209,7 +209,7 @@ def test_full_size_octree_matches_oracle(oracle, gpu_ctx, subdiv, depth, start):
     v, f = bumpy_icosphere(subdiv)
     box = box_with_margin(v)
     gm = S.Mesh(v, f, gpu_ctx)
-    gt = S.OctreeSdf(gm, box, depth, start, 1e-3)
+    gt = S.OctreeSdf(gm, box, depth, start, 1e-3, num_threads=2)
     om = oracle.Mesh(v, f)
     ot = oracle.Octree(om, box, depth, start, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
     assert np.array_equal(ot.data(), gt.get_octree_data())
@@ -242,13 +242,13 @@ def test_sharded_build_through_rccl_world1(small):
     try:
         dev = torch.device("cuda", 0)
         tree, info = sdist.build_octree_sharded(small["gm"], small["box"], 5, 2, 1e-3, 0, 1, dev)
-        full = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3)
+        full = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, num_threads=2)
         assert np.array_equal(tree.get_octree_data(), full.get_octree_data())
         assert tree.info.value_range == full.info.value_range and tree.info.min_border_value == full.info.min_border_value
         assert list(tree.info.leaves_per_depth) == list(full.info.leaves_per_depth)
         # CONTINUITY: the traversal exchange (acquire / all-reduce callbacks) over RCCL
         ct, tm = sdist.build_continuity_sharded(small["gm"], small["box"], 5, 2, 1e-3, 0, 1, dev)
-        c1 = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+        c1 = S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
         assert tm["exchange_bytes"] > 0 and np.array_equal(ct.get_octree_data(), c1.get_octree_data())
     finally:
         if created:
@@ -262,7 +262,7 @@ def test_other_termination_rules_match_oracle(small, oracle, rule, params, algor
     import sdflib_amd as S
     depth, start = (4, 2) if rule == 0 else (5, 2)
     oc = oracle.Octree(small["om"], small["box"], depth, start, params[0], rule=rule, param1=params[1], continuity=(algorithm == 2))
-    gt = S.OctreeSdf(small["gm"], small["box"], depth, start, init_algorithm=algorithm, termination_rule=rule, rule_params=params)
+    gt = S.OctreeSdf(small["gm"], small["box"], depth, start, init_algorithm=algorithm, termination_rule=rule, rule_params=params, num_threads=2)
     assert np.array_equal(oc.data(), gt.get_octree_data())
     if rule == 0:
         assert gt.info.num_leaves == 8 ** depth
@@ -270,34 +270,34 @@ def test_other_termination_rules_match_oracle(small, oracle, rule, params, algor
 
 def test_edge_cases_and_error_codes(small, gpu_ctx):
     import sdflib_amd as S
-    t = S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3)
+    t = S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, num_threads=2)
     # empty query batch, single query, queries far outside the box (box distance + min border value)
     assert len(t.get_distance(np.zeros((0, 3), np.float32))) == 0
     d = t.get_distance(np.array([[100.0, 0.0, 0.0]], np.float32))
     assert 90 < d[0] < 110
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], small["box"], 3, 5, 1e-3)                       # start depth > depth
+        S.OctreeSdf(small["gm"], small["box"], 3, 5, 1e-3, num_threads=2)                       # start depth > depth
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, init_algorithm=S.ALG_UNIFORM)
+        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, init_algorithm=S.ALG_UNIFORM, num_threads=2)
     with pytest.raises(S.SdfHipError):
         S.Mesh(small["v"], np.array([[0, 1, 10 ** 6]], np.uint32), gpu_ctx)     # index out of range
     with pytest.raises(S.SdfHipError):
         S.ExactOctreeSdf(small["gm"], small["box"], 4, 3, 16)                   # start depth must be <= depth - 2
     bad = small["box"].copy(); bad[3] = bad[0]
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], bad, 4, 2, 1e-3)                                # empty box
+        S.OctreeSdf(small["gm"], bad, 4, 2, 1e-3, num_threads=2)                                # empty box
     nanbox = small["box"].copy(); nanbox[1] = np.nan
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], nanbox, 4, 2, 1e-3)                             # NaN box
+        S.OctreeSdf(small["gm"], nanbox, 4, 2, 1e-3, num_threads=2)                             # NaN box
     with pytest.raises(S.SdfHipError):
         S.ExactOctreeSdf(small["gm"], nanbox, 4, 1, 16)
     vn = small["v"].copy(); vn[3, 1] = np.inf
     with pytest.raises(S.SdfHipError):
         S.Mesh(vn, small["f"], gpu_ctx)                                          # non-finite vertex
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3)                      # depth beyond the 10-bit lattice coordinates
+        S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3, num_threads=2)                      # depth beyond the 10-bit lattice coordinates
     with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, termination_rule=7)   # unknown rule
+        S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, termination_rule=7, num_threads=2)   # unknown rule
     # NaN / infinite query points are answered (NaN in, NaN or the box distance out), never a fault
     q = np.array([[np.nan, 0, 0], [np.inf, 0, 0], [0, -np.inf, 0], [1e30, 1e30, 1e30]], np.float32)
     out = t.get_distance(q, gradient=True)
@@ -324,7 +324,7 @@ def test_seam_welding_matches_oracle(oracle, gpu_ctx):
     assert np.array_equal(bits(raw.triangle_data()), bits(oracle.Mesh(sv, sf).triangle_data()))
     box = box_with_margin(sv)
     ot = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
-    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3, num_threads=2)
     go, oo = gt.get_octree_data(), ot.data()
     assert go.shape == oo.shape
     assert np.array_equal(go, oo)
@@ -366,7 +366,7 @@ def test_one_million_triangle_build_properties(gpu_ctx):
     assert len(f) == 1310720
     box = box_with_margin(v)
     mesh = S.Mesh(v, f, gpu_ctx)
-    full = S.OctreeSdf(mesh, box, 8, 3, 1e-3)
+    full = S.OctreeSdf(mesh, box, 8, 3, 1e-3, num_threads=2)
     words = full.get_octree_data()
     info = full.info
     assert info.num_traversals < info.num_samples and info.num_leaves > 250000
@@ -410,7 +410,7 @@ def test_nearest_triangle_far_from_the_origin_and_at_other_scales(oracle, gpu_ct
     pts = np.concatenate([pts, near])
     assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts))
     ot = oracle.Octree(om, box, 5, 2, 1e-3 * scale, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
-    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3 * scale)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3 * scale, num_threads=2)
     assert np.array_equal(ot.data(), gt.get_octree_data())
 
 
@@ -434,7 +434,7 @@ def test_degenerate_triangles_behave_like_the_reference(oracle, gpu_ctx):
     ids = gm.nearest_triangle(pts)
     assert np.array_equal(om.nearest(pts), ids) and ids.max() < len(f) - 3
     ot = oracle.Octree(om, box, 5, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
-    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3)
+    gt = S.OctreeSdf(gm, box, 5, 2, 1e-3, num_threads=2)
     assert np.array_equal(ot.data(), gt.get_octree_data())
     assert np.array_equal(ot.query(pts), gt.get_distance(pts), equal_nan=True)
 
@@ -482,7 +482,7 @@ def test_deep_tree_depth_9_matches_oracle(oracle, gpu_ctx):
     from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
     v, f = bumpy_icosphere(5)
     box = box_with_margin(v)
-    gt = S.OctreeSdf(S.Mesh(v, f, gpu_ctx), box, 9, 3, 2e-4)
+    gt = S.OctreeSdf(S.Mesh(v, f, gpu_ctx), box, 9, 3, 2e-4, num_threads=2)
     assert gt.info.num_words > 400_000_000 and gt.info.num_traversals < gt.info.num_samples
     ot = oracle.Octree(oracle.Mesh(v, f), box, 9, 3, 2e-4, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
     assert np.array_equal(ot.data(), gt.get_octree_data())
@@ -495,7 +495,7 @@ def test_concurrent_host_threads_query_one_tree(small):
     import threading
     import sdflib_amd as S
     from sdflib_amd.meshgen import random_points_in_box
-    tree = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3)
+    tree = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, num_threads=2)
     exact = S.ExactOctreeSdf(small["gm"], small["box"], 5, 2, 16)
     sets = [random_points_in_box(small["box"], n, seed=40 + i) for i, n in enumerate((1, 777, 30000, 200000))]
     want = [(tree.get_distance(p, gradient=True), exact.get_distance(p)) for p in sets]
@@ -535,7 +535,7 @@ from oracle import pyoracle as O
 from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
 v, f = bumpy_icosphere(2); box = box_with_margin(v)
 m = S.Mesh(v, f)
-t = S.OctreeSdf(m, box, 5, 2, 1e-3); e = S.ExactOctreeSdf(m, box, 4, 1, 8)
+t = S.OctreeSdf(m, box, 5, 2, 1e-3, num_threads=2); e = S.ExactOctreeSdf(m, box, 4, 1, 8)
 om = O.Mesh(v, f); ot = O.Octree(om, box, 5, 2, 1e-3); oe = O.Exact(om, box, 4, 1, 8)
 pts = random_points_in_box(box, 40001, seed=3); pts[::97] *= 3.0
 d0, g0 = ot.query(pts, grad=True); e0 = oe.query(pts)
@@ -565,9 +565,9 @@ def test_concurrent_builds_on_one_context_are_serialised(small, oracle):
     from sdflib_amd.meshgen import random_points_in_box
     gm, box = small["gm"], small["box"]
     pts = random_points_in_box(box, 50000, seed=2)
-    ref = dict(a=S.OctreeSdf(gm, box, 6, 3, 1e-3).get_octree_data(), b=S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY).get_octree_data(),
+    ref = dict(a=S.OctreeSdf(gm, box, 6, 3, 1e-3, num_threads=2).get_octree_data(), b=S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2).get_octree_data(),
                c=S.ExactOctreeSdf(gm, box, 5, 2, 16).download())
-    live = S.OctreeSdf(gm, box, 5, 2, 1e-3); want = live.get_distance(pts)
+    live = S.OctreeSdf(gm, box, 5, 2, 1e-3, num_threads=2); want = live.get_distance(pts)
     out, errors = {}, []
 
     def run(name, fn):
@@ -577,8 +577,8 @@ def test_concurrent_builds_on_one_context_are_serialised(small, oracle):
         except Exception as ex:      # noqa: BLE001
             errors.append(f"{name}: {ex!r}")
 
-    jobs = [("a", lambda: S.OctreeSdf(gm, box, 6, 3, 1e-3).get_octree_data()),
-            ("b", lambda: S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY).get_octree_data()),
+    jobs = [("a", lambda: S.OctreeSdf(gm, box, 6, 3, 1e-3, num_threads=2).get_octree_data()),
+            ("b", lambda: S.OctreeSdf(gm, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2).get_octree_data()),
             ("c", lambda: S.ExactOctreeSdf(gm, box, 5, 2, 16).download()),
             ("q", lambda: [live.get_distance(pts) for _ in range(10)][-1])]
     th = [threading.Thread(target=run, args=j) for j in jobs]
@@ -602,7 +602,7 @@ def test_bvh_export_import(small, oracle, gpu_ctx):
     assert other.build_bvh() == 0.0                                  # nothing left to plan
     pts = random_points_in_box(small["box"], 50000, seed=12)
     assert np.array_equal(other.nearest_triangle(pts), small["om"].nearest(pts))
-    assert np.array_equal(S.OctreeSdf(other, small["box"], 5, 2, 1e-3).get_octree_data(), S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3).get_octree_data())
+    assert np.array_equal(S.OctreeSdf(other, small["box"], 5, 2, 1e-3, num_threads=2).get_octree_data(), S.OctreeSdf(small["gm"], small["box"], 5, 2, 1e-3, num_threads=2).get_octree_data())
     a, b = other.bvh_arrays()
     assert np.array_equal(a.view(np.uint64), sph.view(np.uint64)) and np.array_equal(b, kids)
     # one-triangle mesh: a single dummy node

@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         probe = ((np.random.default_rng(5).random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
         assert np.array_equal(mesh.nearest_triangle(probe), ref_mesh.nearest_triangle(probe)), "shared BVH differs from a locally planned one"
         tree, _ = sdist.build_octree_sharded(mesh, box, 6, 3, 1e-3, rank, world, dev)
-        single = S.OctreeSdf(mesh, box, 6, 3, 1e-3)
+        single = S.OctreeSdf(mesh, box, 6, 3, 1e-3, num_threads=2)
         assert np.array_equal(tree.get_octree_data(), single.get_octree_data()), "sharded OctreeSdf differs from the single build"
         assert tree.info.value_range == single.info.value_range and tree.info.min_border_value == single.info.min_border_value
         assert list(tree.info.leaves_per_depth) == list(single.info.leaves_per_depth)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
         assert ex.info.max_triangles_in_leafs == ex1.info.max_triangles_in_leafs
         # CONTINUITY: every rank builds the whole tree, the traversals of each sample batch are shared through the exchange
         ct, tm = sdist.build_continuity_sharded(mesh, box, 6, 3, 1e-3, rank, world, dev)
-        c1 = S.OctreeSdf(mesh, box, 6, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY)      # exchange removed again: a plain local build
+        c1 = S.OctreeSdf(mesh, box, 6, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)      # exchange removed again: a plain local build
         assert tm["exchange_bytes"] > 0
         assert np.array_equal(ct.get_octree_data(), c1.get_octree_data()), "CONTINUITY tree built with shared traversals differs from the single build"
         assert ct.info.value_range == c1.info.value_range and ct.info.min_border_value == c1.info.min_border_value

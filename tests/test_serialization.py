@@ -31,7 +31,7 @@ def test_save_load_query_round_trip_on_gpu(tmp_path, gpu_ctx):
     box = box_with_margin(v)
     m = S.Mesh(v, f, gpu_ctx)
     pts = random_points_in_box(box, 20000, seed=1)
-    t = S.OctreeSdf(m, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    t = S.OctreeSdf(m, box, 5, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
     t.save_to_file(str(tmp_path / "oct.bin"))
     t2 = S.load_from_file(str(tmp_path / "oct.bin"), gpu_ctx)
     assert isinstance(t2, S.OctreeSdf) and np.array_equal(t.get_octree_data(), t2.get_octree_data())

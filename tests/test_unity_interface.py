@@ -105,3 +105,19 @@ def test_unity_interface_matches_oracle(tmp_path, oracle):
     assert L.getStartGridSize(e) == 0 and L.getOctreeDataSize(e) == 0      # OctreeSdf only in the reference (dynamic_cast, :140-154)
     L.deleteSdf(e)
     assert L.loadSdf(str(tmp_path / "missing.bin").encode()) is None       # loadFromFile -> nullptr
+
+
+def test_entry_points_never_throw_through_the_c_abi(tmp_path):
+    """a failing constructor / loader (here: depth beyond the lattice limit, start depth > depth, a corrupt file; on a
+    box without a GPU also 'no HIP device') must come back as NULL, not as a C++ exception unwinding into the host process."""
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    L = _load()
+    v, f = bumpy_icosphere(1)
+    bb = [float(x) for x in box_with_margin(v)]
+    v = np.ascontiguousarray(v, dtype=np.float32); f = np.ascontiguousarray(f, dtype=np.uint32)
+    assert L.createOctreeSdf(v.ctypes.data, len(v), f.ctypes.data, f.size, *bb, 2, 11, 1e-3, 1) is None
+    assert L.createOctreeSdf(v.ctypes.data, len(v), f.ctypes.data, f.size, *bb, 6, 3, 1e-3, 1) is None
+    assert L.createExactOctreeSdf(v.ctypes.data, len(v), f.ctypes.data, f.size, *bb, 9, 3, 16, 1) is None
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"\x01" + b"\x00" * 7)
+    assert L.loadSdf(str(bad).encode()) is None

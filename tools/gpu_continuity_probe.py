@@ -9,7 +9,7 @@ start = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 v, f = bumpy_icosphere(s); box = box_with_margin(v)
 m = S.Mesh(v, f); m.build_bvh()
 for it in range(2):
-    t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY); dt = time.time() - t
+    t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2); dt = time.time() - t
     i = oc.info
     print(f"continuity build {dt:.3f}s words={i.num_words} leaves={i.num_leaves} samples={i.num_samples} rescheduled={i.post_pass_scheduled}")
     del oc

@@ -30,11 +30,11 @@ def worker(rank, world, port, seed0, cases, q):
             mesh = S.Mesh(v, f, ctx)
             pts = (box[:3] + rng.random((20000, 3), dtype=np.float32) * (box[3:] - box[:3])).astype(np.float32)
             tree, _ = sdist.build_octree_sharded(mesh, box, depth, start, thr, rank, world, dev)
-            single = S.OctreeSdf(mesh, box, depth, start, thr)
+            single = S.OctreeSdf(mesh, box, depth, start, thr, num_threads=2)
             assert np.array_equal(tree.get_octree_data(), single.get_octree_data()), f"seed {s}: sharded OctreeSdf"
             assert np.array_equal(bits(tree.get_distance(pts)), bits(single.get_distance(pts))), f"seed {s}: sharded OctreeSdf answers"
             ct, _ = sdist.build_continuity_sharded(mesh, box, depth, start, thr, rank, world, dev)
-            c1 = S.OctreeSdf(mesh, box, depth, start, thr, init_algorithm=S.ALG_CONTINUITY)
+            c1 = S.OctreeSdf(mesh, box, depth, start, thr, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
             assert np.array_equal(ct.get_octree_data(), c1.get_octree_data()), f"seed {s}: CONTINUITY with shared traversals"
             edepth = int(rng.integers(start + 2, start + 5)); mint = int(rng.choice([2, 8, 32]))
             ex, _ = sdist.build_exact_sharded(mesh, box, edepth, start, mint, rank, world, dev)

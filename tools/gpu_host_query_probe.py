@@ -5,7 +5,7 @@ import numpy as np
 import sdflib_amd as S
 from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
 v, f = bumpy_icosphere(6); box = box_with_margin(v)
-m = S.Mesh(v, f); oc = S.OctreeSdf(m, box, 7, 3, 1e-3)
+m = S.Mesh(v, f); oc = S.OctreeSdf(m, box, 7, 3, 1e-3, num_threads=2)
 for n in (1_000_000, 10_000_000):
     pts = random_points_in_box(oc.get_grid_bounding_box(), n, seed=3)
     oc.get_distance(pts[:1000])

@@ -15,7 +15,7 @@ ctx = S.Context(0, use_torch_stream=True)
 t = time.time(); m = S.Mesh(v, f, ctx); print(f"mesh upload+triangle data {time.time()-t:.3f}s")
 print(f"bvh build (host planner + upload) {m.build_bvh():.3f}s")
 for it in range(2):
-    t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3); dt = time.time() - t
+    t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3, num_threads=2); dt = time.time() - t
     i = oc.info
     print(f"octree build {dt:.3f}s (samples {i.seconds_samples:.3f}s decide {i.seconds_decide:.3f}s) words={i.num_words} ({i.num_words*4/1e6:.1f} MB) leaves={i.num_leaves} nodes={i.num_nodes} samples={i.num_samples}")
     if it == 0: del oc

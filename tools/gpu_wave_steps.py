@@ -14,7 +14,7 @@ level = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 depth, start = 8, 3
 v, f = bumpy_icosphere(s); box = box_with_margin(v)
 m = S.Mesh(v, f); m.build_bvh()
-tree = S.OctreeSdf(m, box, depth, start, 1e-3)
+tree = S.OctreeSdf(m, box, depth, start, 1e-3, num_threads=2)
 words = tree.get_octree_data()
 bb = tree.get_grid_bounding_box(); size = float(bb[3] - bb[0])
 G = 2 ** start
