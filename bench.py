@@ -47,6 +47,19 @@ def _pmc_traffic(args):
     return None, None
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with one rank per GPU (RCCL), the command the
+    driver itself uses.  The re-executed ranks see WORLD_SIZE and take the normal path; rank 0 prints the one JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +77,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (gradient, fast eval, 256^3 grid, ExactOctreeSdf)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _self_launch(args.gpus)          # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,7 +92,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -158,9 +173,14 @@ def main():
                      "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
                      "copy_bw_measured_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved_gbs / copy_gbs, 4),
                      "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
-        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **{k: round(v, 4) for k, v in binfo.items()}},
+        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **_r4(binfo)},
     }
 
+    if world > 1:       # collective sanity: every rank contributes its rank + 1; the sum proves all N ranks were in the communicator
+        chk = torch.tensor([rank + 1], dtype=torch.int64, device=torch.device("cpu") if one_device else dev)
+        dist.all_reduce(chk)
+        result["collectives"] = {"backend": dist.get_backend(), "ranks_seen": int(binfo.get("ranks_seen", 0)), "rank_sum_ok": bool(int(chk.item()) == world * (world + 1) // 2),
+                                 "octree_bytes_all_gathered_per_rank": int(binfo.get("exchange_bytes", 0))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
     if not args.no_extras:
@@ -172,6 +192,10 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _r4(d):
+    return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}
 
 
 def measured_copy_gbs(dev):
@@ -252,7 +276,7 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1):
     t0 = time.perf_counter()
     if world > 1:       # start cells sharded over the ranks, one exchange (distributed.build_exact_sharded)
         ex, einfo = sdist.build_exact_sharded(mesh, box, 7, 3, 128, rank, world, dev)
-        einfo = {k: round(v, 4) for k, v in einfo.items()}
+        einfo = _r4(einfo)
     else:
         ex = S.ExactOctreeSdf(mesh, box, 7, 3, 128)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
@@ -311,7 +335,7 @@ def build_1m(ctx, rank, world, dev):
     dt = time.perf_counter() - t0
     i = tree.info
     return {"triangles": int(len(f)), "octree_build_s": round(dt, 4), "mesh_prep_s": round(prep, 4), "bvh_host_planner_s": round(bvh_s, 4),
-            "words": int(i.num_words), "leaves": int(i.num_leaves), **{k: round(v, 4) for k, v in binfo.items()}}
+            "words": int(i.num_words), "leaves": int(i.num_leaves), **({"bvh_share_s": round(bvh_s, 4)} if world > 1 else {}), **_r4(binfo)}
 
 
 if __name__ == "__main__":

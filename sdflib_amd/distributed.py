@@ -66,8 +66,9 @@ def _collective_device(dev, group=None):
     return torch.device("cpu") if dist.get_backend(group) == "gloo" else dev
 
 
-def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, group=None):
+def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, group=None, stats=None):
     """Collective part: returns the full node array (int32 view of the u32 words) on every rank.
+    `stats` (dict, optional) receives ranks_seen and bytes_all_gathered (what the two padded all-gathers delivered to THIS rank).
 
     grid_local: this rank's start-grid words (len = cells[1]-cells[0]); body_local: its bodies with ABSOLUTE indices
     already applied for offset = num_cells + sum(body_words of lower ranks)."""
@@ -87,6 +88,10 @@ def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, 
     dist.all_gather_into_tensor(gb, pb, group=group)
     dist.all_gather_into_tensor(gg, pg, group=group)
     total = num_cells + int(sizes.sum())
+    if total >= (1 << 30):
+        raise ValueError(f"assembled node array has {total} words: beyond the 30-bit node index of the reference layout")
+    if stats is not None:
+        stats["ranks_seen"] = int(len(meta)); stats["bytes_all_gathered"] = int(4 * (gb.numel() + gg.numel()))
     full = torch.empty(total, dtype=torch.int32, device=dev)
     off = num_cells
     for r in range(world):
@@ -121,7 +126,8 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
     body_local = torch.empty(max(int(info.body_words), 1), dtype=torch.int32, device=dev)
     shard.emit(offset, grid_local, body_local)
     cdev = _collective_device(dev, group)
-    full = exchange_and_assemble(grid_local.to(cdev), body_local.to(cdev), info.body_words, ranges[rank], num_cells, group).to(dev)
+    xstats = {}
+    full = exchange_and_assemble(grid_local.to(cdev), body_local.to(cdev), info.body_words, ranges[rank], num_cells, group, xstats).to(dev)
     stats = torch.tensor([info.value_range, -info.min_border_value], dtype=torch.float32, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX, group=group)
     lpd = torch.tensor(list(info.leaves_per_depth), dtype=torch.int64, device=cdev)
@@ -134,7 +140,8 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
     tree._override = {"leaves_per_depth": [int(x) for x in lpd.cpu().tolist()], "num_leaves": int(cnt[0]), "num_nodes": int(cnt[1]), "num_traversals": int(cnt[3]),
                       "num_samples": int(cnt[2])}
     shard.close()
-    return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1}
+    return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1, "exchange_bytes": xstats.get("bytes_all_gathered", 0), "ranks_seen": xstats.get("ranks_seen", 0),
+                  "backend": dist.get_backend(group)}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

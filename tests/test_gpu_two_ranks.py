@@ -82,14 +82,18 @@ def test_sharded_builds_with_several_ranks_on_one_gpu(world):
     assert all(msg == "ok" for _, msg in results), "\n".join(str(m) for _, m in results)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N>1 path (rendezvous from the environment, sharded build, barrier-bracketed timing, MAX over ranks, one JSON
+@pytest.mark.parametrize("launcher", ["torchrun", "self"])
+def test_bench_two_ranks_on_one_gpu(launcher):
+    """launcher=self: `python bench.py --gpus 2` with no WORLD_SIZE in the environment must start its own two ranks.
+    bench.py's N>1 path (rendezvous from the environment, sharded build, barrier-bracketed timing, MAX over ranks, one JSON
     line from rank 0) with two ranks sharing the GPU through the gloo test hook."""
     import json
     import subprocess
     env = dict(os.environ, SDFHIP_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(33500 + os.getpid() % 2000),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--subdiv", "5", "--depth", "6", "--queries", "1000000",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(33500 + os.getpid() % 2000)]
+    cmd = (head if launcher == "torchrun" else [sys.executable]) + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--subdiv", "5", "--depth", "6", "--queries", "1000000",
            "--no-cpu-baseline", "--no-build-1m"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -99,5 +103,6 @@ def test_bench_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert abs(d["value"] - 2 * d["per_gpu_mqueries_s"]) < 1e-6 * d["value"] + 0.02
     assert d["roofline"]["frac"] > 0 and d["build"]["exchange_s"] >= 0
+    assert d["collectives"]["ranks_seen"] == 2 and d["collectives"]["rank_sum_ok"] and d["collectives"]["octree_bytes_all_gathered_per_rank"] > 0
     c = d["extras"]["continuity_octree"]
     assert c["ranks_sharing_traversals"] == 2 and c["exchange_bytes"] > 0 and c["words"] > 0
