@@ -27,24 +27,80 @@ from sdflib_amd import distributed as sdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 
 
-def _pmc_traffic(args):
-    """HBM-side bytes per launch of the timed kernel from the committed rocprofv3 --pmc summary of this same command
-    (profiles/rNN_bench_pmc.csv, written by tools/profile_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes).  FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads on gfx950; both are reported in KB.  None if no summary for
-    this configuration is available (a bench run cannot collect counters itself)."""
+def _pmc_rows():
+    """Rows of the newest committed rocprofv3 --pmc summary of this same command (profiles/rNN_bench_pmc.csv, written by
+    tools/profile_bench.sh + tools/summarize_rocpd.py: separate FETCH_SIZE / WRITE_SIZE / TCC_HIT+MISS passes, per-dispatch averages,
+    the query and calibration kernels split by grid size).  A bench run cannot collect counters itself."""
     import csv, glob
-    if args.queries != 10_000_000 or args.subdiv != 7 or args.depth != 8 or args.gradient or args.eval != "exact":
-        return None, None
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_bench_pmc.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.csv")))
     for path in reversed(files):
         try:
-            for row in csv.DictReader(open(path)):
-                if row["kernel"].replace(" ", "") == "sdfhip::k_octree_query<0,false>" and row["FETCH_SIZE_avg_per_dispatch"] and row["WRITE_SIZE_avg_per_dispatch"]:
-                    fetch_kb, write_kb = float(row["FETCH_SIZE_avg_per_dispatch"]), float(row["WRITE_SIZE_avg_per_dispatch"])
-                    return int(2 * fetch_kb * 1024 + write_kb * 1024), os.path.join("profiles", os.path.basename(path)) + " (FETCH_SIZE x2 + WRITE_SIZE, per launch)"
+            rows = {row["kernel"].replace(" ", ""): row for row in csv.DictReader(open(path))}
+            if rows:
+                return rows, os.path.join("profiles", os.path.basename(path))
         except Exception:
             continue
-    return None, None
+    return {}, None
+
+
+def _pmc_lookup(rows, kernel, n_threads):
+    """The row of `kernel` launched over n_threads lanes (grid-split name first, then the plain name of older summaries)."""
+    grid = (n_threads + 255) // 256 * 256
+    for key in (f"{kernel}@{grid}", f"{kernel}@{grid // 256}", kernel):
+        r = rows.get(key)
+        if r and r.get("FETCH_SIZE_avg_per_dispatch") and r.get("WRITE_SIZE_avg_per_dispatch"):
+            return r
+    return None
+
+
+def _traffic_block(rows, src, kernel, n_threads, compulsory_bytes):
+    """roofline.traffic and its provenance.  FETCH_SIZE / WRITE_SIZE are reported in KB.  MI355X_MICROARCH.md calibrates FETCH_SIZE (x2) for
+    coalesced 16-B/lane streaming reads ONLY; this kernel is a per-lane 256-B gather, so the factor is measured on that pattern: the
+    calibration kernel (sdfhip_test_gather_blocks, same loads, every 256-B block of a 2.56 GB array exactly once -> known bytes) runs in
+    the same profiled command and fetch_calibration = its known read bytes / its reported FETCH_SIZE.  Without a calibration row the
+    counter is used AS REPORTED (factor 1), which the TCC_MISS x 64 B cross-check supports."""
+    r = _pmc_lookup(rows, kernel, n_threads)
+    if r is None:
+        return {"traffic": None, "traffic_source": None}
+    fetch, write = float(r["FETCH_SIZE_avg_per_dispatch"]) * 1024, float(r["WRITE_SIZE_avg_per_dispatch"]) * 1024
+    hit, miss = float(r.get("TCC_HIT_sum_avg_per_dispatch") or 0), float(r.get("TCC_MISS_sum_avg_per_dispatch") or 0)
+    factor, cal_note = 1.0, "no calibration row: FETCH_SIZE as reported"
+    c = _pmc_lookup(rows, "sdfhip::k_gather_blocks", CALIB_BLOCKS)
+    if c is not None:
+        known = CALIB_BLOCKS * (256 + 4)            # every block once + its 4-byte id
+        factor = known / (float(c["FETCH_SIZE_avg_per_dispatch"]) * 1024)
+        cal_note = f"k_gather_blocks: {known} B known / {int(float(c['FETCH_SIZE_avg_per_dispatch']) * 1024)} B reported"
+    return {"traffic": int(fetch * factor + write), "traffic_source": f"{src} (FETCH_SIZE x fetch_calibration + WRITE_SIZE, per launch)",
+            "fabric_bytes_reported": int(fetch), "write_bytes_reported": int(write), "fetch_calibration": round(factor, 3), "fetch_calibration_from": cal_note,
+            "tcc_miss_x64_bytes": int(miss * 64) if miss else None, "l2_hit": round(hit / (hit + miss), 4) if hit + miss > 0 else None,
+            "compulsory_hbm_bytes": int(compulsory_bytes)}
+
+
+CALIB_BLOCKS = 10_000_000      # 256-B blocks of the calibration array (2.56 GB: ten times the Infinity Cache)
+
+
+def octree_query_roofline(info, start_depth, n, kernel_ms, gradient, rows, src, kernel):
+    """SURVEY.md 8(d) "Q": algorithmic bytes per query = point 12 + distance 4 (+ gradient 12) + 256 coefficients + 4 x mean dependent node loads
+    (mean over uniform-random points, from the leaf-per-depth histogram).  achieved = those bytes / the kernel's HIP-event time; peak = HBM spec."""
+    lpd = np.array(list(info.leaves_per_depth), dtype=np.float64)
+    prob = np.array([lpd[d] / 8.0 ** d for d in range(16)])
+    mean_loads = float(sum(prob[d] * (d - start_depth + 1) for d in range(16)) / max(prob.sum(), 1e-30))
+    bytes_per_query = 12 + 4 + (12 if gradient else 0) + 256 + 4 * mean_loads
+    achieved = bytes_per_query * n / (kernel_ms * 1e-3) / 1e9
+    tree_bytes = 4 * int(info.num_words)
+    io_bytes = n * (16 + (12 if gradient else 0))
+    working_set = tree_bytes + io_bytes
+    # compulsory HBM bytes of ONE launch in steady state: whatever of the working set the 256 MB Infinity Cache cannot keep between launches
+    # (nothing if it fits; otherwise the streams always, and of the tree at most min(tree, 256 B x queries))
+    fits = working_set < 256 * 2 ** 20
+    compulsory = 0 if fits else io_bytes + min(tree_bytes, 256 * n)
+    r = {"bound": "hbm", "kernel": kernel.split("::")[-1], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4)}
+    r.update(_traffic_block(rows, src, kernel, n, compulsory))
+    r.update({"algorithmic_bytes_per_launch": int(round(bytes_per_query * n)), "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3),
+              "kernel_ms": round(kernel_ms, 4), "working_set_bytes": int(working_set), "infinity_cache_resident": bool(fits),
+              "limiter": ("L2-miss gather latency served by the Infinity Cache (working set < 256 MB): frac is against the HBM peak the kernel never has to touch; "
+                          "the HBM-resident figure is extras.deep_tree_d9.roofline") if fits else "HBM gather (working set exceeds the 256 MB Infinity Cache)"})
+    return r
 
 
 def _self_launch(n):
@@ -146,18 +202,15 @@ def main():
         elapsed = float(tmax.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
-    # ---- algorithmic bytes per query: point + result + path words + 256 B coefficients ----
-    lpd = np.array(list(info.leaves_per_depth), dtype=np.float64)
-    prob = np.array([lpd[d] / 8.0 ** d for d in range(16)])
-    mean_loads = float(sum(prob[d] * (d - args.start_depth + 1) for d in range(16)) / max(prob.sum(), 1e-30))
-    bytes_per_query = 12 + 4 + (12 if args.gradient else 0) + 256 + 4 * mean_loads
-    achieved_gbs = bytes_per_query * args.queries / (kernel_ms * 1e-3) / 1e9
+    rows, src = _pmc_rows() if (args.subdiv == 7 and args.depth == 8 and args.start_depth == 3) else ({}, None)
+    kname = f"sdfhip::k_octree_query<{0 if args.eval == 'exact' else 1},{'true' if args.gradient else 'false'}>"
+    roof = octree_query_roofline(info, args.start_depth, args.queries, kernel_ms, args.gradient, rows, src, kname)
 
     total_queries = args.queries * world * args.steps
     value = total_queries / elapsed / 1e6
 
-    traffic, traffic_src = _pmc_traffic(args)
     copy_gbs = measured_copy_gbs(dev)
+    roof["copy_bw_measured_gbs"] = round(copy_gbs, 1); roof["frac_of_measured_copy"] = round(roof["achieved"] / copy_gbs, 4)
     result = {
         "metric": "Mqueries/sec getDistance() (OctreeSdf, whole job)", "value": round(value, 2), "unit": "Mqueries/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -167,12 +220,7 @@ def main():
                    "eval": args.eval, "gradient": bool(args.gradient), "queries_per_gpu": args.queries,
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
-        "roofline": {"bound": "hbm", "kernel": "k_octree_query", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "algorithmic_bytes_per_launch": int(round(bytes_per_query * args.queries)),
-                     "bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "kernel_ms": round(kernel_ms, 4),
-                     "copy_bw_measured_gbs": round(copy_gbs, 1), "frac_of_measured_copy": round(achieved_gbs / copy_gbs, 4),
-                     "note": "achieved = algorithmic bytes / HIP-event kernel time; the 80 MB tree is Infinity-Cache resident, see DESIGN.md"},
+        "roofline": roof,
         "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **_r4(binfo)},
     }
 
@@ -184,7 +232,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline(v, f, box, args, pts)
     if not args.no_extras:
-        result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world)
+        result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world, rows, src)
     if not args.no_build_1m:
         result["build_1m"] = build_1m(ctx, rank, world, dev)
     if rank == 0:
@@ -249,7 +297,7 @@ def _time_ms(fn, reps=5):
     return a.elapsed_time(b) / reps
 
 
-def extras(tree, mesh, box, pts, out, dev, rank, world=1):
+def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     """Secondary per-GPU measurements (rank-local, untimed region): the other BASELINE.json configs on the same mesh."""
     n = pts.shape[0]
     outg = torch.empty((n, 3), dtype=torch.float32, device=dev)
@@ -311,7 +359,45 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1):
     r["fit_mfma_build"] = {"build_s": round(dt, 4), "words": int(mi.num_words), "same_size_as_exact_fit": bool(int(mi.num_words) == int(tree.info.num_words)),
                            "decisions_rechecked_with_exact_fit": int(mi.fit_rechecks), "nodes": int(mi.num_nodes)}
     mt.close()
+    if len(mesh.indices) >= 300_000:          # the headline configuration only (short test runs of this script skip the 1.7 GB tree)
+        r["deep_tree_d9"] = deep_tree(mesh, box, dev, rows or {}, src)
+        r["gather_calibration"] = gather_calibration(mesh.ctx, dev)
     return r
+
+
+DEEP_QUERIES = 12_000_000      # not 10 M: the profile summaries tell the two launches of the same kernel apart by grid size
+
+
+def deep_tree(mesh, box, dev, rows, src):
+    """The same query kernel on a tree that does NOT fit the 256 MB Infinity Cache: depth 9, threshold 2e-4 (about 1.7 GB of node array; the
+    tree tests/test_gpu_octree.py::test_deep_tree_depth_9_matches_oracle checks against the oracle) -> an HBM-bound gather figure."""
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t = S.OctreeSdf(mesh, box, 9, 3, 2e-4, num_threads=2)
+    torch.cuda.synchronize(); build_s = time.perf_counter() - t0
+    i = t.info
+    gen = torch.Generator(device=dev); gen.manual_seed(4321)
+    bb = t.get_grid_bounding_box(); size = float(bb[3] - bb[0])
+    pts = (torch.tensor(bb[:3], device=dev) + torch.rand((DEEP_QUERIES, 3), generator=gen, device=dev) * (size * 0.999999)).contiguous()
+    out = torch.empty(DEEP_QUERIES, dtype=torch.float32, device=dev)
+    ms = _time_ms(lambda: t.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out), reps=10)
+    roof = octree_query_roofline(i, 3, DEEP_QUERIES, ms, False, rows, src, "sdfhip::k_octree_query<0,false>")
+    t.close()
+    return {"build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves), "queries": DEEP_QUERIES, "query_ms": round(ms, 4),
+            "mqueries_s": round(DEEP_QUERIES / ms / 1e3, 1), "roofline": roof}
+
+
+def gather_calibration(ctx, dev):
+    """One launch pair of the counter-calibration kernel (see _traffic_block): also a direct measurement of the 256-B-gather ceiling from HBM."""
+    import ctypes as C
+    from sdflib_amd._lib import lib, check
+    data = torch.empty(64 * CALIB_BLOCKS, dtype=torch.int32, device=dev).fill_(1)
+    ids = torch.randperm(CALIB_BLOCKS, device=dev, dtype=torch.int64).to(torch.int32).contiguous()
+    out = torch.empty(CALIB_BLOCKS, dtype=torch.float32, device=dev)
+    fn = lambda: check(lib().sdfhip_test_gather_blocks(ctx.h, C.c_void_p(data.data_ptr()), C.c_void_p(ids.data_ptr()), CALIB_BLOCKS, C.c_void_p(out.data_ptr())))
+    ms = _time_ms(fn, reps=5)
+    byts = CALIB_BLOCKS * (256 + 4 + 4)
+    return {"blocks": CALIB_BLOCKS, "ms": round(ms, 4), "known_bytes": byts, "gb_s": round(byts / ms / 1e6, 1), "hbm_frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4),
+            "note": "random permutation of 256-B blocks over 2.56 GB, 16 x dwordx4 per lane: the HBM ceiling of the query kernel's access pattern"}
 
 
 def build_1m(ctx, rank, world, dev):

@@ -270,6 +270,10 @@ int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* 
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode);
 int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr,
                             uint64_t n, uint8_t* out);
+/* Profiling aid (device pointers, enqueued on the context's stream): lane i reads the 256-byte block dev_block_ids[i] of dev_data with the
+ * query kernel's load pattern (16 x dwordx4) and writes one float.  With a permutation of block ids the bytes that must cross the fabric
+ * are known exactly, which calibrates rocprofv3's FETCH_SIZE for this access pattern (bench.py, tools/profile_bench.sh). */
+int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const uint32_t* dev_block_ids, uint64_t n, float* dev_out);
 
 #ifdef __cplusplus
 }

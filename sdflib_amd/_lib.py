@@ -95,6 +95,7 @@ SIGNATURES = {
     "sdfhip_exact_query": (_int, [_vp, _vp, _u64, _vp, _vp, _vp, _int]),
     "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
     "sdfhip_is_near_minimize": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
+    "sdfhip_test_gather_blocks": (_int, [_vp, _vp, _vp, _u64, _vp]),
 }
 
 

@@ -26,11 +26,35 @@ __global__ void k_is_near(const float* __restrict__ half, const float* __restric
     out[i] = isNearMinimize(half[i], r, F3{t[0], t[1], t[2]}, F3{t[3], t[4], t[5]}, F3{t[6], t[7], t[8]}, thr[i]) ? 1 : 0;
 }
 
+// Counter calibration for the query kernel's access pattern (MI355X_MICROARCH.md: FETCH_SIZE is calibrated for coalesced 16-B/lane
+// streaming reads only): one lane per 256-byte block, 16 x dwordx4 like k_octree_query's coefficient load, blocks chosen by the
+// caller (a permutation -> every block exactly once -> the bytes that must cross the fabric are known exactly).
+__global__ void __launch_bounds__(256) k_gather_blocks(const uint32_t* __restrict__ data, const uint32_t* __restrict__ block, uint64_t n, float* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4* src = reinterpret_cast<const float4*>(data + 64ull * block[i]);
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const float4 v = src[q]; acc += (v.x + v.y) + (v.z + v.w); }
+    out[i] = acc;
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
 
 extern "C" {
+
+int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const uint32_t* dev_block_ids, uint64_t n, float* dev_out) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(ctx && dev_data && dev_block_ids && dev_out, "NULL argument");
+    if (n == 0) return SDFHIP_OK;
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
+    SDF_HIP_CHECK(hipGetLastError());
+    return SDFHIP_OK;
+    SDF_API_END
+}
 
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode) {
     SDF_API_BEGIN

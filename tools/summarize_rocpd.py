@@ -20,17 +20,25 @@ def short(name):
     return name[:90]
 
 
+SPLIT_BY_GRID = ("k_octree_query<", "k_gather_blocks")     # the same kernel is launched on different workloads: keep them apart
+
+
+def keyed(name, grid):
+    k = short(name)
+    return f"{k}@{int(grid)}" if grid is not None and any(t in k for t in SPLIT_BY_GRID) else k
+
+
 def main(src, prefix):
     os.makedirs(os.path.dirname(prefix) or ".", exist_ok=True)
     db = sqlite3.connect(os.path.join(src, "trace", "bench_results.db"))
-    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
-    tot = sum(r[2] for r in rows)
+    rows = db.execute("select name, grid_x, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name, grid_x order by sum(duration) desc").fetchall()
+    tot = sum(r[3] for r in rows)
     with open(prefix + "_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "percent"])
         agg = {}
-        for name, n, s, a, mn, mx in rows:
-            k = short(name)
+        for name, grid, n, s, a, mn, mx in rows:
+            k = keyed(name, grid)
             e = agg.setdefault(k, [0, 0, 1e30, 0])
             e[0] += n; e[1] += s; e[2] = min(e[2], mn); e[3] = max(e[3], mx)
         for k, (n, s, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -42,9 +50,13 @@ def main(src, prefix):
         if not os.path.exists(p):
             continue
         d = sqlite3.connect(p)
-        for name, cname, n, avg in d.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"):
+        for name, grid, cname, n, avg in d.execute("select kernel_name, grid_size_x, counter_name, count(*), avg(value) from counters_collection group by kernel_name, grid_size_x, counter_name"):
             if cname in counters:
-                out.setdefault(short(name), {})[cname] = (n, avg)
+                k = keyed(name, grid)
+                if k in out and cname in out[k]:          # same short name from several template instances: weighted mean
+                    n0, a0 = out[k][cname]; out[k][cname] = (n0 + n, (a0 * n0 + avg * n) / (n0 + n))
+                else:
+                    out.setdefault(k, {})[cname] = (n, avg)
     with open(prefix + "_pmc.csv", "w", newline="") as f:
         w = csv.writer(f)
         cols = ["FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"]
@@ -53,7 +65,7 @@ def main(src, prefix):
             if not k.startswith("sdfhip"):
                 continue
             n = max(x[0] for x in v.values())
-            w.writerow([k, n] + [f"{v[c][1]:.3f}" if c in v else "" for c in cols] + ["FETCH/WRITE_SIZE in KB as reported (gfx950: FETCH_SIZE under-reports wide streaming reads by 2x)"])
+            w.writerow([k, n] + [f"{v[c][1]:.3f}" if c in v else "" for c in cols] + ["FETCH/WRITE_SIZE in KB as reported; kernel@N = launches over N work-items"])
     with open(prefix + "_pmc_sq.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches"] + [c + "_avg_per_dispatch" for c in SQ])
