@@ -55,7 +55,7 @@ struct ContinuityBuilder {
     const MeshView mesh; const std::vector<TriangleData>& td; const SphereBvh& bvh; OctreeSdfData& out;
     uint32_t startDepth, maxDepth; int rule; float sqThr, param1;
     std::vector<uint32_t>& oc;            // mOctreeData
-    uint64_t numQueries = 0, numResubdivided = 0;
+    uint64_t numQueries = 0, numResubdivided = 0;        // numQueries is updated atomically: Iter 1 runs under OpenMP
     ContinuityBuilder(const MeshView& m, const std::vector<TriangleData>& t, const SphereBvh& b, OctreeSdfData& o) : mesh(m), td(t), bvh(b), out(o), oc(o.data) {}
 
     bool isLeaf(uint32_t at) const { return (oc[at] & LEAF_BIT) != 0; }
@@ -63,7 +63,11 @@ struct ContinuityBuilder {
     uint32_t childrenIndex(uint32_t at) const { return oc[at] & INDEX_MASK; }
     void setValues(uint32_t at, bool leaf, uint32_t index) { oc[at] = (index & INDEX_MASK) | (leaf ? LEAF_BIT : 0u); }
 
-    void sample(V3 p, float outv[8], uint32_t& info) { numQueries++; info = bvh.nearestTriangle(p); pointValues(p, info, mesh, td, outv); }
+    void sample(V3 p, float outv[8], uint32_t& info) {
+        #pragma omp atomic
+        numQueries++;
+        info = bvh.nearestTriangle(p); pointValues(p, info, mesh, td, outv);
+    }
     // calculateVerticesInfo<19>: bit (18-i) of mask set -> interpolate from coeff, else exact sample
     void midPoints(CNode& n, uint32_t mask) {
         const Stencil& st = stencil();
@@ -174,9 +178,13 @@ struct ContinuityBuilder {
 
         for (uint32_t cd = sod; cd <= maxDepth; cd++) {
             // ---------------- Iter 1
+            // The reference runs this loop under OpenMP too (OctreeSdfBreadthFirstNoDelay.h:246-370): a node reads only words of
+            // shallower levels (final since the previous level) and writes its own word; with the lattice cache off every sample is a
+            // pure function of its position, so the result does not depend on the thread count.
             if (cd < maxDepth) {
-                const size_t cnt = buf[cd].size();
-                for (size_t id = 0; id < cnt; id++) {
+                const int64_t cnt = (int64_t)buf[cd].size();
+                #pragma omp parallel for schedule(dynamic, 16)
+                for (int64_t id = 0; id < cnt; id++) {
                     CNode& node = buf[cd][id];
                     if (node.ignore) continue;
                     uint32_t word = 0xFFFFFFFFu;

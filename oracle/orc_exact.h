@@ -13,6 +13,7 @@
 // startOctreeDepth as the subtree root depth) — parity for this structure is defined single-threaded.
 #pragma once
 #include "orc_octree.h"
+#include <memory>
 
 namespace orc {
 
@@ -79,9 +80,13 @@ struct ExactBuilder {
     uint64_t cullTests = 0;
 
     const std::vector<TriangleData>* meshTd = nullptr;      // the mesh's TriangleData (calculateMeshTriangleData(mesh): welded when the mesh carries its box)
+    const std::vector<TriangleData>* tris = nullptr;        // what the searches read: out.triangles, or the main builder's for a per-subtree builder
     ExactBuilder(const MeshView& m, ExactOctreeData& o, const std::vector<TriangleData>* td = nullptr) : mesh(m), out(o), meshTd(td) {}
 
     struct Node { uint32_t nodeIndex; uint32_t depth; V3 center; float size; uint32_t vi[8]; };
+    // Parallel canonical build (test speed-up only, see runParallel): start cells collected in emission order instead of being processed
+    struct Task { Node node; std::shared_ptr<const std::vector<uint32_t>> parentList; };
+    std::vector<Task>* collect = nullptr;
 
     uint32_t bruteNearest(V3 p, const std::vector<uint32_t>& list) {
         if (useCache) {
@@ -90,12 +95,12 @@ struct ExactBuilder {
             Entry& e = cache[((iz & 31u) << 10) | ((iy & 31u) << 5) | (ix & 31u)];
             if (e.x == ix && e.y == iy && e.z == iz) return e.info;
             uint32_t best = 0; float bd = INFINITY;
-            for (uint32_t t : list) { const float d = sqDistPointTriangle(p, out.triangles[t]); if (d < bd) { best = t; bd = d; } }
+            for (uint32_t t : list) { const float d = sqDistPointTriangle(p, (*tris)[t]); if (d < bd) { best = t; bd = d; } }
             e = Entry{ix, iy, iz, best};
             return best;
         }
         uint32_t best = 0; float bd = INFINITY;
-        for (uint32_t t : list) { const float d = sqDistPointTriangle(p, out.triangles[t]); if (d < bd) { best = t; bd = d; } }
+        for (uint32_t t : list) { const float d = sqDistPointTriangle(p, (*tris)[t]); if (d < bd) { best = t; bd = d; } }
         return best;
     }
 
@@ -105,7 +110,7 @@ struct ExactBuilder {
         for (int i = 0; i < 8; i++) {
             minDist[i] = INFINITY;
             for (int c = 0; c < 8; c++) {
-                region[i][c] = std::sqrt(sqDistPointTriangle(n.center + CORNER_REL[c] * n.size, out.triangles[n.vi[i]]));
+                region[i][c] = std::sqrt(sqDistPointTriangle(n.center + CORNER_REL[c] * n.size, (*tris)[n.vi[i]]));
                 minDist[i] = gmin(minDist[i], region[i][c]);
             }
             for (int c = 0; c < 8; c++) region[i][c] -= minDist[i];
@@ -164,11 +169,17 @@ struct ExactBuilder {
                 for (int j = 0; j < 8; j++) { const int s = st.childSrc[c][j]; ch[c].vi[j] = s >= 0 ? midInfo[s] : n.vi[-s - 1]; }
             }
             std::array<std::vector<uint32_t>, 8> chLists;
+            std::shared_ptr<const std::vector<uint32_t>> shared;
             for (int c = 7; c >= 0; c--) {
                 Node cn = ch[c];
                 if (cn.depth == startDepth) {
                     V3 f = (cn.center - out.box.min) / out.startGridCellSize;
                     cn.nodeIndex = (uint32_t)((int)std::floor(f.z) * out.startGridXY + (int)std::floor(f.y) * out.startGridSize + (int)std::floor(f.x));
+                    if (collect) {      // parallel build: the subtree is processed later by its own builder (nothing above the start depth emits)
+                        if (!shared) shared = std::make_shared<const std::vector<uint32_t>>(nodeList);
+                        collect->push_back(Task{cn, shared});
+                        continue;
+                    }
                 }
                 process(cn, nodeList, chLists[c]);
             }
@@ -192,7 +203,7 @@ struct ExactBuilder {
                 for (int c = 0; c < 8; c++) {
                     const uint32_t at = (uint32_t)out.masks.size();
                     out.masks.resize(out.masks.size() + nb);
-                    out.nodes[2 * (childrenAt + c) + 1] = at; out.nodeHasTriIdx[childrenAt + c] = 1;
+                    out.nodes[2 * (childrenAt + c) + 1] = at; out.nodeHasTriIdx[childrenAt + c] = 2;     // 2 = offset into masks (1 = into sets); exported as 1
                     std::memcpy(out.masks.data() + at, maskBuf[c].data(), nb);
                 }
                 if (n.depth == out.bitEncodingStartDepth) {
@@ -207,8 +218,16 @@ struct ExactBuilder {
         }
     }
 
-    void run(const Box& inBox, uint32_t depth, uint32_t startDepth_, uint32_t minTri, bool vertexCache) {
+    // threads > 1: canonical mode only (no lattice cache).  The reference's own multi-thread branch is NOT what runs here (it is
+    // incorrect for startDepth >= 2, see the header): the start cells' subtrees are built by independent builders — nothing but
+    // the three output arrays and the leaf statistics couples them — and concatenated in the single-thread emission order with
+    // their indices rebased, which reproduces the sequential arrays bit for bit (tests/test_oracle_kats.py checks that).
+    void run(const Box& inBox, uint32_t depth, uint32_t startDepth_, uint32_t minTri, bool vertexCache, int threads = 1) {
         startDepth = startDepth_; maxDepth = depth; minTriangles = minTri; useCache = vertexCache;
+        tris = &out.triangles;
+        std::vector<Task> tasks;
+        const bool parallel = threads > 1 && !vertexCache && depth >= 2 && depth - 2 >= startDepth_;
+        if (parallel) collect = &tasks;
         out.maxDepth = depth;
         const V3 bs = inBox.size();
         const float maxSize = gmax(gmax(bs.x, bs.y), bs.z);
@@ -244,14 +263,61 @@ struct ExactBuilder {
             for (int c = 0; c < 8; c++) n.vi[c] = bruteNearest(n.center + CORNER_REL[c] * n.size, all);
             roots.push_back(n);
         }
+        std::shared_ptr<const std::vector<uint32_t>> sharedAll;
         for (int r = (int)roots.size() - 1; r >= 0; r--) {
             Node n = roots[r];
             if (n.depth == startDepth) {
                 V3 f = (n.center - out.box.min) / out.startGridCellSize;
                 n.nodeIndex = (uint32_t)((int)std::floor(f.z) * out.startGridXY + (int)std::floor(f.y) * out.startGridSize + (int)std::floor(f.x));
+                if (collect) {
+                    if (!sharedAll) sharedAll = std::make_shared<const std::vector<uint32_t>>(all);
+                    collect->push_back(Task{n, sharedAll});
+                    continue;
+                }
             }
             std::vector<uint32_t> list;
             process(n, all, list);
+        }
+        if (parallel) { collect = nullptr; runTasks(tasks, threads); }
+    }
+
+    void runTasks(const std::vector<Task>& tasks, int threads) {
+        const size_t nt = tasks.size();
+        std::vector<ExactOctreeData> local(nt);
+        std::vector<uint64_t> cull(nt, 0);
+        #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+        for (int64_t k = 0; k < (int64_t)nt; k++) {
+            ExactOctreeData& L = local[k];
+            L.box = out.box; L.startGridSize = out.startGridSize; L.startGridXY = out.startGridXY; L.startDepth = out.startDepth;
+            L.startGridCellSize = out.startGridCellSize; L.maxDepth = out.maxDepth; L.bitEncodingStartDepth = out.bitEncodingStartDepth;
+            L.bitsPerIndex = out.bitsPerIndex; L.minTrianglesInLeafs = out.minTrianglesInLeafs;
+            ExactBuilder b(mesh, L);
+            b.startDepth = startDepth; b.maxDepth = maxDepth; b.minTriangles = minTriangles; b.useCache = false;
+            b.coordToId = coordToId; b.minPoint = minPoint; b.tris = tris;
+            b.growNodes(1);                       // local node 0 = the start cell; its body follows from local index 1
+            Node n = tasks[k].node; n.nodeIndex = 0;
+            std::vector<uint32_t> list;
+            b.process(n, *tasks[k].parentList, list);
+            cull[k] = b.cullTests;
+        }
+        for (size_t k = 0; k < nt; k++) {
+            const ExactOctreeData& L = local[k];
+            const uint32_t bodyBase = (uint32_t)numNodes(), setBase = (uint32_t)out.sets.size(), maskBase = (uint32_t)out.masks.size();
+            const size_t ln = L.nodes.size() / 2;
+            growNodes(numNodes() + (ln - 1));
+            for (size_t i = 0; i < ln; i++) {
+                const uint32_t g = i == 0 ? tasks[k].node.nodeIndex : bodyBase + (uint32_t)(i - 1);
+                uint32_t w0 = L.nodes[2 * i], w1 = L.nodes[2 * i + 1];
+                if (w0 != 0xFFFFFFFFu) w0 = (w0 & 0x7FFFFFFFu) + (bodyBase - 1u);          // local child block >= 1 -> global
+                const uint8_t kind = L.nodeHasTriIdx[i];
+                if (kind == 1) w1 += setBase; else if (kind == 2) w1 += maskBase;
+                out.nodes[2 * g] = w0; out.nodes[2 * g + 1] = w1; out.nodeHasTriIdx[g] = kind;
+            }
+            out.sets.insert(out.sets.end(), L.sets.begin(), L.sets.end());
+            out.masks.insert(out.masks.end(), L.masks.begin(), L.masks.end());
+            if (L.maxTrianglesInLeafs > out.maxTrianglesInLeafs) out.maxTrianglesInLeafs = L.maxTrianglesInLeafs;
+            if (L.maxTrianglesEncodedInLeafs > out.maxTrianglesEncodedInLeafs) out.maxTrianglesEncodedInLeafs = L.maxTrianglesEncodedInLeafs;
+            cullTests += cull[k];
         }
     }
 };

@@ -51,6 +51,7 @@ def lib():
             "orc_octree_query": (None, [vp, vp, u64, vp, vp, C.c_int]),
             "orc_octree_query_raw": (None, [vp, u64, vp, i32, f32, vp, u64, vp, vp, C.c_int]),
             "orc_exact_build": (vp, [vp, vp, u32, u32, u32, C.c_int]), "orc_exact_destroy": (None, [vp]),
+            "orc_exact_build_mt": (vp, [vp, vp, u32, u32, u32, C.c_int, C.c_int]),
             "orc_exact_sizes": (None, [vp, vp, vp, vp, vp, vp, vp, vp]), "orc_exact_data": (None, [vp, vp, vp, vp, vp]),
             "orc_exact_query": (None, [vp, vp, u64, vp, vp, vp, C.c_int]),
         }
@@ -207,11 +208,12 @@ def octree_query_raw(data, box6, start_grid_size, min_border, pts, grad=False, t
 
 
 class Exact:
-    """Oracle ExactOctreeSdf (single-thread semantics)."""
+    """Oracle ExactOctreeSdf (single-thread semantics).  threads != 1 (0 = all cores) builds the start cells concurrently in canonical
+    mode (vertex_cache False) — the same arrays as the sequential build, only faster (full-size GPU parity tests)."""
 
-    def __init__(self, mesh, box6, depth, start_depth=1, min_triangles=128, vertex_cache=False):
+    def __init__(self, mesh, box6, depth, start_depth=1, min_triangles=128, vertex_cache=False, threads=1):
         self.mesh = mesh
-        self.h = lib().orc_exact_build(mesh.h, _p(_f32(box6)), depth, start_depth, min_triangles, int(vertex_cache))
+        self.h = lib().orc_exact_build_mt(mesh.h, _p(_f32(box6)), depth, start_depth, min_triangles, int(vertex_cache), int(threads))
         nn, ns, nm, cull = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
         bits, ml, me = C.c_uint32(), C.c_uint32(), C.c_uint32()
         lib().orc_exact_sizes(self.h, C.byref(nn), C.byref(ns), C.byref(nm), C.byref(bits), C.byref(ml), C.byref(me), C.byref(cull))

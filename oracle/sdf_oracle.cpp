@@ -177,9 +177,18 @@ void orc_octree_query_raw(const uint32_t* data, uint64_t size, const float box6[
 }
 
 orc_exact* orc_exact_build(orc_mesh* m, const float box6[6], uint32_t depth, uint32_t startDepth, uint32_t minTri, int cache) {
+    return orc_exact_build_mt(m, box6, depth, startDepth, minTri, cache, 1);
+}
+// threads > 1 (0 = all cores): canonical mode only; start cells built concurrently, arrays identical to the sequential build
+orc_exact* orc_exact_build_mt(orc_mesh* m, const float box6[6], uint32_t depth, uint32_t startDepth, uint32_t minTri, int cache, int threads) {
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#else
+    threads = 1;
+#endif
     orc_exact* e = new orc_exact();
     ExactBuilder b(m->view(), e->d, &m->td);
-    b.run(ldbox(box6), depth, startDepth, minTri, cache != 0);
+    b.run(ldbox(box6), depth, startDepth, minTri, cache != 0, threads);
     e->cullTests = b.cullTests;
     return e;
 }
@@ -190,7 +199,7 @@ void orc_exact_sizes(orc_exact* e, uint64_t* nn, uint64_t* ns, uint64_t* nm, uin
 }
 void orc_exact_data(orc_exact* e, uint32_t* nodes, uint8_t* has, uint32_t* sets, uint8_t* masks) {
     std::memcpy(nodes, e->d.nodes.data(), e->d.nodes.size() * 4);
-    std::memcpy(has, e->d.nodeHasTriIdx.data(), e->d.nodeHasTriIdx.size());
+    for (size_t i = 0; i < e->d.nodeHasTriIdx.size(); i++) has[i] = e->d.nodeHasTriIdx[i] ? 1 : 0;      // internally 1 = set offset, 2 = mask offset
     std::memcpy(sets, e->d.sets.data(), e->d.sets.size() * 4);
     if (!e->d.masks.empty()) std::memcpy(masks, e->d.masks.data(), e->d.masks.size());
 }

@@ -45,6 +45,7 @@ int orc_is_near_minimize(float half, const float radius[8], const float tri[9], 
 orc_octree* orc_octree_build(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, int rule,
                              float p0, float p1, int vertex_cache, int layout);
 /* OctreeSdf CONTINUITY builder (canonical mode, single layout) */
+/* Iter 1 of every level runs under OpenMP like the reference's (OctreeSdfBreadthFirstNoDelay.h:246-370); canonical mode is thread-count invariant */
 orc_octree* orc_octree_build_continuity(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, int rule, float p0, float p1);
 void orc_stencil_tables(float* mid_rel_57, int32_t* child_src_64, float* mid_weight_19);
 void orc_neighbour_masks(uint32_t* out24);
@@ -59,6 +60,8 @@ void orc_octree_query_raw(const uint32_t* data, uint64_t size, const float box6[
                           const float* pts, uint64_t n, float* out_dist, float* out_grad, int num_threads);
 
 orc_exact* orc_exact_build(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, uint32_t min_triangles, int vertex_cache);
+/* the same arrays from `threads` OpenMP threads over the start cells (0 = all cores); canonical mode (vertex_cache = 0) only, otherwise sequential */
+orc_exact* orc_exact_build_mt(orc_mesh*, const float box6[6], uint32_t depth, uint32_t start_depth, uint32_t min_triangles, int vertex_cache, int threads);
 void orc_exact_destroy(orc_exact*);
 void orc_exact_sizes(orc_exact*, uint64_t* num_nodes, uint64_t* num_set_words, uint64_t* num_mask_bytes, uint32_t* bits_per_index,
                      uint32_t* max_tri_in_leafs, uint32_t* max_tri_encoded, uint64_t* cull_tests);

@@ -1,0 +1,112 @@
+"""BASELINE.json configs at FULL size on the GPU, against the CPU oracle (VERDICT r1 "configs_untested"):
+  C2  s=7 (327 680 triangles) OctreeSdf depth 8 / start 3 / 1e-3: node array, 10 M distances AND gradients bit for bit;
+      the same mesh through the CONTINUITY builder (the exporter's default): whole 44.5 M-word array;
+  C3  ExactOctreeSdf depth 7 / start 3 / min 128: nodes, written-flags, bit-packed sets, byte masks, 200 k queries with triangle ids;
+  C5  256^3 lattice (cell centres, x fastest) value + gradient on the C2 tree: bit-exact in EVAL_EXACT, <= 1e-5 / 2e-4 in EVAL_FAST.
+The oracle runs under OpenMP on the box's host cores (canonical mode is thread-count invariant: tests/test_oracle_kats.py)."""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2(oracle, gpu_ctx):
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    v, f = bumpy_icosphere(7)
+    box = box_with_margin(v)
+    gm, om = S.Mesh(v, f, gpu_ctx), oracle.Mesh(v, f)
+    gt = S.OctreeSdf(gm, box, 8, 3, 1e-3, num_threads=2)
+    ot = oracle.Octree(om, box, 8, 3, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    return dict(v=v, f=f, box=box, gm=gm, om=om, gt=gt, ot=ot)
+
+
+def test_c2_array_and_ten_million_distances_and_gradients(c2):
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gt, ot = c2["gt"], c2["ot"]
+    assert np.array_equal(ot.data(), gt.get_octree_data())
+    assert np.float32(gt.info.value_range) == np.float32(ot.value_range) and np.float32(gt.info.min_border_value) == np.float32(ot.min_border)
+    pts = random_points_in_box(c2["box"], 10_000_000, seed=1234)
+    pts[:100000] = (pts[:100000] - 0.0) * 1.7          # a share of the points outside the grid box (box distance + min border value)
+    d0, g0 = ot.query(pts, grad=True)
+    d1, g1 = gt.get_distance(pts, gradient=True, eval_mode=S.EVAL_EXACT)
+    assert np.array_equal(bits(d0), bits(d1))
+    assert np.array_equal(bits(g0), bits(g1))
+    d2, g2 = gt.get_distance(pts, gradient=True, eval_mode=S.EVAL_FAST)
+    inside = slice(100000, None)
+    assert np.abs(d2 - d0).max() <= 1e-5
+    assert np.abs(g2[inside] - g0[inside]).max() <= 2e-4
+
+
+def test_c5_lattice_256_value_and_gradient(c2):
+    import sdflib_amd as S
+    gt, ot = c2["gt"], c2["ot"]
+    bb = gt.get_grid_bounding_box()
+    n = 256
+    step = np.full(3, np.float32(bb[3] - bb[0]) / np.float32(n), dtype=np.float32)
+    origin = (bb[:3] + np.float32(0.5) * step).astype(np.float32)
+    # the lattice points exactly as the kernel generates them: origin + float(i) * step, fp32, no FMA
+    ax = [(origin[a] + np.arange(n, dtype=np.float32) * step[a]).astype(np.float32) for a in range(3)]
+    pts = np.empty((n, n, n, 3), dtype=np.float32)           # [z, y, x]: x fastest
+    pts[..., 0] = ax[0][None, None, :]; pts[..., 1] = ax[1][None, :, None]; pts[..., 2] = ax[2][:, None, None]
+    pts = pts.reshape(-1, 3)
+    d0, g0 = ot.query(pts, grad=True)
+    d1, g1 = gt.get_distance_grid(origin, step, (n, n, n), gradient=True, eval_mode=S.EVAL_EXACT)
+    assert np.array_equal(bits(d0), bits(d1))
+    assert np.array_equal(bits(g0), bits(g1))
+    d2, g2 = gt.get_distance_grid(origin, step, (n, n, n), gradient=True, eval_mode=S.EVAL_FAST)
+    assert np.abs(d2 - d0).max() <= 1e-5
+    assert np.abs(g2 - g0).max() <= 2e-4
+    # value-only lattice launches and a non-cubic, offset sub-lattice (ragged shape)
+    assert np.array_equal(bits(gt.get_distance_grid(origin, step, (n, n, n), eval_mode=S.EVAL_EXACT)), bits(d0))
+    sub = gt.get_distance_grid(origin + 3 * step, step * np.float32(2), (100, 37, 5), eval_mode=S.EVAL_EXACT)
+    sp = np.empty((5, 37, 100, 3), dtype=np.float32)
+    o2, s2 = (origin + 3 * step).astype(np.float32), (step * np.float32(2)).astype(np.float32)
+    sp[..., 0] = (o2[0] + np.arange(100, dtype=np.float32) * s2[0])[None, None, :]
+    sp[..., 1] = (o2[1] + np.arange(37, dtype=np.float32) * s2[1])[None, :, None]
+    sp[..., 2] = (o2[2] + np.arange(5, dtype=np.float32) * s2[2])[:, None, None]
+    assert np.array_equal(bits(sub), bits(ot.query(sp.reshape(-1, 3))))
+
+
+def test_c2_size_continuity_array(c2, oracle):
+    """The exporter's default builder at the C2 size: 44.5 M words equal to the oracle's, plus queries on it."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gc = S.OctreeSdf(c2["gm"], c2["box"], 8, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    oc = oracle.Octree(c2["om"], c2["box"], 8, 3, 1e-3, continuity=True)
+    a, b = oc.data(), gc.get_octree_data()
+    assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.float32(gc.info.min_border_value) == np.float32(oc.min_border)
+    pts = random_points_in_box(c2["box"], 1_000_000, seed=99)
+    d0, g0 = oc.query(pts, grad=True)
+    d1, g1 = gc.get_distance(pts, gradient=True, eval_mode=S.EVAL_EXACT)
+    assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(bits(g0), bits(g1))
+    gc.close()
+
+
+def test_c3_exact_octree_full_size_arrays(c2, oracle):
+    """BASELINE configs[2]: every array of the depth-7 / min-128 ExactOctreeSdf and 200 k queries (distance, gradient, triangle id)."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    ge = S.ExactOctreeSdf(c2["gm"], c2["box"], 7, 3, 128)
+    oe = oracle.Exact(c2["om"], c2["box"], 7, 3, 128, threads=0)
+    i = ge.info
+    assert (i.num_nodes, i.num_set_words, i.num_mask_bytes) == (oe.num_nodes, oe.num_set_words, oe.num_mask_bytes)
+    assert (i.max_triangles_in_leafs, i.max_triangles_encoded_in_leafs, i.bits_per_index) == (oe.max_tri_in_leafs, oe.max_tri_encoded, oe.bits_per_index)
+    assert i.cull_tests == oe.cull_tests
+    for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    pts = random_points_in_box(c2["box"], 200_000, seed=11)
+    pts[:2000] *= 1.9
+    d0, g0, t0 = oe.query(pts, grad=True, tri=True)
+    d1, g1, t1 = ge.get_distance(pts, gradient=True, triangle=True)
+    box = ge.get_grid_bounding_box()
+    inside = ((pts >= box[:3]) & (pts < box[3:])).all(axis=1)       # outside the grid the reference returns the box distance: no triangle, no gradient
+    assert (~inside).sum() > 100
+    assert np.array_equal(bits(d0), bits(d1))
+    assert np.array_equal(bits(g0[inside]), bits(g1[inside])) and np.array_equal(t0[inside], t1[inside])
+    ge.close()

@@ -201,7 +201,7 @@ def test_mfma_build_has_identical_topology_and_close_coefficients(small):
     assert abs(a.info.min_border_value - b.info.min_border_value) < 5e-5 and a.info.value_range == b.info.value_range
 
 
-@pytest.mark.parametrize("subdiv,depth,start", [(6, 7, 3), (7, 8, 3)])
+@pytest.mark.parametrize("subdiv,depth,start", [(6, 7, 3)])       # (7, 8, 3) = BASELINE configs[1]: tests/test_gpu_baseline_configs.py
 def test_full_size_octree_matches_oracle(oracle, gpu_ctx, subdiv, depth, start):
     """BASELINE.json configs[1] at full size (s=7: 327 680 triangles, depth 8): whole node array + 10 M queries."""
     import sdflib_amd as S

@@ -266,3 +266,37 @@ def test_seam_welding_repairs_a_triangle_soup(oracle):
     r = np.linalg.norm(pts, axis=1)
     far = np.abs(r - 1.0) > 0.05
     assert np.array_equal(np.sign(sd[far]), np.sign(r[far] - 1.0))
+
+
+@pytest.mark.parametrize("subdiv,depth,start,min_tri", [(3, 5, 1, 16), (3, 5, 2, 16), (4, 6, 3, 32), (3, 4, 2, 8), (2, 5, 3, 4)])
+def test_parallel_exact_build_equals_the_sequential_one(oracle, subdiv, depth, start, min_tri):
+    """The OpenMP-over-start-cells Exact build (used by the full-size GPU parity test to keep the oracle under a minute) must write
+    the very arrays of the sequential canonical build: nodes, written-flags, bit-packed sets, byte masks, leaf statistics, cull count."""
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    v, f = bumpy_icosphere(subdiv)
+    box = box_with_margin(v)
+    om = oracle.Mesh(v, f)
+    a = oracle.Exact(om, box, depth, start, min_tri, threads=1)
+    for threads in (3, 0):
+        b = oracle.Exact(om, box, depth, start, min_tri, threads=threads)
+        assert (a.num_nodes, a.num_set_words, a.num_mask_bytes, a.max_tri_in_leafs, a.max_tri_encoded, a.cull_tests) == \
+               (b.num_nodes, b.num_set_words, b.num_mask_bytes, b.max_tri_in_leafs, b.max_tri_encoded, b.cull_tests)
+        for x, y in zip(a.data(), b.data()):
+            assert np.array_equal(x, y)
+
+
+def test_continuity_oracle_is_thread_count_invariant(oracle, monkeypatch):
+    """Iter 1 of the CONTINUITY oracle runs under OpenMP (like the reference's); canonical mode must not depend on the thread count."""
+    import ctypes
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    v, f = bumpy_icosphere(3)
+    box = box_with_margin(v)
+    om = oracle.Mesh(v, f)
+    omp = ctypes.CDLL("libgomp.so.1")
+    outs = []
+    for threads in (1, 5):
+        omp.omp_set_num_threads(threads)
+        t = oracle.Octree(om, box, 5, 2, 1e-3, continuity=True)
+        outs.append((t.data(), t.value_range, t.min_border, t.num_bvh_queries))
+    omp.omp_set_num_threads(os.cpu_count() or 1)
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
