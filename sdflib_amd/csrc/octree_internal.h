@@ -34,8 +34,16 @@ struct sdfhip_octree {
     sdfhip_ctx* ctx = nullptr;
     sdfhip_octree_info info{};
     sdfhip_octree_params params{};
-    sdfhip::DevBuf<uint32_t> data;          // full node array (when available)
+    sdfhip::DevBuf<uint32_t> data;          // full node array (when available): the reference's mOctreeData layout, what download / emit return
     bool hasData = false;
+    // Query-side layout, derived from `data` on the first query (octree_query.hip, ensureQueryLayout): the node words alone, packed
+    // breadth-first (a few MB: the dependent loads of the walk stay in L2), and the leaves' coefficients as 256-byte-ALIGNED blocks
+    // (a block is exactly two 128-byte lines; in `data` a block starts at any multiple of 4 bytes and straddles three).
+    sdfhip::DevBuf<uint32_t> qTopo;         // [G^3 start cells][level 1 blocks]...: inner word = index of the 8-word child block, leaf word = LEAF_BIT | block id
+    sdfhip::DevBuf<float> qCoef;            // 64 floats per leaf, block id order
+    uint64_t qNodes = 0, qLeaves = 0;
+    bool qReady = false;
+    std::mutex qLock;
     // construction state kept between build_shard and emit_shard
     std::vector<std::unique_ptr<sdfhip::BuildLevel>> levels;   // index = depth - startOctreeDepth
     uint32_t startOctreeDepth = 0;

@@ -14,7 +14,8 @@
 namespace sdfhip {
 
 struct QueryTree {
-    const uint32_t* data;
+    const uint32_t* topo;       // packed node words (sdfhip_octree::qTopo)
+    const float* coef;          // 256-byte aligned coefficient blocks (sdfhip_octree::qCoef)
     float bminx, bminy, bminz, bmaxx, bmaxy, bmaxz;
     float cellSize, minBorder;
     int G;
@@ -56,10 +57,10 @@ SDF_DEV bool locateLeaf(const QueryTree& t, F3 p, uint32_t& at, F3& f) {
     const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
     f = F3{f.x - flx, f.y - fly, f.z - flz};
     if (ix < 0 || ix >= t.G || iy < 0 || iy >= t.G || iz < 0 || iz >= t.G) return false;
-    uint32_t w = t.data[(iz * t.G + iy) * t.G + ix];
+    uint32_t w = t.topo[(iz * t.G + iy) * t.G + ix];
     while (!(w & LEAF_BIT)) {
         const uint32_t child = ((f.z >= 0.5f) ? 4u : 0u) + ((f.y >= 0.5f) ? 2u : 0u) + ((f.x >= 0.5f) ? 1u : 0u);
-        w = t.data[(w & INDEX_MASK) + child];
+        w = t.topo[(w & INDEX_MASK) + child];
         f = F3{gfract(2.0f * f.x), gfract(2.0f * f.y), gfract(2.0f * f.z)};
     }
     at = w & INDEX_MASK;
@@ -74,14 +75,9 @@ SDF_DEV float queryOne(const QueryTree& t, F3 p, float* grad) {
         return boxDistance(t, p) + t.minBorder;
     }
     float c[64];
-    if ((at & 3u) == 0u) {
-        const float4* src = reinterpret_cast<const float4*>(t.data + at);
+    const float4* src = reinterpret_cast<const float4*>(t.coef + 64ull * at);        // `at` = block id: 256-byte aligned, two cache lines
 #pragma unroll
-        for (int q = 0; q < 16; q++) { const float4 v = src[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
-    } else {
-#pragma unroll
-        for (int q = 0; q < 64; q++) c[q] = __uint_as_float(t.data[at + q]);
-    }
+    for (int q = 0; q < 16; q++) { const float4 v = src[q]; c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; }
     auto cf = [&](int n) { return c[n]; };
     if (EVAL == SDFHIP_EVAL_EXACT) {
         if (GRAD) {
@@ -125,9 +121,105 @@ __global__ void __launch_bounds__(256) k_octree_query_grid(QueryTree t, F3 origi
     if (GRAD) { grad[3 * i] = g[0]; grad[3 * i + 1] = g[1]; grad[3 * i + 2] = g[2]; }
 }
 
+// ---- query-side layout -------------------------------------------------------------------------------------------------
+// One breadth-first sweep over `data` per level.  Ranks are handed out per wave (ballot + one atomic per wave), so that the children
+// of neighbouring nodes — and the coefficient blocks of neighbouring leaves — stay neighbours in the packed arrays.
+SDF_DEV uint32_t waveRank(bool take, uint32_t* counter) {
+    const uint64_t m = __ballot(take);
+    const uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    if (m != 0ull) {
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+    }
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+// counters: [0] inner nodes of this level, [1] leaves so far (all levels), [2] malformed words
+__global__ void k_ql_level(const uint32_t* __restrict__ data, uint64_t numWords, const uint32_t* __restrict__ src, uint32_t count, uint32_t* __restrict__ rank,
+                           uint32_t* __restrict__ nextSrc, uint32_t* __restrict__ counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = j < count;
+    const uint32_t w = live ? data[src ? src[j] : j] : LEAF_BIT;
+    const bool leaf = (w & LEAF_BIT) != 0u;
+    const uint64_t idx = w & INDEX_MASK;
+    const bool bad = live && (leaf ? idx + 64u > numWords : (idx + 8u > numWords || idx == 0u));
+    const uint32_t rl = waveRank(live && leaf && !bad, counters + 1);
+    const uint32_t ri = waveRank(live && !leaf && !bad, counters);
+    if (!live) return;
+    if (bad) { atomicAdd(counters + 2, 1u); rank[j] = LEAF_BIT; return; }
+    if (leaf) rank[j] = LEAF_BIT | rl;
+    else {
+        rank[j] = ri;
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; c++) nextSrc[8u * ri + c] = (uint32_t)idx + c;
+    }
+}
+__global__ void k_ql_fill(const uint32_t* __restrict__ data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ rank, uint32_t count,
+                          uint32_t* __restrict__ topoLevel, uint32_t nextLevelBase, float* __restrict__ coef) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t r = rank[j];
+    if (!(r & LEAF_BIT)) { topoLevel[j] = nextLevelBase + 8u * r; return; }
+    topoLevel[j] = r;
+    const uint32_t* from = data + (data[src ? src[j] : j] & INDEX_MASK);
+    float4* to = reinterpret_cast<float4*>(coef + 64ull * (r & INDEX_MASK));
+#pragma unroll
+    for (int q = 0; q < 16; q++) to[q] = make_float4(__uint_as_float(from[4 * q]), __uint_as_float(from[4 * q + 1]), __uint_as_float(from[4 * q + 2]), __uint_as_float(from[4 * q + 3]));
+}
+
+static int ensureQueryLayout(sdfhip_octree* T) {
+    std::lock_guard<std::mutex> own(T->qLock);
+    if (T->qReady) return SDFHIP_OK;
+    sdfhip_ctx* ctx = T->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t numWords = T->info.num_words;
+    const uint64_t G = (uint64_t)T->info.start_grid_size, G3 = G * G * G;
+    SDF_REQUIRE(G3 >= 1 && G3 <= numWords && G3 < (1ull << 30), "start grid does not fit the node array");
+    struct Level { DevBuf<uint32_t> src, rank; uint32_t count = 0; };
+    std::vector<std::unique_ptr<Level>> levels;
+    DevBuf<uint32_t> counters;
+    SDF_TRY(counters.reserve(3));
+    SDF_HIP_CHECK(hipMemsetAsync(counters.p, 0, 12, st));
+    std::unique_ptr<Level> cur(new Level());
+    cur->count = (uint32_t)G3;                                     // level 0 = the start grid, read in place (src == nullptr)
+    uint64_t total = 0;
+    uint32_t h[3] = {0, 0, 0};
+    for (;;) {
+        total += cur->count;
+        SDF_REQUIRE(levels.size() < 32 && total <= numWords, "node array is not a valid octree (too deep or cyclic)");
+        SDF_TRY(cur->rank.reserve(cur->count));
+        std::unique_ptr<Level> next(new Level());
+        SDF_TRY(next->src.reserve(8ull * cur->count));
+        SDF_HIP_CHECK(hipMemsetAsync(counters.p, 0, 4, st));
+        k_ql_level<<<gridFor(cur->count, 256), 256, 0, st>>>(T->data.p, numWords, levels.empty() ? nullptr : cur->src.p, cur->count, cur->rank.p, next->src.p, counters.p);
+        SDF_HIP_CHECK(hipMemcpyAsync(h, counters.p, 12, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_REQUIRE(h[2] == 0, "node array is not a valid octree (index out of range)");
+        levels.push_back(std::move(cur));
+        if (h[0] == 0) break;
+        SDF_REQUIRE(8ull * h[0] < (1ull << 30), "tree too large for the query layout");
+        next->count = 8u * h[0];
+        cur = std::move(next);
+    }
+    SDF_REQUIRE(total < (1ull << 30), "tree too large for the query layout");
+    const uint64_t leaves = h[1];
+    SDF_TRY(T->qTopo.reserve(total)); SDF_TRY(T->qCoef.reserve(64ull * (leaves ? leaves : 1)));
+    uint64_t base = 0;
+    for (size_t i = 0; i < levels.size(); i++) {
+        Level& L = *levels[i];
+        k_ql_fill<<<gridFor(L.count, 256), 256, 0, st>>>(T->data.p, i == 0 ? nullptr : L.src.p, L.rank.p, L.count, T->qTopo.p + base, (uint32_t)(base + L.count), T->qCoef.p);
+        base += L.count;
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));           // the level buffers are released below
+    T->qNodes = total; T->qLeaves = leaves; T->qReady = true;
+    return SDFHIP_OK;
+}
+
 static QueryTree makeQueryTree(const sdfhip_octree* T) {
     QueryTree q;
-    q.data = T->data.p;
+    q.topo = T->qTopo.p; q.coef = T->qCoef.p;
     q.bminx = T->info.box_min[0]; q.bminy = T->info.box_min[1]; q.bminz = T->info.box_min[2];
     q.bmaxx = T->info.box_max[0]; q.bmaxy = T->info.box_max[1]; q.bmaxz = T->info.box_max[2];
     q.cellSize = T->cellSize; q.minBorder = T->info.min_border_value; q.G = T->info.start_grid_size;
@@ -157,6 +249,7 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    SDF_TRY(ensureQueryLayout(T));
     std::unique_lock<std::mutex> own(ctx->stage.lock, std::defer_lock);
     if (where == SDFHIP_HOST && 12 * n <= sdfhip_stage::kStageKeepBytes) own.try_lock();
     DevBuf<float> pp, pd, pg;
@@ -199,6 +292,7 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    SDF_TRY(ensureQueryLayout(T));
     DevBuf<float> dd, dg;
     float* d = out_dist; float* g = out_grad;
     if (where == SDFHIP_HOST) {
