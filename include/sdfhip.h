@@ -175,6 +175,8 @@ typedef struct sdfhip_octree_info {
     float start_grid_cell_size;     /* mStartGridCellSize: a BUILT tree takes it from the input box's largest extent (OctreeSdf.cpp:43-52),
                                        a LOADED one from the stored box (OctreeSdf.h:233); far from the origin the two differ in the last bit */
     float reserved0;
+    uint64_t num_nearest_fallbacks; /* of num_traversals: queries the two-phase nearest search (fp32 candidates + exact tie replay) handed to the
+                                       order-exact fp64 traversal because it could not decide them with certainty */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {

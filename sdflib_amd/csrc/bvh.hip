@@ -18,7 +18,7 @@
 // threads: same comparisons on the same data in each sub-range, same result, critical path O(n) instead of O(n log n).
 // sdfhip_test_sort_matches_std() (tests/test_abi.py) compares it with std::sort on tie-heavy inputs.
 #include "sdfhip_internal.h"
-#include "dev_bvh.h"
+#include "dev_bvh_fast.h"
 #include <algorithm>
 #include <limits>
 #include <thread>
@@ -242,7 +242,36 @@ __global__ void k_tri_verts(const float* __restrict__ verts, const uint32_t* __r
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = gid / 12u, k = gid - 12u * t;
     if (t >= numTriangles) return;
-    triV[gid] = (k < 9u) ? verts[3 * (size_t)idx[3 * (size_t)t + k / 3u] + (k % 3u)] : 0.f;
+    float v = 0.f;
+    if (k < 9u) v = verts[3 * (size_t)idx[3 * (size_t)t + k / 3u] + (k % 3u)];
+    else if (k == 9u) {
+        // flag (nearly) degenerate triangles: sin^2 of the angle at v0 below 1e-3, a zero edge, or anything not finite.  The fp32
+        // point/triangle distance divides by det = |e0|^2 |e1|^2 sin^2; its error bound (dev_bvh_fast.h) holds for the others only.
+        const uint32_t a = idx[3 * (size_t)t], b = idx[3 * (size_t)t + 1], c = idx[3 * (size_t)t + 2];
+        const F3 v0 = F3{verts[3 * (size_t)a], verts[3 * (size_t)a + 1], verts[3 * (size_t)a + 2]};
+        const F3 e0 = F3{verts[3 * (size_t)b], verts[3 * (size_t)b + 1], verts[3 * (size_t)b + 2]} - v0, e1 = F3{verts[3 * (size_t)c], verts[3 * (size_t)c + 1], verts[3 * (size_t)c + 2]} - v0;
+        const float a00 = dot(e0, e0), a01 = dot(e0, e1), a11 = dot(e1, e1);
+        const float det = fabsf(a00 * a11 - a01 * a01);
+        v = (det > 1e-3f * (a00 * a11) && a00 * a11 > 0.f && a00 * a11 < 1e37f) ? 0.f : 1.f;
+    }
+    triV[gid] = v;
+}
+
+// Leaf-order position of every triangle from the child references alone: inner nodes are numbered in pre-order and the node over
+// [b, e) splits at (b + e) / 2, so the range of inner node i follows from i by arithmetic (descend from the root: the left subtree
+// of a node holds the inner indices node + 1 .. node + (mid - b) - 1); its leaf children sit at the ends of that range.
+__global__ void k_tri_ranks(const int2* __restrict__ kids, uint32_t numTriangles, uint32_t* __restrict__ triRank) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (numTriangles == 1u) { if (i == 0u) triRank[0] = 0u; return; }
+    if (i >= numTriangles - 1u) return;
+    uint32_t node = 0, b = 0, e = numTriangles;
+    while (node != i) {
+        const uint32_t mid = (b + e) >> 1;
+        if (i < node + (mid - b)) { node = node + 1u; e = mid; } else { node = node + (mid - b); b = mid; }
+    }
+    const int2 k = kids[i];
+    if (k.x < 0) triRank[~k.x] = b;
+    if (k.y < 0) triRank[~k.y] = e - 1u;
 }
 
 __global__ void __launch_bounds__(128) k_nearest(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
@@ -308,6 +337,8 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
         k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
     k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
+    SDF_TRY(mesh->dTriRank.reserve(T));
+    k_tri_ranks<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), T, mesh->dTriRank.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     mesh->numBvhNodes = nn;
@@ -401,7 +432,13 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
         SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
         p = dp.p; o = dout.p;
     }
-    k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
+    if (nearestExactOnly() || n >= (1ull << 31)) k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
+    else {
+        NearScratch near;
+        int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
+        SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), p, (uint32_t)n, o, near, depth + 2, 0u, 1u));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));             // `near` is released on return
+    }
     SDF_HIP_CHECK(hipGetLastError());
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out_ids, dout.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));

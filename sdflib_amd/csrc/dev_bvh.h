@@ -15,8 +15,12 @@
 //   sph32: 32 B per inner node = the same two spheres rounded to fp32 [cx cy cz r | cx cy cz r]: the traversal first brackets
 //          each sphere distance in fp32 from these (half the bytes, a quarter of the load instructions per lane) and only
 //          fetches the fp64 line when the bracket cannot decide a comparison.
-//   triV : 48 B per triangle = its three fp32 vertices gathered once [v0.xyz v1.x | v1.yz v2.xy | v2.z - - -], so a leaf
-//          visit reads one contiguous record instead of three indices plus three scattered vertices.
+//   triV : 48 B per triangle = its three fp32 vertices gathered once [v0.xyz v1.x | v1.yz v2.xy | v2.z flag - -], so a leaf
+//          visit reads one contiguous record instead of three indices plus three scattered vertices; flag != 0 marks a (nearly)
+//          degenerate triangle, whose fp32 distance is not trusted by the candidate search (dev_bvh_fast.h).
+//   triRank: u32 per triangle = its position in the tree's leaf order (the planner's final `order` array); the node over the
+//          leaf range [b, e) splits at (b + e) / 2 and inner nodes are numbered in pre-order, so ranks make the tree navigable
+//          by arithmetic alone (dev_bvh_fast.h).
 // Inner nodes are numbered in the reference's pre-order (left subtree first); the traversal order is the reference's.
 #pragma once
 #include "dev_math.h"
@@ -27,10 +31,10 @@ namespace sdfhip {
 constexpr double BVH_NO_BOUND = 1.7976931348623157e308;     // std::numeric_limits<double>::max(): the reference's start value
 constexpr double BVH_HUGE = 1e300;
 
-struct BvhDev { const double2* sph; const int2* kids; const float4* triV; uint32_t numTriangles; const float4* sph32; float coordScale; };
+struct BvhDev { const double2* sph; const int2* kids; const float4* triV; uint32_t numTriangles; const float4* sph32; float coordScale; const uint32_t* triRank; };
 static inline BvhDev meshBvh(const sdfhip_mesh* m) {
     return BvhDev{reinterpret_cast<const double2*>(m->dBvhSph.p), reinterpret_cast<const int2*>(m->dBvhKids.p), reinterpret_cast<const float4*>(m->dTriVerts.p), m->numTriangles,
-                  reinterpret_cast<const float4*>(m->dBvhSph32.p), m->bvhCoordScale};
+                  reinterpret_cast<const float4*>(m->dBvhSph32.p), m->bvhCoordScale, m->dTriRank.p};
 }
 
 struct D3 { double x, y, z; };

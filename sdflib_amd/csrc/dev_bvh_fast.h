@@ -1,0 +1,356 @@
+// Nearest-triangle search in two phases: an ORDER-FREE fp32 candidate search + an exact, order-aware resolution.  PRODUCT code.
+//
+// What has to come out is the id the reference's fp64 traversal returns (dev_bvh.h: nearer child first, strict '<', the farther child
+// tested after the nearer subtree) — which, among triangles tied to within rounding (the nearest feature is an edge or a vertex for
+// most points), depends on its visiting order.  dev_bvh.h reproduces that traversal step by step; its cost is the fp64 arithmetic of
+// every visit (Eberly's point/triangle routine above all) executed by a wave in which few lanes need it at any moment.
+// Here the work is split so that almost all of it is free of the order and of fp64:
+//
+//  1. k_near_candidates — per lane, any order, fp32 only: a branch-and-bound over the same tree (fp32 spheres, 48-byte triangle
+//     records) with CONSERVATIVE tests: U2 is an upper bound of the true minimum squared distance (fp32 value + its error bound),
+//     a child is skipped only if its sphere's lower bound (fp32 value - its error bound) exceeds U, a triangle is recorded as a
+//     candidate iff its fp32 distance minus its error bound does not exceed U2.  Every triangle whose exact distance is within
+//     ~1e-6 (relative) of the minimum ends up in the list (<= NEAR_K ids per query; overflow -> phase 3).
+//  2. k_near_resolve — exact: the fp64 squared distance (the reference's formula, dev_bvh.h) of every candidate gives the minimum
+//     d and the TIED set N = {d2 <= dmin2 (1 + 4e-12)}.  One member: it is the answer.  Otherwise the reference's decisions are
+//     replayed on N alone: the triangles of N are visited in the reference's static order (at every inner node the child with the
+//     smaller fp64 sphere distance first), a triangle is adopted iff d2 < best^2 (best = sqrt of the adopted d2), and after the
+//     first adoption a subtree is entered only if its fp64 sphere distance is < best — the very comparisons of the reference.
+//     Why that is the reference's answer: started with best = beta = dmin (1 + 1e-9) instead of +inf, the reference's traversal
+//     visits a subset of its nodes in the same order; until it adopts its first triangle below beta the unbounded run has
+//     best >= beta, so it visits and adopts that triangle too, and from then on the two runs are in the same state.  Triangles in
+//     (dmin (1 + 4e-12), beta) can only change `best` by amounts far above the rounding that decides ties, i.e. no decision about
+//     a member of N.  Before the first adoption every ancestor of a member of N passes its test (sphere bound <= d (1 + 4e-16) <
+//     beta), so those tests need not be evaluated.  The tree is navigated without loads: inner nodes are numbered in pre-order and
+//     a node over the sorted range [b, e) splits at (b + e) / 2, so ranges and child indices follow from arithmetic on the
+//     triangles' ranks (triRank).
+//  3. k_near_fallback — whatever 1 or 2 cannot decide with certainty (candidate list overflow, more than NEAR_MAX_TIES ties, a
+//     zero distance) is answered by the exact traversal of dev_bvh.h.  The count is reported (sdfhip_octree_info.num_nearest_fallbacks).
+#pragma once
+#include "dev_bvh.h"
+#include <string.h>
+
+namespace sdfhip {
+namespace {
+
+constexpr int NEAR_K = 16;
+constexpr int NEAR_MAX_TIES = 9;
+constexpr uint32_t NEAR_OVERFLOW = 0xFFu;
+constexpr uint32_t NEAR_UNRESOLVED = 0xFFFFFFFFu;
+
+// Eberly's routine in fp32 (same region logic as dev_bvh.h's fp64 one).  scale = |p - v0|^2 + |e0|^2 + |e1|^2 bounds the magnitude of
+// every term of the result: |returned - exact| <= 4e-6 * scale for triangles that are not flagged degenerate (k_tri_verts).
+SDF_DEV float pointTriangleSq32(F3 point, F3 v0, F3 v1, F3 v2, float& scale, float& c) {
+    const F3 diff = v0 - point, e0 = v1 - v0, e1 = v2 - v0;
+    const float a00 = dot(e0, e0), a01 = dot(e0, e1), a11 = dot(e1, e1);
+    const float b0 = dot(diff, e0), b1 = dot(diff, e1);
+    c = dot(diff, diff);
+    scale = c + a00 + a11;
+    const float det = fabsf(a00 * a11 - a01 * a01);
+    const float s = a01 * b1 - a11 * b0;
+    const float t = a01 * b0 - a00 * b1;
+    enum { V0, V1, V2, E01, E02, R0, E12S, E12T };
+    const float e12den = a00 - 2.0f * a01 + a11;
+    const int alongE02 = (b1 >= 0) ? V0 : ((-b1 >= a11) ? V2 : E02);
+    const int alongE01 = (b0 >= 0) ? V0 : ((-b0 >= a00) ? V1 : E01);
+    const bool sNeg = s < 0, tNeg = t < 0;
+    const int kIn = sNeg ? (tNeg ? ((b0 < 0) ? ((-b0 >= a00) ? V1 : E01) : alongE02) : alongE02) : (tNeg ? alongE01 : R0);
+    const float r2a = a01 + b0, r2b = a11 + b1, n2 = r2b - r2a;
+    const int k2 = (r2b > r2a) ? ((n2 >= e12den) ? V1 : E12S) : ((r2b <= 0) ? V2 : ((b1 >= 0) ? V0 : E02));
+    const float r6a = a01 + b1, r6b = a00 + b0, n6 = r6b - r6a;
+    const int k6 = (r6b > r6a) ? ((n6 >= e12den) ? V2 : E12T) : ((r6b <= 0) ? V1 : ((b0 >= 0) ? V0 : E01));
+    const float n1 = a11 + b1 - a01 - b0;
+    const int k1 = (n1 <= 0) ? V2 : ((n1 >= e12den) ? V1 : E12S);
+    const bool inside = s + t <= det;
+    const int kind = inside ? kIn : (sNeg ? k2 : (tNeg ? k6 : k1));
+    float numer = sNeg ? n2 : (tNeg ? n6 : n1);
+    numer = (kind == R0) ? 1.0f : ((kind == E01) ? -b0 : ((kind == E02) ? -b1 : ((kind >= E12S) ? numer : 0.0f)));
+    const float denom = (kind == R0) ? det : ((kind == E01) ? a00 : ((kind == E02) ? a11 : ((kind >= E12S) ? e12den : 1.0f)));
+    const float q = numer / denom;
+    const float sq = (kind == R0) ? s * q : ((kind == E12S) ? q : 1.0f - q);
+    const float tq = (kind == R0) ? t * q : ((kind == E12T) ? q : 1.0f - q);
+    float d2 = sq * (a00 * sq + a01 * tq + 2.0f * b0) + tq * (a01 * sq + a11 * tq + 2.0f * b1) + c;
+    d2 = (kind == V0) ? c : d2;
+    d2 = (kind == V1) ? a00 + 2.0f * b0 + c : d2;
+    d2 = (kind == V2) ? a11 + 2.0f * b1 + c : d2;
+    d2 = (kind == E01) ? b0 * q + c : d2;
+    d2 = (kind == E02) ? b1 * q + c : d2;
+    return d2;
+}
+
+// fp32 distance of one triangle record with its error bound: (lower, upper) bounds of the exact squared distance
+struct TriBounds { float lo, hi; };
+SDF_DEV TriBounds triBounds32(const BvhDev& b, uint32_t t, F3 p) {
+    const float4 q0 = b.triV[3 * (size_t)t], q1 = b.triV[3 * (size_t)t + 1], q2 = b.triV[3 * (size_t)t + 2];
+    float scale, c;
+    const float d2 = pointTriangleSq32(p, F3{q0.x, q0.y, q0.z}, F3{q0.w, q1.x, q1.y}, F3{q1.z, q1.w, q2.x}, scale, c);
+    const float slack = 4e-6f * scale + 1e-37f;
+    if (q2.y != 0.f || !(scale < 1e37f) || !(d2 == d2)) return TriBounds{0.f, c * 1.000002f + 1e-37f};   // degenerate record, overflow or NaN: only |p - v0|^2 is trusted, as an upper bound
+    return TriBounds{d2 - slack, d2 + slack};
+}
+
+// conservative lower bound of the distance to a sphere from its fp32 copy (sphereApprox32's bracket, doubled)
+SDF_DEV float sphereLower32(float4 sp, F3 p, float coordScale) {
+    const float dx = p.x - sp.x, dy = p.y - sp.y, dz = p.z - sp.z;
+    const float a = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);
+    return (a - sp.w) - 2.0f * (1e-6f * (a + sp.w) + 5e-7f * coordScale);
+}
+
+// ---- phase 1 ---------------------------------------------------------------------------------------------------------
+// Every iteration of a lane is ONE pop: a stack entry (child reference + the lower bound of its sphere, kept as a half rounded
+// DOWN) is dropped if the bound has been overtaken, expanded if it is an inner node (both children tested, the survivors pushed,
+// the nearer one on top), or — a triangle — put into the lane's queue of pending evaluations.  The queues are drained by the whole
+// wave at once (when some lane's queue is full, or nobody has nodes left): the fp32 point/triangle routine is the longest stretch
+// of code of the search, and run per visit it would execute for the two or three lanes that happen to sit at a leaf.
+SDF_DEV unsigned short halfRoundedDown(float f) {
+    const _Float16 h = (_Float16)f;
+    unsigned short bits = __builtin_bit_cast(unsigned short, h);
+    if ((float)h > f) bits = (bits == 0u) ? (unsigned short)0x8001u : ((bits & 0x8000u) ? (unsigned short)(bits + 1u) : (unsigned short)(bits - 1u));
+    return bits;
+}
+SDF_DEV float halfBitsToFloat(unsigned short bits) { return (float)__builtin_bit_cast(_Float16, bits); }
+
+constexpr int NEAR_QUEUE = 4;              // pending triangle evaluations per lane
+constexpr int NEAR_DRAIN_LANES = 40;       // a drain round is worth its instructions once this many lanes have one pending
+
+// PERSISTENT waves: a lane that has finished its query takes the next one (one atomic per wave and refill), so a wave stays full
+// until the work runs out instead of idling behind its longest traversal (half the lanes of a wave, measured).  The queries are
+// dealt in Morton order; XCD x serves the x-th contiguous eighth of them (its L2 then holds the BVH of one region of space) and
+// moves on to the other eighths when its own is exhausted.
+// cand: [NEAR_K][numReps] ids; candCount[r] = number of ids written or NEAR_OVERFLOW.  counters: 8 u32, zero before the launch.
+// LDS: references u32 [stackDepth][BLOCK], queue u32 [NEAR_QUEUE][BLOCK], bounds u16 [stackDepth][BLOCK].
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand,
+                                                           uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters) {
+    extern __shared__ uint32_t s_near_stack[];
+    uint32_t* stkRef = s_near_stack + threadIdx.x;
+    uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
+    unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;
+    // this rank's queries: the 128-query blocks blk with blk % world == rank, numbered consecutively
+    const uint32_t allBlocks = (numReps + 127u) / 128u;
+    const uint32_t mine = allBlocks > rank ? (allBlocks - rank + world - 1u) / world : 0u;
+    const uint32_t total = mine * 128u;
+    const uint32_t per = ((mine + 7u) / 8u) * 128u;             // queries per XCD range
+    const uint32_t lane = __lane_id();
+    uint32_t xcd = blockIdx.x & 7u; uint32_t tried = 0;
+    uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
+    float U = 3.0e38f, U2 = 3.0e38f;            // upper bounds of the minimum distance / squared distance
+    uint32_t nc = 0; bool overflow = false;
+    int sp = 0, nq = 0;
+    bool have = false, done = false;
+    for (;;) {
+        // ---- refill
+        uint64_t idle = __ballot(!have && !done);
+        while (idle != 0ull) {
+            const uint32_t want = (uint32_t)__popcll(idle);
+            const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((unsigned long long)idle) - 1)) base = atomicAdd(counters + xcd, want);
+            base = __shfl(base, __ffsll((unsigned long long)idle) - 1) + lo;
+            if (!have && !done) {
+                const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (q < hi) {
+                    const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
+                    if (rr < numReps) {
+                        r = rr; have = true;
+                        p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+                        U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0;
+                        if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; }
+                        else { stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // the root, bound = -65504
+                    }
+                }
+            }
+            idle = __ballot(!have && !done);
+            if (idle != 0ull && base + want >= hi) {          // this range is exhausted (uniform over the wave): move on, or stop after all eight
+                tried++;
+                if (tried >= 8u) { if (!have) done = true; idle = 0ull; }
+                else xcd = (xcd + 1u) & 7u;
+            }
+        }
+        if (__ballot(have) == 0ull) break;
+        // ---- one pop per walking lane
+        const bool walking = have && sp > 0;
+        if (walking && nq < NEAR_QUEUE) {
+            sp--;
+            const int ref = (int)stkRef[sp * BLOCK];
+            const float lbound = halfBitsToFloat(stkLb[sp * BLOCK]);
+            if (!(lbound > U)) {
+                if (ref >= 0) {
+                    const int2 k = b.kids[ref];
+                    const float lL = sphereLower32(b.sph32[2 * (size_t)ref], p, b.coordScale), lR = sphereLower32(b.sph32[2 * (size_t)ref + 1], p, b.coordScale);
+                    const bool lf = lL < lR;
+                    const float lN = lf ? lL : lR, lF = lf ? lR : lL;
+                    if (!(lF > U)) { stkRef[sp * BLOCK] = (uint32_t)(lf ? k.y : k.x); stkLb[sp * BLOCK] = halfRoundedDown(lF); sp++; }
+                    if (!(lN > U)) { stkRef[sp * BLOCK] = (uint32_t)(lf ? k.x : k.y); stkLb[sp * BLOCK] = halfRoundedDown(lN); sp++; }
+                } else { queue[nq * BLOCK] = (uint32_t)~ref; nq++; }
+            }
+        }
+        // ---- one drain round when enough lanes have a triangle pending, a lane is stuck on a full queue, or nobody walks any more
+        const uint64_t pend = __ballot(have && nq > 0);
+        if (pend != 0ull && (__popcll(pend) >= NEAR_DRAIN_LANES || __ballot(have && nq >= NEAR_QUEUE) != 0ull || __ballot(have && sp > 0) == 0ull)) {
+            if (have && nq > 0) {
+                nq--;
+                const uint32_t t = queue[nq * BLOCK];
+                const TriBounds tb = triBounds32(b, t, p);
+                if (tb.lo <= U2) {
+                    if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; }
+                    if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
+                        uint32_t keep = 0;
+                        for (uint32_t i = 0; i < nc; i++) {
+                            const uint32_t id = cand[(size_t)i * numReps + r];
+                            if (triBounds32(b, id, p).lo <= U2) { cand[(size_t)keep * numReps + r] = id; keep++; }
+                        }
+                        nc = keep;
+                    }
+                    if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; nc++; } else overflow = true;
+                }
+            }
+        }
+        // ---- finished queries
+        if (have && sp == 0 && nq == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false; }
+    }
+}
+
+// ---- phase 2 ---------------------------------------------------------------------------------------------------------
+// node over the sorted range [b, e): left child = inner node + 1 over [b, mid), right child = inner node + (mid - b) over [mid, e)
+struct SimFrame { uint32_t node, b, e, info; };      // info = lo | hi << 8 | side << 16 (the child of `node` to enter: tested at pop time)
+
+template <int BLOCK>
+SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint32_t* __restrict__ ids, uint32_t* __restrict__ rk, uint32_t* __restrict__ frames) {
+    // sort the tied candidates by rank (position in the tree's leaf order): subsets of a subtree are then contiguous
+    for (int i = 0; i < n2; i++) rk[i * BLOCK] = bvh.triRank[ids[i * BLOCK]];
+    for (int i = 1; i < n2; i++) {
+        const uint32_t kr = rk[i * BLOCK], ki = ids[i * BLOCK];
+        int j = i - 1;
+        while (j >= 0 && rk[j * BLOCK] > kr) { rk[(j + 1) * BLOCK] = rk[j * BLOCK]; ids[(j + 1) * BLOCK] = ids[j * BLOCK]; j--; }
+        rk[(j + 1) * BLOCK] = kr; ids[(j + 1) * BLOCK] = ki;
+    }
+    double best = sqrt(dmin2) * (1.0 + 1e-9);
+    int bestTri = -1;
+    bool adopted = false;
+    int fsp = 0;
+    uint32_t node = 0, b = 0, e = bvh.numTriangles; int lo = 0, hi = n2;
+    bool pending = true;           // a subproblem (node, [b,e), [lo,hi)) is loaded
+    for (;;) {
+        if (!pending) {
+            if (fsp == 0) break;
+            fsp--;
+            const uint32_t pn = frames[(4 * fsp) * BLOCK], pb = frames[(4 * fsp + 1) * BLOCK], pe = frames[(4 * fsp + 2) * BLOCK], info = frames[(4 * fsp + 3) * BLOCK];
+            const int side = (int)((info >> 16) & 1u);
+            // the deferred (farther) child: its test sees the distance found in the nearer subtree, as in the reference
+            if (adopted && !sphereCloser(sphereTerms(bvh.sph + 4 * (size_t)pn, side, p), best)) continue;
+            const uint32_t mid = (pb + pe) >> 1;
+            node = side ? pn + (mid - pb) : pn + 1u; b = side ? mid : pb; e = side ? pe : mid;
+            lo = (int)(info & 0xFFu); hi = (int)((info >> 8) & 0xFFu);
+            pending = true;
+        }
+        if (e - b == 1u) {                                           // a leaf: exactly one candidate left, this triangle
+            const uint32_t t = ids[lo * BLOCK];
+            const double d2 = triangleSq(bvh, t, p);
+            if (d2 < best * best) { best = sqrt(d2); bestTri = (int)t; adopted = true; }
+            pending = false;
+            continue;
+        }
+        const uint32_t mid = (b + e) >> 1;
+        int s = lo;
+        while (s < hi && rk[s * BLOCK] < mid) s++;
+        if (s == lo || s == hi) {                                    // all candidates on one side: the other subtree cannot touch a tie
+            const int side = (s == lo) ? 1 : 0;
+            if (adopted && !sphereCloser(sphereTerms(bvh.sph + 4 * (size_t)node, side, p), best)) { pending = false; continue; }
+            const uint32_t nn = side ? node + (mid - b) : node + 1u;
+            if (side) b = mid; else e = mid;
+            node = nn;
+            continue;
+        }
+        // candidates on both sides: the reference's order decides who is visited first
+        const double2* nd = bvh.sph + 4 * (size_t)node;
+        const double dL = sphereDistExact(sphereTerms(nd, 0, p)), dR = sphereDistExact(sphereTerms(nd, 1, p));
+        const bool leftFirst = dL < dR;
+        const int second = leftFirst ? 1 : 0;
+        frames[(4 * fsp) * BLOCK] = node; frames[(4 * fsp + 1) * BLOCK] = b; frames[(4 * fsp + 2) * BLOCK] = e;
+        frames[(4 * fsp + 3) * BLOCK] = (second ? ((uint32_t)s | ((uint32_t)hi << 8)) : ((uint32_t)lo | ((uint32_t)s << 8))) | ((uint32_t)second << 16);
+        fsp++;
+        if (adopted && !((leftFirst ? dL : dR) < best)) { pending = false; continue; }
+        const uint32_t nn = leftFirst ? node + 1u : node + (mid - b);
+        if (leftFirst) { e = mid; hi = s; } else { b = mid; lo = s; }
+        node = nn;
+    }
+    return bestTri < 0 ? NEAR_UNRESOLVED : (uint32_t)bestTri;
+}
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand,
+                                                        const uint8_t* __restrict__ candCount, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
+                                                        uint32_t* __restrict__ fbCount, uint32_t rank, uint32_t world) {
+    __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK], s_frames[4 * (NEAR_MAX_TIES - 1) * BLOCK];
+    const uint64_t r64 = ((uint64_t)blockIdx.x * world + rank) * BLOCK + threadIdx.x;
+    if (r64 >= numReps) return;
+    const uint32_t r = (uint32_t)r64;
+    const F3 pf = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+    const D3 p = D3{(double)pf.x, (double)pf.y, (double)pf.z};
+    const uint32_t nc = candCount[r];
+    uint32_t res = NEAR_UNRESOLVED;
+    if (nc != NEAR_OVERFLOW && nc > 0u) {
+        double dmin2 = BVH_NO_BOUND;
+        for (uint32_t i = 0; i < nc; i++) { const double d2 = triangleSq(b, cand[(size_t)i * numReps + r], p); dmin2 = d2 < dmin2 ? d2 : dmin2; }
+        if (dmin2 >= 1e-200) {
+            const double thr = dmin2 * (1.0 + 4e-12);
+            uint32_t* ids = s_ids + threadIdx.x;
+            int n2 = 0;
+            for (uint32_t i = 0; i < nc; i++) {
+                const uint32_t id = cand[(size_t)i * numReps + r];
+                if (triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
+            }
+            if (n2 == 1) res = ids[0];
+            else if (n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x);
+        }
+    }
+    out[r] = res;
+    if (res == NEAR_UNRESOLVED) fbList[atomicAdd(fbCount, 1u)] = r;
+}
+
+// ---- phase 3 ---------------------------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* __restrict__ pos, const uint32_t* __restrict__ fbList, uint32_t* __restrict__ fbCount,
+                                                         uint32_t first, uint32_t* __restrict__ out) {
+    extern __shared__ uint32_t s_fb_stack[];
+    const uint32_t count = *fbCount;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && first == 0u) atomicAdd(fbCount + 1, count);       // running total of a build (fbCount[0] restarts with every batch)
+    for (uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const uint32_t r = fbList[i];
+        out[r] = bvhNearest<BLOCK>(b, F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]}, s_fb_stack + threadIdx.x);
+    }
+}
+
+// ---- host driver -------------------------------------------------------------------------------------------------------
+struct NearScratch {
+    DevBuf<uint32_t> cand, fbList, fbCount; DevBuf<uint8_t> candCount;      // fbCount[0]: this batch's list length, fbCount[1]: total since reset(), [2..9]: work counters
+    bool counterReady = false;
+    void reset() { counterReady = false; }
+};
+static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
+
+// Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  stackDepth = BVH depth + 2.
+static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, uint32_t n, uint32_t* out, NearScratch& S, int stackDepth, uint32_t rank, uint32_t world) {
+    if (n == 0) return SDFHIP_OK;
+    const uint32_t blocks = gridFor(n, 128);
+    const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
+    if (!mine) return SDFHIP_OK;
+    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n));
+    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(10)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 40, st)); S.counterReady = true; }
+    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
+    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 32, st));     // and so are the work counters of the persistent waves
+    const int sd = stackDepth + 1;              // both children of a node may be pushed: one entry more than the order-exact traversal needs
+    const size_t lds = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (size_t)sd * 128 * 2;
+    static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 8u;
+    uint32_t grid = 256u * perCU;
+    if (grid > mine) grid = mine;
+    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2);
+    k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
+    k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out);
+    SDF_HIP_CHECK(hipGetLastError());
+    return SDFHIP_OK;
+}
+
+}  // namespace
+}  // namespace sdfhip

@@ -503,6 +503,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         T->hasData = true;
         T->levels.clear();
     }
+    SDF_TRY(sampleFallbacks(st, SS, T->info.num_nearest_fallbacks));
     T->info.seconds_total = nowSeconds() - tStart;
     *out = T.release();
     return SDFHIP_OK;

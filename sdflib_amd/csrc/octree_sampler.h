@@ -1,7 +1,7 @@
 // Exact distance samples shared by the NO_CONTINUITY and CONTINUITY builders (device + host helpers).  PRODUCT code.
 // Included by octree_build.hip and octree_continuity.hip; everything here has internal linkage.
 #pragma once
-#include "dev_bvh.h"
+#include "dev_bvh_fast.h"
 #include "dev_tricubic.h"
 #include <hipcub/hipcub.hpp>
 
@@ -98,10 +98,15 @@ __global__ void k_sample_mark(SampleBatch B, const uint64_t* __restrict__ key, c
     }
     isRep[j] = rep ? 1u : 0u;
 }
-__global__ void k_sample_rep_list(const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ val, uint32_t total,
-                                  uint32_t* __restrict__ repSample) {
+__global__ void k_sample_rep_list(SampleBatch B, const uint32_t* __restrict__ isRep, const uint32_t* __restrict__ scan, const uint32_t* __restrict__ val, uint32_t total,
+                                  uint32_t* __restrict__ repSample, float* __restrict__ repPos) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < total && isRep[j]) repSample[scan[j]] = val[j];
+    if (j < total && isRep[j]) {
+        const uint32_t slot = scan[j];
+        repSample[slot] = val[j];
+        const F3 p = samplePosition(B, val[j]);
+        repPos[3 * (size_t)slot] = p.x; repPos[3 * (size_t)slot + 1] = p.y; repPos[3 * (size_t)slot + 2] = p.z;
+    }
 }
 // With `world` > 1 this launch covers only the 128-representative blocks b with b % world == rank (dealt round-robin so that
 // every rank gets the same mix of short and long traversals); the other blocks' ids arrive through the exchange.
@@ -130,7 +135,8 @@ __global__ void k_sample_values(MeshDev m, SampleBatch B, const uint32_t* __rest
 
 // scratch of the sampler, reused across levels (grows only)
 struct SampleScratch {
-    DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
+    DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<float> repPos; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
+    NearScratch near;                               // candidate lists / fallback list of the two-phase nearest search (dev_bvh_fast.h)
     const sdfhip_exchange* exchange = nullptr;      // set by the CONTINUITY builder when the context has one (world > 1)
     bool pending = false; SampleBatch pendingBatch; uint32_t pendingReps = 0; uint32_t* pendingTri = nullptr;
 };
@@ -157,19 +163,23 @@ static int sampleBatchBegin(hipStream_t st, const MeshDev& md, const SampleBatch
     SDF_HIP_CHECK(hipMemcpyAsync(&lastFlag, S.isRep.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const uint32_t numReps = lastScan + lastFlag;
-    SDF_TRY(S.repSample.reserve(numReps));
-    k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p);
+    SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repPos.reserve(3 * (size_t)numReps));
+    k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(B, S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p, S.repPos.p);
     const uint32_t blocks = gridFor(numReps, 128);
+    const bool exactOnly = nearestExactOnly();
+    const int stackDepth = (int)(stackBytes / (128 * sizeof(uint32_t)));
     if (S.exchange) {
         const uint32_t rank = (uint32_t)S.exchange->rank, world = (uint32_t)S.exchange->world;
         S.pendingTri = S.exchange->acquire(S.exchange->user, numReps);
         SDF_REQUIRE(S.pendingTri, "exchange: acquire failed");
         const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
-        if (mine) k_sample_nearest<128><<<xcdGrid(mine), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, rank, world);
+        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, S.near, stackDepth, rank, world));
+        else if (mine) k_sample_nearest<128><<<xcdGrid(mine), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, rank, world);
     } else {
         SDF_TRY(S.repTri.reserve(numReps));
         S.pendingTri = S.repTri.p;
-        k_sample_nearest<128><<<xcdGrid(blocks), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, 0u, 1u);   // 64 / 256 lanes per block measured the same
+        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, S.near, stackDepth, 0u, 1u));
+        else k_sample_nearest<128><<<xcdGrid(blocks), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, 0u, 1u);   // 64 / 256 lanes per block measured the same
     }
     SDF_HIP_CHECK(hipGetLastError());
     S.pending = true; S.pendingBatch = B; S.pendingReps = numReps;
@@ -191,6 +201,16 @@ static int sampleBatchEnd(hipStream_t st, const MeshDev& md, SampleScratch& S) {
 static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, SampleScratch& S, size_t stackBytes, uint64_t& traversals) {
     SDF_TRY(sampleBatchBegin(st, md, B, S, stackBytes, traversals));
     return sampleBatchEnd(st, md, S);
+}
+// total of fallbacks since the scratch was created (synchronises the stream)
+static int sampleFallbacks(hipStream_t st, SampleScratch& S, uint64_t& out) {
+    out = 0;
+    if (!S.near.counterReady) return SDFHIP_OK;
+    uint32_t h = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&h, S.near.fbCount.p + 1, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    out = h;
+    return SDFHIP_OK;
 }
 // the 19 mid-points of one level
 static int sampleMidPoints(hipStream_t st, const MeshDev& md, const uint32_t* coord, const float* center, float half, uint32_t n, float* mid, int stride,

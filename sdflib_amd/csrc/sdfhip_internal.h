@@ -146,6 +146,7 @@ struct sdfhip_mesh {
     sdfhip::DevBuf<float> dBvhSph32;      // fp32 copy of the spheres (8 floats per inner node), see dev_bvh.h
     float bvhCoordScale = 0.f;            // max |coordinate| of the mesh: bounds the fp32 rounding of the sphere centres
     sdfhip::DevBuf<float> dTriVerts;
+    sdfhip::DevBuf<uint32_t> dTriRank;    // leaf-order position of every triangle, see dev_bvh.h
     uint64_t numBvhNodes = 0;             // inner nodes (= numTriangles - 1)
     bool hasBvh = false;
     uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
