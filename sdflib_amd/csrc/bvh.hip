@@ -274,6 +274,66 @@ __global__ void k_tri_ranks(const int2* __restrict__ kids, uint32_t numTriangles
     if (k.y < 0) triRank[~k.y] = e - 1u;
 }
 
+// 4-wide nodes for the candidate search (layout: dev_bvh.h).  One thread per binary inner node; nodes at odd depths are skipped.
+// The radius of a child is inflated by the MEASURED distance between its fp64 centre and the centre the traversal will decode
+// (same expression: fmaf(q, scale, origin)), then rounded up to a half: the decoded sphere contains the reference's sphere.
+__device__ __forceinline__ unsigned short halfRoundedUp(float f) {
+    const _Float16 h = (_Float16)f;
+    unsigned short bits = __builtin_bit_cast(unsigned short, h);
+    if ((float)h < f) bits = (bits == 0x8000u) ? (unsigned short)0x0001u : ((bits & 0x8000u) ? (unsigned short)(bits - 1u) : (unsigned short)(bits + 1u));
+    return bits;
+}
+__global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, uint32_t numTriangles, uint4* __restrict__ wide) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (numTriangles < 2u || i >= numTriangles - 1u) return;
+    uint32_t node = 0, b = 0, e = numTriangles, depth = 0;
+    while (node != i) {
+        const uint32_t mid = (b + e) >> 1;
+        if (i < node + (mid - b)) { node = node + 1u; e = mid; } else { node = node + (mid - b); b = mid; }
+        depth++;
+    }
+    if (depth & 1u) return;
+    double cx[4], cy[4], cz[4], cr[4]; int ref[4]; int n = 0;
+    const int2 k0 = kids[i];
+    for (int s1 = 0; s1 < 2; s1++) {
+        const int c1 = s1 ? k0.y : k0.x;
+        if (c1 < 0) {
+            const double2 a = sph[4 * (size_t)i + 2 * s1], bb = sph[4 * (size_t)i + 2 * s1 + 1];
+            cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = c1; n++;
+        } else {
+            const int2 k1 = kids[c1];
+            for (int s2 = 0; s2 < 2; s2++) {
+                const double2 a = sph[4 * (size_t)c1 + 2 * s2], bb = sph[4 * (size_t)c1 + 2 * s2 + 1];
+                cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = s2 ? k1.y : k1.x; n++;
+            }
+        }
+    }
+    double lo[3] = {cx[0], cy[0], cz[0]}, hi[3] = {cx[0], cy[0], cz[0]};
+    for (int c = 1; c < n; c++) {
+        lo[0] = fmin(lo[0], cx[c]); hi[0] = fmax(hi[0], cx[c]); lo[1] = fmin(lo[1], cy[c]); hi[1] = fmax(hi[1], cy[c]); lo[2] = fmin(lo[2], cz[c]); hi[2] = fmax(hi[2], cz[c]);
+    }
+    const float ox = (float)lo[0], oy = (float)lo[1], oz = (float)lo[2];
+    float scale = (float)(fmax(fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) / 65535.0);
+    if (!(scale > 1e-30f)) scale = 1e-30f;
+    uint32_t w[16];
+    w[0] = __float_as_uint(ox); w[1] = __float_as_uint(oy); w[2] = __float_as_uint(oz); w[3] = __float_as_uint(scale);
+    for (int c = 0; c < 4; c++) {
+        uint32_t qx = 0, qy = 0, qz = 0; unsigned short rh = 0xFC00u; int rr = 0;       // empty slot: radius -inf
+        if (c < n) {
+            auto quant = [&](double v, float o) { double q = rint((v - (double)o) / (double)scale); if (!(q >= 0.0)) q = 0.0; if (q > 65535.0) q = 65535.0; return (uint32_t)q; };
+            qx = quant(cx[c], ox); qy = quant(cy[c], oy); qz = quant(cz[c], oz);
+            const double dx = (double)fmaf((float)qx, scale, ox) - cx[c], dy = (double)fmaf((float)qy, scale, oy) - cy[c], dz = (double)fmaf((float)qz, scale, oz) - cz[c];
+            const double rInfl = (cr[c] + sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-9) + 1e-300;
+            float rf = (float)rInfl; if ((double)rf < rInfl) rf = nextafterf(rf, 3.0e38f);
+            rh = halfRoundedUp(rf);                      // +inf when the radius exceeds the half range: the child is then always visited
+            rr = ref[c];
+        }
+        w[4 + 2 * c] = qx | (qy << 16); w[5 + 2 * c] = qz | ((uint32_t)rh << 16); w[12 + c] = (uint32_t)rr;
+    }
+    uint4* out = wide + 4 * (size_t)i;
+    out[0] = make_uint4(w[0], w[1], w[2], w[3]); out[1] = make_uint4(w[4], w[5], w[6], w[7]); out[2] = make_uint4(w[8], w[9], w[10], w[11]); out[3] = make_uint4(w[12], w[13], w[14], w[15]);
+}
+
 __global__ void __launch_bounds__(128) k_nearest(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
     __shared__ uint32_t s_stack[BVH_STACK * 128];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -337,6 +397,8 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
         k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
     k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
+    SDF_TRY(mesh->dBvhWide.reserve(16 * (size_t)(nn ? nn : 1)));
+    k_wide_nodes<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), T, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
     SDF_TRY(mesh->dTriRank.reserve(T));
     k_tri_ranks<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), T, mesh->dTriRank.p);
     SDF_HIP_CHECK(hipGetLastError());

@@ -18,6 +18,10 @@
 //   triV : 48 B per triangle = its three fp32 vertices gathered once [v0.xyz v1.x | v1.yz v2.xy | v2.z flag - -], so a leaf
 //          visit reads one contiguous record instead of three indices plus three scattered vertices; flag != 0 marks a (nearly)
 //          degenerate triangle, whose fp32 distance is not trusted by the candidate search (dev_bvh_fast.h).
+//   wide : 64 B per inner node at an EVEN depth = that node and its children collapsed into one 4-wide node for the order-free
+//          candidate search (dev_bvh_fast.h): [origin.xyz scale | 4 x (centre as 3 x u16 on the node's own grid, radius as a half
+//          rounded up and inflated by the quantisation error) | 4 child references (>= 0: inner node at the next even depth,
+//          < 0: ~triangle)]; an empty slot has radius -inf.  One visit = one 64-byte line instead of two lines per binary level.
 //   triRank: u32 per triangle = its position in the tree's leaf order (the planner's final `order` array); the node over the
 //          leaf range [b, e) splits at (b + e) / 2 and inner nodes are numbered in pre-order, so ranks make the tree navigable
 //          by arithmetic alone (dev_bvh_fast.h).
@@ -31,10 +35,10 @@ namespace sdfhip {
 constexpr double BVH_NO_BOUND = 1.7976931348623157e308;     // std::numeric_limits<double>::max(): the reference's start value
 constexpr double BVH_HUGE = 1e300;
 
-struct BvhDev { const double2* sph; const int2* kids; const float4* triV; uint32_t numTriangles; const float4* sph32; float coordScale; const uint32_t* triRank; };
+struct BvhDev { const double2* sph; const int2* kids; const float4* triV; uint32_t numTriangles; const float4* sph32; float coordScale; const uint32_t* triRank; const float4* wide; };
 static inline BvhDev meshBvh(const sdfhip_mesh* m) {
     return BvhDev{reinterpret_cast<const double2*>(m->dBvhSph.p), reinterpret_cast<const int2*>(m->dBvhKids.p), reinterpret_cast<const float4*>(m->dTriVerts.p), m->numTriangles,
-                  reinterpret_cast<const float4*>(m->dBvhSph32.p), m->bvhCoordScale, m->dTriRank.p};
+                  reinterpret_cast<const float4*>(m->dBvhSph32.p), m->bvhCoordScale, m->dTriRank.p, reinterpret_cast<const float4*>(m->dBvhWide.p)};
 }
 
 struct D3 { double x, y, z; };

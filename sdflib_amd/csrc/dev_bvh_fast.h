@@ -121,7 +121,8 @@ constexpr int NEAR_DRAIN_LANES = 40;       // a drain round is worth its instruc
 // LDS: references u32 [stackDepth][BLOCK], queue u32 [NEAR_QUEUE][BLOCK], bounds u16 [stackDepth][BLOCK].
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand,
-                                                           uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters) {
+                                                           uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
+                                                           uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount) {
     extern __shared__ uint32_t s_near_stack[];
     uint32_t* stkRef = s_near_stack + threadIdx.x;
     uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
@@ -137,6 +138,8 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
     float U = 3.0e38f, U2 = 3.0e38f;            // upper bounds of the minimum distance / squared distance
     uint32_t nc = 0; bool overflow = false;
     int sp = 0, nq = 0;
+    uint32_t steps = 0;
+    int mode = 0, seedRef = 0;        // 1: greedy first descent (nearest child only, nothing pushed) to get a bound; 2: waiting for its triangle
     bool have = false, done = false;
     for (;;) {
         // ---- refill
@@ -154,9 +157,12 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                     if (rr < numReps) {
                         r = rr; have = true;
                         p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
-                        U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0;
-                        if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; }
-                        else { stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // the root, bound = -65504
+                        U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; steps = 0;
+                        // With no bound yet the first descent would push every sibling it passes (three per level): it is made
+                        // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one
+                        // triangle and leaves few entries behind — the stacks can be short, and LDS per lane is what limits the waves per CU.
+                        if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
+                        else { sp = 1; mode = 1; seedRef = 0; }
                     }
                 }
             }
@@ -168,46 +174,179 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
             }
         }
         if (__ballot(have) == 0ull) break;
-        // ---- one pop per walking lane
-        const bool walking = have && sp > 0;
+        // ---- one pop per walking lane: a 4-wide node (one 64-byte line) or a triangle
+        if (have && mode == 2 && nq == 0) { mode = 0; stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // seeded: the root, bound = -65504
+        const bool walking = have && sp > 0 && mode != 2;
         if (walking && nq < NEAR_QUEUE) {
-            sp--;
-            const int ref = (int)stkRef[sp * BLOCK];
-            const float lbound = halfBitsToFloat(stkLb[sp * BLOCK]);
+            int ref; float lbound;
+            if (mode == 1) { ref = seedRef; lbound = -3.0e38f; }
+            else { sp--; steps++; ref = (int)stkRef[sp * BLOCK]; lbound = halfBitsToFloat(stkLb[sp * BLOCK]); }
             if (!(lbound > U)) {
-                if (ref >= 0) {
-                    const int2 k = b.kids[ref];
-                    const float lL = sphereLower32(b.sph32[2 * (size_t)ref], p, b.coordScale), lR = sphereLower32(b.sph32[2 * (size_t)ref + 1], p, b.coordScale);
-                    const bool lf = lL < lR;
-                    const float lN = lf ? lL : lR, lF = lf ? lR : lL;
-                    if (!(lF > U)) { stkRef[sp * BLOCK] = (uint32_t)(lf ? k.y : k.x); stkLb[sp * BLOCK] = halfRoundedDown(lF); sp++; }
-                    if (!(lN > U)) { stkRef[sp * BLOCK] = (uint32_t)(lf ? k.x : k.y); stkLb[sp * BLOCK] = halfRoundedDown(lN); sp++; }
+                if (ref >= 0 && sp + 4 > stackDepth) steps = 0xFFFFFFF0u;        // the (short) stack would overflow: a job for k_near_long
+                else if (ref >= 0) {
+                    const float4* nd = b.wide + 4 * (size_t)ref;
+                    const float4 h = nd[0], s01 = nd[1], s23 = nd[2], rf = nd[3];
+                    const uint32_t sw[8] = {__float_as_uint(s01.x), __float_as_uint(s01.y), __float_as_uint(s01.z), __float_as_uint(s01.w),
+                                            __float_as_uint(s23.x), __float_as_uint(s23.y), __float_as_uint(s23.z), __float_as_uint(s23.w)};
+                    float l[4]; uint32_t cr[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const float dx = p.x - fmaf((float)(sw[2 * c] & 0xFFFFu), h.w, h.x), dy = p.y - fmaf((float)(sw[2 * c] >> 16), h.w, h.y), dz = p.z - fmaf((float)(sw[2 * c + 1] & 0xFFFFu), h.w, h.z);
+                        const float rad = halfBitsToFloat((unsigned short)(sw[2 * c + 1] >> 16));
+                        const float a = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+                        l[c] = rad < 0.f ? 3.4e38f : (a - rad) - 2e-6f * (a + rad);      // conservative: fp32 error of a and of the difference
+                    }
+                    // sort the four by bound (ascending), push the survivors farthest first: the nearest is popped next
+#define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
+                    SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
+#undef SDF_CE
+                    if (mode == 1) {
+                        seedRef = (int)cr[0];
+                        if (seedRef < 0) { queue[nq * BLOCK] = (uint32_t)~seedRef; nq++; mode = 2; }
+                    } else {
+#pragma unroll
+                        for (int c = 3; c >= 0; c--)
+                            if (!(l[c] > U)) { stkRef[sp * BLOCK] = cr[c]; stkLb[sp * BLOCK] = halfRoundedDown(l[c]); sp++; }
+                    }
                 } else { queue[nq * BLOCK] = (uint32_t)~ref; nq++; }
             }
         }
         // ---- one drain round when enough lanes have a triangle pending, a lane is stuck on a full queue, or nobody walks any more
         const uint64_t pend = __ballot(have && nq > 0);
-        if (pend != 0ull && (__popcll(pend) >= NEAR_DRAIN_LANES || __ballot(have && nq >= NEAR_QUEUE) != 0ull || __ballot(have && sp > 0) == 0ull)) {
+        if (pend != 0ull && (__popcll(pend) >= NEAR_DRAIN_LANES || __ballot(have && (nq >= NEAR_QUEUE || mode == 2)) != 0ull || __ballot(have && sp > 0 && mode != 2) == 0ull)) {
             if (have && nq > 0) {
                 nq--;
                 const uint32_t t = queue[nq * BLOCK];
                 const TriBounds tb = triBounds32(b, t, p);
                 if (tb.lo <= U2) {
                     if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; }
-                    if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
-                        uint32_t keep = 0;
-                        for (uint32_t i = 0; i < nc; i++) {
-                            const uint32_t id = cand[(size_t)i * numReps + r];
-                            if (triBounds32(b, id, p).lo <= U2) { cand[(size_t)keep * numReps + r] = id; keep++; }
+                    if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
+                        if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
+                            uint32_t keep = 0;
+                            for (uint32_t i = 0; i < nc; i++) {
+                                const uint32_t id = cand[(size_t)i * numReps + r];
+                                if (triBounds32(b, id, p).lo <= U2) { cand[(size_t)keep * numReps + r] = id; keep++; }
+                            }
+                            nc = keep;
                         }
-                        nc = keep;
+                        if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; nc++; } else overflow = true;
                     }
-                    if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; nc++; } else overflow = true;
                 }
             }
         }
-        // ---- finished queries
-        if (have && sp == 0 && nq == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false; }
+        // ---- finished queries; a query that turns out to be long (a point with thousands of almost equidistant triangles) is
+        // handed to k_near_long, where a whole wave works on it: left to one lane, its dependent chain of pops alone outlasts the
+        // rest of the launch (measured: the longest of 1.5 M traversals took as long as all the others together)
+        if (have && sp == 0 && nq == 0 && mode == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false; }
+        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; }
+    }
+}
+
+// ---- phase 1b: one wave per long query ------------------------------------------------------------------------------------
+// The stack is shared by the wave: every step pops up to 64 entries (one per lane), expands them, evaluates the popped triangles,
+// lowers the common bound to the best of the 64 and pushes the survivors (farthest children first).  Candidates are collected in
+// LDS with their lower bounds and filtered against the FINAL bound before they are written out.
+constexpr int NEAR_LONG_STACK = 6144, NEAR_LONG_CAND = 1024;
+__global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ longList,
+                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, uint8_t* __restrict__ candCount) {
+    __shared__ uint2 s_stack[NEAR_LONG_STACK];
+    __shared__ uint2 s_cand[NEAR_LONG_CAND];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const uint32_t count = *longCount;
+    for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x) {
+        const uint32_t r = longList[qi];
+        const F3 p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+        float U = 3.0e38f, U2 = 3.0e38f;
+        uint32_t size = 1, nc = 0; bool overflow = false;
+        __syncthreads();
+        if (lane == 0) s_stack[0] = make_uint2(0u, 0xFF7FFFFFu);      // the root, bound = -FLT_MAX
+        __syncthreads();
+        while (size > 0 && !overflow) {
+            const uint32_t take = size < 64u ? size : 64u;
+            const bool active = lane < take;
+            const uint2 e = active ? s_stack[size - 1u - lane] : make_uint2(0u, 0u);
+            size -= take;
+            __syncthreads();                                           // everybody has read its entry before anything is pushed
+            const int ref = (int)e.x;
+            const bool live = active && !(__uint_as_float(e.y) > U);
+            // triangles first: they lower the bound the children are tested against
+            float lo = 3.4e38f, hi = 3.4e38f;
+            if (live && ref < 0) { const TriBounds tb = triBounds32(b, (uint32_t)~ref, p); lo = tb.lo; hi = tb.hi; }
+            float m = hi;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+            if (m < U2) { U2 = m; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; }
+            const bool isCand = live && ref < 0 && lo <= U2;
+            {
+                const uint64_t cm = __ballot(isCand);
+                if (nc + (uint32_t)__popcll(cm) > (uint32_t)NEAR_LONG_CAND) {      // compact the collected candidates against the current bound
+                    __syncthreads();
+                    uint32_t keep = 0;
+                    for (uint32_t base = 0; base < nc; base += 64u) {
+                        const bool in = base + lane < nc;
+                        const uint2 c = in ? s_cand[base + lane] : make_uint2(0u, 0u);
+                        const bool k = in && __uint_as_float(c.y) <= U2;
+                        const uint64_t km = __ballot(k);
+                        __syncthreads();
+                        if (k) s_cand[keep + (uint32_t)__popcll(km & below)] = c;
+                        keep += (uint32_t)__popcll(km);
+                        __syncthreads();
+                    }
+                    nc = keep;
+                    if (nc + (uint32_t)__popcll(cm) > (uint32_t)NEAR_LONG_CAND) overflow = true;
+                }
+                if (!overflow) {
+                    if (isCand) s_cand[nc + (uint32_t)__popcll(cm & below)] = make_uint2((uint32_t)~ref, __float_as_uint(lo));
+                    nc += (uint32_t)__popcll(cm);
+                }
+            }
+            // inner nodes: bounds of the four children
+            float l[4] = {3.4e38f, 3.4e38f, 3.4e38f, 3.4e38f}; uint32_t cr[4] = {0u, 0u, 0u, 0u};
+            if (live && ref >= 0) {
+                const float4* nd = b.wide + 4 * (size_t)ref;
+                const float4 h = nd[0], s01 = nd[1], s23 = nd[2], rf = nd[3];
+                const uint32_t sw[8] = {__float_as_uint(s01.x), __float_as_uint(s01.y), __float_as_uint(s01.z), __float_as_uint(s01.w),
+                                        __float_as_uint(s23.x), __float_as_uint(s23.y), __float_as_uint(s23.z), __float_as_uint(s23.w)};
+                cr[0] = __float_as_uint(rf.x); cr[1] = __float_as_uint(rf.y); cr[2] = __float_as_uint(rf.z); cr[3] = __float_as_uint(rf.w);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float dx = p.x - fmaf((float)(sw[2 * c] & 0xFFFFu), h.w, h.x), dy = p.y - fmaf((float)(sw[2 * c] >> 16), h.w, h.y), dz = p.z - fmaf((float)(sw[2 * c + 1] & 0xFFFFu), h.w, h.z);
+                    const float rad = halfBitsToFloat((unsigned short)(sw[2 * c + 1] >> 16));
+                    const float a = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+                    l[c] = rad < 0.f ? 3.4e38f : (a - rad) - 2e-6f * (a + rad);
+                }
+#define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
+                SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
+#undef SDF_CE
+            }
+            // push: the lanes' farthest children first, their nearest last (popped next)
+#pragma unroll
+            for (int c = 3; c >= 0; c--) {
+                const bool keep = !(l[c] > U);
+                const uint64_t km = __ballot(keep);
+                const uint32_t n = (uint32_t)__popcll(km);
+                if (size + n > (uint32_t)NEAR_LONG_STACK) { overflow = true; break; }
+                if (keep) s_stack[size + (uint32_t)__popcll(km & below)] = make_uint2(cr[c], __float_as_uint(l[c]));
+                size += n;
+            }
+            __syncthreads();
+        }
+        // the candidates that survive the final bound
+        uint32_t out = 0;
+        if (!overflow) {
+            for (uint32_t base = 0; base < nc; base += 64u) {
+                const bool in = base + lane < nc;
+                const uint2 c = in ? s_cand[base + lane] : make_uint2(0u, 0u);
+                const bool k = in && __uint_as_float(c.y) <= U2;
+                const uint64_t km = __ballot(k);
+                const uint32_t at = out + (uint32_t)__popcll(km & below);
+                if (k && at < (uint32_t)NEAR_K) cand[(size_t)at * numReps + r] = c.x;
+                out += (uint32_t)__popcll(km);
+            }
+            if (out > (uint32_t)NEAR_K) overflow = true;
+        }
+        if (lane == 0) candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : out);
     }
 }
 
@@ -324,7 +463,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* 
 
 // ---- host driver -------------------------------------------------------------------------------------------------------
 struct NearScratch {
-    DevBuf<uint32_t> cand, fbList, fbCount; DevBuf<uint8_t> candCount;      // fbCount[0]: this batch's list length, fbCount[1]: total since reset(), [2..9]: work counters
+    DevBuf<uint32_t> cand, fbList, fbCount, longList; DevBuf<uint8_t> candCount;      // fbCount[0]: this batch's fallback list length, [1]: total since reset(), [2..9]: work counters, [10]: long list length, [11]: total long
     bool counterReady = false;
     void reset() { counterReady = false; }
 };
@@ -336,16 +475,22 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     const uint32_t blocks = gridFor(n, 128);
     const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
     if (!mine) return SDFHIP_OK;
-    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n));
-    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(10)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 40, st)); S.counterReady = true; }
+    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
+    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(12)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 48, st)); S.counterReady = true; }
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
-    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 32, st));     // and so are the work counters of the persistent waves
-    const int sd = stackDepth + 1;              // both children of a node may be pushed: one entry more than the order-exact traversal needs
+    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 36, st));     // and so are the work counters of the persistent waves and the long list
+    // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
+    // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
+    const int worst = 3 * (stackDepth / 2 + 1) + 2;
+    static const int cap = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 20;
+    const int sd = worst < cap ? worst : cap;
     const size_t lds = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (size_t)sd * 128 * 2;
     static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 8u;
     uint32_t grid = 256u * perCU;
     if (grid > mine) grid = mine;
-    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2);
+    static const uint32_t maxSteps = getenv("SDFHIP_NEAR_LONG") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LONG")) : 1536u;
+    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10);
+    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candCount.p);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out);
     SDF_HIP_CHECK(hipGetLastError());

@@ -147,6 +147,7 @@ struct sdfhip_mesh {
     float bvhCoordScale = 0.f;            // max |coordinate| of the mesh: bounds the fp32 rounding of the sphere centres
     sdfhip::DevBuf<float> dTriVerts;
     sdfhip::DevBuf<uint32_t> dTriRank;    // leaf-order position of every triangle, see dev_bvh.h
+    sdfhip::DevBuf<float> dBvhWide;       // 16 floats per inner node (used at even depths): 4-wide quantised nodes, see dev_bvh.h
     uint64_t numBvhNodes = 0;             // inner nodes (= numTriangles - 1)
     bool hasBvh = false;
     uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
