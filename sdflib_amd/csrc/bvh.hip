@@ -283,8 +283,20 @@ __device__ __forceinline__ unsigned short halfRoundedUp(float f) {
     if ((float)h < f) bits = (bits == 0x8000u) ? (unsigned short)0x0001u : ((bits & 0x8000u) ? (unsigned short)(bits - 1u) : (unsigned short)(bits + 1u));
     return bits;
 }
-__global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, uint32_t numTriangles, uint4* __restrict__ wide) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_tri_at_rank(const uint32_t* __restrict__ triRank, uint32_t numTriangles, uint32_t* __restrict__ triAtRank) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < numTriangles) triAtRank[triRank[t]] = t;
+}
+// A child of a wide node = a sphere AND a slab: every vertex x of its triangles satisfies |x - c'| <= r' and |m . (x - c')| <= W, with
+// c' the DECODED centre, m the DECODED direction (3 x snorm16 of the normalised sum of the subtree's area normals: a smooth patch is
+// thin along it) and r', W measured against those decoded values here, so that nothing about the quantisation has to be bounded
+// analytically.  Subtrees above WIDE_SLAB_MAX triangles get no slab (W = +inf): it would not be thin, and the loops below are per thread.
+constexpr uint32_t WIDE_SLAB_MAX = 2048;
+__global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
+                             uint32_t numTriangles, uint4* __restrict__ wide) {
+    // 16 lanes per node: they share the (cheap) header work and stride over the children's triangles for the two reductions
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 4, sub = gid & 15u;
     if (numTriangles < 2u || i >= numTriangles - 1u) return;
     uint32_t node = 0, b = 0, e = numTriangles, depth = 0;
     while (node != i) {
@@ -293,18 +305,21 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
         depth++;
     }
     if (depth & 1u) return;
-    double cx[4], cy[4], cz[4], cr[4]; int ref[4]; int n = 0;
+    double cx[4], cy[4], cz[4], cr[4]; int ref[4]; uint32_t rb[4], re[4]; int n = 0;
     const int2 k0 = kids[i];
+    const uint32_t mid0 = (b + e) >> 1;
     for (int s1 = 0; s1 < 2; s1++) {
         const int c1 = s1 ? k0.y : k0.x;
+        const uint32_t b1 = s1 ? mid0 : b, e1 = s1 ? e : mid0;
         if (c1 < 0) {
             const double2 a = sph[4 * (size_t)i + 2 * s1], bb = sph[4 * (size_t)i + 2 * s1 + 1];
-            cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = c1; n++;
+            cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = c1; rb[n] = b1; re[n] = e1; n++;
         } else {
             const int2 k1 = kids[c1];
+            const uint32_t mid1 = (b1 + e1) >> 1;
             for (int s2 = 0; s2 < 2; s2++) {
                 const double2 a = sph[4 * (size_t)c1 + 2 * s2], bb = sph[4 * (size_t)c1 + 2 * s2 + 1];
-                cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = s2 ? k1.y : k1.x; n++;
+                cx[n] = a.x; cy[n] = a.y; cz[n] = bb.x; cr[n] = bb.y; ref[n] = s2 ? k1.y : k1.x; rb[n] = s2 ? mid1 : b1; re[n] = s2 ? e1 : mid1; n++;
             }
         }
     }
@@ -315,23 +330,55 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
     const float ox = (float)lo[0], oy = (float)lo[1], oz = (float)lo[2];
     float scale = (float)(fmax(fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) / 65535.0);
     if (!(scale > 1e-30f)) scale = 1e-30f;
-    uint32_t w[16];
-    w[0] = __float_as_uint(ox); w[1] = __float_as_uint(oy); w[2] = __float_as_uint(oz); w[3] = __float_as_uint(scale);
+    uint4* out = wide + 8 * (size_t)i;
+    if (sub == 0u) out[0] = make_uint4(__float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz), __float_as_uint(scale));
+    uint32_t refs[4] = {0u, 0u, 0u, 0u};
     for (int c = 0; c < 4; c++) {
-        uint32_t qx = 0, qy = 0, qz = 0; unsigned short rh = 0xFC00u; int rr = 0;       // empty slot: radius -inf
+        uint32_t qx = 0, qy = 0, qz = 0, mx = 0, my = 0, mz = 0; unsigned short rh = 0xFC00u, wh = 0x7C00u;       // empty slot: radius -inf
         if (c < n) {
             auto quant = [&](double v, float o) { double q = rint((v - (double)o) / (double)scale); if (!(q >= 0.0)) q = 0.0; if (q > 65535.0) q = 65535.0; return (uint32_t)q; };
             qx = quant(cx[c], ox); qy = quant(cy[c], oy); qz = quant(cz[c], oz);
-            const double dx = (double)fmaf((float)qx, scale, ox) - cx[c], dy = (double)fmaf((float)qy, scale, oy) - cy[c], dz = (double)fmaf((float)qz, scale, oz) - cz[c];
-            const double rInfl = (cr[c] + sqrt(dx * dx + dy * dy + dz * dz)) * (1.0 + 1e-9) + 1e-300;
+            const double dcx = (double)fmaf((float)qx, scale, ox), dcy = (double)fmaf((float)qy, scale, oy), dcz = (double)fmaf((float)qz, scale, oz);   // the decoded centre
+            const double ex = dcx - cx[c], ey = dcy - cy[c], ez = dcz - cz[c];
+            const double rInfl = (cr[c] + sqrt(ex * ex + ey * ey + ez * ez)) * (1.0 + 1e-9) + 1e-300;
             float rf = (float)rInfl; if ((double)rf < rInfl) rf = nextafterf(rf, 3.0e38f);
             rh = halfRoundedUp(rf);                      // +inf when the radius exceeds the half range: the child is then always visited
-            rr = ref[c];
+            refs[c] = (uint32_t)ref[c];
+            const uint32_t cnt = re[c] - rb[c];
+            if (cnt <= WIDE_SLAB_MAX) {
+                double sx = 0, sy = 0, sz = 0;
+                for (uint32_t k = rb[c] + sub; k < re[c]; k += 16u) {
+                    const uint32_t t = triAtRank[k];
+                    const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+                    const double ux = (double)q0.w - q0.x, uy = (double)q1.x - q0.y, uz = (double)q1.y - q0.z, vx = (double)q1.z - q0.x, vy = (double)q1.w - q0.y, vz = (double)q2.x - q0.z;
+                    sx += uy * vz - uz * vy; sy += uz * vx - ux * vz; sz += ux * vy - uy * vx;
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sy += __shfl_xor(sy, o, 16); sz += __shfl_xor(sz, o, 16); }
+                const double len = sqrt(sx * sx + sy * sy + sz * sz);
+                if (len > 1e-300 && len < 1e300) {
+                    auto snorm = [&](double v) { double q = rint(v / len * 32767.0); if (q < -32767.0) q = -32767.0; if (q > 32767.0) q = 32767.0; return (int)q; };
+                    const int ix = snorm(sx), iy = snorm(sy), iz = snorm(sz);
+                    const double dmx = (double)((float)ix * (1.0f / 32767.0f)), dmy = (double)((float)iy * (1.0f / 32767.0f)), dmz = (double)((float)iz * (1.0f / 32767.0f));   // the decoded direction
+                    double W = 0.0;
+                    for (uint32_t k = rb[c] + sub; k < re[c]; k += 16u) {
+                        const uint32_t t = triAtRank[k];
+                        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+                        const double px[3] = {q0.x, q0.w, q1.z}, py[3] = {q0.y, q1.x, q1.w}, pz[3] = {q0.z, q1.y, q2.x};
+                        for (int j = 0; j < 3; j++) W = fmax(W, fabs(dmx * (px[j] - dcx) + dmy * (py[j] - dcy) + dmz * (pz[j] - dcz)));
+                    }
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) W = fmax(W, __shfl_xor(W, o, 16));
+                    const double Winfl = W * (1.0 + 1e-9) + 1e-300;
+                    float wf = (float)Winfl; if ((double)wf < Winfl) wf = nextafterf(wf, 3.0e38f);
+                    wh = halfRoundedUp(wf);
+                    mx = (uint32_t)(ix & 0xFFFF); my = (uint32_t)(iy & 0xFFFF); mz = (uint32_t)(iz & 0xFFFF);
+                }
+            }
         }
-        w[4 + 2 * c] = qx | (qy << 16); w[5 + 2 * c] = qz | ((uint32_t)rh << 16); w[12 + c] = (uint32_t)rr;
+        if (sub == 0u) out[1 + c] = make_uint4(qx | (qy << 16), qz | ((uint32_t)rh << 16), mx | (my << 16), mz | ((uint32_t)wh << 16));
     }
-    uint4* out = wide + 4 * (size_t)i;
-    out[0] = make_uint4(w[0], w[1], w[2], w[3]); out[1] = make_uint4(w[4], w[5], w[6], w[7]); out[2] = make_uint4(w[8], w[9], w[10], w[11]); out[3] = make_uint4(w[12], w[13], w[14], w[15]);
+    if (sub == 0u) out[5] = make_uint4(refs[0], refs[1], refs[2], refs[3]);
 }
 
 __global__ void __launch_bounds__(128) k_nearest(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
@@ -397,10 +444,14 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
         k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
     k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
-    SDF_TRY(mesh->dBvhWide.reserve(16 * (size_t)(nn ? nn : 1)));
-    k_wide_nodes<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), T, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
     SDF_TRY(mesh->dTriRank.reserve(T));
     k_tri_ranks<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), T, mesh->dTriRank.p);
+    DevBuf<uint32_t> triAtRank;
+    SDF_TRY(triAtRank.reserve(T));
+    k_tri_at_rank<<<gridFor(T, 256), 256, 0, st>>>(mesh->dTriRank.p, T, triAtRank.p);
+    SDF_TRY(mesh->dBvhWide.reserve(32 * (size_t)(nn ? nn : 1)));
+    k_wide_nodes<<<gridFor(16ull * T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), reinterpret_cast<const float4*>(mesh->dTriVerts.p),
+                                               triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     mesh->numBvhNodes = nn;
@@ -496,10 +547,10 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
     }
     if (nearestExactOnly() || n >= (1ull << 31)) k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
     else {
-        NearScratch near;
+        std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);      // the context's scratch is shared with the builders
         int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
-        SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), p, (uint32_t)n, o, near, depth + 2, 0u, 1u));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));             // `near` is released on return
+        SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), p, (uint32_t)n, o, mesh->ctx->nearScratch, depth + 2, 0u, 1u));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
     SDF_HIP_CHECK(hipGetLastError());
     if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(out_ids, dout.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, st));

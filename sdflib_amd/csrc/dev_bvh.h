@@ -18,10 +18,11 @@
 //   triV : 48 B per triangle = its three fp32 vertices gathered once [v0.xyz v1.x | v1.yz v2.xy | v2.z flag - -], so a leaf
 //          visit reads one contiguous record instead of three indices plus three scattered vertices; flag != 0 marks a (nearly)
 //          degenerate triangle, whose fp32 distance is not trusted by the candidate search (dev_bvh_fast.h).
-//   wide : 64 B per inner node at an EVEN depth = that node and its children collapsed into one 4-wide node for the order-free
-//          candidate search (dev_bvh_fast.h): [origin.xyz scale | 4 x (centre as 3 x u16 on the node's own grid, radius as a half
-//          rounded up and inflated by the quantisation error) | 4 child references (>= 0: inner node at the next even depth,
-//          < 0: ~triangle)]; an empty slot has radius -inf.  One visit = one 64-byte line instead of two lines per binary level.
+//   wide : 128 B per inner node at an EVEN depth = that node and its children collapsed into one 4-wide node for the order-free
+//          candidate search (dev_bvh_fast.h): [origin.xyz scale | 4 x 16 B (centre as 3 x u16 on the node's own grid, radius as a
+//          half, slab direction as 3 x snorm16, slab half-width as a half; both halves rounded up after measuring them against the
+//          DECODED centre / direction) | 4 child references (>= 0: inner node at the next even depth, < 0: ~triangle) | pad];
+//          an empty slot has radius -inf, a child without a slab has width +inf.
 //   triRank: u32 per triangle = its position in the tree's leaf order (the planner's final `order` array); the node over the
 //          leaf range [b, e) splits at (b + e) / 2 and inner nodes are numbered in pre-order, so ranks make the tree navigable
 //          by arithmetic alone (dev_bvh_fast.h).

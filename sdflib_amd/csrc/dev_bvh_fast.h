@@ -96,12 +96,6 @@ SDF_DEV float sphereLower32(float4 sp, F3 p, float coordScale) {
     return (a - sp.w) - 2.0f * (1e-6f * (a + sp.w) + 5e-7f * coordScale);
 }
 
-// ---- phase 1 ---------------------------------------------------------------------------------------------------------
-// Every iteration of a lane is ONE pop: a stack entry (child reference + the lower bound of its sphere, kept as a half rounded
-// DOWN) is dropped if the bound has been overtaken, expanded if it is an inner node (both children tested, the survivors pushed,
-// the nearer one on top), or — a triangle — put into the lane's queue of pending evaluations.  The queues are drained by the whole
-// wave at once (when some lane's queue is full, or nobody has nodes left): the fp32 point/triangle routine is the longest stretch
-// of code of the search, and run per visit it would execute for the two or three lanes that happen to sit at a leaf.
 SDF_DEV unsigned short halfRoundedDown(float f) {
     const _Float16 h = (_Float16)f;
     unsigned short bits = __builtin_bit_cast(unsigned short, h);
@@ -110,8 +104,44 @@ SDF_DEV unsigned short halfRoundedDown(float f) {
 }
 SDF_DEV float halfBitsToFloat(unsigned short bits) { return (float)__builtin_bit_cast(_Float16, bits); }
 
+// Lower bounds of the distance from p to the four children of a wide node (layout: dev_bvh.h) and their references.
+// A child is a sphere AND a slab |m . (x - c)| <= W: the distance to their intersection is at least
+//   sqrt( max(h - W, 0)^2 / |m|^2 + max(rho - r, 0)^2 ),  h = |m . v|, rho^2 = |v|^2 - h^2 / |m|^2, v = p - c,
+// and at least |v| - r.  For a point "above" a smooth patch of the surface the sphere bound is loose by the patch's radius, the
+// slab's by its sagitta only; measured on the bumpy sphere it cuts the visits of a far-field query by three.
+// Every term is rounded in the conservative direction (|m| = 1 +- 1e-4, fp32 products within 2e-6 of |v|).
+SDF_DEV void wideBounds(const float4* __restrict__ nd, F3 p, float l[4], uint32_t cr[4]) {
+    const float4 h = nd[0], rf = nd[5];
+    cr[0] = __float_as_uint(rf.x); cr[1] = __float_as_uint(rf.y); cr[2] = __float_as_uint(rf.z); cr[3] = __float_as_uint(rf.w);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float4 q = nd[1 + c];
+        const uint32_t w0 = __float_as_uint(q.x), w1 = __float_as_uint(q.y), w2 = __float_as_uint(q.z), w3 = __float_as_uint(q.w);
+        const float vx = p.x - fmaf((float)(w0 & 0xFFFFu), h.w, h.x), vy = p.y - fmaf((float)(w0 >> 16), h.w, h.y), vz = p.z - fmaf((float)(w1 & 0xFFFFu), h.w, h.z);
+        const float rad = halfBitsToFloat((unsigned short)(w1 >> 16)), W = halfBitsToFloat((unsigned short)(w3 >> 16));
+        const float mx = (float)(short)(w2 & 0xFFFFu) * (1.0f / 32767.0f), my = (float)(short)(w2 >> 16) * (1.0f / 32767.0f), mz = (float)(short)(w3 & 0xFFFFu) * (1.0f / 32767.0f);
+        const float v2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+        const float a = __builtin_amdgcn_sqrtf(v2);
+        const float ls = (a - rad) - 2e-6f * (a + rad);
+        const float hm = fabsf(fmaf(mx, vx, fmaf(my, vy, mz * vz)));
+        const float up = fmaxf(hm * 0.9999f - 3e-6f * a - W, 0.f) * 0.9999f;                       // (h - W) / |m|, rounded down
+        const float rho2 = fmaxf(v2 * 0.999996f - hm * hm * 1.0003f - 6e-6f * v2, 0.f);           // |v|^2 - h^2 / |m|^2, rounded down
+        const float lat = fmaxf(__builtin_amdgcn_sqrtf(rho2) * 0.999999f - rad, 0.f);
+        const float ld = __builtin_amdgcn_sqrtf(fmaf(up, up, lat * lat)) * 0.999998f;
+        l[c] = rad < 0.f ? 3.4e38f : fmaxf(ls, (W < 6.0e4f) ? ld : -3.4e38f);
+    }
+}
+
+// ---- phase 1 ---------------------------------------------------------------------------------------------------------
+// Every iteration of a lane is ONE pop: a stack entry (child reference + the lower bound of its sphere, kept as a half rounded
+// DOWN) is dropped if the bound has been overtaken, expanded if it is an inner node (both children tested, the survivors pushed,
+// the nearer one on top), or — a triangle — put into the lane's queue of pending evaluations.  The queues are drained by the whole
+// wave at once (when some lane's queue is full, or nobody has nodes left): the fp32 point/triangle routine is the longest stretch
+// of code of the search, and run per visit it would execute for the two or three lanes that happen to sit at a leaf.
+
 constexpr int NEAR_QUEUE = 4;              // pending triangle evaluations per lane
-constexpr int NEAR_DRAIN_LANES = 40;       // a drain round is worth its instructions once this many lanes have one pending
+constexpr int NEAR_DRAIN_LANES = 40;
+constexpr int NEAR_CHUNK = 32;              // queries a wave takes per atomic       // a drain round is worth its instructions once this many lanes have one pending
 
 // PERSISTENT waves: a lane that has finished its query takes the next one (one atomic per wave and refill), so a wave stays full
 // until the work runs out instead of idling behind its longest traversal (half the lanes of a wave, measured).  The queries are
@@ -122,8 +152,10 @@ constexpr int NEAR_DRAIN_LANES = 40;       // a drain round is worth its instruc
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand,
                                                            uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
-                                                           uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount) {
+                                                           uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
+                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk) {
     extern __shared__ uint32_t s_near_stack[];
+    uint32_t stIter = 0, stPop = 0, stPruned = 0, stExpand = 0, stTri = 0, stSeed = 0, stDrain = 0;
     uint32_t* stkRef = s_near_stack + threadIdx.x;
     uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
     unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;
@@ -134,6 +166,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
     const uint32_t per = ((mine + 7u) / 8u) * 128u;             // queries per XCD range
     const uint32_t lane = __lane_id();
     uint32_t xcd = blockIdx.x & 7u; uint32_t tried = 0;
+    uint32_t chunkNext = 0, chunkEnd = 0;        // wave-uniform
     uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
     float U = 3.0e38f, U2 = 3.0e38f;            // upper bounds of the minimum distance / squared distance
     uint32_t nc = 0; bool overflow = false;
@@ -142,60 +175,54 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
     int mode = 0, seedRef = 0;        // 1: greedy first descent (nearest child only, nothing pushed) to get a bound; 2: waiting for its triangle
     bool have = false, done = false;
     for (;;) {
-        // ---- refill
+        // ---- refill: the wave owns a chunk [chunkNext, chunkEnd) of its XCD's range and hands it out lane by lane; ONE atomic per chunk
+        // (an atomic per refill was measured to serialise the whole launch on eight addresses)
         uint64_t idle = __ballot(!have && !done);
         while (idle != 0ull) {
-            const uint32_t want = (uint32_t)__popcll(idle);
-            const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
-            uint32_t base = 0;
-            if (lane == (uint32_t)(__ffsll((unsigned long long)idle) - 1)) base = atomicAdd(counters + xcd, want);
-            base = __shfl(base, __ffsll((unsigned long long)idle) - 1) + lo;
-            if (!have && !done) {
-                const uint32_t q = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                if (q < hi) {
-                    const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
-                    if (rr < numReps) {
-                        r = rr; have = true;
-                        p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
-                        U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; steps = 0;
-                        // With no bound yet the first descent would push every sibling it passes (three per level): it is made
-                        // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one
-                        // triangle and leaves few entries behind — the stacks can be short, and LDS per lane is what limits the waves per CU.
-                        if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
-                        else { sp = 1; mode = 1; seedRef = 0; }
-                    }
+            if (chunkNext >= chunkEnd) {
+                if (tried >= 8u) { if (!have) done = true; break; }
+                const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(counters + xcd, chunk);
+                base = __shfl(base, 0) + lo;
+                if (base >= hi) { tried++; xcd = (xcd + 1u) & 7u; continue; }       // this range is exhausted: the next XCD's, or stop after all eight
+                chunkNext = base; chunkEnd = (base + chunk < hi) ? base + chunk : hi;
+            }
+            const uint32_t avail = chunkEnd - chunkNext;
+            const uint32_t slot = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!have && !done && slot < avail) {
+                const uint32_t q = chunkNext + slot;
+                const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
+                if (rr < numReps) {
+                    r = rr; have = true;
+                    p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+                    U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; steps = 0;
+                    // With no bound yet the first descent would push every sibling it passes (three per level): it is made
+                    // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one triangle.
+                    if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
+                    else { sp = 1; mode = 1; seedRef = 0; }
                 }
             }
-            idle = __ballot(!have && !done);
-            if (idle != 0ull && base + want >= hi) {          // this range is exhausted (uniform over the wave): move on, or stop after all eight
-                tried++;
-                if (tried >= 8u) { if (!have) done = true; idle = 0ull; }
-                else xcd = (xcd + 1u) & 7u;
-            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            chunkNext += want < avail ? want : avail;
+            idle = __ballot(!have && !done);          // lanes that drew a query beyond numReps (the padded tail) draw again
         }
         if (__ballot(have) == 0ull) break;
+        if (have) stIter++;
         // ---- one pop per walking lane: a 4-wide node (one 64-byte line) or a triangle
         if (have && mode == 2 && nq == 0) { mode = 0; stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // seeded: the root, bound = -65504
         const bool walking = have && sp > 0 && mode != 2;
         if (walking && nq < NEAR_QUEUE) {
             int ref; float lbound;
-            if (mode == 1) { ref = seedRef; lbound = -3.0e38f; }
-            else { sp--; steps++; ref = (int)stkRef[sp * BLOCK]; lbound = halfBitsToFloat(stkLb[sp * BLOCK]); }
+            if (mode == 1) { ref = seedRef; lbound = -3.0e38f; stSeed++; }
+            else { sp--; steps++; ref = (int)stkRef[sp * BLOCK]; lbound = halfBitsToFloat(stkLb[sp * BLOCK]); stPop++; }
+            if (lbound > U) stPruned++;
             if (!(lbound > U)) {
                 if (ref >= 0 && sp + 4 > stackDepth) steps = 0xFFFFFFF0u;        // the (short) stack would overflow: a job for k_near_long
                 else if (ref >= 0) {
-                    const float4* nd = b.wide + 4 * (size_t)ref;
-                    const float4 h = nd[0], s01 = nd[1], s23 = nd[2], rf = nd[3];
-                    const uint32_t sw[8] = {__float_as_uint(s01.x), __float_as_uint(s01.y), __float_as_uint(s01.z), __float_as_uint(s01.w),
-                                            __float_as_uint(s23.x), __float_as_uint(s23.y), __float_as_uint(s23.z), __float_as_uint(s23.w)};
-                    float l[4]; uint32_t cr[4] = {__float_as_uint(rf.x), __float_as_uint(rf.y), __float_as_uint(rf.z), __float_as_uint(rf.w)};
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const float dx = p.x - fmaf((float)(sw[2 * c] & 0xFFFFu), h.w, h.x), dy = p.y - fmaf((float)(sw[2 * c] >> 16), h.w, h.y), dz = p.z - fmaf((float)(sw[2 * c + 1] & 0xFFFFu), h.w, h.z);
-                        const float rad = halfBitsToFloat((unsigned short)(sw[2 * c + 1] >> 16));
-                        const float a = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-                        l[c] = rad < 0.f ? 3.4e38f : (a - rad) - 2e-6f * (a + rad);      // conservative: fp32 error of a and of the difference
-                    }
+                    float l[4]; uint32_t cr[4];
+                    wideBounds(b.wide + 8 * (size_t)ref, p, l, cr);
+                    stExpand++;
                     // sort the four by bound (ascending), push the survivors farthest first: the nearest is popped next
 #define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
                     SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
@@ -213,9 +240,10 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
         }
         // ---- one drain round when enough lanes have a triangle pending, a lane is stuck on a full queue, or nobody walks any more
         const uint64_t pend = __ballot(have && nq > 0);
-        if (pend != 0ull && (__popcll(pend) >= NEAR_DRAIN_LANES || __ballot(have && (nq >= NEAR_QUEUE || mode == 2)) != 0ull || __ballot(have && sp > 0 && mode != 2) == 0ull)) {
+        if (pend != 0ull && (__popcll(pend) >= drainLanes || __ballot(have && nq >= NEAR_QUEUE) != 0ull || __ballot(have && sp > 0 && mode != 2) == 0ull)) {
+            if (have) stDrain++;
             if (have && nq > 0) {
-                nq--;
+                nq--; stTri++;
                 const uint32_t t = queue[nq * BLOCK];
                 const TriBounds tb = triBounds32(b, t, p);
                 if (tb.lo <= U2) {
@@ -237,7 +265,15 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
         // ---- finished queries; a query that turns out to be long (a point with thousands of almost equidistant triangles) is
         // handed to k_near_long, where a whole wave works on it: left to one lane, its dependent chain of pops alone outlasts the
         // rest of the launch (measured: the longest of 1.5 M traversals took as long as all the others together)
-        if (have && sp == 0 && nq == 0 && mode == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false; }
+        if (have && sp == 0 && nq == 0 && mode == 0) {
+            candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false;
+            if (stats) {
+                atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)stIter); atomicAdd(stats + 2, (unsigned long long)stPop); atomicAdd(stats + 3, (unsigned long long)stPruned);
+                atomicAdd(stats + 4, (unsigned long long)stExpand); atomicAdd(stats + 5, (unsigned long long)stTri); atomicAdd(stats + 6, (unsigned long long)stSeed); atomicAdd(stats + 7, (unsigned long long)stDrain);
+                atomicAdd(stats + 8, (unsigned long long)nc);
+            }
+            stIter = stPop = stPruned = stExpand = stTri = stSeed = stDrain = 0;
+        }
         if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; }
     }
 }
@@ -304,18 +340,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
             // inner nodes: bounds of the four children
             float l[4] = {3.4e38f, 3.4e38f, 3.4e38f, 3.4e38f}; uint32_t cr[4] = {0u, 0u, 0u, 0u};
             if (live && ref >= 0) {
-                const float4* nd = b.wide + 4 * (size_t)ref;
-                const float4 h = nd[0], s01 = nd[1], s23 = nd[2], rf = nd[3];
-                const uint32_t sw[8] = {__float_as_uint(s01.x), __float_as_uint(s01.y), __float_as_uint(s01.z), __float_as_uint(s01.w),
-                                        __float_as_uint(s23.x), __float_as_uint(s23.y), __float_as_uint(s23.z), __float_as_uint(s23.w)};
-                cr[0] = __float_as_uint(rf.x); cr[1] = __float_as_uint(rf.y); cr[2] = __float_as_uint(rf.z); cr[3] = __float_as_uint(rf.w);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const float dx = p.x - fmaf((float)(sw[2 * c] & 0xFFFFu), h.w, h.x), dy = p.y - fmaf((float)(sw[2 * c] >> 16), h.w, h.y), dz = p.z - fmaf((float)(sw[2 * c + 1] & 0xFFFFu), h.w, h.z);
-                    const float rad = halfBitsToFloat((unsigned short)(sw[2 * c + 1] >> 16));
-                    const float a = __builtin_amdgcn_sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
-                    l[c] = rad < 0.f ? 3.4e38f : (a - rad) - 2e-6f * (a + rad);
-                }
+                wideBounds(b.wide + 8 * (size_t)ref, p, l, cr);
 #define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
                 SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
 #undef SDF_CE
@@ -462,11 +487,9 @@ __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* 
 }
 
 // ---- host driver -------------------------------------------------------------------------------------------------------
-struct NearScratch {
-    DevBuf<uint32_t> cand, fbList, fbCount, longList; DevBuf<uint8_t> candCount;      // fbCount[0]: this batch's fallback list length, [1]: total since reset(), [2..9]: work counters, [10]: long list length, [11]: total long
-    bool counterReady = false;
-    void reset() { counterReady = false; }
-};
+typedef sdfhip_near_scratch NearScratch;
+// the scratch buffers are ordinary allocations, whatever allocation scope the caller is in
+struct NearPlainAlloc { AllocState saved; NearPlainAlloc() { saved = tlsAlloc(); tlsAlloc().active = false; } ~NearPlainAlloc() { tlsAlloc() = saved; } };
 static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
 
 // Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  stackDepth = BVH depth + 2.
@@ -475,6 +498,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     const uint32_t blocks = gridFor(n, 128);
     const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
     if (!mine) return SDFHIP_OK;
+    NearPlainAlloc plain;
     SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
     if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(12)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 48, st)); S.counterReady = true; }
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
@@ -482,14 +506,27 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
     // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
     const int worst = 3 * (stackDepth / 2 + 1) + 2;
-    static const int cap = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 20;
+    static const int cap = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 32;
     const int sd = worst < cap ? worst : cap;
     const size_t lds = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (size_t)sd * 128 * 2;
     static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 8u;
     uint32_t grid = 256u * perCU;
     if (grid > mine) grid = mine;
     static const uint32_t maxSteps = getenv("SDFHIP_NEAR_LONG") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LONG")) : 1536u;
-    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10);
+    static const bool wantStats = getenv("SDFHIP_NEAR_STATS") != nullptr;
+    static const uint32_t chunk = getenv("SDFHIP_NEAR_CHUNK") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_CHUNK")) : (uint32_t)NEAR_CHUNK;
+    static const int drainLanes = getenv("SDFHIP_NEAR_DRAIN") ? atoi(getenv("SDFHIP_NEAR_DRAIN")) : NEAR_DRAIN_LANES;
+    DevBuf<unsigned long long> stats;
+    if (wantStats) { SDF_TRY(stats.reserve(16)); SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 128, st)); }
+    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
+                                                            wantStats ? stats.p : nullptr, drainLanes, chunk);
+    if (wantStats) {
+        unsigned long long h[9];
+        SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
+        const double q = (double)(h[0] ? h[0] : 1);
+        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f\n",
+                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q);
+    }
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candCount.p);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out);

@@ -336,6 +336,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
 
     double tSamples = 0, tDecide = 0;
     SampleScratch SS;
+    SS.near = &ctx->nearScratch; ctx->nearScratch.counterReady = false;      // (builds on one context are serialised by its buildLock)
     std::unique_ptr<BuildLevel> spec[2];            // complete levels startDepth+1 and +2, sampled speculatively (may stay empty)
     const uint64_t SPEC_SAMPLE_LIMIT = 1500000;
     {   // Levels down to the start depth exist a priori: create their geometry now and take ALL their samples (the 8 corners of the

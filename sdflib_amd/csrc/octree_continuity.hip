@@ -685,6 +685,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
 
     uint64_t numRescheduled = 0, ppRoots = 0, ppNodes = 0, ppSplits = 0;
     SampleScratch SS;
+    SS.near = &ctx->nearScratch; ctx->nearScratch.counterReady = false;      // (builds on one context are serialised by its buildLock)
     if (ctx->exchange.world >= 1 && ctx->exchange.acquire) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
     DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist, wordVals; std::vector<uint32_t> hWordVals;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will

@@ -136,7 +136,7 @@ __global__ void k_sample_values(MeshDev m, SampleBatch B, const uint32_t* __rest
 // scratch of the sampler, reused across levels (grows only)
 struct SampleScratch {
     DevBuf<uint64_t> key, keyS; DevBuf<uint32_t> val, valS, isRep, scan, repSample, repTri; DevBuf<float> repPos; DevBuf<unsigned char> tmp; size_t tmpBytes = 0;
-    NearScratch near;                               // candidate lists / fallback list of the two-phase nearest search (dev_bvh_fast.h)
+    NearScratch* near = nullptr;                    // the context's scratch of the two-phase nearest search (dev_bvh_fast.h); set by the builders
     const sdfhip_exchange* exchange = nullptr;      // set by the CONTINUITY builder when the context has one (world > 1)
     bool pending = false; SampleBatch pendingBatch; uint32_t pendingReps = 0; uint32_t* pendingTri = nullptr;
 };
@@ -173,12 +173,12 @@ static int sampleBatchBegin(hipStream_t st, const MeshDev& md, const SampleBatch
         S.pendingTri = S.exchange->acquire(S.exchange->user, numReps);
         SDF_REQUIRE(S.pendingTri, "exchange: acquire failed");
         const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
-        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, S.near, stackDepth, rank, world));
+        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, *S.near, stackDepth, rank, world));
         else if (mine) k_sample_nearest<128><<<xcdGrid(mine), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, rank, world);
     } else {
         SDF_TRY(S.repTri.reserve(numReps));
         S.pendingTri = S.repTri.p;
-        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, S.near, stackDepth, 0u, 1u));
+        if (!exactOnly) SDF_TRY(nearestTwoPhase(st, md.bvh, S.repPos.p, numReps, S.pendingTri, *S.near, stackDepth, 0u, 1u));
         else k_sample_nearest<128><<<xcdGrid(blocks), 128, stackBytes, st>>>(md.bvh, B, S.repSample.p, numReps, S.pendingTri, 0u, 1u);   // 64 / 256 lanes per block measured the same
     }
     SDF_HIP_CHECK(hipGetLastError());
@@ -205,9 +205,9 @@ static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, 
 // total of fallbacks since the scratch was created (synchronises the stream)
 static int sampleFallbacks(hipStream_t st, SampleScratch& S, uint64_t& out) {
     out = 0;
-    if (!S.near.counterReady) return SDFHIP_OK;
+    if (!S.near || !S.near->counterReady) return SDFHIP_OK;
     uint32_t h = 0;
-    SDF_HIP_CHECK(hipMemcpyAsync(&h, S.near.fbCount.p + 1, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&h, S.near->fbCount.p + 1, 4, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     out = h;
     return SDFHIP_OK;

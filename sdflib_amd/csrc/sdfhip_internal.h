@@ -57,7 +57,7 @@ struct AllocState { hipStream_t stream = nullptr; bool active = false; };
 inline AllocState& tlsAlloc() { static thread_local AllocState s; return s; }
 struct AllocScope {
     AllocState prev;
-    explicit AllocScope(hipStream_t s) { prev = tlsAlloc(); tlsAlloc().stream = s; tlsAlloc().active = true; }
+    explicit AllocScope(hipStream_t s) { prev = tlsAlloc(); tlsAlloc().stream = s; tlsAlloc().active = !getenv("SDFHIP_NO_POOL"); }
     ~AllocScope() { tlsAlloc() = prev; }
     AllocScope(const AllocScope&) = delete;
     AllocScope& operator=(const AllocScope&) = delete;
@@ -119,8 +119,16 @@ struct sdfhip_stage {
     static constexpr size_t kStageKeepBytes = 64u << 20;
 };
 
+// Scratch of the two-phase nearest-triangle search (dev_bvh_fast.h), kept with the context: plain device allocations that grow and
+// are reused by every build (they are the largest transient buffers of a build: 64 B per query).  Used under the context's buildLock.
+struct sdfhip_near_scratch {
+    sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList; sdfhip::DevBuf<uint8_t> candCount;   // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters, [10]: long list length
+    bool counterReady = false;
+};
+
 struct sdfhip_ctx {
     sdfhip_stage stage;
+    sdfhip_near_scratch nearScratch;
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownsStream = false;
