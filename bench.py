@@ -221,7 +221,7 @@ def main():
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
         "roofline": roof,
-        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), **_r4(binfo)},
+        "build": {"octree_build_s": round(build_s, 4), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), "nearest_fallbacks": int(info.num_nearest_fallbacks), **_r4(binfo)},
     }
 
     if world > 1:       # collective sanity: every rank contributes its rank + 1; the sum proves all N ranks were in the communicator
@@ -332,7 +332,8 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     q = pts
     ms = _time_ms(lambda: ex.get_distance(q, out=out), reps=3)
     r["exact_octree_d7_min128"] = {"build_s": round(dt, 4), "nodes": int(i.num_nodes), "cull_tests": int(i.cull_tests), "max_triangles_in_leafs": int(i.max_triangles_in_leafs),
-                                  "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1), **einfo}
+                                  "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1), **einfo,
+                                  "roofline": exact_query_roofline(ex, q, ms)}
     ex.close()
     # CONTINUITY builder (SdfExporter's default) on the same mesh / depth
     # (N > 1: every rank builds the whole tree, the BVH traversals of each sample batch are shared out, one all-reduce per batch)
@@ -359,10 +360,57 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     r["fit_mfma_build"] = {"build_s": round(dt, 4), "words": int(mi.num_words), "same_size_as_exact_fit": bool(int(mi.num_words) == int(tree.info.num_words)),
                            "decisions_rechecked_with_exact_fit": int(mi.fit_rechecks), "nodes": int(mi.num_nodes)}
     mt.close()
+    if len(mesh.indices) >= 300_000:
+        r["torus_knot_328k"] = knot_workload(mesh.ctx, dev, pts.shape[0])
     if len(mesh.indices) >= 300_000:          # the headline configuration only (short test runs of this script skip the 1.7 GB tree)
         r["deep_tree_d9"] = deep_tree(mesh, box, dev, rows or {}, src)
         r["gather_calibration"] = gather_calibration(mesh.ctx, dev)
     return r
+
+
+def exact_query_roofline(ex, pts, ms, sample=20000):
+    """SURVEY.md 8(d) "X": per query 16 B of I/O + k x 148 B of TriangleData + the packed-set bytes, k = triangles of the query's leaf after the
+    mask chain.  The mean k is taken over a sample of the timed points by walking the DOWNLOADED arrays on the host (measurement code).
+    The leaf-sorted kernel stages a leaf's triangles once per tile for all its queries, so the bytes it moves are far below this
+    per-query figure (frac may exceed 1): the honest limiter is the k point/triangle evaluations per query, reported as a flop rate."""
+    nodes, has, sets, masks = ex.download()
+    i = ex.info
+    bb = ex.get_grid_bounding_box(); G = int(i.start_grid_size); cell = float(i.start_grid_cell_size)
+    p = pts[:sample].cpu().numpy().astype(np.float32)
+    ks = np.zeros(len(p), dtype=np.int64); setbytes = np.zeros(len(p), dtype=np.int64)
+    pop8 = np.array([bin(x).count("1") for x in range(256)], dtype=np.int64)
+    def popfirst(off, n):                  # set bits among the first n bits (MSB first) of the mask starting at byte `off`
+        full, rem = n // 8, n % 8
+        c = int(pop8[masks[off:off + full]].sum())
+        if rem: c += int(pop8[masks[off + full] >> (8 - rem)])
+        return c
+    for qi in range(len(p)):
+        f = (p[qi] - bb[:3]) / np.float32(cell)
+        ijk = np.floor(f).astype(np.int64)
+        if (ijk < 0).any() or (ijk >= G).any(): continue
+        f = f - np.floor(f)
+        node = int((ijk[2] * G + ijk[1]) * G + ijk[0]); depth = int(i.start_depth)
+        def child(nd, f):
+            c = (4 if f[2] > 0.5 else 0) + (2 if f[1] > 0.5 else 0) + (1 if f[0] > 0.5 else 0)
+            f = 2 * f; f = f - np.floor(f)
+            return int(nodes[nd, 0] & 0x7FFFFFFF) + c, f
+        leaf = lambda nd: bool(nodes[nd, 0] >> 31)
+        while not leaf(node) and depth < int(i.bit_encoding_start_depth):
+            node, f = child(node, f); depth += 1
+        cnt = int(sets[nodes[node, 1]]); k = cnt
+        setbytes[qi] = 4 + (cnt * int(i.bits_per_index) + 7) // 8
+        if not leaf(node):
+            node, f = child(node, f); k = popfirst(int(nodes[node, 1]), cnt)
+            if not leaf(node):
+                node, f = child(node, f); k = popfirst(int(nodes[node, 1]), k)
+        ks[qi] = k
+    mean_k = float(ks.mean()); bytes_q = 16 + 148 * mean_k + float(setbytes.mean())
+    n = pts.shape[0]
+    gbs = bytes_q * n / (ms * 1e-3) / 1e9
+    flops = 70.0 * mean_k * n / (ms * 1e-3)            # ~70 flop per fp32 point/triangle squared distance in the triangle's frame
+    return {"mean_k": round(mean_k, 1), "max_k_sampled": int(ks.max()), "bytes_per_query_8d": round(bytes_q, 1), "algorithmic_gb_s": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 3),
+            "pair_evaluations_per_s": round(mean_k * n / (ms * 1e-3) / 1e9, 1), "tflop_s": round(flops / 1e12, 2), "fp32_vector_frac": round(flops / 157.3e12, 4),
+            "note": "8(d) bytes are per query; a leaf's triangles are staged once per tile for all its queries, so real traffic is far lower and the kernel is bound by the k distance evaluations"}
 
 
 DEEP_QUERIES = 12_000_000      # not 10 M: the profile summaries tell the two launches of the same kernel apart by grid size
@@ -384,6 +432,35 @@ def deep_tree(mesh, box, dev, rows, src):
     t.close()
     return {"build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves), "queries": DEEP_QUERIES, "query_ms": round(ms, 4),
             "mqueries_s": round(DEEP_QUERIES / ms / 1e3, 1), "roofline": roof}
+
+
+def knot_workload(ctx, dev, n):
+    """The C2 / C3 pipeline on geometry that is not a displaced sphere: a 327 680-triangle tube around a (2,3) torus knot (genus 1, not
+    star-shaped, thin, close to itself): BVH planner, both structures' builds, 10 M queries each."""
+    from sdflib_amd.meshgen import torus_knot
+    v, f = torus_knot()
+    box = box_with_margin(v)
+    t0 = time.perf_counter(); m = S.Mesh(v, f, ctx); prep = time.perf_counter() - t0
+    bvh_s = m.build_bvh()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    t = S.OctreeSdf(m, box, 8, 3, 1e-3, num_threads=2)
+    torch.cuda.synchronize(); build_s = time.perf_counter() - t0
+    i = t.info
+    gen = torch.Generator(device=dev); gen.manual_seed(77)
+    bb = t.get_grid_bounding_box(); size = float(bb[3] - bb[0])
+    pts = (torch.tensor(bb[:3], device=dev) + torch.rand((n, 3), generator=gen, device=dev) * (size * 0.999999)).contiguous()
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    ms = _time_ms(lambda: t.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ex = S.ExactOctreeSdf(m, box, 7, 3, 128)
+    torch.cuda.synchronize(); ebuild = time.perf_counter() - t0
+    ems = _time_ms(lambda: ex.get_distance(pts, out=out), reps=3)
+    r = {"triangles": int(len(f)), "mesh_prep_s": round(prep, 4), "bvh_host_planner_s": round(bvh_s, 4), "octree_build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves),
+         "bvh_traversals": int(i.num_traversals), "nearest_fallbacks": int(i.num_nearest_fallbacks), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1),
+         "exact_build_s": round(ebuild, 4), "exact_nodes": int(ex.info.num_nodes), "exact_max_triangles_in_leafs": int(ex.info.max_triangles_in_leafs),
+         "exact_query_ms": round(ems, 3), "exact_mqueries_s": round(n / ems / 1e3, 1)}
+    ex.close(); t.close()
+    return r
 
 
 def gather_calibration(ctx, dev):

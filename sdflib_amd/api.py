@@ -242,7 +242,7 @@ class OctreeSdf:
             for d, n in enumerate(ov["leaves_per_depth"]):
                 i.leaves_per_depth[d] = n
             i.num_leaves, i.num_nodes, i.num_samples = ov["num_leaves"], ov["num_nodes"], ov["num_samples"]
-            i.num_traversals = ov.get("num_traversals", 0)
+            i.num_traversals = ov.get("num_traversals", 0); i.num_nearest_fallbacks = ov.get("num_nearest_fallbacks", 0)
         return i
 
     # reference getters

@@ -131,14 +131,14 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
     stats = torch.tensor([info.value_range, -info.min_border_value], dtype=torch.float32, device=cdev)
     dist.all_reduce(stats, op=dist.ReduceOp.MAX, group=group)
     lpd = torch.tensor(list(info.leaves_per_depth), dtype=torch.int64, device=cdev)
-    cnt = torch.tensor([info.num_leaves, info.num_nodes, info.num_samples, info.num_traversals], dtype=torch.int64, device=cdev)
+    cnt = torch.tensor([info.num_leaves, info.num_nodes, info.num_samples, info.num_traversals, info.num_nearest_fallbacks], dtype=torch.int64, device=cdev)
     dist.all_reduce(lpd, group=group); dist.all_reduce(cnt, group=group)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     tree = api.OctreeSdf.from_data(mesh.ctx, full, info.box_min, info.box_max, info.start_grid_size, info.max_depth,
                                    float(stats[0].item()), float(-stats[1].item()), where=api.DEVICE, cell_size=info.start_grid_cell_size)
     tree._override = {"leaves_per_depth": [int(x) for x in lpd.cpu().tolist()], "num_leaves": int(cnt[0]), "num_nodes": int(cnt[1]), "num_traversals": int(cnt[3]),
-                      "num_samples": int(cnt[2])}
+                      "num_samples": int(cnt[2]), "num_nearest_fallbacks": int(cnt[4])}
     shard.close()
     return tree, {"shard_build_s": t1 - t0, "exchange_s": t2 - t1, "exchange_bytes": xstats.get("bytes_all_gathered", 0), "ranks_seen": xstats.get("ranks_seen", 0),
                   "backend": dist.get_backend(group)}

@@ -61,6 +61,33 @@ def bumpy_icosphere(subdivisions):
     return np.ascontiguousarray(v * r[:, None], dtype=np.float32), f
 
 
+def torus_knot(nu=1024, nv=160, p=2, q=3, big=1.0, small=0.45, tube=0.16, ripple=0.12):
+    """Tube around a (p, q) torus knot: a closed manifold of genus 1 that is NOT star-shaped — thin, strongly curved, passing close to
+    itself, with a rippled cross-section (creases of varying sharpness) — so that tree sizes and traversal statistics measured on the
+    bumpy spheres can be checked against a different kind of geometry.  2 * nu * nv triangles (defaults: 327 680), outward winding.
+    The frame comes from the carrier torus: n1 = the torus normal at the curve point (perpendicular to every curve on the torus),
+    n2 = tangent x n1; everything is evaluated in float64 and rounded once to float32 (deterministic)."""
+    u = np.arange(nu, dtype=np.float64) * (2.0 * np.pi / nu)
+    cu, su, cq, sq = np.cos(p * u), np.sin(p * u), np.cos(q * u), np.sin(q * u)
+    rad = big + small * cq
+    c = np.stack([rad * cu, rad * su, small * sq], axis=1)
+    dc = np.stack([-small * q * sq * cu - rad * p * su, -small * q * sq * su + rad * p * cu, small * q * cq], axis=1)
+    t = dc / np.linalg.norm(dc, axis=1)[:, None]
+    n1 = np.stack([cu * cq, su * cq, sq], axis=1)
+    n1 = n1 - (n1 * t).sum(axis=1)[:, None] * t
+    n1 /= np.linalg.norm(n1, axis=1)[:, None]
+    n2 = np.cross(t, n1)
+    v = np.arange(nv, dtype=np.float64) * (2.0 * np.pi / nv)
+    rr = tube * (1.0 + ripple * np.cos(5.0 * v)[None, :] * np.cos(7.0 * u)[:, None])          # [nu, nv]
+    pts = c[:, None, :] + rr[:, :, None] * (np.cos(v)[None, :, None] * n1[:, None, :] + np.sin(v)[None, :, None] * n2[:, None, :])
+    verts = np.ascontiguousarray(pts.reshape(-1, 3), dtype=np.float32)
+    i = np.arange(nu)[:, None]; j = np.arange(nv)[None, :]
+    a = (i * nv + j).reshape(-1); b = (((i + 1) % nu) * nv + j).reshape(-1)
+    cidx = (((i + 1) % nu) * nv + (j + 1) % nv).reshape(-1); d = (i * nv + (j + 1) % nv).reshape(-1)
+    f = np.concatenate([np.stack([a, cidx, b], axis=1), np.stack([a, d, cidx], axis=1)], axis=0).astype(np.uint32)
+    return verts, np.ascontiguousarray(f)
+
+
 def cube_mesh():
     """Axis-aligned unit cube (12 triangles, 8 shared vertices), outward winding."""
     v = np.array([[-.5, -.5, -.5], [.5, -.5, -.5], [.5, .5, -.5], [-.5, .5, -.5],

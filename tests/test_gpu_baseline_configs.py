@@ -110,3 +110,37 @@ def test_c3_exact_octree_full_size_arrays(c2, oracle):
     assert np.array_equal(bits(d0), bits(d1))
     assert np.array_equal(bits(g0[inside]), bits(g1[inside])) and np.array_equal(t0[inside], t1[inside])
     ge.close()
+
+
+def test_non_star_shaped_geometry_torus_knot(oracle, gpu_ctx):
+    """A closed tube around a (2,3) torus knot (genus 1, not star-shaped, thin, passing close to itself): TriangleData, nearest ids
+    (far field, near the surface, on the knot's axis), both OctreeSdf builders, ExactOctreeSdf arrays and queries — against the oracle."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import torus_knot, box_with_margin, random_points_in_box
+    v, f = torus_knot(384, 56)                  # 43 008 triangles
+    box = box_with_margin(v)
+    gm, om = S.Mesh(v, f, gpu_ctx), oracle.Mesh(v, f)
+    assert np.array_equal(bits(om.triangle_data()), bits(gm.triangle_data()))
+    rng = np.random.default_rng(5)
+    pts = random_points_in_box(box, 400_000, seed=8)
+    near = (v[rng.integers(0, len(v), 200_000)] + rng.normal(0, 0.02, (200_000, 3))).astype(np.float32)
+    u = rng.random(100_000) * 2 * np.pi                                                   # points on / around the knot's centre line
+    rad = 1.0 + 0.45 * np.cos(3 * u)
+    axis = (np.stack([rad * np.cos(2 * u), rad * np.sin(2 * u), 0.45 * np.sin(3 * u)], axis=1) + rng.normal(0, 0.01, (100_000, 3))).astype(np.float32)
+    allp = np.concatenate([pts, near, axis]).astype(np.float32)
+    assert np.array_equal(om.nearest(allp), gm.nearest_triangle(allp))
+    ot = oracle.Octree(om, box, 7, 3, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    gt = S.OctreeSdf(gm, box, 7, 3, 1e-3, num_threads=2)
+    assert np.array_equal(ot.data(), gt.get_octree_data())
+    assert gt.info.num_nearest_fallbacks <= gt.info.num_traversals // 100          # the two-phase search decides (almost) everything itself
+    d0, g0 = ot.query(allp, grad=True); d1, g1 = gt.get_distance(allp, gradient=True)
+    assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(bits(g0), bits(g1))
+    oc = oracle.Octree(om, box, 6, 2, 1e-3, continuity=True)
+    gc = S.OctreeSdf(gm, box, 6, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY)
+    assert np.array_equal(oc.data(), gc.get_octree_data())
+    oe = oracle.Exact(om, box, 6, 2, 32, threads=0); ge = S.ExactOctreeSdf(gm, box, 6, 2, 32)
+    for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    inside = ((allp >= ge.get_grid_bounding_box()[:3]) & (allp < ge.get_grid_bounding_box()[3:])).all(axis=1)
+    e0, t0 = oe.query(allp, tri=True); e1, t1 = ge.get_distance(allp, triangle=True)
+    assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0[inside], t1[inside])
