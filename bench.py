@@ -334,7 +334,7 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     r["exact_octree_d7_min128"] = {"build_s": round(dt, 4), "nodes": int(i.num_nodes), "cull_tests": int(i.cull_tests), "max_triangles_in_leafs": int(i.max_triangles_in_leafs),
                                   "queries": int(len(q)), "query_ms": round(ms, 3), "mqueries_s": round(len(q) / ms / 1e3, 1), **einfo,
                                   "roofline": exact_query_roofline(ex, q, ms)}
-    ex.close()
+    ex_for_scalar = ex
     # CONTINUITY builder (SdfExporter's default) on the same mesh / depth
     # (N > 1: every rank builds the whole tree, the BVH traversals of each sample batch are shared out, one all-reduce per batch)
     cinfo = {}
@@ -360,6 +360,8 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     r["fit_mfma_build"] = {"build_s": round(dt, 4), "words": int(mi.num_words), "same_size_as_exact_fit": bool(int(mi.num_words) == int(tree.info.num_words)),
                            "decisions_rechecked_with_exact_fit": int(mi.fit_rechecks), "nodes": int(mi.num_nodes)}
     mt.close()
+    r["host_pointer_api"] = host_pointer(tree, ex_for_scalar, pts, dev)
+    ex_for_scalar.close()
     if len(mesh.indices) >= 300_000:
         r["torus_knot_328k"] = knot_workload(mesh.ctx, dev, pts.shape[0])
     if len(mesh.indices) >= 300_000:          # the headline configuration only (short test runs of this script skip the 1.7 GB tree)
@@ -432,6 +434,44 @@ def deep_tree(mesh, box, dev, rows, src):
     t.close()
     return {"build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves), "queries": DEEP_QUERIES, "query_ms": round(ms, 4),
             "mqueries_s": round(DEEP_QUERIES / ms / 1e3, 1), "roofline": roof}
+
+
+def host_pointer(tree, ex, pts, dev):
+    """The drop-in boundary as the reference's callers use it: HOST arrays in, host arrays out (PCIe inside the call), and the scalar
+    getDistance.  Large calls are pipelined (caller's arrays pinned piece by piece, upload / kernel / download overlapped on two streams);
+    one-point calls are answered on host copies of the arrays.  The link ceilings are measured here with pinned torch tensors."""
+    import ctypes as C
+    from sdflib_amd._lib import lib, check
+    n = pts.shape[0]
+    hp = pts.cpu().numpy().copy()
+    hd = np.empty(n, dtype=np.float32); hg = np.empty((n, 3), dtype=np.float32)
+    def best(fn, reps=4):
+        fn(); b = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); b = min(b, time.perf_counter() - t0)
+        return b
+    t_val = best(lambda: tree.get_distance(hp, out=hd))
+    t_grad = best(lambda: tree.get_distance(hp, gradient=True, out=hd, out_grad=hg))
+    # link ceilings: pinned host tensors, one direction at a time
+    pin_in = torch.empty((n, 3), dtype=torch.float32).pin_memory(); pin_out = torch.empty(n, dtype=torch.float32).pin_memory()
+    dv = torch.empty((n, 3), dtype=torch.float32, device=dev); do = torch.empty(n, dtype=torch.float32, device=dev)
+    def h2d(): dv.copy_(pin_in, non_blocking=True); torch.cuda.synchronize()
+    def d2h(): pin_out.copy_(do, non_blocking=True); torch.cuda.synchronize()
+    t_up, t_down = best(h2d), best(d2h)
+    up_gbs, down_gbs = 12 * n / t_up / 1e9, 4 * n / t_down / 1e9
+    bound_seq = t_up + t_down                       # upload then download, kernel hidden: what one direction at a time allows
+    # scalar calls through the C ABI (ctypes call overhead included)
+    p1 = hp[:1].copy(); d1 = np.empty(1, dtype=np.float32)
+    def scalar(fn, reps=3000):
+        fn(); t0 = time.perf_counter()
+        for _ in range(reps): fn()
+        return (time.perf_counter() - t0) / reps * 1e6
+    us_oct = scalar(lambda: lib().sdfhip_octree_query(tree.h, p1.ctypes.data_as(C.c_void_p), 1, d1.ctypes.data_as(C.c_void_p), None, 0, S.EVAL_EXACT))
+    us_ex = scalar(lambda: lib().sdfhip_exact_query(ex.h, p1.ctypes.data_as(C.c_void_p), 1, d1.ctypes.data_as(C.c_void_p), None, None, 0))
+    return {"queries": int(n), "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
+            "pcie_pinned_h2d_gb_s": round(up_gbs, 1), "pcie_pinned_d2h_gb_s": round(down_gbs, 1), "pcie_bound_ms": round(bound_seq * 1e3, 3),
+            "frac_of_pcie_bound": round(bound_seq / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),
+            "note": "bound = pinned upload + pinned download of the same arrays, one after the other (measured on this box); scalar = one point through the C ABI from ctypes"}
 
 
 def knot_workload(ctx, dev, n):

@@ -281,8 +281,9 @@ class OctreeSdf:
             self.ctx._torch_outputs_ready()
             return (d, g) if gradient else d
         pts = _np(points, np.float32).reshape(-1, 3)
-        d = np.empty(len(pts), dtype=np.float32)
-        g = np.zeros((len(pts), 3), dtype=np.float32) if gradient else None
+        d = out if out is not None else np.empty(len(pts), dtype=np.float32)
+        g = (out_grad if out_grad is not None else np.zeros((len(pts), 3), dtype=np.float32)) if gradient else None
+        assert d.dtype == np.float32 and d.flags.c_contiguous and d.size == len(pts)
         check(lib().sdfhip_octree_query(self.h, _ptr(pts), len(pts), _ptr(d), _ptr(g), HOST, eval_mode))
         return (d, g) if gradient else d
 

@@ -246,6 +246,7 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
     SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
+    if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     if (ctx->ownsStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SDFHIP_OK;

@@ -71,7 +71,7 @@ SDF_DEV void tricubicFit(float (&s)[64], float nodeSize, float (&out)[64]) {
 
 // ---- literal-order evaluation ("EXACT") -------------------------------------------------------------------
 template <typename CF>   // CF: callable n -> coefficient
-SDF_DEV float tricubicValueExact(CF c, F3 f) {
+SDF_HD float tricubicValueExact(CF c, F3 f) {
     float acc = 0.0f;
 #pragma unroll
     for (int n = 0; n < 64; n++) {
@@ -89,7 +89,7 @@ SDF_DEV float tricubicValueExact(CF c, F3 f) {
 }
 
 template <int EX, int EY, int EZ, typename CF>
-SDF_DEV float tricubicDerivExact(CF c, F3 f) {
+SDF_HD float tricubicDerivExact(CF c, F3 f) {
     float acc = 0.0f;
     bool first = true;
 #pragma unroll
@@ -111,7 +111,7 @@ SDF_DEV float tricubicDerivExact(CF c, F3 f) {
 
 // ---- separable Horner with FMA ("FAST"): same polynomial, different rounding (<= 1e-5 abs in practice) -------
 template <typename CF>
-SDF_DEV float tricubicValueFast(CF c, F3 f) {
+SDF_HD float tricubicValueFast(CF c, F3 f) {
     float zacc = 0.f;
 #pragma unroll
     for (int k = 3; k >= 0; k--) {
@@ -128,7 +128,7 @@ SDF_DEV float tricubicValueFast(CF c, F3 f) {
 }
 // value and gradient together: for each (j,k) row evaluate p(x) and p'(x), then two nested Horner passes.
 template <typename CF>
-SDF_DEV float tricubicValueGradFast(CF c, F3 f, F3& g) {
+SDF_HD float tricubicValueGradFast(CF c, F3 f, F3& g) {
     float v = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
     for (int k = 3; k >= 0; k--) {

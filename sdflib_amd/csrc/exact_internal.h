@@ -46,6 +46,8 @@ struct sdfhip_exact {
     sdfhip::DevBuf<uint8_t> masks;
     std::vector<std::unique_ptr<sdfhip::ExLevel>> levels;
     bool built = false;
+    // host copies for the scalar / few-point entry (exact_query.hip, ensureHostCopy): fetched on first use
+    std::vector<uint32_t> hNodes, hSets; std::vector<uint8_t> hMasks; std::vector<float> hTri; bool hostReady = false; std::mutex hostLock;
     // emission plan: per start cell (local order) the offset of its body / sets / masks relative to the first one emitted
     std::vector<uint32_t> relB, relS, relM; uint64_t bodyNodes = 0; uint32_t sod = 0;
     // sharded build (sdfhip_exact_build_shard): the start cells of this shard (z-major ids, ascending); levels stay alive until emit

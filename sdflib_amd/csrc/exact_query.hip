@@ -18,18 +18,17 @@ struct ExactView {
     int G; uint32_t startDepth, bitEnc, bits;
 };
 
-SDF_DEV uint32_t unpackIndex(const uint32_t* __restrict__ set, uint32_t bIdx, uint32_t bits) {
+SDF_HD uint32_t unpackIndex(const uint32_t* __restrict__ set, uint32_t bIdx, uint32_t bits) {
     const uint32_t w = bIdx >> 5, bit = bIdx & 31u;
     return ((set[w] << bit) >> (32u - bits)) | (uint32_t)((unsigned long long)set[w + 1] >> (64u - (bit + bits)));
 }
-SDF_DEV bool maskBit(const uint8_t* __restrict__ m, uint32_t k) { return (m[k >> 3] & (0x80u >> (k & 7u))) != 0; }
+SDF_HD bool maskBit(const uint8_t* __restrict__ m, uint32_t k) { return (m[k >> 3] & (0x80u >> (k & 7u))) != 0; }
 
-template <bool GRAD>
-__global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
-                                                     uint32_t* __restrict__ tri) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const F3 p = F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+// One query, as the reference answers it.  HOSTSIDE = true: the same code compiled for the host, reading host copies of the arrays (the
+// 37-float TriangleData instead of the packed frames: the same numbers) — what sdfhip_exact_query runs for a handful of points, where a
+// kernel launch + two PCIe hops + a stream synchronisation (tens of microseconds) would dwarf the microseconds of work.
+template <bool GRAD, bool HOSTSIDE>
+SDF_HD float exactOne(const ExactView& v, F3 p, float* grad, uint32_t* tri) {
     F3 f = F3{(p.x - v.bminx) / v.cellSize, (p.y - v.bminy) / v.cellSize, (p.z - v.bminz) / v.cellSize};
     const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
     const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
@@ -40,9 +39,8 @@ __global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* _
         const F3 d = p - center;
         const F3 q = F3{fabsf(d.x), fabsf(d.y), fabsf(d.z)} - 0.5f * size;
         const F3 qm = F3{gmax(q.x, 0.f), gmax(q.y, 0.f), gmax(q.z, 0.f)};
-        dist[i] = (length(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f)) + sqrtf(3.0f) * size.x;
-        if (tri) tri[i] = 0;
-        return;
+        if (tri) *tri = 0;
+        return (length(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f)) + sqrtf(3.0f) * size.x;
     }
     uint32_t node = (uint32_t)((iz * v.G + iy) * v.G + ix);
     auto isLeaf = [&](uint32_t nd) { return (v.nodes[2 * (size_t)nd] & 0x80000000u) != 0u; };
@@ -70,18 +68,47 @@ __global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* _
             if (m2 && !maskBit(m2, k)) continue;
         }
         const uint32_t ti = unpackIndex(set + 1, t * v.bits, v.bits);
-        TriFrame fr; loadFramePacked(v.frames, ti, fr);
+        TriFrame fr;
+        if constexpr (HOSTSIDE) loadFrame(v.td + (size_t)TD_FLOATS * ti, fr); else loadFramePacked(v.frames, ti, fr);
         const float d = sqDistPointTriangle(p, fr);
         if (d < best) { best = d; bestTri = ti; }
     }
+    if (tri) *tri = bestTri;
     if (GRAD) {
         F3 g;
-        dist[i] = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, g);
-        grad[3 * i] = g.x; grad[3 * i + 1] = g.y; grad[3 * i + 2] = g.z;
-    } else dist[i] = signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
-    if (tri) tri[i] = bestTri;
+        const float d = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, g);
+        grad[0] = g.x; grad[1] = g.y; grad[2] = g.z;
+        return d;
+    }
+    return signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
 }
 
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_exact_query(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
+                                                     uint32_t* __restrict__ tri) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t t = 0;
+    dist[i] = exactOne<GRAD, false>(v, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, GRAD ? grad + 3 * i : nullptr, tri ? &t : nullptr);
+    if (tri) tri[i] = t;
+}
+
+
+constexpr uint64_t kHostScalarMax = 32;
+static int ensureHostCopy(sdfhip_exact* T) {
+    std::lock_guard<std::mutex> own(T->hostLock);
+    if (T->hostReady) return SDFHIP_OK;
+    hipStream_t st = T->ctx->stream;
+    const sdfhip_exact_info& I = T->info;
+    T->hNodes.resize(2 * I.num_nodes); T->hSets.resize(I.num_set_words + 2, 0u); T->hMasks.resize(I.num_mask_bytes + 1, 0); T->hTri.resize((size_t)TD_FLOATS * I.num_triangles);
+    SDF_HIP_CHECK(hipMemcpyAsync(T->hNodes.data(), T->nodes.p, 8 * I.num_nodes, hipMemcpyDeviceToHost, st));
+    if (I.num_set_words) SDF_HIP_CHECK(hipMemcpyAsync(T->hSets.data(), T->sets.p, 4 * I.num_set_words, hipMemcpyDeviceToHost, st));
+    if (I.num_mask_bytes) SDF_HIP_CHECK(hipMemcpyAsync(T->hMasks.data(), T->masks.p, I.num_mask_bytes, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(T->hTri.data(), T->tri(), sizeof(float) * TD_FLOATS * I.num_triangles, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    T->hostReady = true;
+    return SDFHIP_OK;
+}
 
 // ---- leaf-sorted, wave-cooperative path (large batches) ------------------------------------------------------------------
 // k_exact_locate walks every query down to its leaf and records (leaf id, set / mask positions); queries are then
@@ -253,6 +280,21 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (where == SDFHIP_HOST && n <= kHostScalarMax) {
+        // the scalar getDistance of the reference's API (and any handful of points): answered by the same code on host copies of the arrays
+        SDF_TRY(ensureHostCopy(T));
+        const sdfhip_exact_info& I = T->info;
+        const ExactView hv{T->hNodes.data(), T->hSets.data(), T->hMasks.data(), T->hTri.data(), nullptr, I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
+                           T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
+        for (uint64_t i = 0; i < n; i++) {
+            const F3 p = F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+            uint32_t t = 0;
+            if (out_grad) { out_grad[3 * i] = 0.f; out_grad[3 * i + 1] = 0.f; out_grad[3 * i + 2] = 0.f; out_dist[i] = exactOne<true, true>(hv, p, out_grad + 3 * i, &t); }
+            else out_dist[i] = exactOne<false, true>(hv, p, nullptr, &t);
+            if (out_tri) out_tri[i] = t;
+        }
+        return SDFHIP_OK;
+    }
     std::unique_lock<std::mutex> stageLock(ctx->stage.lock, std::defer_lock);
     if (where == SDFHIP_HOST && 12 * n <= sdfhip_stage::kStageKeepBytes) stageLock.try_lock();
     DevBuf<float> pp, pd, pg; DevBuf<uint32_t> pt;

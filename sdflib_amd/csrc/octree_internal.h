@@ -44,6 +44,7 @@ struct sdfhip_octree {
     uint64_t qNodes = 0, qLeaves = 0;
     bool qReady = false;
     std::mutex qLock;
+    std::vector<uint32_t> hTopo; std::vector<float> hCoef; bool hReady = false;      // host copies for the scalar entry (octree_query.hip)
     // construction state kept between build_shard and emit_shard
     std::vector<std::unique_ptr<sdfhip::BuildLevel>> levels;   // index = depth - startOctreeDepth
     uint32_t startOctreeDepth = 0;

@@ -21,7 +21,7 @@ struct QueryTree {
     int G;
 };
 
-SDF_DEV float boxDistance(const QueryTree& t, F3 p) {
+SDF_HD float boxDistance(const QueryTree& t, F3 p) {
     const F3 size = F3{t.bmaxx - t.bminx, t.bmaxy - t.bminy, t.bmaxz - t.bminz};
     const F3 center = F3{t.bminx, t.bminy, t.bminz} + 0.5f * size;
     const F3 d = p - center;
@@ -32,7 +32,7 @@ SDF_DEV float boxDistance(const QueryTree& t, F3 p) {
 
 // BoundingBox::getDistance(point, outGradient) as written in the reference (full size, uncentred point; only
 // the selected component is written in the 'inside' branch).
-SDF_DEV float boxDistanceGrad(const QueryTree& t, F3 p, float* g) {
+SDF_HD float boxDistanceGrad(const QueryTree& t, F3 p, float* g) {
     const float size[3] = {t.bmaxx - t.bminx, t.bmaxy - t.bminy, t.bmaxz - t.bminz};
     const float pt[3] = {p.x, p.y, p.z};
     float a[3];
@@ -51,7 +51,7 @@ SDF_DEV float boxDistanceGrad(const QueryTree& t, F3 p, float* g) {
 
 // Walk from the start grid to the leaf holding p: index of its 64 coefficients and the local coordinates in [0,1)^3.
 // Returns false for points outside the start grid.
-SDF_DEV bool locateLeaf(const QueryTree& t, F3 p, uint32_t& at, F3& f) {
+SDF_HD bool locateLeaf(const QueryTree& t, F3 p, uint32_t& at, F3& f) {
     f = F3{(p.x - t.bminx) / t.cellSize, (p.y - t.bminy) / t.cellSize, (p.z - t.bminz) / t.cellSize};
     const float flx = floorf(f.x), fly = floorf(f.y), flz = floorf(f.z);
     const int ix = (int)flx, iy = (int)fly, iz = (int)flz;
@@ -68,7 +68,7 @@ SDF_DEV bool locateLeaf(const QueryTree& t, F3 p, uint32_t& at, F3& f) {
 }
 
 template <int EVAL, bool GRAD>
-SDF_DEV float queryOne(const QueryTree& t, F3 p, float* grad) {
+SDF_HD float queryOne(const QueryTree& t, F3 p, float* grad) {
     uint32_t at; F3 f;
     if (!locateLeaf(t, p, at, f)) {
         if (GRAD) return boxDistanceGrad(t, p, grad) + t.minBorder;
@@ -217,6 +217,21 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     return SDFHIP_OK;
 }
 
+// host copies of the query layout for the scalar / few-point entry: the same queryOne, compiled for the host
+constexpr uint64_t kOctreeHostScalarMax = 32;
+static int ensureHostLayout(sdfhip_octree* T) {
+    SDF_TRY(ensureQueryLayout(T));
+    std::lock_guard<std::mutex> own(T->qLock);
+    if (T->hReady) return SDFHIP_OK;
+    hipStream_t st = T->ctx->stream;
+    T->hTopo.resize(T->qNodes); T->hCoef.resize(64 * (T->qLeaves ? T->qLeaves : 1));
+    SDF_HIP_CHECK(hipMemcpyAsync(T->hTopo.data(), T->qTopo.p, 4 * T->qNodes, hipMemcpyDeviceToHost, st));
+    if (T->qLeaves) SDF_HIP_CHECK(hipMemcpyAsync(T->hCoef.data(), T->qCoef.p, 256 * T->qLeaves, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    T->hReady = true;
+    return SDFHIP_OK;
+}
+
 static QueryTree makeQueryTree(const sdfhip_octree* T) {
     QueryTree q;
     q.topo = T->qTopo.p; q.coef = T->qCoef.p;
@@ -224,6 +239,76 @@ static QueryTree makeQueryTree(const sdfhip_octree* T) {
     q.bmaxx = T->info.box_max[0]; q.bmaxy = T->info.box_max[1]; q.bmaxz = T->info.box_max[2];
     q.cellSize = T->cellSize; q.minBorder = T->info.min_border_value; q.G = T->info.start_grid_size;
     return q;
+}
+
+template <typename... A>
+static void launchQuery(int eval_mode, bool grad, unsigned blocks, hipStream_t st, A... a) {
+    if (eval_mode == SDFHIP_EVAL_EXACT) {
+        if (grad) k_octree_query<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(a...);
+        else k_octree_query<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(a...);
+    } else {
+        if (grad) k_octree_query<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(a...);
+        else k_octree_query<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(a...);
+    }
+}
+
+// Large host-pointer queries (the reference API hands over host arrays): a kernel of 0.05 ms per million points sits between two PCIe
+// hops, and copies from / to PAGEABLE memory run at 35-42 GB/s (measured, staged by the runtime) against 57 GB/s for pinned memory.
+// The caller's arrays are therefore pinned IN PLACE, piece by piece (hipHostRegister, 8 MiB at a time: ~0.1 ms, on the host, while the
+// previous piece is on the wire), each piece goes up asynchronously, the points it completes are evaluated at once and their results
+// flow back on a second stream while the next piece goes up.  Returns 1 when it did not run (registration refused: the plain path
+// answers), SDFHIP_OK or an error otherwise; *done = points answered.
+static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int eval_mode, float* dp, float* dd, float* dg, uint64_t* done) {
+    *done = 0;
+    sdfhip_ctx* ctx = T->ctx;
+    hipStream_t st = ctx->stream;
+    {
+        std::lock_guard<std::mutex> g(ctx->copyStreamLock);
+        if (!ctx->copyStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
+    }
+    hipStream_t back = ctx->copyStream;
+    const uintptr_t PAGE = 4096, PIECE = 8u << 20;
+    struct Reg { void* p; };
+    std::vector<Reg> regs;
+    auto pin = [&](uintptr_t b, uintptr_t e) { if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
+    auto unpinAll = [&]() { for (const Reg& r : regs) (void)hipHostUnregister(r.p); regs.clear(); };
+    const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = inB & ~(PAGE - 1), end = (inE + PAGE - 1) & ~(PAGE - 1);
+    const uint64_t pieces = (end - base + PIECE - 1) / PIECE;
+    auto pieceEnd = [&](uint64_t k) { const uintptr_t e = base + (k + 1) * PIECE; return e < end ? e : end; };
+    if (!pin(base, pieceEnd(0))) return 1;
+    const QueryTree q = makeQueryTree(T);
+    hipEvent_t ev;
+    SDF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc = SDFHIP_OK;
+    uint64_t launched = 0; bool outPinned = false;
+    for (uint64_t k = 0; k < pieces && rc == SDFHIP_OK; k++) {
+        const uintptr_t b = k == 0 ? inB : base + k * PIECE, e = pieceEnd(k) < inE ? pieceEnd(k) : inE;
+        if (hipMemcpyAsync((char*)dp + (b - inB), (const void*)b, e - b, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+        const uint64_t avail = (e == inE) ? n : (e - inB) / 12;
+        if (!outPinned) {          // the result arrays: pinned while the first piece is on the wire
+            const uintptr_t ob = (uintptr_t)out_dist & ~(PAGE - 1), oe = ((uintptr_t)out_dist + 4 * n + PAGE - 1) & ~(PAGE - 1);
+            bool ok = pin(ob, oe);
+            if (ok && out_grad) { const uintptr_t gb = (uintptr_t)out_grad & ~(PAGE - 1), ge = ((uintptr_t)out_grad + 12 * n + PAGE - 1) & ~(PAGE - 1); ok = pin(gb, ge); }
+            if (!ok) break;        // answered so far: nothing; the plain path takes over
+            outPinned = true;
+        }
+        if (avail > launched) {
+            const uint64_t m = avail - launched;
+            launchQuery(eval_mode, out_grad != nullptr, gridFor(m, 256), st, q, dp + 3 * launched, m, dd + launched, out_grad ? dg + 3 * launched : nullptr);
+            if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(back, ev, 0) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            if (hipMemcpyAsync(out_dist + launched, dd + launched, 4 * m, hipMemcpyDeviceToHost, back) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            if (out_grad && hipMemcpyAsync(out_grad + 3 * launched, dg + 3 * launched, 12 * m, hipMemcpyDeviceToHost, back) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            launched = avail;
+        }
+        if (k + 1 < pieces && !pin(base + (k + 1) * PIECE, pieceEnd(k + 1))) break;      // refused: the plain path finishes the rest
+    }
+    const hipError_t e1 = hipStreamSynchronize(st), e2 = hipStreamSynchronize(back);
+    (void)hipEventDestroy(ev);
+    unpinAll();
+    if (rc == SDFHIP_OK && (e1 != hipSuccess || e2 != hipSuccess)) { setError("pipelined query failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return SDFHIP_E_HIP; }
+    if (rc != SDFHIP_OK) { setError("pipelined query: HIP call failed"); return rc; }
+    *done = outPinned ? launched : 0;
+    return SDFHIP_OK;
 }
 
 }  // namespace sdfhip
@@ -249,6 +334,21 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     sdfhip_ctx* ctx = T->ctx;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    if (where == SDFHIP_HOST && n <= kOctreeHostScalarMax) {
+        // the scalar getDistance of the reference's API (and any handful of points): a kernel launch, two PCIe hops and a stream
+        // synchronisation cost tens of microseconds; the same code on host copies of the arrays answers in about one
+        SDF_TRY(ensureHostLayout(T));
+        QueryTree hq = makeQueryTree(T);
+        hq.topo = T->hTopo.data(); hq.coef = T->hCoef.data();
+        for (uint64_t i = 0; i < n; i++) {
+            const F3 p = F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+            float g[3] = {0.f, 0.f, 0.f};
+            if (eval_mode == SDFHIP_EVAL_EXACT) out_dist[i] = out_grad ? queryOne<SDFHIP_EVAL_EXACT, true>(hq, p, g) : queryOne<SDFHIP_EVAL_EXACT, false>(hq, p, g);
+            else out_dist[i] = out_grad ? queryOne<SDFHIP_EVAL_FAST, true>(hq, p, g) : queryOne<SDFHIP_EVAL_FAST, false>(hq, p, g);
+            if (out_grad) { out_grad[3 * i] = g[0]; out_grad[3 * i + 1] = g[1]; out_grad[3 * i + 2] = g[2]; }
+        }
+        return SDFHIP_OK;
+    }
     SDF_TRY(ensureQueryLayout(T));
     std::unique_lock<std::mutex> own(ctx->stage.lock, std::defer_lock);
     if (where == SDFHIP_HOST && 12 * n <= sdfhip_stage::kStageKeepBytes) own.try_lock();
@@ -258,6 +358,17 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     if (where == SDFHIP_HOST) {
         SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dd.reserve(n));
         if (out_grad) SDF_TRY(dg.reserve(3 * n));
+        static const bool noPipe = getenv("SDFHIP_NO_PIPELINE") != nullptr;
+        if (!noPipe && 12 * n >= (32ull << 20)) {
+            uint64_t done = 0;
+            const int prc = queryHostPipelined(T, xyz, n, out_dist, out_grad, eval_mode, dp.p, dd.p, out_grad ? dg.p : nullptr, &done);
+            if (prc < 0) return prc;
+            if (done == n) return SDFHIP_OK;
+            if (done > 0) {        // a later piece could not be pinned: the rest through the plain path
+                own.unlock();
+                return sdfhip_octree_query(T, xyz + 3 * done, n - done, out_dist + done, out_grad ? out_grad + 3 * done : nullptr, where, eval_mode);
+            }
+        }
         SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, 12 * n, hipMemcpyHostToDevice, st));
         p = dp.p; d = dd.p; g = out_grad ? dg.p : nullptr;
     }

@@ -116,7 +116,7 @@ static inline uint64_t queryChunk(bool hostBuffers) {
 // hipMalloc / hipFree.  Guarded by a try-lock: a second host thread simply allocates privately.
 struct sdfhip_stage {
     sdfhip::DevBuf<float> pts, dist, grad; sdfhip::DevBuf<uint32_t> ids; std::mutex lock;
-    static constexpr size_t kStageKeepBytes = 64u << 20;
+    static constexpr size_t kStageKeepBytes = 256u << 20;
 };
 
 // Scratch of the two-phase nearest-triangle search (dev_bvh_fast.h), kept with the context: plain device allocations that grow and
@@ -132,6 +132,8 @@ struct sdfhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownsStream = false;
+    hipStream_t copyStream = nullptr;      // results flow back on this one while the next piece of a large host-pointer query goes up (created on first use)
+    std::mutex copyStreamLock;
     hipDeviceProp_t prop;
     // Builds (mesh preparation, BVH, octrees) on one context run one at a time: they share the stream-ordered allocator's scope and,
     // with an exchange installed, must stay in collective order.  Queries take no part in this and run concurrently.

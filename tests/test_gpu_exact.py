@@ -198,3 +198,22 @@ def test_tree_keeps_a_temporary_mesh_alive(gpu_ctx, oracle):
     want = oracle.Exact(oracle.Mesh(v, f), box, 5, 1, 16).query(pts)
     assert np.array_equal(bits(t.get_distance(pts)), bits(want))
     del junk
+
+
+def test_exact_scalar_host_entry_equals_device_and_oracle(small, oracle):
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    ex = oracle.Exact(small["om"], small["box"], 6, 2, 32)
+    gx = S.ExactOctreeSdf(small["gm"], small["box"], 6, 2, 32)
+    pts = random_points_in_box(small["box"], 20000, seed=41)
+    pts[::9] *= 2.0
+    d0, g0, t0 = ex.query(pts, grad=True, tri=True)
+    dd, gd, td = gx.get_distance(pts, gradient=True, triangle=True)           # device (sorted path)
+    box = gx.get_grid_bounding_box()
+    inside = ((pts >= box[:3]) & (pts < box[3:])).all(axis=1)
+    for k in range(0, 20000, 97):
+        m = 1 + (k % 32)
+        ds, gs, ts = gx.get_distance(pts[k:k + m], gradient=True, triangle=True)      # host copies (<= 32 points)
+        assert np.array_equal(bits(ds), bits(d0[k:k + m])) and np.array_equal(bits(ds), bits(dd[k:k + m]))
+        ins = inside[k:k + m]
+        assert np.array_equal(bits(gs[ins]), bits(g0[k:k + m][ins])) and np.array_equal(ts[ins], t0[k:k + m][ins])

@@ -609,3 +609,44 @@ def test_bvh_export_import(small, oracle, gpu_ctx):
     tiny = S.Mesh(small["v"][:3], np.array([[0, 1, 2]], np.uint32), gpu_ctx)
     s1, k1 = tiny.bvh_arrays()
     assert s1.shape == (8,) and k1.shape == (2,)
+
+
+def test_scalar_and_small_host_batches_are_answered_like_the_device(small, oracle):
+    """The host-side entry of the library (a handful of points with host pointers: the scalar getDistance of the reference's API) runs
+    the same code on host copies of the arrays: results must equal the device path's and the oracle's bit for bit, both eval modes,
+    with gradients, inside and outside the box."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gt = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, num_threads=2)
+    ot = oracle.Octree(small["om"], small["box"], 6, 3, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    pts = random_points_in_box(small["box"], 4000, seed=17)
+    pts[::7] *= 2.5
+    d0, g0 = ot.query(pts, grad=True)
+    for mode in (S.EVAL_EXACT, S.EVAL_FAST):
+        dd, gd = gt.get_distance(pts, gradient=True, eval_mode=mode)                    # device (4000 points)
+        for k in range(0, 4000, 23):
+            m = 1 + (k % 31)
+            ds, gs = gt.get_distance(pts[k:k + m], gradient=True, eval_mode=mode)       # host (<= 32 points)
+            assert np.array_equal(bits(ds), bits(dd[k:k + m])) and np.array_equal(bits(gs), bits(gd[k:k + m]))
+            assert np.array_equal(bits(gt.get_distance(pts[k:k + 1], eval_mode=mode)), bits(dd[k:k + 1]))
+        if mode == S.EVAL_EXACT:
+            assert np.array_equal(bits(dd), bits(d0)) and np.array_equal(bits(gd), bits(g0))
+
+
+def test_large_host_pointer_queries_are_pipelined_and_identical(small):
+    """Host arrays of 3 M points (beyond the 32 MiB threshold): pinned piece by piece, uploaded / evaluated / downloaded in a pipeline.
+    Same bits as the device-resident path; misaligned views of larger arrays (the pieces are page aligned, the arrays need not be)."""
+    import torch
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gt = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, num_threads=2)
+    n = 3_000_001
+    big = np.empty((n + 5, 3), dtype=np.float32)
+    big[:] = random_points_in_box(small["box"], n + 5, seed=23)
+    pts = big[3:3 + n]                                   # 36 bytes into the allocation: not page aligned
+    want, wantg = gt.get_distance(torch.from_numpy(pts.copy()).cuda(), gradient=True)
+    outbuf = np.empty(n + 3, dtype=np.float32); gbuf = np.empty((n + 1, 3), dtype=np.float32)
+    d, g = gt.get_distance(pts, gradient=True, out=outbuf[1:1 + n], out_grad=gbuf[1:1 + n])
+    assert np.array_equal(bits(d), bits(want.cpu().numpy())) and np.array_equal(bits(g), bits(wantg.cpu().numpy()))
+    d2 = gt.get_distance(pts)
+    assert np.array_equal(bits(d2), bits(d))
