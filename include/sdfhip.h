@@ -268,6 +268,35 @@ int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host);
 int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad /* nullable */,
                        uint32_t* out_triangle /* nullable */, int where);
 
+/* ---- several GPUs in ONE process (C / C++ callers; the multi-PROCESS flavour is sdflib_amd/distributed.py) -------------------------
+ * Reference decomposition: the OpenMP loops over start cells + merge of OctreeSdf (src/sdf/OctreeSdfDepthFirst.h:433-503) and of
+ * ExactOctreeSdf (include/SdfLib/ExactOctreeSdfDepthFirst.h:534-622); what SdfExporter gets with --num_threads (src/tools/SdfExporter/main.cpp:143-171).
+ * sdfhip_multi_create makes one context per device id and, when the ids are distinct, an RCCL communicator over them (librccl.so is bound
+ * at run time).  A build shards the start cells over the devices (one host thread each), emits every shard at its absolute offsets and
+ * reassembles the array(s) on EVERY device with one in-place all-gather-v (ncclBroadcast per shard inside one group, over xGMI).  The same
+ * device id listed several times (one-GPU test boxes) selects device-to-device copies instead of RCCL.  Outputs: out_trees[rank] (and
+ * out_meshes[rank]) live on device_ids[rank]; all trees are identical and identical to the single-device build.
+ * NO_CONTINUITY and ExactOctreeSdf builds are sharded; a CONTINUITY tree is built on the first device and broadcast. */
+typedef struct sdfhip_multi sdfhip_multi;
+typedef struct sdfhip_multi_stats {
+    int32_t ranks, uses_rccl;
+    uint64_t bytes_exchanged;                                   /* bytes every device received in the last build's all-gather */
+    double seconds_bvh, seconds_shards, seconds_exchange;       /* of the last build: BVH plan + install, slowest shard, exchange + wrap */
+} sdfhip_multi_stats;
+int sdfhip_multi_create(const int* device_ids, int n, sdfhip_multi** out);
+int sdfhip_multi_destroy(sdfhip_multi* multi);
+int sdfhip_multi_size(sdfhip_multi* multi);
+sdfhip_ctx* sdfhip_multi_ctx(sdfhip_multi* multi, int rank);
+const char* sdfhip_multi_transport(sdfhip_multi* multi);       /* "rccl" or "copy" */
+int sdfhip_multi_get_stats(sdfhip_multi* multi, sdfhip_multi_stats* out);
+/* bbox6: the loader's bounding box (enables seam welding, see sdfhip_mesh_create_ex) or NULL.  out_meshes may be NULL (the meshes are then freed). */
+int sdfhip_multi_octree_build(sdfhip_multi* multi, const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, const float* bbox6,
+                              const sdfhip_octree_params* params, sdfhip_mesh** out_meshes, sdfhip_octree** out_trees);
+/* out_meshes is required: an ExactOctreeSdf reads its mesh's TriangleData (free trees first, then meshes). */
+int sdfhip_multi_exact_build(sdfhip_multi* multi, const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, const float* bbox6,
+                             const float box_min[3], const float box_max[3], uint32_t max_depth, uint32_t start_depth, uint32_t min_triangles_per_node,
+                             sdfhip_mesh** out_meshes, sdfhip_exact** out_trees);
+
 /* ---- building blocks exposed for parity tests (device execution, host pointers) --------------------------- */
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode);
 int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr,

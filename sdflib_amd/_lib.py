@@ -40,6 +40,11 @@ class ExactInfo(C.Structure):
                 ("start_grid_cell_size", C.c_float), ("reserved0", C.c_float)]
 
 
+class MultiStats(C.Structure):
+    _fields_ = [("ranks", C.c_int32), ("uses_rccl", C.c_int32), ("bytes_exchanged", C.c_uint64), ("seconds_bvh", C.c_double), ("seconds_shards", C.c_double),
+                ("seconds_exchange", C.c_double)]
+
+
 ACQUIRE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)
 ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
 
@@ -96,6 +101,14 @@ SIGNATURES = {
     "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
     "sdfhip_is_near_minimize": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
     "sdfhip_test_gather_blocks": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sdfhip_multi_create": (_int, [_vp, _int, C.POINTER(_vp)]),
+    "sdfhip_multi_destroy": (_int, [_vp]),
+    "sdfhip_multi_size": (_int, [_vp]),
+    "sdfhip_multi_ctx": (_vp, [_vp, _int]),
+    "sdfhip_multi_transport": (C.c_char_p, [_vp]),
+    "sdfhip_multi_get_stats": (_int, [_vp, C.POINTER(MultiStats)]),
+    "sdfhip_multi_octree_build": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(OctreeParams), _vp, _vp]),
+    "sdfhip_multi_exact_build": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp]),
 }
 
 

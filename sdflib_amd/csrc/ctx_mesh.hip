@@ -247,7 +247,11 @@ int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
     SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
     if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
-    if (ctx->ownsStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->ownsStream && ctx->stream) {
+        (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+        BigBlockCache::get().trimStream(ctx->device, ctx->stream);           // the cached big blocks of this context's stream
+        (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
     return SDFHIP_OK;
     SDF_API_END

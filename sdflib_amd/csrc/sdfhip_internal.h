@@ -63,22 +63,84 @@ struct AllocScope {
     AllocScope& operator=(const AllocScope&) = delete;
 };
 
+// LARGE transient blocks (>= kBigBlock) do not come from HIP's stream-ordered pool but from this cache of plain allocations, one free list
+// per (device, stream): a block released by its owner goes back to the list of the stream it was used on and is handed to a later
+// request on the SAME stream, so reuse is ordered by the stream exactly like hipMallocAsync / hipFreeAsync, without their cost or a
+// device synchronisation.  Why not the HIP pool for these: with the system runtime of this image (C / C++ hosts; Python binds torch's
+// older runtime) a build that requested a large block from the pool in mid-flight — 167 MB of culling scratch, 31 MB of candidate
+// lists — intermittently produced wrong arrays or faulted in a LATER kernel, deterministically gone with plain allocations; small
+// blocks (hundreds per build) stay with the pool.  Cached blocks are freed when their context is destroyed (trimStream).
+struct BigBlockCache {
+    struct Block { void* p; size_t bytes; };
+    struct Key { int device; hipStream_t stream; bool operator<(const Key& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
+    std::mutex m; std::vector<std::pair<Key, std::vector<Block>>> lists;
+    static BigBlockCache& get() { static BigBlockCache c; return c; }
+    std::vector<Block>& listOf(Key k) { for (auto& e : lists) if (!(e.first < k) && !(k < e.first)) return e.second; lists.emplace_back(k, std::vector<Block>()); return lists.back().second; }
+    hipError_t alloc(void** out, size_t bytes, hipStream_t st, size_t* got) {
+        int dev = 0; (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> g(m);
+            std::vector<Block>& L = listOf(Key{dev, st});
+            size_t best = (size_t)-1;
+            for (size_t i = 0; i < L.size(); i++) if (L[i].bytes >= bytes && L[i].bytes <= 2 * bytes && (best == (size_t)-1 || L[i].bytes < L[best].bytes)) best = i;
+            if (best != (size_t)-1) { *out = L[best].p; *got = L[best].bytes; L[best] = L.back(); L.pop_back(); return hipSuccess; }
+        }
+        const size_t rounded = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+        *got = rounded;
+        return hipMalloc(out, rounded);
+    }
+    void release(void* p, size_t bytes, int dev, hipStream_t st) { std::lock_guard<std::mutex> g(m); listOf(Key{dev, st}).push_back(Block{p, bytes}); }
+    void trimStream(int dev, hipStream_t st) {
+        std::vector<Block> drop;
+        { std::lock_guard<std::mutex> g(m); drop.swap(listOf(Key{dev, st})); }
+        for (const Block& b : drop) (void)hipFree(b.p);
+    }
+};
+constexpr size_t kBigBlock = 4u << 20;
+
+// diagnostic (SDFHIP_ALLOC_CHECK): registry of the live device blocks; a new block overlapping a live one is reported
+struct AllocRegistry {
+    std::mutex m; std::vector<std::pair<uintptr_t, size_t>> live;
+    static AllocRegistry& get() { static AllocRegistry r; return r; }
+    static bool on() { static const bool v = getenv("SDFHIP_ALLOC_CHECK") != nullptr; return v; }
+    void add(void* p, size_t bytes) {
+        std::lock_guard<std::mutex> g(m);
+        const uintptr_t b = (uintptr_t)p, e = b + bytes;
+        for (auto& r : live) if (b < r.first + r.second && r.first < e) fprintf(stderr, "[sdfhip] ALLOC OVERLAP: new [%p, +%zu) overlaps live [%p, +%zu)\n", p, bytes, (void*)r.first, r.second);
+        live.emplace_back(b, bytes);
+    }
+    void remove(void* p) {
+        std::lock_guard<std::mutex> g(m);
+        for (size_t i = 0; i < live.size(); i++) if (live[i].first == (uintptr_t)p) { live[i] = live.back(); live.pop_back(); return; }
+        fprintf(stderr, "[sdfhip] ALLOC CHECK: freeing unknown block %p\n", p);
+    }
+};
+
 // Device allocation owned by one object; freed in the destructor.
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
     bool pooled = false;
+    hipStream_t poolStream = nullptr;      // the stream a pooled block was allocated on (and is given back on)
+    size_t cachedBytes = 0; int cachedDevice = 0;      // > 0: a block of BigBlockCache (its real size)
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), pooled(o.pooled) { o.p = nullptr; o.n = 0; }
-    DevBuf& operator=(DevBuf&& o) noexcept { release(); p = o.p; n = o.n; pooled = o.pooled; o.p = nullptr; o.n = 0; return *this; }
+    DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), pooled(o.pooled), poolStream(o.poolStream), cachedBytes(o.cachedBytes), cachedDevice(o.cachedDevice) { o.p = nullptr; o.n = 0; o.cachedBytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        release(); p = o.p; n = o.n; pooled = o.pooled; poolStream = o.poolStream; cachedBytes = o.cachedBytes; cachedDevice = o.cachedDevice; o.p = nullptr; o.n = 0; o.cachedBytes = 0;
+        return *this;
+    }
     ~DevBuf() { release(); }
     void release() {
         if (!p) return;
+        if (AllocRegistry::on()) AllocRegistry::get().remove(p);
         const double t0 = nowSeconds();
-        if (pooled && tlsAlloc().active) (void)hipFreeAsync(p, tlsAlloc().stream);
+        // a block of the stream-ordered pool goes back through hipFreeAsync on the stream it came from, also when its owner (a tree, a mesh)
+        // is destroyed long after the build; a cached big block returns to its stream's free list
+        if (cachedBytes) { BigBlockCache::get().release(p, cachedBytes, cachedDevice, poolStream); cachedBytes = 0; }
+        else if (pooled) { if (hipFreeAsync(p, poolStream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); } }
         else (void)hipFree(p);
         g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
         p = nullptr; n = 0;
@@ -90,11 +152,22 @@ struct DevBuf {
         if (count == 0) count = 1;
         const double t0 = nowSeconds();
         hipError_t e;
-        if (tlsAlloc().active) { e = hipMallocAsync((void**)&p, count * sizeof(T), tlsAlloc().stream); pooled = true; }
+        if (tlsAlloc().active && count * sizeof(T) >= kBigBlock) {
+            e = BigBlockCache::get().alloc((void**)&p, count * sizeof(T), tlsAlloc().stream, &cachedBytes);
+            pooled = true; poolStream = tlsAlloc().stream; (void)hipGetDevice(&cachedDevice);
+            if (e != hipSuccess) cachedBytes = 0;
+        }
+        else if (tlsAlloc().active) { e = hipMallocAsync((void**)&p, count * sizeof(T), tlsAlloc().stream); pooled = true; poolStream = tlsAlloc().stream; }
         else { e = hipMalloc((void**)&p, count * sizeof(T)); pooled = false; }
         g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
         if (e != hipSuccess) { p = nullptr; setError("device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return SDFHIP_E_HIP; }
         n = count;
+        if (AllocRegistry::on()) AllocRegistry::get().add(p, count * sizeof(T));
+        // diagnostic: SDFHIP_POISON_ALLOC fills every new buffer with 0xCD so that code relying on fresh (zeroed) memory shows up in the tests
+        // (a stream-ordered pool hands back blocks with their old contents)
+        static const bool poison = getenv("SDFHIP_POISON_ALLOC") != nullptr;
+        static const int fill = poison ? (int)strtol(getenv("SDFHIP_POISON_ALLOC"), nullptr, 0) : 0;       // SDFHIP_POISON_ALLOC=0xCD (or 0: zero fill)
+        if (poison) { if (pooled) (void)hipMemsetAsync(p, fill, count * sizeof(T), tlsAlloc().stream); else { (void)hipMemset(p, fill, count * sizeof(T)); (void)hipDeviceSynchronize(); } }
         return SDFHIP_OK;
     }
 };

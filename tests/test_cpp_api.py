@@ -142,3 +142,27 @@ def test_built_tree_keeps_the_builds_cell_size_far_from_the_origin(tmp_path, ora
     assert r.returncode == 0, r.stdout + r.stderr
     assert "octree scalar-vs-batched mismatches 0" in r.stdout, r.stdout
     assert "reloaded-vs-built mismatches" in r.stdout and "reloaded-vs-built mismatches 0" not in r.stdout, r.stdout      # loaded != built here, as in the reference
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,transport", [("0", "rccl"), ("0,0", "copy"), ("0,0,0,0,0", "copy")])
+def test_in_process_multi_gpu_builds_equal_the_single_device_ones(tmp_path, devices, transport):
+    """sdfhip_multi_*: what a C / C++ host gets on a multi-GPU node.  One GPU here: a one-rank RCCL communicator runs the
+    real ncclBroadcast-based all-gather-v; the same device listed several times runs the N-rank shard / offset / reassembly logic with
+    device-to-device copies as the transport (RCCL refuses duplicate devices)."""
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
+    exe = "/tmp/sdflib_amd_test_cpp_multi"
+    libdir = os.path.join(ROOT, "sdflib_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_cpp_multi.cpp"),
+                           "-L", libdir, "-lsdfhip", f"-Wl,-rpath,{libdir}", "-o", exe])
+    v, f = bumpy_icosphere(4)
+    box = np.asarray(box_with_margin(v), dtype=np.float32)
+    p = lambda n: os.path.join(tmp_path, n)
+    v.tofile(p("v.bin")); f.tofile(p("f.bin")); box.tofile(p("box.bin"))
+    r = subprocess.run([exe, p("v.bin"), p("f.bin"), p("box.bin"), devices], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"transport {transport}" in r.stdout, r.stdout
+    lines = [l for l in r.stdout.splitlines() if "mismatches" in l]
+    assert len(lines) == 3 and all("mismatches 0 scalars_equal 1" in l for l in lines), r.stdout
+    if devices != "0":
+        assert "bytes_exchanged 0" not in lines[0], r.stdout
