@@ -22,26 +22,38 @@ public:
     ExactOctreeSdf() {}
     ExactOctreeSdf(const Mesh& mesh, BoundingBox box, uint32_t maxDepth, uint32_t startDepth = 1, uint32_t minTrianglesPerNode = 128, uint32_t numThreads = 1) {
         (void)numThreads;   // the GPU build always produces the single-thread (correct) array
-        sdfhip_ctx* ctx = detail::defaultContext();
         const BoundingBox& mb = mesh.getBoundingBox();     // only a computed box (file loader / computeBoundingBox) enables seam welding
         const float mbox[6] = {mb.min.x, mb.min.y, mb.min.z, mb.max.x, mb.max.y, mb.max.z};
-        detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
-                                            mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
-                                            (mb.min.x <= mb.max.x) ? mbox : nullptr, &mMesh));
         const float bmin[3] = {box.min.x, box.min.y, box.min.z}, bmax[3] = {box.max.x, box.max.y, box.max.z};
-        detail::check(sdfhip_exact_build(ctx, mMesh, bmin, bmax, maxDepth, startDepth, minTrianglesPerNode, &mTree));
+        sdfhip_multi* multi = detail::defaultMulti();
+        if (multi && (1u << (3 * startDepth)) >= (uint32_t)sdfhip_multi_size(multi)) {
+            // SDFLIB_DEVICES: start cells sharded over the devices, the three arrays reassembled on each of them (same arrays as one device builds)
+            const size_t n = (size_t)sdfhip_multi_size(multi);
+            std::vector<sdfhip_exact*> trees(n, nullptr); std::vector<sdfhip_mesh*> meshes(n, nullptr);
+            detail::check(sdfhip_multi_exact_build(multi, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(), mesh.getIndices().data(),
+                                                   (uint32_t)(mesh.getIndices().size() / 3), (mb.min.x <= mb.max.x) ? mbox : nullptr, bmin, bmax, maxDepth, startDepth, minTrianglesPerNode,
+                                                   meshes.data(), trees.data()));
+            mTree = trees[0]; mMesh = meshes[0];
+            mReplicas.assign(trees.begin() + 1, trees.end()); mReplicaMeshes.assign(meshes.begin() + 1, meshes.end());
+        } else {
+            sdfhip_ctx* ctx = detail::defaultContext();
+            detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                                mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
+                                                (mb.min.x <= mb.max.x) ? mbox : nullptr, &mMesh));
+            detail::check(sdfhip_exact_build(ctx, mMesh, bmin, bmax, maxDepth, startDepth, minTrianglesPerNode, &mTree));
+        }
         detail::check(sdfhip_exact_get_info(mTree, &mInfo));
         mBox = BoundingBox(glm::vec3(mInfo.box_min[0], mInfo.box_min[1], mInfo.box_min[2]), glm::vec3(mInfo.box_max[0], mInfo.box_max[1], mInfo.box_max[2]));
     }
-    ~ExactOctreeSdf() override { if (mTree) sdfhip_exact_destroy(mTree); if (mMesh) sdfhip_mesh_destroy(mMesh); }
+    ~ExactOctreeSdf() override { release(); }
     ExactOctreeSdf(const ExactOctreeSdf&) = delete;
     ExactOctreeSdf& operator=(const ExactOctreeSdf&) = delete;
     ExactOctreeSdf(ExactOctreeSdf&& o) noexcept { *this = std::move(o); }
     ExactOctreeSdf& operator=(ExactOctreeSdf&& o) noexcept {
         if (this != &o) {
-            if (mTree) sdfhip_exact_destroy(mTree);
-            if (mMesh) sdfhip_mesh_destroy(mMesh);
+            release();
             mTree = o.mTree; o.mTree = nullptr; mMesh = o.mMesh; o.mMesh = nullptr; mInfo = o.mInfo; mBox = o.mBox;
+            mReplicas = std::move(o.mReplicas); o.mReplicas.clear(); mReplicaMeshes = std::move(o.mReplicaMeshes); o.mReplicaMeshes.clear();
         }
         return *this;
     }
@@ -68,8 +80,16 @@ public:
     float getDistance(glm::vec3 sample) const override { float d; getDistances(&sample, 1, &d); return d; }
     float getDistance(glm::vec3 sample, glm::vec3& outGradient) const override { float d; getDistances(&sample, 1, &d, &outGradient); return d; }
     void getDistances(const glm::vec3* samples, size_t n, float* outDistances, glm::vec3* outGradients = nullptr) const override {
-        detail::check(sdfhip_exact_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), nullptr, SDFHIP_HOST));
+        if (mReplicas.empty() || n < (1u << 16)) {
+            detail::check(sdfhip_exact_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), nullptr, SDFHIP_HOST));
+            return;
+        }
+        detail::splitOver(1 + mReplicas.size(), n, [&](size_t k, size_t b, size_t e) {      // one replica per device of the multi-GPU build
+            sdfhip_exact* t = k == 0 ? mTree : mReplicas[k - 1];
+            detail::check(sdfhip_exact_query(t, reinterpret_cast<const float*>(samples + b), e - b, outDistances + b, outGradients ? reinterpret_cast<float*>(outGradients + b) : nullptr, nullptr, SDFHIP_HOST));
+        });
     }
+    size_t getNumDeviceReplicas() const { return 1 + mReplicas.size(); }
     sdfhip_exact* handle() const { return mTree; }
 
     // archive body of include/SdfLib/ExactOctreeSdf.h:138-165: mBox, mStartGridSize, mStartDepth, mMinTrianglesInLeafs,
@@ -88,8 +108,7 @@ public:
         sdfhip_exact* t = nullptr;
         detail::check(sdfhip_exact_from_data(detail::defaultContext(), &info, reinterpret_cast<const uint32_t*>(nodes.data()), sets.data(), masks.data(),
                                              reinterpret_cast<const float*>(td.data()), &t));
-        if (mTree) sdfhip_exact_destroy(mTree);
-        if (mMesh) { sdfhip_mesh_destroy(mMesh); mMesh = nullptr; }
+        release();
         mTree = t;
         detail::check(sdfhip_exact_get_info(mTree, &mInfo));
         mBox = BoundingBox(glm::vec3(box[0], box[1], box[2]), glm::vec3(box[3], box[4], box[5]));
@@ -110,8 +129,16 @@ protected:
     }
 
 private:
+    void release() {
+        if (mTree) sdfhip_exact_destroy(mTree);
+        for (sdfhip_exact* t : mReplicas) if (t) sdfhip_exact_destroy(t);
+        if (mMesh) sdfhip_mesh_destroy(mMesh);
+        for (sdfhip_mesh* m : mReplicaMeshes) if (m) sdfhip_mesh_destroy(m);
+        mTree = nullptr; mMesh = nullptr; mReplicas.clear(); mReplicaMeshes.clear();
+    }
     sdfhip_mesh* mMesh = nullptr;
     sdfhip_exact* mTree = nullptr;
+    std::vector<sdfhip_exact*> mReplicas; std::vector<sdfhip_mesh*> mReplicaMeshes;      // SDFLIB_DEVICES: the same tree on the other devices
     sdfhip_exact_info mInfo{};
     BoundingBox mBox;
 };

@@ -52,13 +52,14 @@ public:
               InitAlgorithm initAlgorithm, uint32_t numThreads = 1) {
         build(mesh, box, depth, startDepth, rule, params, initAlgorithm, numThreads);
     }
-    ~OctreeSdf() override { if (mTree) sdfhip_octree_destroy(mTree); }
+    ~OctreeSdf() override { release(); }
     OctreeSdf(const OctreeSdf&) = delete;
     OctreeSdf& operator=(const OctreeSdf&) = delete;
     OctreeSdf(OctreeSdf&& o) noexcept { *this = std::move(o); }
     OctreeSdf& operator=(OctreeSdf&& o) noexcept {
         if (this != &o) {
-            if (mTree) sdfhip_octree_destroy(mTree);
+            release();
+            mReplicas = std::move(o.mReplicas); o.mReplicas.clear();
             mTree = o.mTree; o.mTree = nullptr; mBox = o.mBox; mValueRange = o.mValueRange; mMinBorderValue = o.mMinBorderValue;
             mStartGridSize = o.mStartGridSize; mStartGridXY = o.mStartGridXY; mStartGridCellSize = o.mStartGridCellSize; mMaxDepth = o.mMaxDepth;
             mOctreeData = std::move(o.mOctreeData);
@@ -81,8 +82,17 @@ public:
     float getDistance(glm::vec3 sample, glm::vec3& outGradient) const override { return eval(sample, &outGradient, outGradient); }
     // batched queries on the GPU
     void getDistances(const glm::vec3* samples, size_t n, float* outDistances, glm::vec3* outGradients = nullptr) const override {
-        detail::check(sdfhip_octree_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), SDFHIP_HOST, SDFHIP_EVAL_EXACT));
+        if (mReplicas.empty() || n < (1u << 18)) {
+            detail::check(sdfhip_octree_query(mTree, reinterpret_cast<const float*>(samples), n, outDistances, reinterpret_cast<float*>(outGradients), SDFHIP_HOST, SDFHIP_EVAL_EXACT));
+            return;
+        }
+        // the tree is replicated on every device of the multi-GPU build: contiguous shares of the batch, one host thread per device
+        detail::splitOver(1 + mReplicas.size(), n, [&](size_t k, size_t b, size_t e) {
+            sdfhip_octree* t = k == 0 ? mTree : mReplicas[k - 1];
+            detail::check(sdfhip_octree_query(t, reinterpret_cast<const float*>(samples + b), e - b, outDistances + b, outGradients ? reinterpret_cast<float*>(outGradients + b) : nullptr, SDFHIP_HOST, SDFHIP_EVAL_EXACT));
+        });
     }
+    size_t getNumDeviceReplicas() const { return 1 + mReplicas.size(); }
     sdfhip_octree* handle() const { return mTree; }
 
     // src/sdf/OctreeSdf.cpp:231-277: leaves per depth weighted by their volume fraction (8^-d of a start cell... of the root)
@@ -110,7 +120,7 @@ public:
         if (grid < 1 || words.size() < (uint64_t)grid * grid * grid) return false;
         sdfhip_octree* t = nullptr;
         detail::check(sdfhip_octree_from_data(detail::defaultContext(), words.data(), words.size(), SDFHIP_HOST, box, box + 3, grid, depth, vr, mb, &t));
-        if (mTree) sdfhip_octree_destroy(mTree);
+        release();
         mTree = t;
         mBox = BoundingBox(glm::vec3(box[0], box[1], box[2]), glm::vec3(box[3], box[4], box[5]));
         mValueRange = vr; mMinBorderValue = mb; mStartGridSize = grid; mStartGridXY = grid * grid; mMaxDepth = depth;
@@ -130,21 +140,30 @@ protected:
 private:
     void build(const Mesh& mesh, BoundingBox box, uint32_t depth, uint32_t startDepth, TerminationRule rule, TerminationRuleParams params,
                InitAlgorithm alg, uint32_t numThreads) {
-        sdfhip_ctx* ctx = detail::defaultContext();
-        sdfhip_mesh* m = nullptr;
         const BoundingBox& mb = mesh.getBoundingBox();     // only a computed box (file loader / computeBoundingBox) enables seam welding
         const float mbox[6] = {mb.min.x, mb.min.y, mb.min.z, mb.max.x, mb.max.y, mb.max.z};
-        detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
-                                            mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
-                                            (mb.min.x <= mb.max.x) ? mbox : nullptr, &m));
         sdfhip_octree_params p{};
         p.box_min[0] = box.min.x; p.box_min[1] = box.min.y; p.box_min[2] = box.min.z;
         p.box_max[0] = box.max.x; p.box_max[1] = box.max.y; p.box_max[2] = box.max.z;
         p.depth = depth; p.start_depth = startDepth; p.rule = (int32_t)rule; p.rule_params[0] = params[0]; p.rule_params[1] = params[1];
         p.algorithm = (int32_t)alg; p.layout = numThreads < 2 ? SDFHIP_LAYOUT_GLOBAL_DFS : SDFHIP_LAYOUT_SUBTREES; p.fit_mode = SDFHIP_FIT_EXACT;
-        int rc = sdfhip_octree_build(ctx, m, &p, &mTree);
-        sdfhip_mesh_destroy(m);
-        detail::check(rc);
+        if (sdfhip_multi* multi = detail::defaultMulti()) {
+            // SDFLIB_DEVICES: sharded over the devices (the reference's numThreads >= 2 array layout), reassembled on each of them
+            p.layout = SDFHIP_LAYOUT_SUBTREES;
+            std::vector<sdfhip_octree*> trees((size_t)sdfhip_multi_size(multi), nullptr);
+            detail::check(sdfhip_multi_octree_build(multi, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(), mesh.getIndices().data(),
+                                                    (uint32_t)(mesh.getIndices().size() / 3), (mb.min.x <= mb.max.x) ? mbox : nullptr, &p, nullptr, trees.data()));
+            mTree = trees[0]; mReplicas.assign(trees.begin() + 1, trees.end());
+        } else {
+            sdfhip_ctx* ctx = detail::defaultContext();
+            sdfhip_mesh* m = nullptr;
+            detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                                mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
+                                                (mb.min.x <= mb.max.x) ? mbox : nullptr, &m));
+            int rc = sdfhip_octree_build(ctx, m, &p, &mTree);
+            sdfhip_mesh_destroy(m);
+            detail::check(rc);
+        }
         sdfhip_octree_info info;
         detail::check(sdfhip_octree_get_info(mTree, &info));
         mBox = BoundingBox(glm::vec3(info.box_min[0], info.box_min[1], info.box_min[2]), glm::vec3(info.box_max[0], info.box_max[1], info.box_max[2]));
@@ -153,6 +172,11 @@ private:
         mStartGridCellSize = info.start_grid_cell_size;      // built: largest extent of the INPUT box / grid size (OctreeSdf.cpp:43-52), not the stored box's
         mOctreeData.resize(info.num_words);
         detail::check(sdfhip_octree_download(mTree, reinterpret_cast<uint32_t*>(mOctreeData.data()), SDFHIP_HOST));
+    }
+    void release() {
+        if (mTree) sdfhip_octree_destroy(mTree);
+        for (sdfhip_octree* t : mReplicas) if (t) sdfhip_octree_destroy(t);
+        mTree = nullptr; mReplicas.clear();
     }
     static float fractf(float x) { return x - std::floor(x); }
     float eval(glm::vec3 p, glm::vec3* grad, glm::vec3& g) const {
@@ -193,6 +217,7 @@ private:
     }
 
     sdfhip_octree* mTree = nullptr;
+    std::vector<sdfhip_octree*> mReplicas;      // SDFLIB_DEVICES: the same tree on the other devices (batched queries are split over them)
     BoundingBox mBox;
     float mValueRange = 0.f, mMinBorderValue = 0.f;
     int mStartGridSize = 0, mStartGridXY = 0;

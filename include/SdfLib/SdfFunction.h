@@ -13,6 +13,8 @@
 #include <vector>
 #include <stdexcept>
 #include <string>
+#include <thread>
+#include <cstdlib>
 #include "utils/Mesh.h"
 #include "../sdfhip.h"
 
@@ -54,6 +56,33 @@ inline sdfhip_ctx* defaultContext() {
     if (!ctx && sdfhip_ctx_create(0, nullptr, SDFHIP_STREAM_PRIVATE, &ctx) != SDFHIP_OK)
         throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
     return ctx;
+}
+// Several GPUs for the constructors: SDFLIB_DEVICES="0,1,2,3" (or "all") in the environment makes OctreeSdf / ExactOctreeSdf build through
+// sdfhip_multi_* — shards over the listed devices, RCCL all-gather, one replica of the tree per device; batched getDistances calls are
+// then split over the replicas.  Unset (or one device): the single-device path.  The multi-process flavour is sdflib_amd/distributed.py.
+inline sdfhip_multi* defaultMulti() {
+    static sdfhip_multi* multi = nullptr; static bool tried = false;
+    if (tried) return multi;
+    tried = true;
+    const char* env = std::getenv("SDFLIB_DEVICES");
+    if (!env || !*env) return nullptr;
+    std::vector<int> devs;
+    if (std::string(env) == "all") { for (int d = 0; d < 64; d++) { sdfhip_ctx* c = nullptr; if (sdfhip_ctx_create(d, nullptr, SDFHIP_STREAM_PRIVATE, &c) != SDFHIP_OK) break; sdfhip_ctx_destroy(c); devs.push_back(d); } }
+    else { std::string tok; for (const char* q = env;; q++) { if (*q == ',' || *q == 0) { if (!tok.empty()) devs.push_back(std::atoi(tok.c_str())); tok.clear(); if (!*q) break; } else tok.push_back(*q); } }
+    if (devs.size() < 2) return nullptr;
+    if (sdfhip_multi_create(devs.data(), (int)devs.size(), &multi) != SDFHIP_OK) throw std::runtime_error(std::string("sdfhip: ") + sdfhip_last_error());
+    return multi;
+}
+// fn(part, begin, end) on one host thread per part of [0, n)
+template <typename F> inline void splitOver(size_t parts, size_t n, F fn) {
+    std::vector<std::thread> th; std::vector<std::string> err(parts);
+    for (size_t k = 0; k < parts; k++) {
+        const size_t b = n * k / parts, e = n * (k + 1) / parts;
+        auto job = [&, k, b, e]() { try { fn(k, b, e); } catch (const std::exception& x) { err[k] = x.what(); } };
+        if (k + 1 < parts) th.emplace_back(job); else job();
+    }
+    for (std::thread& t : th) t.join();
+    for (const std::string& m : err) if (!m.empty()) throw std::runtime_error(m);
 }
 template <typename T> inline void put(std::ostream& os, const T& v) { os.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
 template <typename T> inline void putVec(std::ostream& os, const T* p, uint64_t n) { put(os, n); os.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(T))); }

@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
     const size_t n = pb.size() / 12;
 
     sdflib::OctreeSdf oct(mesh, box, 5, 2, 1e-3f, sdflib::OctreeSdf::InitAlgorithm::NO_CONTINUITY, 2);
-    std::printf("octree words %zu grid %d range %.9g border %.9g\n", oct.getOctreeData().size(), oct.getStartGridSize().x, oct.getOctreeValueRange(), oct.getOctreeMinBorderValue());
+    std::printf("octree words %zu grid %d range %.9g border %.9g replicas %zu\n", oct.getOctreeData().size(), oct.getStartGridSize().x, oct.getOctreeValueRange(), oct.getOctreeMinBorderValue(),
+                oct.getNumDeviceReplicas());
     std::vector<float> d(n); std::vector<glm::vec3> g(n);
     const sdflib::SdfFunction& f = oct;
     f.getDistances(pts, n, d.data(), g.data());

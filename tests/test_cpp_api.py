@@ -28,18 +28,25 @@ def test_cpp_headers_compile_and_link():
 
 
 @pytest.mark.gpu
-def test_cpp_api_matches_oracle(tmp_path, oracle):
+@pytest.mark.parametrize("devices", ["", "0,0,0"])
+def test_cpp_api_matches_oracle(tmp_path, oracle, devices):
+    """devices: SDFLIB_DEVICES for the C++ classes — '' = one device; '0,0,0' = the in-process multi-GPU path (three shards, replicas,
+    split batched queries) on the one GPU of this box; every number and file must come out the same."""
     from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
     _compile()
     v, f = bumpy_icosphere(2)
     box = box_with_margin(v)
-    pts = random_points_in_box(box, 5000, seed=17)
+    pts = random_points_in_box(box, 300000 if devices else 5000, seed=17)       # the multi-device classes split batches of >= 2^18 (2^16) points
     pts[:50] *= 3.0
     p = lambda n: os.path.join(tmp_path, n)
     v.tofile(p("v.bin")); f.tofile(p("f.bin")); pts.tofile(p("p.bin"))
-    r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin"), p("oct.bin"), p("exact.bin")], capture_output=True, text=True)
+    env = dict(os.environ)
+    env.pop("SDFLIB_DEVICES", None)
+    if devices: env["SDFLIB_DEVICES"] = devices
+    r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin"), p("oct.bin"), p("exact.bin")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "scalar-vs-batched mismatches 0" in r.stdout and "reloaded-vs-built mismatches 0" in r.stdout
+    assert f"replicas {3 if devices else 1}" in r.stdout, r.stdout
     # a start grid of 4^3 unit cells: the leaf volumes add up to 8^-startDepth * 64 = 1 (OctreeSdf.cpp:270-276 weights from depth 0)
     total = float(r.stdout.split("depth density levels")[1].split("total")[1].split()[0])
     assert abs(total - 1.0) < 1e-6

@@ -22,7 +22,8 @@ static void usage(const char* exe) {
     std::fprintf(stderr,
         "SdfExporter export an sdf\n  %s model_path output_path [-d depth] [--start_depth n] [--termination_rule trapezoidal_rule|simpsons_rule|by_distance_rule|none]\n"
         "      [--termination_threshold t] [--termination_threshold_by_distance t] [--min_triangles_per_node n] [--sdf_format octree|exact_octree]\n"
-        "      [--algorithm uniform|no_continuity|continuity] [-n|--normalize] [--bb_margin percent] [--num_threads n]\n", exe);
+        "      [--algorithm uniform|no_continuity|continuity] [-n|--normalize] [--bb_margin percent] [--num_threads n]\n"
+        "      [--devices 0,1,...|all]   (addition: build on several GPUs of this node; same as SDFLIB_DEVICES in the environment)\n", exe);
 }
 
 int main(int argc, char** argv) {
@@ -43,6 +44,7 @@ int main(int argc, char** argv) {
         } else positional.push_back(a);
     }
     if (positional.empty()) { std::fprintf(stderr, "Error: No model_path specified\n"); usage(argv[0]); return 1; }
+    if (opt.count("devices")) setenv("SDFLIB_DEVICES", opt["devices"].c_str(), 1);      // read by the classes' constructors (include/SdfLib/SdfFunction.h, detail::defaultMulti)
     auto has = [&](const char* k) { return opt.count(k) != 0; };
     auto num = [&](const char* k, double dflt) { return has(k) ? std::atof(opt[k].c_str()) : dflt; };
     const std::string sdfFormat = has("sdf_format") ? opt["sdf_format"] : "octree";
