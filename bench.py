@@ -313,9 +313,10 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     gbytes = 256 ** 3 * 16 + words * 4          # SURVEY 8(d) "G": 16 B written per point + the tree read once
     r["grid256_value_and_gradient"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
                                        "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "note": "reference-order polynomial (~1100 flop/point): ALU bound, not HBM bound"}
-    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_FAST, device_out=True))
+    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_FAST, device_out=True), reps=40)
     r["grid256_value_and_gradient_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
-                                                 "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+                                                 "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                 "note": "leaf-driven (k_lattice_columns): leaves emit their lattice points, no per-point walk or division; same bits as the point kernel's EVAL_FAST"}
     # ExactOctreeSdf (BASELINE configs[2]): depth 7, start 3, min_triangles_per_node 128
     einfo = {}
     torch.cuda.synchronize()
@@ -460,18 +461,26 @@ def host_pointer(tree, ex, pts, dev):
     t_up, t_down = best(h2d), best(d2h)
     up_gbs, down_gbs = 12 * n / t_up / 1e9, 4 * n / t_down / 1e9
     bound_seq = t_up + t_down                       # upload then download, kernel hidden: what one direction at a time allows
-    # scalar calls through the C ABI (ctypes call overhead included)
-    p1 = hp[:1].copy(); d1 = np.empty(1, dtype=np.float32)
-    def scalar(fn, reps=3000):
-        fn(); t0 = time.perf_counter()
-        for _ in range(reps): fn()
-        return (time.perf_counter() - t0) / reps * 1e6
-    us_oct = scalar(lambda: lib().sdfhip_octree_query(tree.h, p1.ctypes.data_as(C.c_void_p), 1, d1.ctypes.data_as(C.c_void_p), None, 0, S.EVAL_EXACT))
-    us_ex = scalar(lambda: lib().sdfhip_exact_query(ex.h, p1.ctypes.data_as(C.c_void_p), 1, d1.ctypes.data_as(C.c_void_p), None, None, 0))
+    # scalar calls through the C ABI: 64 different points, pointers converted once (a ctypes call costs ~0.5 us itself); best of 3 rounds
+    # (the first thousand calls after a bulk phase run several times slower: interpreter / allocator warm-up, not the library)
+    sp = hp[:64].copy(); d1 = np.empty(1, dtype=np.float32)
+    dptr = C.c_void_p(d1.ctypes.data)
+    ptrs = [C.c_void_p(sp[i].ctypes.data) for i in range(len(sp))]
+    L = lib()
+    def scalar(fn, rounds=3, reps=20):
+        b = float("inf")
+        for _ in range(rounds):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for q in ptrs: fn(q)
+            b = min(b, (time.perf_counter() - t0) / (reps * len(ptrs)) * 1e6)
+        return b
+    us_oct = scalar(lambda q: L.sdfhip_octree_query(tree.h, q, 1, dptr, None, 0, S.EVAL_EXACT))
+    us_ex = scalar(lambda q: L.sdfhip_exact_query(ex.h, q, 1, dptr, None, None, 0))
     return {"queries": int(n), "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
             "pcie_pinned_h2d_gb_s": round(up_gbs, 1), "pcie_pinned_d2h_gb_s": round(down_gbs, 1), "pcie_bound_ms": round(bound_seq * 1e3, 3),
             "frac_of_pcie_bound": round(bound_seq / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),
-            "note": "bound = pinned upload + pinned download of the same arrays, one after the other (measured on this box); scalar = one point through the C ABI from ctypes"}
+            "note": "bound = pinned upload + pinned download of the same arrays, one after the other (measured on this box); scalar = one point per call through the C ABI from ctypes, mean over 64 random points of the box"}
 
 
 def knot_workload(ctx, dev, n):

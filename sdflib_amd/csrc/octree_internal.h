@@ -45,6 +45,22 @@ struct sdfhip_octree {
     bool qReady = false;
     std::mutex qLock;
     std::vector<uint32_t> hTopo; std::vector<float> hCoef; bool hReady = false;      // host copies for the scalar entry (octree_query.hip)
+    // Leaf-driven lattice evaluation (octree_query.hip, ensureLatticePlan): per level of the packed layout its node count and the
+    // number of its first leaf block; every leaf's integer cell coordinates; and the plan of the last lattice asked for.
+    std::vector<uint32_t> qLevelNodes, qLevelLeafBase;      // [levels], [levels + 1]
+    sdfhip::DevBuf<uint32_t> qLeafCell;     // 2 words per leaf: x | y << 16, z   (cell coordinates at the leaf's own level)
+    bool cellsReady = false;
+    struct LatticeClass { uint32_t level, leafBase, leafCount, mx, my, mz; };
+    struct LatticePlan {
+        float origin[3] = {0, 0, 0}, step[3] = {0, 0, 0};
+        uint32_t n[3] = {0, 0, 0};
+        bool valid = false, leafDriven = false, outside = false;
+        sdfhip::DevBuf<float> F;            // nx + ny + nz : start-cell coordinate of every lattice index per axis (the point walk's first value)
+        sdfhip::DevBuf<uint16_t> ranges;    // 6 per leaf : x0, x1, y0, y1, z0, z1 (lattice indices inside the leaf, half open)
+        std::vector<LatticeClass> classes;
+        sdfhip::DevBuf<uint32_t> groupWaveBase, groupLeafBase, sortedLeaf, waveDesc;      // the wave list (octree_query.hip, k_lat_waves); waveDesc = uint4 per wave
+        uint32_t waves = 0;
+    } lattice;
     // construction state kept between build_shard and emit_shard
     std::vector<std::unique_ptr<sdfhip::BuildLevel>> levels;   // index = depth - startOctreeDepth
     uint32_t startOctreeDepth = 0;

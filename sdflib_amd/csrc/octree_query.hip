@@ -10,6 +10,9 @@
 // separable Horner scheme with FMA.  Compile with -ffp-contract=off.
 #include "octree_internal.h"
 #include "dev_tricubic.h"
+#include <string.h>
+#include <cmath>
+#include <hipcub/hipcub.hpp>
 
 namespace sdfhip {
 
@@ -185,6 +188,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     cur->count = (uint32_t)G3;                                     // level 0 = the start grid, read in place (src == nullptr)
     uint64_t total = 0;
     uint32_t h[3] = {0, 0, 0};
+    std::vector<uint32_t> levelNodes, levelLeafBase(1, 0u);
     for (;;) {
         total += cur->count;
         SDF_REQUIRE(levels.size() < 32 && total <= numWords, "node array is not a valid octree (too deep or cyclic)");
@@ -196,6 +200,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
         SDF_HIP_CHECK(hipMemcpyAsync(h, counters.p, 12, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         SDF_REQUIRE(h[2] == 0, "node array is not a valid octree (index out of range)");
+        levelNodes.push_back(cur->count); levelLeafBase.push_back(h[1]);
         levels.push_back(std::move(cur));
         if (h[0] == 0) break;
         SDF_REQUIRE(8ull * h[0] < (1ull << 30), "tree too large for the query layout");
@@ -213,7 +218,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     }
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));           // the level buffers are released below
-    T->qNodes = total; T->qLeaves = leaves; T->qReady = true;
+    T->qNodes = total; T->qLeaves = leaves; T->qLevelNodes = levelNodes; T->qLevelLeafBase = levelLeafBase; T->qReady = true;
     return SDFHIP_OK;
 }
 
@@ -229,6 +234,310 @@ static int ensureHostLayout(sdfhip_octree* T) {
     if (T->qLeaves) SDF_HIP_CHECK(hipMemcpyAsync(T->hCoef.data(), T->qCoef.p, 256 * T->qLeaves, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     T->hReady = true;
+    return SDFHIP_OK;
+}
+
+// ---- leaf-driven lattice evaluation ------------------------------------------------------------------------------------
+// A lattice query in the point kernel pays, per point, three IEEE divisions, the walk and sixteen coefficient loads before its ~190
+// flop of separable Horner: 300 instructions, a third of them spent finding out what the neighbouring points found out too.  Here the
+// LEAVES are streamed and each emits the lattice points it contains:
+//   * the walk's first value f0(i) = ((origin + i * step) - boxMin) / cellSize depends on the axis index alone: three tables of
+//     n floats (k_lat_tables) replace 3 n^3 divisions.  f0 is monotone in i (every operation is), so the indices a leaf [a, b) owns on
+//     an axis are the range [lower_bound(a), lower_bound(b)) of that table (k_lat_ranges) — by construction the leaf the point walk
+//     reaches — and the walk's final local coordinate, fract(2 fract(2 ... fract(f0))), equals fract(2^l f0): every step is exact;
+//   * one lane takes one (x, y) COLUMN of a leaf's points: the x- and y-contractions of tricubicValueGradFast (176 of its 192 flop)
+//     do not depend on z and are done once, each point of the column then costs 16 FMAs — in the very order of the point kernel's
+//     EVAL_FAST code, so both paths give identical bits;
+//   * leaves of one level have (nearly) the same number of points, so a launch per level keeps the lanes of a wave in step.
+// Points outside the start grid (box distance) are written by k_lattice_outside.  The plan (tables, ranges, per-level launch shapes)
+// is kept with the tree for the next call with the same lattice.  EVAL_EXACT keeps the point kernel: the reference's term order
+// cannot be contracted.
+__global__ void k_lc_root(uint32_t G, uint32_t count, uint32_t* __restrict__ cell) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t x = j % G, y = (j / G) % G, z = j / (G * G);
+    cell[2 * j] = x | (y << 16); cell[2 * j + 1] = z;
+}
+__global__ void k_lc_level(const uint32_t* __restrict__ topoLevel, uint32_t count, uint32_t nextLevelBase, const uint32_t* __restrict__ cell, uint32_t* __restrict__ nextCell,
+                           uint32_t* __restrict__ leafCell) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t w = topoLevel[j], xy = cell[2 * j], z = cell[2 * j + 1];
+    if (w & LEAF_BIT) { leafCell[2 * (size_t)(w & INDEX_MASK)] = xy; leafCell[2 * (size_t)(w & INDEX_MASK) + 1] = z; return; }
+    const uint32_t to = w - nextLevelBase, x2 = (xy & 0xFFFFu) << 1, y2 = (xy >> 16) << 1, z2 = z << 1;
+#pragma unroll
+    for (uint32_t c = 0; c < 8u; c++) { nextCell[2 * (size_t)(to + c)] = (x2 | (c & 1u)) | ((y2 | ((c >> 1) & 1u)) << 16); nextCell[2 * (size_t)(to + c) + 1] = z2 | (c >> 2); }
+}
+// caller holds T->qLock
+static int ensureLeafCells(sdfhip_octree* T) {
+    if (T->cellsReady) return SDFHIP_OK;
+    hipStream_t st = T->ctx->stream;
+    const uint32_t G = (uint32_t)T->info.start_grid_size;
+    uint32_t widest = 0;
+    for (uint32_t c : T->qLevelNodes) widest = c > widest ? c : widest;
+    DevBuf<uint32_t> a, b;
+    SDF_TRY(a.reserve(2ull * widest)); SDF_TRY(b.reserve(2ull * widest));
+    SDF_TRY(T->qLeafCell.reserve(2ull * (T->qLeaves ? T->qLeaves : 1)));
+    k_lc_root<<<gridFor(T->qLevelNodes[0], 256), 256, 0, st>>>(G, T->qLevelNodes[0], a.p);
+    uint64_t base = 0;
+    uint32_t* cur = a.p; uint32_t* nxt = b.p;
+    for (size_t l = 0; l < T->qLevelNodes.size(); l++) {
+        const uint32_t count = T->qLevelNodes[l];
+        k_lc_level<<<gridFor(count, 256), 256, 0, st>>>(T->qTopo.p + base, count, (uint32_t)(base + count), cur, nxt, T->qLeafCell.p);
+        base += count;
+        uint32_t* t = cur; cur = nxt; nxt = t;
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));            // a and b are released here
+    T->cellsReady = true;
+    return SDFHIP_OK;
+}
+
+constexpr int kLatMaxLevels = 16;
+struct LatLevels { uint32_t leafBase[kLatMaxLevels + 1]; int levels; };
+
+__global__ void k_lat_tables(float* __restrict__ F, F3 origin, F3 step, F3 bmin, float cellSize, uint32_t nx, uint32_t ny, uint32_t nz) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nx + ny + nz) return;
+    // the operations of k_octree_query_grid + locateLeaf, per axis
+    if (j < nx) F[j] = ((origin.x + (float)j * step.x) - bmin.x) / cellSize;
+    else if (j < nx + ny) F[j] = ((origin.y + (float)(j - nx) * step.y) - bmin.y) / cellSize;
+    else F[j] = ((origin.z + (float)(j - nx - ny) * step.z) - bmin.z) / cellSize;
+}
+SDF_DEV uint32_t latLowerBound(const float* __restrict__ F, uint32_t n, float a) {      // first i with F[i] >= a  (F non-decreasing)
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (F[mid] >= a) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+// dims: 3 words per level = the largest number of lattice indices a leaf of the level owns per axis
+__global__ void k_lat_ranges(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, const float* __restrict__ F, uint32_t nx, uint32_t ny, uint32_t nz,
+                             uint16_t* __restrict__ ranges, uint32_t* __restrict__ dims) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= leaves) return;
+    int l = 0;
+    while (l + 1 < L.levels && i >= L.leafBase[l + 1]) l++;
+    const float inv = __uint_as_float((uint32_t)(127 - l) << 23);          // 2^-l
+    const uint32_t xy = leafCell[2 * (size_t)i], cz = leafCell[2 * (size_t)i + 1], cx = xy & 0xFFFFu, cy = xy >> 16;
+    const uint32_t x0 = latLowerBound(F, nx, (float)cx * inv), x1 = latLowerBound(F, nx, (float)(cx + 1u) * inv);
+    const uint32_t y0 = latLowerBound(F + nx, ny, (float)cy * inv), y1 = latLowerBound(F + nx, ny, (float)(cy + 1u) * inv);
+    const uint32_t z0 = latLowerBound(F + nx + ny, nz, (float)cz * inv), z1 = latLowerBound(F + nx + ny, nz, (float)(cz + 1u) * inv);
+    uint16_t* r = ranges + 6 * (size_t)i;
+    r[0] = (uint16_t)x0; r[1] = (uint16_t)x1; r[2] = (uint16_t)y0; r[3] = (uint16_t)y1; r[4] = (uint16_t)z0; r[5] = (uint16_t)z1;
+    if (x1 > x0 && y1 > y0 && z1 > z0) { atomicMax(dims + 3 * l, x1 - x0); atomicMax(dims + 3 * l + 1, y1 - y0); atomicMax(dims + 3 * l + 2, z1 - z0); }
+}
+
+// Work order.  A leaf narrower than a cache line writes partial lines; they are completed by its x-neighbours, which may be leaves of
+// other levels.  If those run much later (a launch per level, or level after level within a launch) the partial lines are written
+// back as they are: a third of the write requests at the memory interface were 32-byte ones.  So the waves are dealt START CELL by
+// start cell, all levels of a cell together (k_lat_groups .. k_lat_waves build the list once per plan): what one cell's leaves leave
+// incomplete, the same cell's other leaves complete while the lines are still in the L2 / the Infinity Cache.  Measured (value +
+// gradient, kernel time): 512^3 789 -> 689 us, 256^3 121 -> 116 us (one launch per level: 187 us; point kernel: 264 us).  What is
+// left is the request rate of the stores themselves — rows of 16-96 bytes, 53 bytes per 64-byte request on average, at three
+// quarters of the request rate a plain fill of the same arrays reaches; the arithmetic and the loads alone take 37 us at 256^3.
+// Group g = startCell * levels + level; a group's leaves take groupCount * cols lanes, rounded up to whole waves.
+struct LatCols { uint32_t mx[kLatMaxLevels], my[kLatMaxLevels]; int levels; uint32_t G; };
+
+SDF_DEV uint32_t latGroupOf(const uint32_t* __restrict__ leafCell, uint32_t leaf, int l, const LatCols& C) {
+    const uint32_t xy = leafCell[2 * (size_t)leaf], cz = leafCell[2 * (size_t)leaf + 1];
+    const uint32_t sx = (xy & 0xFFFFu) >> l, sy = (xy >> 16) >> l, sz = cz >> l;
+    return ((sz * C.G + sy) * C.G + sx) * (uint32_t)C.levels + (uint32_t)l;
+}
+__global__ void k_lat_groups(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, LatCols C, const uint16_t* __restrict__ ranges, uint32_t* __restrict__ groupCount) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= leaves) return;
+    const uint16_t* r = ranges + 6 * (size_t)i;
+    if (r[1] <= r[0] || r[3] <= r[2] || r[5] <= r[4]) return;               // owns no lattice point
+    int l = 0;
+    while (l + 1 < L.levels && i >= L.leafBase[l + 1]) l++;
+    atomicAdd(groupCount + latGroupOf(leafCell, i, l, C), 1u);
+}
+// per group: waves it needs (scan input)
+__global__ void k_lat_group_waves(const uint32_t* __restrict__ groupCount, uint32_t groups, LatCols C, uint32_t* __restrict__ groupWaves) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    const uint32_t l = g % (uint32_t)C.levels;
+    groupWaves[g] = (uint32_t)(((uint64_t)groupCount[g] * C.mx[l] * C.my[l] + 63ull) >> 6);
+}
+__global__ void k_lat_scatter(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, LatCols C, const uint16_t* __restrict__ ranges,
+                              const uint32_t* __restrict__ groupLeafBase, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sortedLeaf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= leaves) return;
+    const uint16_t* r = ranges + 6 * (size_t)i;
+    if (r[1] <= r[0] || r[3] <= r[2] || r[5] <= r[4]) return;
+    int l = 0;
+    while (l + 1 < L.levels && i >= L.leafBase[l + 1]) l++;
+    const uint32_t g = latGroupOf(leafCell, i, l, C);
+    sortedLeaf[groupLeafBase[g] + atomicAdd(cursor + g, 1u)] = i;
+}
+// wave descriptor: {first sorted leaf of the group, leaves in the group, level, index of the wave within the group}
+__global__ void k_lat_waves(const uint32_t* __restrict__ groupWaveBase, const uint32_t* __restrict__ groupLeafBase, const uint32_t* __restrict__ groupCount, uint32_t groups,
+                            uint32_t levels, uint32_t waves, uint4* __restrict__ desc) {
+    const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= waves) return;
+    uint32_t lo = 0, hi = groups;                   // last group whose base is <= w  (groupWaveBase is non-decreasing, [groups] = waves)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (groupWaveBase[mid] <= w) lo = mid; else hi = mid; }
+    while (lo + 1 < groups && groupWaveBase[lo + 1] <= w) lo++;           // skip empty groups sharing the base
+    desc[w] = make_uint4(groupLeafBase[lo], groupCount[lo], lo % levels, w - groupWaveBase[lo]);
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_lattice_columns(const float* __restrict__ coef, const float* __restrict__ F, const uint16_t* __restrict__ ranges,
+                                                         const uint4* __restrict__ desc, const uint32_t* __restrict__ sortedLeaf, uint32_t waves, LatCols C,
+                                                         uint32_t nx, uint32_t ny, float* __restrict__ dist, float* __restrict__ grad) {
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= waves) return;
+    const uint4 D = desc[w];
+    const uint32_t level = __builtin_amdgcn_readfirstlane(D.z);
+    const uint32_t mx = C.mx[level], my = C.my[level];
+    const float scale = __uint_as_float((127u + level) << 23);               // 2^level
+    const uint32_t tid = __builtin_amdgcn_readfirstlane(D.w) * 64u + (threadIdx.x & 63u);
+    const uint32_t cols = mx * my, rel = tid / cols;
+    if (rel >= D.y) return;
+    const uint32_t col = tid - rel * cols, ly = col / mx, lx = col - ly * mx;
+    const uint32_t leaf = sortedLeaf[D.x + rel];
+    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ranges + 6 * (size_t)leaf);
+    const uint32_t rx = r32[0], ry = r32[1], rz = r32[2];
+    const uint32_t x = (rx & 0xFFFFu) + lx, y = (ry & 0xFFFFu) + ly, z0 = rz & 0xFFFFu, z1 = rz >> 16;
+    if (x >= (rx >> 16) || y >= (ry >> 16) || z0 >= z1) return;
+    const float* Fz = F + nx + ny;
+    float tzNext = Fz[z0];
+    const float tx = F[x] * scale, ty = F[nx + y] * scale;
+    const float fx = tx - floorf(tx), fy = ty - floorf(ty);
+    const float4* src = reinterpret_cast<const float4*>(coef + 64ull * leaf);
+    float yv[4], ygx[4], ygy[4];
+#pragma unroll
+    for (int k = 3; k >= 0; k--) {
+        float v = 0.f, gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int j = 3; j >= 0; j--) {
+            const float4 q = src[j + 4 * k];
+            const float px = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(q.w, fx, q.z), fx, q.y), fx, q.x);
+            if (GRAD) {
+                const float dx = __builtin_fmaf(__builtin_fmaf(3.f * q.w, fx, 2.f * q.z), fx, q.y);
+                gy = __builtin_fmaf(gy, fy, v);
+                gx = __builtin_fmaf(gx, fy, dx);
+            }
+            v = __builtin_fmaf(v, fy, px);
+        }
+        yv[k] = v; ygx[k] = gx; ygy[k] = gy;
+    }
+    size_t at = ((size_t)z0 * ny + y) * nx + x;
+    const size_t plane = (size_t)nx * ny;
+    for (uint32_t z = z0; z < z1; z++, at += plane) {
+        const float tz = tzNext * scale, fz = tz - floorf(tz);
+        tzNext = Fz[z + 1];                         // (the table has one spare entry) in flight while this point is evaluated and stored
+        float v = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (GRAD) { gz = __builtin_fmaf(gz, fz, v); gx = __builtin_fmaf(gx, fz, ygx[k]); gy = __builtin_fmaf(gy, fz, ygy[k]); }
+            v = __builtin_fmaf(v, fz, yv[k]);
+        }
+        dist[at] = v;
+        if (GRAD) { const F3 g = normalize(F3{gx, gy, gz}); grad[3 * at] = g.x; grad[3 * at + 1] = g.y; grad[3 * at + 2] = g.z; }
+    }
+}
+
+// lattice points outside the start grid: the point kernel's box-distance branch
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_lattice_outside(QueryTree t, const float* __restrict__ F, F3 origin, F3 step, uint32_t nx, uint32_t ny, float* __restrict__ dist,
+                                                         float* __restrict__ grad) {
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, z = blockIdx.z;
+    if (x >= nx) return;
+    const float G = (float)t.G;
+    const float a = floorf(F[x]), b = floorf(F[nx + y]), c = floorf(F[nx + ny + z]);
+    if (a >= 0.f && a < G && b >= 0.f && b < G && c >= 0.f && c < G) return;
+    const F3 p = F3{origin.x + (float)x * step.x, origin.y + (float)y * step.y, origin.z + (float)z * step.z};
+    const size_t at = ((size_t)z * ny + y) * nx + x;
+    float g[3] = {0.f, 0.f, 0.f};
+    dist[at] = (GRAD ? boxDistanceGrad(t, p, g) : boxDistance(t, p)) + t.minBorder;
+    if (GRAD) { grad[3 * at] = g[0]; grad[3 * at + 1] = g[1]; grad[3 * at + 2] = g[2]; }
+}
+
+// caller holds T->qLock.  Leaves the plan with leafDriven == false when the point kernel is the better (or only) choice.
+static int ensureLatticePlan(sdfhip_octree* T, const float origin[3], const float step[3], uint32_t nx, uint32_t ny, uint32_t nz) {
+    sdfhip_octree::LatticePlan& P = T->lattice;
+    if (P.valid && !memcmp(P.origin, origin, 12) && !memcmp(P.step, step, 12) && P.n[0] == nx && P.n[1] == ny && P.n[2] == nz) return SDFHIP_OK;
+    P.valid = false; P.leafDriven = false; P.outside = false; P.classes.clear();
+    memcpy(P.origin, origin, 12); memcpy(P.step, step, 12); P.n[0] = nx; P.n[1] = ny; P.n[2] = nz;
+    const int levels = (int)T->qLevelNodes.size();
+    const uint64_t G = (uint64_t)T->info.start_grid_size;
+    bool ok = levels >= 1 && levels <= kLatMaxLevels && (G << (levels - 1)) <= 65536ull && nx <= 65535u && ny <= 65535u && nz <= 65535u && T->qLeaves > 0;
+    for (int a = 0; a < 3; a++) ok = ok && std::isfinite(origin[a]) && std::isfinite(step[a]) && step[a] > 0.f;      // the tables must be non-decreasing
+    if (!ok) { P.valid = true; return SDFHIP_OK; }
+    hipStream_t st = T->ctx->stream;
+    SDF_TRY(ensureLeafCells(T));
+    const uint32_t nt = nx + ny + nz;
+    SDF_TRY(P.F.reserve(nt + 1)); SDF_TRY(P.ranges.reserve(6ull * T->qLeaves));      // + 1: the column kernel reads one entry ahead
+    DevBuf<uint32_t> dims;
+    SDF_TRY(dims.reserve(3 * kLatMaxLevels));
+    SDF_HIP_CHECK(hipMemsetAsync(dims.p, 0, 12 * kLatMaxLevels, st));
+    LatLevels L{};
+    L.levels = levels;
+    for (int l = 0; l <= levels; l++) L.leafBase[l] = T->qLevelLeafBase[(size_t)l];
+    k_lat_tables<<<gridFor(nt, 256), 256, 0, st>>>(P.F.p, F3{origin[0], origin[1], origin[2]}, F3{step[0], step[1], step[2]},
+                                                   F3{T->info.box_min[0], T->info.box_min[1], T->info.box_min[2]}, T->cellSize, nx, ny, nz);
+    k_lat_ranges<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, P.F.p, nx, ny, nz, P.ranges.p, dims.p);
+    uint32_t hd[3 * kLatMaxLevels];
+    float ends[6];
+    SDF_HIP_CHECK(hipMemcpyAsync(hd, dims.p, sizeof(hd), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 0, P.F.p, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 1, P.F.p + nx - 1, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 2, P.F.p + nx, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 3, P.F.p + nx + ny - 1, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 4, P.F.p + nx + ny, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(ends + 5, P.F.p + nt - 1, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    for (int a = 0; a < 6; a++) {
+        if (!std::isfinite(ends[a]) || std::fabs(ends[a]) >= 16777216.f) { P.valid = true; return SDFHIP_OK; }       // the point kernel answers
+        if (std::floor(ends[a]) < 0.f || std::floor(ends[a]) >= (float)G) P.outside = true;
+    }
+    // lanes launched vs points: a lattice much coarser than the leaves would launch mostly empty columns
+    double slots = 0;
+    for (int l = 0; l < levels; l++) {
+        const uint32_t count = T->qLevelLeafBase[(size_t)l + 1] - T->qLevelLeafBase[(size_t)l];
+        const uint32_t mx = hd[3 * l], my = hd[3 * l + 1], mz = hd[3 * l + 2];
+        if (!count || !mx || !my || !mz) continue;
+        if ((double)count * mx * my >= 2147483648.0) { P.valid = true; return SDFHIP_OK; }
+        slots += (double)count * mx * my * mz;
+        P.classes.push_back(sdfhip_octree::LatticeClass{(uint32_t)l, T->qLevelLeafBase[(size_t)l], count, mx, my, mz});
+    }
+    P.leafDriven = slots <= 2.0 * (double)nx * ny * nz + 1e6;
+    const uint64_t groups = G * G * G * (uint64_t)levels;
+    if (P.leafDriven && groups > (1ull << 24)) P.leafDriven = false;
+    if (P.leafDriven) {
+        // the wave list: start cell by start cell, all levels of a cell together (see k_lattice_columns)
+        LatCols C{};
+        C.levels = levels; C.G = (uint32_t)G;
+        for (const sdfhip_octree::LatticeClass& c : P.classes) { C.mx[c.level] = c.mx; C.my[c.level] = c.my; }
+        DevBuf<uint32_t> count, wavesOf, cursor;
+        SDF_TRY(count.reserve(groups)); SDF_TRY(wavesOf.reserve(groups + 1)); SDF_TRY(cursor.reserve(groups));
+        SDF_TRY(P.groupWaveBase.reserve(groups + 1)); SDF_TRY(P.groupLeafBase.reserve(groups + 1)); SDF_TRY(P.sortedLeaf.reserve(T->qLeaves));
+        SDF_HIP_CHECK(hipMemsetAsync(count.p, 0, 4 * groups, st));
+        SDF_HIP_CHECK(hipMemsetAsync(cursor.p, 0, 4 * groups, st));
+        k_lat_groups<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, count.p);
+        k_lat_group_waves<<<gridFor(groups, 256), 256, 0, st>>>(count.p, (uint32_t)groups, C, wavesOf.p);
+        size_t need = 0;
+        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, wavesOf.p, P.groupWaveBase.p, (int)groups, st));
+        DevBuf<uint8_t> tmp;
+        SDF_TRY(tmp.reserve(need + 16));
+        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, wavesOf.p, P.groupWaveBase.p, (int)groups, st));
+        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, count.p, P.groupLeafBase.p, (int)groups, st));
+        uint32_t lastBase = 0, lastWaves = 0;
+        SDF_HIP_CHECK(hipMemcpyAsync(&lastBase, P.groupWaveBase.p + groups - 1, 4, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(&lastWaves, wavesOf.p + groups - 1, 4, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        P.waves = lastBase + lastWaves;
+        if (P.waves == 0 || P.waves >= (1u << 30)) P.leafDriven = false;
+        else {
+            SDF_TRY(P.waveDesc.reserve(4ull * P.waves));
+            k_lat_scatter<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, P.groupLeafBase.p, cursor.p, P.sortedLeaf.p);
+            k_lat_waves<<<gridFor(P.waves, 256), 256, 0, st>>>(P.groupWaveBase.p, P.groupLeafBase.p, count.p, (uint32_t)groups, (uint32_t)levels, P.waves,
+                                                            reinterpret_cast<uint4*>(P.waveDesc.p));
+            SDF_HIP_CHECK(hipGetLastError());
+            SDF_HIP_CHECK(hipStreamSynchronize(st));        // the temporaries are released here
+        }
+    }
+    P.valid = true;
     return SDFHIP_OK;
 }
 
@@ -414,7 +723,29 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
     const QueryTree q = makeQueryTree(T);
     const F3 o = F3{origin[0], origin[1], origin[2]}, s = F3{step[0], step[1], step[2]};
     const unsigned blocks = gridFor(n, 256);
-    if (eval_mode == SDFHIP_EVAL_EXACT) {
+    static const bool noLeafDriven = getenv("SDFHIP_LATTICE_POINTS") != nullptr;      // A/B switch: always the point kernel
+    bool answered = false;
+    if (eval_mode == SDFHIP_EVAL_FAST && !noLeafDriven) {
+        std::lock_guard<std::mutex> own(T->qLock);
+        SDF_TRY(ensureLatticePlan(T, origin, step, nx, ny, nz));
+        const sdfhip_octree::LatticePlan& P = T->lattice;
+        if (P.leafDriven) {
+            LatCols C{};
+            C.levels = (int)T->qLevelNodes.size(); C.G = (uint32_t)T->info.start_grid_size;
+            for (const sdfhip_octree::LatticeClass& c : P.classes) { C.mx[c.level] = c.mx; C.my[c.level] = c.my; }
+            const uint4* desc = reinterpret_cast<const uint4*>(P.waveDesc.p);
+            if (g) k_lattice_columns<true><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, g);
+            else k_lattice_columns<false><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, nullptr);
+            if (P.outside) {
+                const dim3 og(gridFor(nx, 256), ny, nz);
+                if (g) k_lattice_outside<true><<<og, 256, 0, st>>>(q, P.F.p, o, s, nx, ny, d, g);
+                else k_lattice_outside<false><<<og, 256, 0, st>>>(q, P.F.p, o, s, nx, ny, d, nullptr);
+            }
+            answered = true;
+        }
+    }
+    if (answered) {
+    } else if (eval_mode == SDFHIP_EVAL_EXACT) {
         if (g) k_octree_query_grid<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, g);
         else k_octree_query_grid<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(q, o, s, nx, ny, nz, d, nullptr);
     } else {

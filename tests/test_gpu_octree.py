@@ -133,6 +133,43 @@ def test_grid_query_matches_point_query(small):
         np.testing.assert_allclose(gf[ok], ge[ok], rtol=0, atol=2e-4)        # unit gradients: normalisation amplifies the 1e-5 of the components
 
 
+def test_leaf_driven_lattice_equals_the_point_kernel_bit_for_bit(small):
+    """EVAL_FAST lattices are answered leaf by leaf (octree_query.hip, k_lattice_columns): the leaf a lattice point lands in, its
+    local coordinates and the order of the FMAs are the point kernel's, so the two paths must agree in every bit — on aligned and
+    unaligned lattices, anisotropic steps, lattices sticking out of the box on either side, single-row lattices, a lattice far
+    coarser than the leaves (the plan falls back to the point kernel) and a repeated call (cached plan)."""
+    import sdflib_amd as S
+    rng = np.random.default_rng(11)
+    for depth, start in ((6, 2), (5, 0), (4, 3)):
+        gt = S.OctreeSdf(small["gm"], small["box"], depth, start, 1e-3, num_threads=2)
+        bb = gt.get_grid_bounding_box()
+        size = np.float32(bb[3] - bb[0])
+        cases = []
+        n = 64
+        st = np.full(3, size / np.float32(n), dtype=np.float32)
+        cases.append((bb[:3] + np.float32(0.5) * st, st, (n, n, n)))                                 # cell centres of depth-6 cells
+        cases.append((bb[:3].copy(), st, (n + 1, n + 1, n + 1)))                                     # cell corners: every point on a boundary
+        cases.append((bb[:3] - 5 * st, (st * np.float32(1.37)).astype(np.float32), (70, 41, 55)))    # sticks out on both sides
+        cases.append((bb[:3] + rng.uniform(0, 0.1, 3).astype(np.float32), (st * rng.uniform(0.3, 3.0, 3)).astype(np.float32), (33, 97, 18)))
+        cases.append((bb[:3] + np.float32(0.3) * size, (st * np.float32(0.01)).astype(np.float32), (50, 1, 50)))   # a thin slab inside one or two leaves
+        cases.append((bb[:3] + np.float32(0.01), np.full(3, size / np.float32(3), dtype=np.float32), (3, 3, 3)))   # coarser than any leaf
+        cases.append(cases[0])
+        for org, stp, dims in cases:
+            org = np.asarray(org, dtype=np.float32); stp = np.asarray(stp, dtype=np.float32)
+            kk, jj, ii = np.meshgrid(np.arange(dims[2]), np.arange(dims[1]), np.arange(dims[0]), indexing="ij")
+            q = np.stack([org[0] + ii.astype(np.float32) * stp[0], org[1] + jj.astype(np.float32) * stp[1], org[2] + kk.astype(np.float32) * stp[2]], axis=-1)
+            q = q.reshape(-1, 3).astype(np.float32)
+            dp, gp = gt.get_distance(q, gradient=True, eval_mode=S.EVAL_FAST)
+            dl, gl = gt.get_distance_grid(org, stp, dims, gradient=True, eval_mode=S.EVAL_FAST)
+            dv = gt.get_distance_grid(org, stp, dims, gradient=False, eval_mode=S.EVAL_FAST)
+            dvp = gt.get_distance(q, gradient=False, eval_mode=S.EVAL_FAST)
+            assert np.array_equal(bits(dl), bits(dp)), (depth, start, dims, int((bits(dl) != bits(dp)).sum()))
+            assert np.array_equal(bits(dv), bits(dvp)), (depth, start, dims)
+            same = bits(gl) == bits(gp)
+            both_nan = np.isnan(gl) & np.isnan(gp)
+            assert (same | both_nan).all(), (depth, start, dims, int((~(same | both_nan)).sum()))
+
+
 def test_sharded_build_emits_the_same_array(small, oracle):
     """Two shards built separately and concatenated by hand == the single-device array (no collective involved)."""
     import sdflib_amd as S
