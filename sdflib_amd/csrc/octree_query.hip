@@ -293,7 +293,7 @@ static int ensureLeafCells(sdfhip_octree* T) {
     return SDFHIP_OK;
 }
 
-constexpr int kLatMaxLevels = 16;
+constexpr int kLatMaxLevels = 14;           // 3 x 13 bits of local cell coordinates in a sort key
 struct LatLevels { uint32_t leafBase[kLatMaxLevels + 1]; int levels; };
 
 __global__ void k_lat_tables(float* __restrict__ F, F3 origin, F3 step, F3 bmin, float cellSize, uint32_t nx, uint32_t ny, uint32_t nz) {
@@ -332,8 +332,11 @@ __global__ void k_lat_ranges(const uint32_t* __restrict__ leafCell, uint32_t lea
 // start cell, all levels of a cell together (k_lat_groups .. k_lat_waves build the list once per plan): what one cell's leaves leave
 // incomplete, the same cell's other leaves complete while the lines are still in the L2 / the Infinity Cache.  Measured (value +
 // gradient, kernel time): 512^3 789 -> 689 us, 256^3 121 -> 116 us (one launch per level: 187 us; point kernel: 264 us).  What is
-// left is the request rate of the stores themselves — rows of 16-96 bytes, 53 bytes per 64-byte request on average, at three
-// quarters of the request rate a plain fill of the same arrays reaches; the arithmetic and the loads alone take 37 us at 256^3.
+// left is the stores themselves: the arithmetic and the loads alone take 37 us at 256^3, and a 200^3 lattice, whose 128 MB of results
+// stay in the Infinity Cache, is written at twice the rate per byte.  A column marches through z, i.e. through planes 256 KB apart:
+// what reaches HBM is a stream of 64-128-byte pieces scattered over many DRAM rows (about 3 TB/s; a sequential fill of the same
+// arrays runs at 6.7 TB/s).  Fuller requests do not help (x-fastest lanes across adjoining leaves, below: same time), nor do
+// non-temporal stores; the z-scatter is what leaf-driven evaluation costs, and it is still 2.2x faster than the point kernel.
 // Group g = startCell * levels + level; a group's leaves take groupCount * cols lanes, rounded up to whole waves.
 struct LatCols { uint32_t mx[kLatMaxLevels], my[kLatMaxLevels]; int levels; uint32_t G; };
 
@@ -355,19 +358,24 @@ __global__ void k_lat_groups(const uint32_t* __restrict__ leafCell, uint32_t lea
 __global__ void k_lat_group_waves(const uint32_t* __restrict__ groupCount, uint32_t groups, LatCols C, uint32_t* __restrict__ groupWaves) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
-    const uint32_t l = g % (uint32_t)C.levels;
-    groupWaves[g] = (uint32_t)(((uint64_t)groupCount[g] * C.mx[l] * C.my[l] + 63ull) >> 6);
+    const uint32_t l = g % (uint32_t)C.levels, cols = C.mx[l] * C.my[l];
+    if (cols != 0u && cols <= 32u) { const uint32_t k = 64u / cols; groupWaves[g] = (groupCount[g] + k - 1u) / k; }      // k whole leaves per wave
+    else groupWaves[g] = (uint32_t)(((uint64_t)groupCount[g] * cols + 63ull) >> 6);
 }
-__global__ void k_lat_scatter(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, LatCols C, const uint16_t* __restrict__ ranges,
-                              const uint32_t* __restrict__ groupLeafBase, uint32_t* __restrict__ cursor, uint32_t* __restrict__ sortedLeaf) {
+// sort key of a leaf: its group, then its cell within the start cell in (z, y, x) order — x-neighbours become list neighbours, so the
+// leaves a wave takes together write adjoining pieces of the same rows.  Leaves without lattice points go to the end.
+__global__ void k_lat_keys(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, LatCols C, const uint16_t* __restrict__ ranges,
+                           uint64_t* __restrict__ key, uint32_t* __restrict__ val) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= leaves) return;
+    val[i] = i;
     const uint16_t* r = ranges + 6 * (size_t)i;
-    if (r[1] <= r[0] || r[3] <= r[2] || r[5] <= r[4]) return;
+    if (r[1] <= r[0] || r[3] <= r[2] || r[5] <= r[4]) { key[i] = ~0ull; return; }
     int l = 0;
     while (l + 1 < L.levels && i >= L.leafBase[l + 1]) l++;
-    const uint32_t g = latGroupOf(leafCell, i, l, C);
-    sortedLeaf[groupLeafBase[g] + atomicAdd(cursor + g, 1u)] = i;
+    const uint32_t xy = leafCell[2 * (size_t)i], cz = leafCell[2 * (size_t)i + 1], m = (1u << l) - 1u;
+    const uint64_t local = ((uint64_t)(cz & m) << (2 * l)) | ((uint64_t)((xy >> 16) & m) << l) | (uint64_t)(xy & 0xFFFFu & m);
+    key[i] = ((uint64_t)latGroupOf(leafCell, i, l, C) << 39) | local;
 }
 // wave descriptor: {first sorted leaf of the group, leaves in the group, level, index of the wave within the group}
 __global__ void k_lat_waves(const uint32_t* __restrict__ groupWaveBase, const uint32_t* __restrict__ groupLeafBase, const uint32_t* __restrict__ groupCount, uint32_t groups,
@@ -390,10 +398,24 @@ __global__ void __launch_bounds__(256) k_lattice_columns(const float* __restrict
     const uint32_t level = __builtin_amdgcn_readfirstlane(D.z);
     const uint32_t mx = C.mx[level], my = C.my[level];
     const float scale = __uint_as_float((127u + level) << 23);               // 2^level
-    const uint32_t tid = __builtin_amdgcn_readfirstlane(D.w) * 64u + (threadIdx.x & 63u);
-    const uint32_t cols = mx * my, rel = tid / cols;
+    const uint32_t wInGroup = __builtin_amdgcn_readfirstlane(D.w), lane = threadIdx.x & 63u, cols = mx * my;
+    uint32_t rel, lx, ly;
+    if (cols <= 32u) {
+        // k whole leaves per wave, lanes x-fastest ACROSS the leaves: where the leaves adjoin in x (the list is sorted that way)
+        // consecutive lanes write consecutive addresses
+        const uint32_t k = 64u / cols, rowLen = k * mx;
+        ly = lane / rowLen;
+        const uint32_t rem = lane - ly * rowLen, li = rem / mx;
+        lx = rem - li * mx;
+        rel = wInGroup * k + li;
+        if (ly >= my) return;
+    } else {
+        const uint32_t tid = wInGroup * 64u + lane;
+        rel = tid / cols;
+        const uint32_t col = tid - rel * cols;
+        ly = col / mx; lx = col - ly * mx;
+    }
     if (rel >= D.y) return;
-    const uint32_t col = tid - rel * cols, ly = col / mx, lx = col - ly * mx;
     const uint32_t leaf = sortedLeaf[D.x + rel];
     const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ranges + 6 * (size_t)leaf);
     const uint32_t rx = r32[0], ry = r32[1], rz = r32[2];
@@ -509,11 +531,11 @@ static int ensureLatticePlan(sdfhip_octree* T, const float origin[3], const floa
         LatCols C{};
         C.levels = levels; C.G = (uint32_t)G;
         for (const sdfhip_octree::LatticeClass& c : P.classes) { C.mx[c.level] = c.mx; C.my[c.level] = c.my; }
-        DevBuf<uint32_t> count, wavesOf, cursor;
-        SDF_TRY(count.reserve(groups)); SDF_TRY(wavesOf.reserve(groups + 1)); SDF_TRY(cursor.reserve(groups));
+        DevBuf<uint32_t> count, wavesOf, val;
+        DevBuf<uint64_t> key, keyS;
+        SDF_TRY(count.reserve(groups)); SDF_TRY(wavesOf.reserve(groups + 1)); SDF_TRY(val.reserve(T->qLeaves)); SDF_TRY(key.reserve(T->qLeaves)); SDF_TRY(keyS.reserve(T->qLeaves));
         SDF_TRY(P.groupWaveBase.reserve(groups + 1)); SDF_TRY(P.groupLeafBase.reserve(groups + 1)); SDF_TRY(P.sortedLeaf.reserve(T->qLeaves));
         SDF_HIP_CHECK(hipMemsetAsync(count.p, 0, 4 * groups, st));
-        SDF_HIP_CHECK(hipMemsetAsync(cursor.p, 0, 4 * groups, st));
         k_lat_groups<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, count.p);
         k_lat_group_waves<<<gridFor(groups, 256), 256, 0, st>>>(count.p, (uint32_t)groups, C, wavesOf.p);
         size_t need = 0;
@@ -530,7 +552,12 @@ static int ensureLatticePlan(sdfhip_octree* T, const float origin[3], const floa
         if (P.waves == 0 || P.waves >= (1u << 30)) P.leafDriven = false;
         else {
             SDF_TRY(P.waveDesc.reserve(4ull * P.waves));
-            k_lat_scatter<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, P.groupLeafBase.p, cursor.p, P.sortedLeaf.p);
+            k_lat_keys<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, key.p, val.p);
+            size_t sortNeed = 0;
+            SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (int)T->qLeaves, 0, 64, st));
+            DevBuf<uint8_t> sortTmp;
+            SDF_TRY(sortTmp.reserve(sortNeed + 16));
+            SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sortTmp.p, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (int)T->qLeaves, 0, 64, st));
             k_lat_waves<<<gridFor(P.waves, 256), 256, 0, st>>>(P.groupWaveBase.p, P.groupLeafBase.p, count.p, (uint32_t)groups, (uint32_t)levels, P.waves,
                                                             reinterpret_cast<uint4*>(P.waveDesc.p));
             SDF_HIP_CHECK(hipGetLastError());
