@@ -12,10 +12,13 @@
 //
 // The keys are full of ties (triangles sharing their first vertex), std::sort is not stable, and the permutation it leaves
 // decides which triangles fall on which side of every median — so the planner has to end with libstdc++'s permutation,
-// not just with a sorted range.  introsortLike() below restates that algorithm (introsort: median-of-3 to the front,
+// not just with a sorted range.  IntroSortLike below restates that algorithm (introsort: median-of-3 to the front,
 // unguarded Hoare partition, recurse right / loop left, 16-element threshold, 2*floor(log2 n) depth limit with heap sort
-// fallback, final insertion sort) so that the independent sub-ranges a partition leaves behind can be handed to other host
-// threads: same comparisons on the same data in each sub-range, same result, critical path O(n) instead of O(n log n).
+// fallback, final insertion sort) so that it can run on several threads: the independent sub-ranges a partition leaves behind are
+// tasks of the planner's pool, and the partition of a large range is itself computed in parallel (parallelPartition) — same
+// comparisons on the same data, same permutation.  What bounds the planner after that is its total work, ~0.8 us of CPU time per
+// triangle (20 levels of gather, sum, AABB, radius and an n log n sort per node): on a host that grants the process 16 CPUs, 0.07 s
+// for 1.31 M triangles however many threads are used.
 // sdfhip_test_sort_matches_std() (tests/test_abi.py) compares it with std::sort on tie-heavy inputs.
 #include "sdfhip_internal.h"
 #include "dev_bvh_fast.h"
@@ -27,18 +30,125 @@
 #include <atomic>
 #include <mutex>
 #include <memory>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <sys/mman.h>
+#include <stdlib.h>
 
 namespace sdfhip {
 
+// ---- helper threads of the planner ---------------------------------------------------------------------------------------
+// The planner's parallelism is nested (a partition inside a sort inside a node inside a subtree) and fine grained (phases of 0.1 - 3
+// ms).  Starting a std::thread for every piece was measured to stop scaling: thread creation takes the process's memory-map lock,
+// and with hundreds of creations in flight the time of a node no longer shrank with its size (12 ms at every one of the top
+// levels of a 1.3 M-triangle tree).  All of it therefore runs as tasks of ONE process-wide pool (created on first use, never torn
+// down; an idle worker looks for work for a few microseconds — the next phase is usually that close — and then sleeps on a
+// condition variable).  A thread that waits for a group of tasks executes queued tasks meanwhile, so waits nested to any depth
+// cannot starve each other however few workers there are.  Three classes of tasks — SHORT (a chunk of a data-parallel phase), MEDIUM
+// (a sub-range of a sort, a centre sum), LONG (a subtree) — and a waiter only helps with classes up to that of what it waits for:
+// a phase that picked up somebody's subtree would stall everything queued behind that phase for the length of the subtree.
+class PlannerPool {
+public:
+    struct Group { std::atomic<int> left{0}; };
+    enum Class { SHORT = 0, MEDIUM = 1, LONG = 2 };
+private:
+    struct Task { std::function<void()> fn; Group* group; };
+    std::mutex m; std::condition_variable cv; std::deque<Task> q[3];
+    std::atomic<int> pending[3]; std::atomic<int> sleepers{0};
+    int workers = 0;
+    bool tryRun(int upTo) {
+        bool any = false;
+        for (int c = 0; c <= upTo; c++) any = any || pending[c].load(std::memory_order_acquire) > 0;
+        if (!any) return false;
+        Task t; bool got = false;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (int c = 0; c <= upTo && !got; c++)
+                if (!q[c].empty()) {
+                    if (c == SHORT) { t = std::move(q[c].front()); q[c].pop_front(); } else { t = std::move(q[c].back()); q[c].pop_back(); }
+                    pending[c].fetch_sub(1, std::memory_order_acq_rel); got = true;
+                }
+        }
+        if (!got) return false;
+        t.fn();
+        if (t.group->left.fetch_sub(1, std::memory_order_acq_rel) == 1 && sleepers.load(std::memory_order_acquire) > 0) {
+            std::lock_guard<std::mutex> g(m);           // a waiter of this group may be asleep (wait() checks its predicate under m)
+            cv.notify_all();
+        }
+        return true;
+    }
+    void worker() {
+        for (;;) {
+            bool ran = false;
+            for (int spin = 0; spin < 2000 && !ran; spin++) { ran = tryRun(LONG); if (!ran) __builtin_ia32_pause(); }
+            if (ran) continue;
+            std::unique_lock<std::mutex> g(m);
+            sleepers.fetch_add(1);
+            cv.wait(g, [&] { return !q[0].empty() || !q[1].empty() || !q[2].empty(); });
+            sleepers.fetch_sub(1);
+        }
+    }
+    PlannerPool() {
+        for (int c = 0; c < 3; c++) pending[c].store(0);
+        unsigned hc = std::thread::hardware_concurrency();
+        workers = (int)(hc ? hc : 1u) - 1; if (workers > 127) workers = 127; if (workers < 0) workers = 0;
+        // a container's CPU quota (cgroup v2 cpu.max = "<quota> <period>"): more runnable threads than about twice the quota only get the
+        // group throttled for the rest of the period (measured on a 256-thread host with a quota of 16: 31 workers 0.07 s, 127 workers 0.07-0.15 s)
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) { const int cap = (int)(2 * quota / period) - 1; if (cap >= 1 && cap < workers) workers = cap; }
+            fclose(f);
+        }
+        if (getenv("SDFHIP_BVH_POOL_THREADS")) workers = std::max(0, atoi(getenv("SDFHIP_BVH_POOL_THREADS")));
+        for (int i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
+    }
+public:
+    static PlannerPool& get() { static PlannerPool* p = new PlannerPool(); return *p; }
+    void spawn(Group& grp, std::function<void()> fn, Class c) {
+        if (workers == 0) { fn(); return; }
+        grp.left.fetch_add(1, std::memory_order_acq_rel);
+        { std::lock_guard<std::mutex> g(m); q[c].push_back(Task{std::move(fn), &grp}); pending[c].fetch_add(1, std::memory_order_acq_rel); }
+        if (sleepers.load(std::memory_order_acquire) > 0) cv.notify_one();
+    }
+    // returns when the group's tasks are done; meanwhile runs queued tasks of classes <= help (never less than the group's own class)
+    void wait(Group& grp, Class help) {
+        int idle = 0;
+        while (grp.left.load(std::memory_order_acquire) > 0) {
+            if (tryRun(help)) { idle = 0; continue; }
+            __builtin_ia32_pause();
+            if (++idle < 2000) continue;
+            // nothing to help with: sleep until the group is done or work appears (a container's CPU quota is shared with the workers —
+            // a subtree's parent spinning for the length of the subtree was measured to get the whole process throttled)
+            std::unique_lock<std::mutex> g(m);
+            sleepers.fetch_add(1);
+            cv.wait(g, [&] {
+                if (grp.left.load(std::memory_order_acquire) <= 0) return true;
+                for (int c = 0; c <= (int)help; c++) if (!q[c].empty()) return true;
+                return false;
+            });
+            sleepers.fetch_sub(1);
+            idle = 0;
+        }
+    }
+    // fn(0 .. parts-1), the caller included
+    void run(int parts, const std::function<void(int)>& fn) {
+        if (parts <= 1 || workers == 0) { for (int i = 0; i < parts; i++) fn(i); return; }
+        Group grp;
+        for (int i = 1; i < parts; i++) spawn(grp, [&fn, i]() { fn(i); }, SHORT);
+        fn(0);
+        wait(grp, SHORT);
+    }
+};
+
 // ---- libstdc++'s std::sort, restated so that it can run on several threads --------------------------------------------
-struct KeyTri { double key; int tri; };
+struct KeyTri { float key; int tri; };           // the key is a vertex coordinate, a float: comparing it as such = comparing the reference's doubles
 static inline bool keyLess(const KeyTri& a, const KeyTri& b) { return a.key < b.key; }
 
-static std::atomic<int> g_sortThreads{0};      // live helper threads of all sorts in flight (soft cap = hardware threads)
 
 struct IntroSortLike {
     int maxThreads = 1;
-    size_t minParallel = 1u << 15;             // ranges below this are finished by the calling thread
+    size_t minParallel = 1u << 13;             // ranges below this are finished by the calling thread
     std::mutex cutMutex; std::vector<size_t> cuts; KeyTri* base = nullptr;
 
     static void moveMedianToFirst(KeyTri* result, KeyTri* a, KeyTri* b, KeyTri* c) {
@@ -60,27 +170,68 @@ struct IntroSortLike {
             ++first;
         }
     }
+    // unguardedPartition(first, last, pivot) on several threads, same final arrangement and return value.  The sequential scans only
+    // ever look at elements no swap has touched yet, so what they do is fixed by the ORIGINAL content: the t-th swap exchanges the
+    // t-th element from the left that is not less than the pivot (L_t) with the t-th from the right that is not greater (R_t), for
+    // as long as L_t < R_t (m swaps), and the scan that ends the loop stops at L_(m+1) or at R_m — now holding a not-less element —
+    // whichever comes first.  So: count both kinds per chunk, lay out the two index lists by prefix sums, find m by bisection,
+    // swap the m pairs in parallel.
+    size_t minParPartition = 1u << 17;         // ranges from this size on are partitioned by several threads
+    // index scratch of the whole sort (2 x one uint32 per element of [base, base + n)); sub-ranges use their own slices.  No allocation
+    // here: a multi-megabyte new / delete is an mmap / munmap, and those serialise every page fault of the process behind them.
+    uint32_t* scratchL = nullptr; uint32_t* scratchR = nullptr;
+    KeyTri* parallelPartition(KeyTri* first, KeyTri* last, KeyTri* pivot) {
+        const size_t n = (size_t)(last - first);
+        int parts = (int)(n / 16384); if (parts > 16) parts = 16; if (parts < 2) parts = 2;
+        const float pk = pivot->key;
+        std::vector<size_t> cl((size_t)parts + 1, 0), cr((size_t)parts + 1, 0);
+        auto lo = [&](int c) { return n * (size_t)c / (size_t)parts; };
+        PlannerPool& pool = PlannerPool::get();
+        pool.run(parts, [&](int c) {
+            size_t a = 0, b = 0;
+            for (size_t i = lo(c), e = lo(c + 1); i < e; i++) { const float k = first[i].key; a += !(k < pk); b += !(pk < k); }
+            cl[(size_t)c + 1] = a; cr[(size_t)c + 1] = b;
+        });
+        for (int c = 0; c < parts; c++) { cl[(size_t)c + 1] += cl[(size_t)c]; cr[(size_t)c + 1] += cr[(size_t)c]; }
+        const size_t nl = cl[(size_t)parts], nr = cr[(size_t)parts];
+        // L ascending; R stored ascending too (R_t = Rasc[nr - t])
+        uint32_t* L = scratchL + (first - base); uint32_t* R = scratchR + (first - base);
+        pool.run(parts, [&](int c) {
+            size_t a = cl[(size_t)c], b = cr[(size_t)c];
+            for (size_t i = lo(c), e = lo(c + 1); i < e; i++) { const float k = first[i].key; if (!(k < pk)) L[a++] = (uint32_t)i; if (!(pk < k)) R[b++] = (uint32_t)i; }
+        });
+        // m = number of t in [1, min(nl, nr)] with L_t < R_t  (L_t increases, R_t decreases with t)
+        size_t lo_t = 0, hi_t = nl < nr ? nl : nr;
+        while (lo_t < hi_t) { const size_t t = (lo_t + hi_t + 1) >> 1; if (L[t - 1] < R[nr - t]) lo_t = t; else hi_t = t - 1; }
+        const size_t m = lo_t;
+        if (m > 0) {
+            int sp = (int)(m / 8192); if (sp > 16) sp = 16; if (sp < 1) sp = 1;
+            pool.run(sp, [&](int c) {
+                for (size_t t = m * (size_t)c / (size_t)sp + 1, e = m * (size_t)(c + 1) / (size_t)sp; t <= e; t++) std::iter_swap(first + L[t - 1], first + R[nr - t]);
+            });
+        }
+        // the scan that ends the loop
+        size_t stop = (m < nl) ? (size_t)L[m] : n;             // L_(m+1) in the original content (n: none; the median-of-3 sentinel rules that out when m == 0)
+        if (m > 0 && (size_t)R[nr - m] < stop) stop = R[nr - m];
+        return first + stop;
+    }
     void loop(KeyTri* first, KeyTri* last, int depthLimit) {
-        std::vector<std::thread> helpers;
+        PlannerPool& pool = PlannerPool::get();
+        PlannerPool::Group helpers;
         while (last - first > 16) {
             if (depthLimit == 0) { std::make_heap(first, last, keyLess); std::sort_heap(first, last, keyLess); break; }
             --depthLimit;
             KeyTri* mid = first + (last - first) / 2;
             moveMedianToFirst(first, first + 1, mid, last - 1);
-            KeyTri* cut = unguardedPartition(first + 1, last, first);
-            bool spawned = false;
-            if ((size_t)(last - cut) >= minParallel && (size_t)(cut - first) >= minParallel) {
-                if (g_sortThreads.fetch_add(1) < maxThreads) {
-                    { std::lock_guard<std::mutex> g(cutMutex); cuts.push_back((size_t)(cut - base)); }
-                    KeyTri* l = last; const int dl = depthLimit;
-                    helpers.emplace_back([this, cut, l, dl]() { loop(cut, l, dl); g_sortThreads.fetch_sub(1); });
-                    spawned = true;
-                } else g_sortThreads.fetch_sub(1);
-            }
-            if (!spawned) loop(cut, last, depthLimit);
+            KeyTri* cut = ((size_t)(last - first) >= minParPartition && maxThreads > 1 && scratchL) ? parallelPartition(first + 1, last, first) : unguardedPartition(first + 1, last, first);
+            if (maxThreads > 1 && (size_t)(last - cut) >= minParallel && (size_t)(cut - first) >= minParallel) {
+                { std::lock_guard<std::mutex> g(cutMutex); cuts.push_back((size_t)(cut - base)); }
+                KeyTri* l = last; const int dl = depthLimit;
+                pool.spawn(helpers, [this, cut, l, dl]() { loop(cut, l, dl); }, PlannerPool::MEDIUM);
+            } else loop(cut, last, depthLimit);
             last = cut;
         }
-        for (std::thread& t : helpers) t.join();
+        pool.wait(helpers, PlannerPool::MEDIUM);
     }
     static void insertionSort(KeyTri* first, KeyTri* last) {       // guarded form; same result as the reference's guarded + unguarded pair
         if (first == last) return;
@@ -94,18 +245,21 @@ struct IntroSortLike {
         if (first == last) return;
         base = first; cuts.clear();
         int lg = 0; for (size_t n = (size_t)(last - first); n > 1; n >>= 1) lg++;
+        const bool trace = (last - first) > 1000000 && getenv("SDFHIP_TIMING"); const double ts0 = nowSeconds();
         loop(first, last, 2 * lg);
+        if (trace) fprintf(stderr, "[sdfhip] root sort: partition phase %.4f s, %zu cuts\n", nowSeconds() - ts0, cuts.size());
         // final insertion sort: elements never cross a partition cut, so the ranges between recorded cuts are independent
         std::sort(cuts.begin(), cuts.end());
-        std::vector<std::thread> helpers;
+        PlannerPool& pool = PlannerPool::get();
+        PlannerPool::Group helpers;
         size_t begin = 0;
         for (size_t k = 0; k <= cuts.size(); k++) {
             const size_t end = (k < cuts.size()) ? cuts[k] : (size_t)(last - first);
-            if (k < cuts.size()) helpers.emplace_back([this, begin, end]() { insertionSort(base + begin, base + end); });
+            if (k < cuts.size()) pool.spawn(helpers, [this, begin, end]() { insertionSort(base + begin, base + end); }, PlannerPool::SHORT);
             else insertionSort(base + begin, base + end);
             begin = end;
         }
-        for (std::thread& t : helpers) t.join();
+        pool.wait(helpers, PlannerPool::SHORT);
     }
 };
 
@@ -117,20 +271,17 @@ struct HostBvhBuilder {
     int maxParallelDepth = 0;
 
     struct D { double x, y, z; };
-    KeyTri* scratchKeys = nullptr; float* scratchLoc = nullptr;      // T entries / 9 T floats, uninitialised, sliced by range
+    KeyTri* scratchKeys = nullptr; float* scratchLoc = nullptr; uint32_t* scratchL = nullptr; uint32_t* scratchR = nullptr;      // T entries / 9 T floats, uninitialised, sliced by range
     const float* triV = nullptr;       // 9 floats per triangle, gathered once (the planner reads every vertex ~2 log2(T) times)
     int sortThreads = 1;
     D vtx(int t, int k) const { const float* q = triV + 9 * (size_t)t + 3 * k; return D{(double)q[0], (double)q[1], (double)q[2]}; }
     static double comp(const D& a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
     static constexpr int kWideRange = 1 << 16;
-    // chunks of [0,n) on helper threads (at most 16, at least 32k items each); fn(i0, i1)
+    // chunks of [0,n) on the planner's pool (at most 16, at least 16k items each); fn(i0, i1)
     template <typename F> static void parallelFor(int n, F fn) {
-        int parts = n / 32768; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
-        std::vector<std::thread> th;
-        for (int p = 1; p < parts; p++) { const int i0 = (int)((long long)n * p / parts), i1 = (int)((long long)n * (p + 1) / parts); th.emplace_back([=]() { fn(i0, i1); }); }
-        fn(0, (int)((long long)n / parts));
-        for (std::thread& t : th) t.join();
+        int parts = n / 16384; if (parts > 16) parts = 16; if (parts < 1) parts = 1;
+        PlannerPool::get().run(parts, [&](int p) { fn((int)((long long)n * p / parts), (int)((long long)n * (p + 1) / parts)); });
     }
 
     // Plans the subtree over order[begin,end): writes its bounding sphere into out[0..3] and returns the reference to it.
@@ -157,37 +308,58 @@ struct HostBvhBuilder {
             // the write-back are order independent and run on helper threads over a contiguous copy of the range.
             const bool trace = depth == 0 && getenv("SDFHIP_TIMING"); double tq = nowSeconds();
             auto lapq = [&](const char* what) { if (trace) { const double now = nowSeconds(); fprintf(stderr, "[sdfhip] bvh root: %s %.4f s\n", what, now - tq); tq = now; } };
-            float* loc = scratchLoc + 9 * (size_t)begin;      // this node's slice of the planner-wide scratch (ranges in flight are disjoint)
-            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) std::memcpy(&loc[9 * (size_t)i], triV + 9 * (size_t)order[begin + i], 36); });
+            const float* loc = triV;                          // the root's range is the identity: no copy needed
+            if (depth != 0) {
+                float* copy = scratchLoc + 9 * (size_t)begin;     // this node's slice of the planner-wide scratch (ranges in flight are disjoint)
+                parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) std::memcpy(&copy[9 * (size_t)i], triV + 9 * (size_t)order[begin + i], 36); });
+                loc = copy;
+            }
             lapq("gather");
-            for (size_t j = 0; j < 3 * (size_t)n; j++) { ce.x += (double)loc[3 * j]; ce.y += (double)loc[3 * j + 1]; ce.z += (double)loc[3 * j + 2]; }
-            lapq("centre sum");
-            const double cnt = (double)(3 * n);
-            ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
+            // the centre sum is a serial chain of 3 n additions per coordinate (2 ms for 1.3 M triangles) that nothing but the radius
+            // waits for: it runs as a task of its own under the AABB, the keys and the sort
+            PlannerPool::Group sumTask;
+            PlannerPool::get().spawn(sumTask, [&]() {
+                double sx = 0.0, sy = 0.0, sz = 0.0;
+                for (size_t j = 0; j < 3 * (size_t)n; j++) { sx += (double)loc[3 * j]; sy += (double)loc[3 * j + 1]; sz += (double)loc[3 * j + 2]; }
+                const double cnt = (double)(3 * n);
+                ce.x = sx / cnt; ce.y = sy / cnt; ce.z = sz / cnt;
+            }, PlannerPool::MEDIUM);
             std::mutex m;
             parallelFor(n, [&](int i0, int i1) {
-                D t{lo, lo, lo}, bt{hi, hi, hi}; double rr = 0.0;
+                D t{lo, lo, lo}, bt{hi, hi, hi};
                 for (size_t j = 3 * (size_t)i0; j < 3 * (size_t)i1; j++) {
                     const D p{(double)loc[3 * j], (double)loc[3 * j + 1], (double)loc[3 * j + 2]};
                     t.x = std::max(t.x, p.x); bt.x = std::min(bt.x, p.x); t.y = std::max(t.y, p.y); bt.y = std::min(bt.y, p.y); t.z = std::max(t.z, p.z); bt.z = std::min(bt.z, p.z);
-                    const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
-                    rr = std::max(rr, dx * dx + dy * dy + dz * dz);
                 }
                 std::lock_guard<std::mutex> g(m);
                 top.x = std::max(top.x, t.x); top.y = std::max(top.y, t.y); top.z = std::max(top.z, t.z);
-                bot.x = std::min(bot.x, bt.x); bot.y = std::min(bot.y, bt.y); bot.z = std::min(bot.z, bt.z); r2 = std::max(r2, rr);
+                bot.x = std::min(bot.x, bt.x); bot.y = std::min(bot.y, bt.y); bot.z = std::min(bot.z, bt.z);
             });
-            lapq("aabb + radius");
+            lapq("aabb");
             const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
             dim = (int)(std::max_element(diag, diag + 3) - diag);
             KeyTri* tmp = scratchKeys + begin;
-            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) tmp[i] = KeyTri{(double)loc[9 * (size_t)i + dim], order[begin + i]}; });
-            IntroSortLike sorter; sorter.maxThreads = sortThreads;
+            parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) tmp[i] = KeyTri{loc[9 * (size_t)i + dim], order[begin + i]}; });
+            IntroSortLike sorter; sorter.maxThreads = sortThreads; sorter.scratchL = scratchL + begin; sorter.scratchR = scratchR + begin;
+            { static const char* e1 = getenv("SDFHIP_BVH_MIN_PARALLEL"); static const char* e2 = getenv("SDFHIP_BVH_PAR_PARTITION");
+              if (e1) sorter.minParallel = (size_t)atol(e1); if (e2) sorter.minParPartition = (size_t)atol(e2); }
             lapq("keys");
             sorter.sort(tmp, tmp + n);
             lapq("sort");
             parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) order[begin + i] = tmp[i].tri; });
             lapq("write back");
+            PlannerPool::get().wait(sumTask, PlannerPool::MEDIUM);
+            lapq("wait for the centre sum");
+            parallelFor(n, [&](int i0, int i1) {
+                double rr = 0.0;
+                for (size_t j = 3 * (size_t)i0; j < 3 * (size_t)i1; j++) {
+                    const double dx = ce.x - (double)loc[3 * j], dy = ce.y - (double)loc[3 * j + 1], dz = ce.z - (double)loc[3 * j + 2];
+                    rr = std::max(rr, dx * dx + dy * dy + dz * dz);
+                }
+                std::lock_guard<std::mutex> g(m);
+                r2 = std::max(r2, rr);
+            });
+            lapq("radius");
         } else {
             for (int i = begin; i < end; i++)
                 for (int k = 0; k < 3; k++) {
@@ -209,7 +381,7 @@ struct HostBvhBuilder {
                 }
             // median split: sort the range by the first vertex's coordinate along `dim`
             KeyTri* tmp = scratchKeys + begin;
-            for (int i = 0; i < n; i++) { const int t = order[begin + i]; tmp[i] = KeyTri{comp(vtx(t, 0), dim), t}; }
+            for (int i = 0; i < n; i++) { const int t = order[begin + i]; tmp[i] = KeyTri{triV[9 * (size_t)t + dim], t}; }
             IntroSortLike sorter; sorter.maxThreads = sortThreads;
             sorter.sort(tmp, tmp + n);
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
@@ -221,9 +393,10 @@ struct HostBvhBuilder {
         double* nd = sph + 8 * (size_t)innerId;
         int refs[2];
         if (depth < maxParallelDepth && n > 4096) {
-            std::thread th([&]() { refs[0] = build(leftId, nd, begin, mid, depth + 1); });
+            PlannerPool::Group both;
+            PlannerPool::get().spawn(both, [&]() { refs[0] = build(leftId, nd, begin, mid, depth + 1); }, PlannerPool::LONG);
             refs[1] = build(rightId, nd + 4, mid, end, depth + 1);
-            th.join();
+            PlannerPool::get().wait(both, PlannerPool::LONG);
         } else {
             refs[0] = build(leftId, nd, begin, mid, depth + 1);
             refs[1] = build(rightId, nd + 4, mid, end, depth + 1);
@@ -472,10 +645,28 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     const uint64_t nn = T - 1;                                   // inner nodes
     // uninitialised on purpose: every slot is written by the planner thread that owns it (first touch happens there, in parallel)
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
-    std::unique_ptr<double[]> sph(new double[nSph]);
-    std::unique_ptr<int[]> kids(new int[nKids]);
-    if (nn == 0) { for (size_t i = 0; i < nSph; i++) sph[i] = 0.0; kids[0] = kids[1] = ~0; }
-    std::unique_ptr<float[]> htvBuf(new float[9 * (size_t)T]);
+    // big arrays: 2 MB-aligned with a huge-page hint — first touch from a hundred threads at once otherwise spends tens of
+    // milliseconds in 4 KB page faults (measured: planner 0.07 -> 0.11 s when its phases got more parallel)
+    struct FreeDeleter { void operator()(void* p) const { free(p); } };
+    auto bigAlloc = [](size_t bytes) -> void* {
+        void* p = nullptr;
+        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        if (posix_memalign(&p, 2u << 20, rounded ? rounded : (2u << 20)) != 0) throw std::bad_alloc();
+        static const bool noThp = getenv("SDFHIP_BVH_NO_THP") != nullptr;
+        if (!noThp) madvise(p, rounded, MADV_HUGEPAGE);
+        // ... and touched up front by a few threads: the planner's hundred-odd workers faulting the same mapping at once was measured
+        // to stall single nodes for 40-60 ms
+        const int parts = (int)std::min<size_t>(16, rounded >> 21);
+        PlannerPool::get().run(parts < 1 ? 1 : parts, [&](int c) {
+            char* q = (char*)p;
+            for (size_t off = rounded * (size_t)c / (size_t)(parts < 1 ? 1 : parts) & ~(size_t)4095, e = rounded * (size_t)(c + 1) / (size_t)(parts < 1 ? 1 : parts); off < e; off += 4096) q[off] = 0;
+        });
+        return p;
+    };
+    std::unique_ptr<double, FreeDeleter> sph((double*)bigAlloc(8 * nSph));
+    std::unique_ptr<int, FreeDeleter> kids((int*)bigAlloc(4 * nKids));
+    if (nn == 0) { for (size_t i = 0; i < nSph; i++) sph.get()[i] = 0.0; kids.get()[0] = kids.get()[1] = ~0; }
+    std::unique_ptr<float, FreeDeleter> htvBuf((float*)bigAlloc(36 * (size_t)T));
     float* htv = htvBuf.get();
     HostBvhBuilder::parallelFor((int)T, [&](int t0, int t1) {
         for (size_t t = (size_t)t0; t < (size_t)t1; t++) for (int k = 0; k < 3; k++) {
@@ -486,8 +677,9 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     const double tGather = nowSeconds();
     HostBvhBuilder b;
     b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.get(); b.kids = kids.get(); b.triV = htv;
-    std::unique_ptr<KeyTri[]> sk(new KeyTri[T]); std::unique_ptr<float[]> sl(new float[9 * (size_t)T]);
-    b.scratchKeys = sk.get(); b.scratchLoc = sl.get();
+    std::unique_ptr<KeyTri, FreeDeleter> sk((KeyTri*)bigAlloc(sizeof(KeyTri) * (size_t)T)); std::unique_ptr<float, FreeDeleter> sl((float*)bigAlloc(36 * (size_t)T));
+    std::unique_ptr<uint32_t, FreeDeleter> sL((uint32_t*)bigAlloc(4 * (size_t)T)), sR((uint32_t*)bigAlloc(4 * (size_t)T));
+    b.scratchKeys = sk.get(); b.scratchLoc = sl.get(); b.scratchL = sL.get(); b.scratchR = sR.get();
     b.order.resize(T);
     for (uint32_t i = 0; i < T; i++) b.order[i] = (int)i;
     unsigned hc = std::thread::hardware_concurrency();
@@ -565,8 +757,9 @@ int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
     SDF_API_BEGIN
     if (!keys) return -1;
     std::vector<KeyTri> a(n), b(n);
-    for (uint64_t i = 0; i < n; i++) a[i] = b[i] = KeyTri{keys[i], (int)i};
-    IntroSortLike s; s.maxThreads = threads; s.minParallel = 64;          // small threshold: exercise the threaded paths
+    for (uint64_t i = 0; i < n; i++) a[i] = b[i] = KeyTri{(float)keys[i], (int)i};
+    IntroSortLike s; s.maxThreads = threads; s.minParallel = 64; s.minParPartition = 200;          // small thresholds: exercise the threaded paths
+    std::vector<uint32_t> sl(n + 1), sr(n + 1); s.scratchL = sl.data(); s.scratchR = sr.data();
     s.sort(a.data(), a.data() + n);
     std::sort(b.begin(), b.end(), keyLess);
     int diff = 0;

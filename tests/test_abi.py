@@ -83,7 +83,7 @@ def test_planner_sort_equals_std_sort():
     for n in (0, 1, 2, 16, 17, 100, 4097, 70001, 400000):
         inputs = [rng.random(n), rng.integers(0, max(1, n // 6 + 1), n).astype(np.float64), np.sort(rng.random(n)),
                   np.sort(rng.integers(0, 50, n).astype(np.float64))[::-1].copy(), np.repeat(rng.random(max(1, n // 3 + 1)), 3)[:n].copy(),
-                  np.zeros(n)]
+                  np.zeros(n), np.tile([1.0, 0.0], n // 2 + 1)[:n].copy(), np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.float64)]
         for keys in inputs:
             keys = np.ascontiguousarray(keys, dtype=np.float64)
             for threads in (1, 6):

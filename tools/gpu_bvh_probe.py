@@ -1,0 +1,14 @@
+"""BVH planner timing (SDFHIP_TIMING=1 prints the phases): icosphere subdivision PROBE_SUBDIV (8 = 1.31 M triangles)."""
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SDFHIP_TIMING", "1")
+import sdflib_amd as S
+from sdflib_amd import meshgen
+sub = int(os.environ.get("PROBE_SUBDIV", "8"))
+v, f = meshgen.bumpy_icosphere(sub)
+print("triangles", len(f), "hardware threads", os.cpu_count(), flush=True)
+for rep in range(int(os.environ.get('PROBE_REPS', '3'))):
+    mesh = S.Mesh(v, f)
+    t0 = time.perf_counter(); s = mesh.build_bvh(); dt = time.perf_counter() - t0
+    print(f"build_bvh: {dt:.4f} s (reported {s})", flush=True)
+    del mesh
