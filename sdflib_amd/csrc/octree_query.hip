@@ -248,7 +248,7 @@ static int ensureHostLayout(sdfhip_octree* T) {
 //   * one lane takes one (x, y) COLUMN of a leaf's points: the x- and y-contractions of tricubicValueGradFast (176 of its 192 flop)
 //     do not depend on z and are done once, each point of the column then costs 16 FMAs — in the very order of the point kernel's
 //     EVAL_FAST code, so both paths give identical bits;
-//   * leaves of one level have (nearly) the same number of points, so a launch per level keeps the lanes of a wave in step.
+//   * leaves of one level have (nearly) the same number of points: a wave only holds leaves of one level, so its lanes stay in step.
 // Points outside the start grid (box distance) are written by k_lattice_outside.  The plan (tables, ranges, per-level launch shapes)
 // is kept with the tree for the next call with the same lattice.  EVAL_EXACT keeps the point kernel: the reference's term order
 // cannot be contracted.
@@ -312,8 +312,11 @@ SDF_DEV uint32_t latLowerBound(const float* __restrict__ F, uint32_t n, float a)
 // dims: 3 words per level = the largest number of lattice indices a leaf of the level owns per axis
 __global__ void k_lat_ranges(const uint32_t* __restrict__ leafCell, uint32_t leaves, LatLevels L, const float* __restrict__ F, uint32_t nx, uint32_t ny, uint32_t nz,
                              uint16_t* __restrict__ ranges, uint32_t* __restrict__ dims) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= leaves) return;
+    __shared__ uint32_t blockDims[3 * kLatMaxLevels];
+    for (uint32_t k = threadIdx.x; k < 3u * kLatMaxLevels; k += blockDim.x) blockDims[k] = 0u;
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = i0 < leaves ? i0 : leaves - 1u;            // (idle lanes repeat the last leaf: same writes, same maxima)
     int l = 0;
     while (l + 1 < L.levels && i >= L.leafBase[l + 1]) l++;
     const float inv = __uint_as_float((uint32_t)(127 - l) << 23);          // 2^-l
@@ -323,7 +326,10 @@ __global__ void k_lat_ranges(const uint32_t* __restrict__ leafCell, uint32_t lea
     const uint32_t z0 = latLowerBound(F + nx + ny, nz, (float)cz * inv), z1 = latLowerBound(F + nx + ny, nz, (float)(cz + 1u) * inv);
     uint16_t* r = ranges + 6 * (size_t)i;
     r[0] = (uint16_t)x0; r[1] = (uint16_t)x1; r[2] = (uint16_t)y0; r[3] = (uint16_t)y1; r[4] = (uint16_t)z0; r[5] = (uint16_t)z1;
-    if (x1 > x0 && y1 > y0 && z1 > z0) { atomicMax(dims + 3 * l, x1 - x0); atomicMax(dims + 3 * l + 1, y1 - y0); atomicMax(dims + 3 * l + 2, z1 - z0); }
+    // per block first (a few hundred thousand atomics on the same dozen addresses took 9.6 ms; this takes microseconds)
+    if (x1 > x0 && y1 > y0 && z1 > z0) { atomicMax(&blockDims[3 * l], x1 - x0); atomicMax(&blockDims[3 * l + 1], y1 - y0); atomicMax(&blockDims[3 * l + 2], z1 - z0); }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < 3u * kLatMaxLevels; k += blockDim.x) if (blockDims[k]) atomicMax(dims + k, blockDims[k]);
 }
 
 // Work order.  A leaf narrower than a cache line writes partial lines; they are completed by its x-neighbours, which may be leaves of

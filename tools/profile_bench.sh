@@ -8,12 +8,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-}"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
 # PMC passes: counters only, with kernel-trace only (no sys/hip/hsa traces)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o bench -- $CMD > $OUT/bench_pmc_l2.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_sq -o bench -- $CMD > $OUT/bench_pmc_sq.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o bench -- $CMD > $OUT/bench_pmc_fetch.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench -- $CMD > $OUT/bench_pmc_write.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o bench -- $CMD > $OUT/bench_pmc_l2.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_sq -o bench -- $CMD > $OUT/bench_pmc_sq.log 2>&1
 cd $REPO
 python tools/summarize_rocpd.py gpurun_out/prof_$TAG gpurun_out/prof_$TAG/summary > gpurun_out/prof_$TAG/summary.txt 2>&1
 rm -f gpurun_out/prof_$TAG/*/bench_results.db          # keep only the text summaries (gpurun_out is capped at 64 MiB)
