@@ -1,15 +1,15 @@
-"""Dev probe: CONTINUITY build timing."""
-import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+"""CONTINUITY build of the C2 configuration with the phase times (SDFHIP_TIMING=1)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SDFHIP_TIMING", "1")
+import torch
 import sdflib_amd as S
-from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
-s = int(sys.argv[1]) if len(sys.argv) > 1 else 7
-depth = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-start = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-v, f = bumpy_icosphere(s); box = box_with_margin(v)
-m = S.Mesh(v, f); m.build_bvh()
-for it in range(2):
-    t = time.time(); oc = S.OctreeSdf(m, box, depth, start, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2); dt = time.time() - t
-    i = oc.info
-    print(f"continuity build {dt:.3f}s words={i.num_words} leaves={i.num_leaves} samples={i.num_samples} rescheduled={i.post_pass_scheduled}")
-    del oc
+from sdflib_amd import meshgen
+v, f = meshgen.bumpy_icosphere(int(os.environ.get("PROBE_SUBDIV", "7")))
+box = meshgen.box_with_margin(v)
+mesh = S.Mesh(v, f); mesh.build_bvh()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    tree = S.OctreeSdf(mesh, box, 8, 3, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
+    torch.cuda.synchronize(); print(f"build {time.perf_counter() - t0:.4f} s, words {tree.info.num_words}", flush=True)
+    del tree
