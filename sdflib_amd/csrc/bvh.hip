@@ -341,7 +341,7 @@ struct HostBvhBuilder {
             KeyTri* tmp = scratchKeys + begin;
             parallelFor(n, [&](int i0, int i1) { for (int i = i0; i < i1; i++) tmp[i] = KeyTri{loc[9 * (size_t)i + dim], order[begin + i]}; });
             IntroSortLike sorter; sorter.maxThreads = sortThreads; sorter.scratchL = scratchL + begin; sorter.scratchR = scratchR + begin;
-            { static const char* e1 = getenv("SDFHIP_BVH_MIN_PARALLEL"); static const char* e2 = getenv("SDFHIP_BVH_PAR_PARTITION");
+            { const char* e1 = getenv("SDFHIP_BVH_MIN_PARALLEL"); const char* e2 = getenv("SDFHIP_BVH_PAR_PARTITION");
               if (e1) sorter.minParallel = (size_t)atol(e1); if (e2) sorter.minParPartition = (size_t)atol(e2); }
             lapq("keys");
             sorter.sort(tmp, tmp + n);
@@ -634,51 +634,46 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
 
 extern "C" {
 
-int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
-    SDF_API_BEGIN
-    SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
-    std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
-    if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
-    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
+// The planner proper: host memory in, host memory out, no device involved.  sph / kids as in HostBvhBuilder (8 doubles + 2 ints per inner
+// node; one dummy node for a one-triangle mesh).  Returns the arrays in 2 MB-aligned blocks (free()).
+struct FreeDeleter { void operator()(void* p) const { free(p); } };
+static void* plannerAlloc(size_t bytes) {
+    // 2 MB-aligned with a huge-page hint, touched up front by a few threads: first touch of a fresh mapping by all the planner's workers
+    // at once was measured to stall single nodes for tens of milliseconds
+    void* p = nullptr;
+    const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    if (posix_memalign(&p, 2u << 20, rounded ? rounded : (2u << 20)) != 0) throw std::bad_alloc();
+    static const bool noThp = getenv("SDFHIP_BVH_NO_THP") != nullptr;
+    if (!noThp) madvise(p, rounded, MADV_HUGEPAGE);
+    int parts = (int)std::min<size_t>(16, rounded >> 21); if (parts < 1) parts = 1;
+    PlannerPool::get().run(parts, [&](int c) {
+        char* q = (char*)p;
+        for (size_t off = (rounded * (size_t)c / (size_t)parts) & ~(size_t)4095, e = rounded * (size_t)(c + 1) / (size_t)parts; off < e; off += 4096) q[off] = 0;
+    });
+    return p;
+}
+struct PlannedBvh { std::unique_ptr<double, FreeDeleter> sph; std::unique_ptr<int, FreeDeleter> kids; double gatherSeconds = 0, planSeconds = 0; int sortThreads = 0, parallelDepth = 0; };
+static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_t T) {
+    PlannedBvh R;
     const double t0 = nowSeconds();
-    const uint32_t T = mesh->numTriangles;
     const uint64_t nn = T - 1;                                   // inner nodes
-    // uninitialised on purpose: every slot is written by the planner thread that owns it (first touch happens there, in parallel)
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
-    // big arrays: 2 MB-aligned with a huge-page hint — first touch from a hundred threads at once otherwise spends tens of
-    // milliseconds in 4 KB page faults (measured: planner 0.07 -> 0.11 s when its phases got more parallel)
-    struct FreeDeleter { void operator()(void* p) const { free(p); } };
-    auto bigAlloc = [](size_t bytes) -> void* {
-        void* p = nullptr;
-        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-        if (posix_memalign(&p, 2u << 20, rounded ? rounded : (2u << 20)) != 0) throw std::bad_alloc();
-        static const bool noThp = getenv("SDFHIP_BVH_NO_THP") != nullptr;
-        if (!noThp) madvise(p, rounded, MADV_HUGEPAGE);
-        // ... and touched up front by a few threads: the planner's hundred-odd workers faulting the same mapping at once was measured
-        // to stall single nodes for 40-60 ms
-        const int parts = (int)std::min<size_t>(16, rounded >> 21);
-        PlannerPool::get().run(parts < 1 ? 1 : parts, [&](int c) {
-            char* q = (char*)p;
-            for (size_t off = rounded * (size_t)c / (size_t)(parts < 1 ? 1 : parts) & ~(size_t)4095, e = rounded * (size_t)(c + 1) / (size_t)(parts < 1 ? 1 : parts); off < e; off += 4096) q[off] = 0;
-        });
-        return p;
-    };
-    std::unique_ptr<double, FreeDeleter> sph((double*)bigAlloc(8 * nSph));
-    std::unique_ptr<int, FreeDeleter> kids((int*)bigAlloc(4 * nKids));
-    if (nn == 0) { for (size_t i = 0; i < nSph; i++) sph.get()[i] = 0.0; kids.get()[0] = kids.get()[1] = ~0; }
-    std::unique_ptr<float, FreeDeleter> htvBuf((float*)bigAlloc(36 * (size_t)T));
+    R.sph.reset((double*)plannerAlloc(8 * nSph));
+    R.kids.reset((int*)plannerAlloc(4 * nKids));
+    if (nn == 0) { for (size_t i = 0; i < nSph; i++) R.sph.get()[i] = 0.0; R.kids.get()[0] = R.kids.get()[1] = ~0; }
+    std::unique_ptr<float, FreeDeleter> htvBuf((float*)plannerAlloc(36 * (size_t)T));
     float* htv = htvBuf.get();
     HostBvhBuilder::parallelFor((int)T, [&](int t0, int t1) {
         for (size_t t = (size_t)t0; t < (size_t)t1; t++) for (int k = 0; k < 3; k++) {
-            const uint32_t v = mesh->hIdx[3 * t + k];
-            htv[9 * t + 3 * k] = mesh->hVerts[3 * (size_t)v]; htv[9 * t + 3 * k + 1] = mesh->hVerts[3 * (size_t)v + 1]; htv[9 * t + 3 * k + 2] = mesh->hVerts[3 * (size_t)v + 2];
+            const uint32_t v = hIdx[3 * t + k];
+            htv[9 * t + 3 * k] = hVerts[3 * (size_t)v]; htv[9 * t + 3 * k + 1] = hVerts[3 * (size_t)v + 1]; htv[9 * t + 3 * k + 2] = hVerts[3 * (size_t)v + 2];
         }
     });
     const double tGather = nowSeconds();
     HostBvhBuilder b;
-    b.verts = mesh->hVerts.data(); b.idx = mesh->hIdx.data(); b.sph = sph.get(); b.kids = kids.get(); b.triV = htv;
-    std::unique_ptr<KeyTri, FreeDeleter> sk((KeyTri*)bigAlloc(sizeof(KeyTri) * (size_t)T)); std::unique_ptr<float, FreeDeleter> sl((float*)bigAlloc(36 * (size_t)T));
-    std::unique_ptr<uint32_t, FreeDeleter> sL((uint32_t*)bigAlloc(4 * (size_t)T)), sR((uint32_t*)bigAlloc(4 * (size_t)T));
+    b.verts = hVerts; b.idx = hIdx; b.sph = R.sph.get(); b.kids = R.kids.get(); b.triV = htv;
+    std::unique_ptr<KeyTri, FreeDeleter> sk((KeyTri*)plannerAlloc(sizeof(KeyTri) * (size_t)T)); std::unique_ptr<float, FreeDeleter> sl((float*)plannerAlloc(36 * (size_t)T));
+    std::unique_ptr<uint32_t, FreeDeleter> sL((uint32_t*)plannerAlloc(4 * (size_t)T)), sR((uint32_t*)plannerAlloc(4 * (size_t)T));
     b.scratchKeys = sk.get(); b.scratchLoc = sl.get(); b.scratchL = sL.get(); b.scratchR = sR.get();
     b.order.resize(T);
     for (uint32_t i = 0; i < T; i++) b.order[i] = (int)i;
@@ -690,10 +685,37 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     if (getenv("SDFHIP_BVH_SORT_THREADS")) b.sortThreads = atoi(getenv("SDFHIP_BVH_SORT_THREADS"));
     double rootSphere[4];
     b.build(0, rootSphere, 0, (int)T, 0);
+    R.gatherSeconds = tGather - t0; R.planSeconds = nowSeconds() - tGather; R.sortThreads = b.sortThreads; R.parallelDepth = b.maxParallelDepth;
+    return R;
+}
+
+int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
+    std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
+    if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
+    { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
+    const double t0 = nowSeconds();
+    PlannedBvh P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles);
     const double tPlanned = nowSeconds();
-    SDF_TRY(installBvh(mesh, sph.get(), kids.get(), SDFHIP_HOST));
-    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", tGather - t0, tPlanned - tGather, b.sortThreads, b.maxParallelDepth, nowSeconds() - tPlanned);
+    SDF_TRY(installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST));
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", P.gatherSeconds, P.planSeconds, P.sortThreads, P.parallelDepth, nowSeconds() - tPlanned);
     if (seconds) *seconds = nowSeconds() - t0;
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+// Test hook (no GPU needed): plans the tree of a mesh given in host memory.  out_spheres: 8 doubles, out_children: 2 ints per inner node
+// (max(T - 1, 1) of them).  The vertices must be finite and the indices in range (sdfhip_mesh_create checks that for real meshes).
+int sdfhip_test_plan_bvh(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, double* out_spheres, int32_t* out_children, double* seconds) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(xyz && indices && out_spheres && out_children && num_triangles >= 1, "bad argument");
+    for (size_t i = 0; i < 3 * (size_t)num_triangles; i++) SDF_REQUIRE(indices[i] < num_vertices, "index out of range");
+    const double t0 = nowSeconds();
+    PlannedBvh P = planBvhHost(xyz, indices, num_triangles);
+    if (seconds) *seconds = nowSeconds() - t0;
+    const size_t nn = num_triangles > 1 ? num_triangles - 1 : 1;
+    memcpy(out_spheres, P.sph.get(), 64 * nn); memcpy(out_children, P.kids.get(), 8 * nn);
     return SDFHIP_OK;
     SDF_API_END
 }
