@@ -33,6 +33,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <chrono>
 #include <sys/mman.h>
 #include <stdlib.h>
 
@@ -215,6 +216,23 @@ struct IntroSortLike {
         if (m > 0 && (size_t)R[nr - m] < stop) stop = R[nr - m];
         return first + stop;
     }
+    // The same construction on one thread: two passes without a data-dependent branch (the scans of the textbook loop mispredict every
+    // other element on unsorted keys: 8-10 cycles per element against ~4 here), same arrangement, same return value.
+    size_t minListPartition = 96;
+    KeyTri* listPartition(KeyTri* first, KeyTri* last, KeyTri* pivot) {
+        const size_t n = (size_t)(last - first);
+        const float pk = pivot->key;
+        uint32_t* L = scratchL + (first - base); uint32_t* R = scratchR + (first - base);
+        size_t nl = 0, nr = 0;
+        for (size_t i = 0; i < n; i++) { const float k = first[i].key; L[nl] = (uint32_t)i; nl += !(k < pk); R[nr] = (uint32_t)i; nr += !(pk < k); }
+        size_t lo_t = 0, hi_t = nl < nr ? nl : nr;
+        while (lo_t < hi_t) { const size_t t = (lo_t + hi_t + 1) >> 1; if (L[t - 1] < R[nr - t]) lo_t = t; else hi_t = t - 1; }
+        const size_t m = lo_t;
+        for (size_t t = 1; t <= m; t++) std::iter_swap(first + L[t - 1], first + R[nr - t]);
+        size_t stop = (m < nl) ? (size_t)L[m] : n;
+        if (m > 0 && (size_t)R[nr - m] < stop) stop = R[nr - m];
+        return first + stop;
+    }
     void loop(KeyTri* first, KeyTri* last, int depthLimit) {
         PlannerPool& pool = PlannerPool::get();
         PlannerPool::Group helpers;
@@ -223,7 +241,9 @@ struct IntroSortLike {
             --depthLimit;
             KeyTri* mid = first + (last - first) / 2;
             moveMedianToFirst(first, first + 1, mid, last - 1);
-            KeyTri* cut = ((size_t)(last - first) >= minParPartition && maxThreads > 1 && scratchL) ? parallelPartition(first + 1, last, first) : unguardedPartition(first + 1, last, first);
+            const size_t len = (size_t)(last - first);
+            KeyTri* cut = (scratchL && len >= minParPartition && maxThreads > 1) ? parallelPartition(first + 1, last, first)
+                        : (scratchL && len >= minListPartition) ? listPartition(first + 1, last, first) : unguardedPartition(first + 1, last, first);
             if (maxThreads > 1 && (size_t)(last - cut) >= minParallel && (size_t)(cut - first) >= minParallel) {
                 { std::lock_guard<std::mutex> g(cutMutex); cuts.push_back((size_t)(cut - base)); }
                 KeyTri* l = last; const int dl = depthLimit;
@@ -361,29 +381,46 @@ struct HostBvhBuilder {
             });
             lapq("radius");
         } else {
-            for (int i = begin; i < end; i++)
+            // one sweep gathers the node's vertices into its slice of the scratch, sums them in range order (the only order-dependent
+            // quantity) and takes the AABB on the floats themselves (exact; same doubles after conversion); the radius and the keys
+            // then read the contiguous copy
+            float* loc = scratchLoc + 9 * (size_t)begin;
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+            const float fhi = std::numeric_limits<float>::max();
+            float tx = -fhi, ty = -fhi, tz = -fhi, bx = fhi, by = fhi, bz = fhi;
+            for (int i = 0; i < n; i++) {
+                const float* q = triV + 9 * (size_t)order[begin + i];
+                float* w = loc + 9 * (size_t)i;
+                for (int k = 0; k < 9; k++) w[k] = q[k];
                 for (int k = 0; k < 3; k++) {
-                    const D p = vtx(order[i], k);
-                    ce.x += p.x; ce.y += p.y; ce.z += p.z;
-                    top.x = std::max(top.x, p.x); bot.x = std::min(bot.x, p.x);
-                    top.y = std::max(top.y, p.y); bot.y = std::min(bot.y, p.y);
-                    top.z = std::max(top.z, p.z); bot.z = std::min(bot.z, p.z);
+                    const float px = q[3 * k], py = q[3 * k + 1], pz = q[3 * k + 2];
+                    sx += (double)px; sy += (double)py; sz += (double)pz;
+                    tx = px > tx ? px : tx; bx = px < bx ? px : bx; ty = py > ty ? py : ty; by = py < by ? py : by; tz = pz > tz ? pz : tz; bz = pz < bz ? pz : bz;
                 }
+            }
             const double cnt = (double)(3 * n);
-            ce.x /= cnt; ce.y /= cnt; ce.z /= cnt;
+            ce.x = sx / cnt; ce.y = sy / cnt; ce.z = sz / cnt;
+            top = D{(double)tx, (double)ty, (double)tz}; bot = D{(double)bx, (double)by, (double)bz};
             const double diag[3] = {top.x - bot.x, top.y - bot.y, top.z - bot.z};
             dim = (int)(std::max_element(diag, diag + 3) - diag);
-            for (int i = begin; i < end; i++)
-                for (int k = 0; k < 3; k++) {
-                    const D p = vtx(order[i], k);
-                    const double dx = ce.x - p.x, dy = ce.y - p.y, dz = ce.z - p.z;
-                    r2 = std::max(r2, dx * dx + dy * dy + dz * dz);
-                }
+            double ra = 0.0, rb = 0.0, rc = 0.0;                 // a maximum: any grouping gives the same value
+            for (int i = 0; i < n; i++) {
+                const float* w = loc + 9 * (size_t)i;
+                const double ax = ce.x - (double)w[0], ay = ce.y - (double)w[1], az = ce.z - (double)w[2];
+                const double bx2 = ce.x - (double)w[3], by2 = ce.y - (double)w[4], bz2 = ce.z - (double)w[5];
+                const double cx2 = ce.x - (double)w[6], cy2 = ce.y - (double)w[7], cz2 = ce.z - (double)w[8];
+                ra = std::max(ra, ax * ax + ay * ay + az * az); rb = std::max(rb, bx2 * bx2 + by2 * by2 + bz2 * bz2); rc = std::max(rc, cx2 * cx2 + cy2 * cy2 + cz2 * cz2);
+            }
+            r2 = std::max(ra, std::max(rb, rc));
             // median split: sort the range by the first vertex's coordinate along `dim`
             KeyTri* tmp = scratchKeys + begin;
-            for (int i = 0; i < n; i++) { const int t = order[begin + i]; tmp[i] = KeyTri{triV[9 * (size_t)t + dim], t}; }
-            IntroSortLike sorter; sorter.maxThreads = sortThreads;
-            sorter.sort(tmp, tmp + n);
+            for (int i = 0; i < n; i++) tmp[i] = KeyTri{loc[9 * (size_t)i + dim], order[begin + i]};
+            if (n <= 16) IntroSortLike::insertionSort(tmp, tmp + n);          // what introsort does with a range this short
+            else {
+                IntroSortLike sorter; sorter.maxThreads = sortThreads; sorter.scratchL = scratchL + begin; sorter.scratchR = scratchR + begin;
+                if (const char* e = getenv("SDFHIP_BVH_LIST_PARTITION")) sorter.minListPartition = (size_t)atol(e);
+                sorter.sort(tmp, tmp + n);
+            }
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
         }
         out[0] = ce.x; out[1] = ce.y; out[2] = ce.z; out[3] = std::sqrt(r2);
