@@ -413,6 +413,41 @@ __global__ void __launch_bounds__(128) kc_pp_sample_all(CMesh m, const OpDev* __
     opSource(op, LT, P, vv, ce, half);
     exactSample(m, ce + midRel((int)mi) * half, scratch + 216 * (size_t)op.scratch + 64 + 8 * mi, s_stack + threadIdx.x);
 }
+// The same samples through the two-phase search (dev_bvh_fast.h): list the positions, search, then evaluate.
+__global__ void __launch_bounds__(128) kc_pp_list(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, float* __restrict__ pos, uint32_t* __restrict__ slot,
+                                                  uint32_t* __restrict__ count) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = gid < 19u * nOps;
+    uint32_t o = 0, mi = 0; OpDev op{};
+    if (active) { o = gid / 19u; mi = gid - 19u * o; op = ops[o]; active = !(op.kind != 0 || op.recycle || (op.samplesMask & (1u << (18 - mi)))); }
+    const uint64_t mask = __ballot(active);
+    if (mask == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (!active) return;
+    const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const float* vv; F3 ce; float half;
+    opSource(op, LT, P, vv, ce, half);
+    const F3 p = ce + midRel((int)mi) * half;
+    pos[3 * (size_t)at] = p.x; pos[3 * (size_t)at + 1] = p.y; pos[3 * (size_t)at + 2] = p.z;
+    slot[at] = gid;
+}
+__global__ void __launch_bounds__(128) kc_pp_values(CMesh m, const OpDev* __restrict__ ops, const float* __restrict__ pos, const uint32_t* __restrict__ slot,
+                                                    const uint32_t* __restrict__ triOf, uint32_t n, float* __restrict__ scratch) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t gid = slot[i], o = gid / 19u, mi = gid - 19u * o, t = triOf[i];
+    const F3 p = F3{pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2]};
+    const uint32_t a = m.idx[3 * t], b = m.idx[3 * t + 1], c = m.idx[3 * t + 2];
+    F3 g;
+    const float d = signedDistPointTriangleGrad(p, m.td + (size_t)TD_FLOATS * t, F3{m.verts[3 * a], m.verts[3 * a + 1], m.verts[3 * a + 2]},
+                                                F3{m.verts[3 * b], m.verts[3 * b + 1], m.verts[3 * b + 2]}, F3{m.verts[3 * c], m.verts[3 * c + 1], m.verts[3 * c + 2]}, g);
+    float* out8 = scratch + 216 * (size_t)ops[o].scratch + 64 + 8 * mi;
+    out8[0] = d; out8[1] = g.x; out8[2] = g.y; out8[3] = g.z; out8[4] = 0.f; out8[5] = 0.f; out8[6] = 0.f; out8[7] = 0.f;
+}
 // children of every subdividing op -> pool
 __global__ void __launch_bounds__(256) kc_pp_children(const OpDev* __restrict__ ops, uint32_t nOps, LevelTable LT, PoolDev P, const float* __restrict__ scratch,
                                                       float* __restrict__ pcenter, float* __restrict__ phalf, float* __restrict__ pvv) {
@@ -687,6 +722,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SampleScratch SS;
     SS.near = &ctx->nearScratch; ctx->nearScratch.counterReady = false;      // (builds on one context are serialised by its buildLock)
     if (ctx->exchange.world >= 1 && ctx->exchange.acquire) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
+    DevBuf<float> ppPos; DevBuf<uint32_t> ppSlot, ppTri, ppCount;      // post-pass samples through the two-phase search
     DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist, wordVals; std::vector<uint32_t> hWordVals;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
         // write the same centres / coordinates again together with everything else — and take the root corners and all their
@@ -984,7 +1020,20 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     if (no) kc_pp_geom<<<gridFor(8ull * no, 256), 256, 0, st>>>(dops.p + gBegin[g], no, LT, PD, pCenter.p, pHalf.p);
                 }
                 const uint32_t na = (uint32_t)all.size();
-                kc_pp_sample_all<<<gridFor(19ull * na, 128), 128, stackBytes, st>>>(md, dops.p, na, LT, PD, scratch.p);
+                if (nearestExactOnly()) kc_pp_sample_all<<<gridFor(19ull * na, 128), 128, stackBytes, st>>>(md, dops.p, na, LT, PD, scratch.p);
+                else {
+                    SDF_TRY(ppPos.reserve(57ull * na)); SDF_TRY(ppSlot.reserve(19ull * na)); SDF_TRY(ppTri.reserve(19ull * na)); SDF_TRY(ppCount.reserve(1));
+                    SDF_HIP_CHECK(hipMemsetAsync(ppCount.p, 0, 4, st));
+                    kc_pp_list<<<gridFor(19ull * na, 128), 128, 0, st>>>(dops.p, na, LT, PD, ppPos.p, ppSlot.p, ppCount.p);
+                    uint32_t ns = 0;
+                    SDF_HIP_CHECK(hipMemcpyAsync(&ns, ppCount.p, 4, hipMemcpyDeviceToHost, st));
+                    SDF_HIP_CHECK(hipStreamSynchronize(st));
+                    if (ns) {
+                        int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
+                        SDF_TRY(nearestTwoPhase(st, md.bvh, ppPos.p, ns, ppTri.p, ctx->nearScratch, depth + 2, 0u, 1u));
+                        kc_pp_values<<<gridFor(ns, 128), 128, 0, st>>>(md, dops.p, ppPos.p, ppSlot.p, ppTri.p, ns, scratch.p);
+                    }
+                }
                 for (size_t g = 0; g + 1 < gBegin.size(); g++) {
                     const uint32_t no = (uint32_t)(gBegin[g + 1] - gBegin[g]);
                     if (!no) continue;
