@@ -308,11 +308,11 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, rows=None, src=None):
     r["value_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1)}
     bb = tree.get_grid_bounding_box(); size = float(bb[3] - bb[0])
     step = np.full(3, size / 256, dtype=np.float32); origin = (bb[:3] + 0.5 * step).astype(np.float32)
-    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_EXACT, device_out=True))
+    ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_EXACT, device_out=True), reps=20)
     words = int(tree.info.num_words)
     gbytes = 256 ** 3 * 16 + words * 4          # SURVEY 8(d) "G": 16 B written per point + the tree read once
     r["grid256_value_and_gradient"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
-                                       "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "note": "reference-order polynomial (~1100 flop/point): ALU bound, not HBM bound"}
+                                       "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4), "note": "reference-order polynomial, leaf-driven (k_lattice_columns_exact: the z-independent prefix of every term once per column, ~500 flop/point instead of 1100): ALU bound, not HBM bound; bit-identical to the point kernel and the oracle"}
     ms = _time_ms(lambda: tree.get_distance_grid(origin, step, (256, 256, 256), gradient=True, eval_mode=S.EVAL_FAST, device_out=True), reps=40)
     r["grid256_value_and_gradient_fast_eval"] = {"ms": round(ms, 4), "mqueries_s": round(256 ** 3 / ms / 1e3, 1), "algorithmic_gb_s": round(gbytes / ms / 1e6, 1),
                                                  "hbm_frac": round(gbytes / ms / 1e6 / HBM_PEAK_GBS, 4),

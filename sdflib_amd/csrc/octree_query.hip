@@ -250,8 +250,7 @@ static int ensureHostLayout(sdfhip_octree* T) {
 //     EVAL_FAST code, so both paths give identical bits;
 //   * leaves of one level have (nearly) the same number of points: a wave only holds leaves of one level, so its lanes stay in step.
 // Points outside the start grid (box distance) are written by k_lattice_outside.  The plan (tables, ranges, per-level launch shapes)
-// is kept with the tree for the next call with the same lattice.  EVAL_EXACT keeps the point kernel: the reference's term order
-// cannot be contracted.
+// is kept with the tree for the next call with the same lattice.  EVAL_EXACT lattices use the same plan (k_lattice_columns_exact).
 __global__ void k_lc_root(uint32_t G, uint32_t count, uint32_t* __restrict__ cell) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
@@ -462,6 +461,101 @@ __global__ void __launch_bounds__(256) k_lattice_columns(const float* __restrict
         }
         dist[at] = v;
         if (GRAD) { const F3 g = normalize(F3{gx, gy, gz}); grad[3 * at] = g.x; grad[3 * at + 1] = g.y; grad[3 * at + 2] = g.z; }
+    }
+}
+
+// EVAL_EXACT by columns.  The reference's literal order (dev_tricubic.h: every term is c * x..x * y..y * z..z from left to right, the terms
+// added one after the other) cannot be contracted — but the part of every term that precedes its z factors, c * x^i * y^j (times the
+// derivative's integer factor), is the same for all points of a column.  Those prefixes are computed once per column; a point then
+// costs the z multiplications and the additions only: about 500 flop for value + gradient instead of 1 100, with results that are
+// the point kernel's bit for bit (same operations in the same order on the same operands).
+template <int EX, int EY, int EZ>
+SDF_DEV void columnPrefixes(const float4* __restrict__ src, float fx, float fy, float (&P)[64]) {
+#pragma unroll
+    for (int n = 0; n < 64; n++) {
+        const int i = n & 3, j = (n >> 2) & 3, k = n >> 4;
+        const int fac = (EX ? i : 1) * (EY ? j : 1) * (EZ ? k : 1);
+        if (fac == 0) { P[n] = 0.f; continue; }
+        const float4 q = src[n >> 2];
+        const float c = (n & 3) == 0 ? q.x : ((n & 3) == 1 ? q.y : ((n & 3) == 2 ? q.z : q.w));
+        float t = (EX || EY || EZ) ? (float)fac * c : c;
+#pragma unroll
+        for (int a = 0; a < i - EX; a++) t = t * fx;
+#pragma unroll
+        for (int a = 0; a < j - EY; a++) t = t * fy;
+        P[n] = t;
+    }
+}
+template <int EX, int EY, int EZ>
+SDF_DEV float columnPoint(const float (&P)[64], float fz) {
+    float acc = 0.0f;
+    bool first = true;
+#pragma unroll
+    for (int n = 0; n < 64; n++) {
+        const int i = n & 3, j = (n >> 2) & 3, k = n >> 4;
+        const int fac = (EX ? i : 1) * (EY ? j : 1) * (EZ ? k : 1);
+        if (fac == 0) continue;
+        float t = P[n];
+#pragma unroll
+        for (int a = 0; a < k - EZ; a++) t = t * fz;
+        if ((EX || EY || EZ) && first) { acc = t; first = false; } else acc = acc + t;       // tricubicValueExact starts from 0.0f + t, the derivatives from t
+    }
+    return acc;
+}
+template <bool GRAD>
+__global__ void __launch_bounds__(256) k_lattice_columns_exact(const float* __restrict__ coef, const float* __restrict__ F, const uint16_t* __restrict__ ranges,
+                                                               const uint4* __restrict__ desc, const uint32_t* __restrict__ sortedLeaf, uint32_t waves, LatCols C,
+                                                               uint32_t nx, uint32_t ny, float* __restrict__ dist, float* __restrict__ grad) {
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= waves) return;
+    const uint4 D = desc[w];
+    const uint32_t level = __builtin_amdgcn_readfirstlane(D.z);
+    const uint32_t mx = C.mx[level], my = C.my[level];
+    const float scale = __uint_as_float((127u + level) << 23);
+    const uint32_t wInGroup = __builtin_amdgcn_readfirstlane(D.w), lane = threadIdx.x & 63u, cols = mx * my;
+    uint32_t rel, lx, ly;
+    if (cols <= 32u) {
+        const uint32_t k = 64u / cols, rowLen = k * mx;
+        ly = lane / rowLen;
+        const uint32_t rem = lane - ly * rowLen, li = rem / mx;
+        lx = rem - li * mx;
+        rel = wInGroup * k + li;
+        if (ly >= my) return;
+    } else {
+        const uint32_t tid = wInGroup * 64u + lane;
+        rel = tid / cols;
+        const uint32_t col = tid - rel * cols;
+        ly = col / mx; lx = col - ly * mx;
+    }
+    if (rel >= D.y) return;
+    const uint32_t leaf = sortedLeaf[D.x + rel];
+    const uint32_t* r32 = reinterpret_cast<const uint32_t*>(ranges + 6 * (size_t)leaf);
+    const uint32_t rx = r32[0], ry = r32[1], rz = r32[2];
+    const uint32_t x = (rx & 0xFFFFu) + lx, y = (ry & 0xFFFFu) + ly, z0 = rz & 0xFFFFu, z1 = rz >> 16;
+    if (x >= (rx >> 16) || y >= (ry >> 16) || z0 >= z1) return;
+    const float* Fz = F + nx + ny;
+    const float tx = F[x] * scale, ty = F[nx + y] * scale;
+    const float fx = tx - floorf(tx), fy = ty - floorf(ty);
+    const float4* src = reinterpret_cast<const float4*>(coef + 64ull * leaf);
+    const size_t plane = (size_t)nx * ny, at0 = ((size_t)z0 * ny + y) * nx + x;
+    {
+        float P[64];
+        columnPrefixes<0, 0, 0>(src, fx, fy, P);
+        size_t at = at0;
+        for (uint32_t z = z0; z < z1; z++, at += plane) {
+            const float tz = Fz[z] * scale, fz = tz - floorf(tz);
+            dist[at] = columnPoint<0, 0, 0>(P, fz);
+        }
+    }
+    if (GRAD) {
+        float PX[64], PY[64], PZ[64];
+        columnPrefixes<1, 0, 0>(src, fx, fy, PX); columnPrefixes<0, 1, 0>(src, fx, fy, PY); columnPrefixes<0, 0, 1>(src, fx, fy, PZ);
+        size_t at = at0;
+        for (uint32_t z = z0; z < z1; z++, at += plane) {
+            const float tz = Fz[z] * scale, fz = tz - floorf(tz);
+            const F3 g = normalize(F3{columnPoint<1, 0, 0>(PX, fz), columnPoint<0, 1, 0>(PY, fz), columnPoint<0, 0, 1>(PZ, fz)});
+            grad[3 * at] = g.x; grad[3 * at + 1] = g.y; grad[3 * at + 2] = g.z;
+        }
     }
 }
 
@@ -758,7 +852,7 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
     const unsigned blocks = gridFor(n, 256);
     static const bool noLeafDriven = getenv("SDFHIP_LATTICE_POINTS") != nullptr;      // A/B switch: always the point kernel
     bool answered = false;
-    if (eval_mode == SDFHIP_EVAL_FAST && !noLeafDriven) {
+    if (!noLeafDriven) {
         std::lock_guard<std::mutex> own(T->qLock);
         SDF_TRY(ensureLatticePlan(T, origin, step, nx, ny, nz));
         const sdfhip_octree::LatticePlan& P = T->lattice;
@@ -767,8 +861,13 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
             C.levels = (int)T->qLevelNodes.size(); C.G = (uint32_t)T->info.start_grid_size;
             for (const sdfhip_octree::LatticeClass& c : P.classes) { C.mx[c.level] = c.mx; C.my[c.level] = c.my; }
             const uint4* desc = reinterpret_cast<const uint4*>(P.waveDesc.p);
-            if (g) k_lattice_columns<true><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, g);
-            else k_lattice_columns<false><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, nullptr);
+            if (eval_mode == SDFHIP_EVAL_FAST) {
+                if (g) k_lattice_columns<true><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, g);
+                else k_lattice_columns<false><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, nullptr);
+            } else {
+                if (g) k_lattice_columns_exact<true><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, g);
+                else k_lattice_columns_exact<false><<<gridFor(P.waves, 4), 256, 0, st>>>(T->qCoef.p, P.F.p, P.ranges.p, desc, P.sortedLeaf.p, P.waves, C, nx, ny, d, nullptr);
+            }
             if (P.outside) {
                 const dim3 og(gridFor(nx, 256), ny, nz);
                 if (g) k_lattice_outside<true><<<og, 256, 0, st>>>(q, P.F.p, o, s, nx, ny, d, g);

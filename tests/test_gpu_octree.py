@@ -168,6 +168,15 @@ def test_leaf_driven_lattice_equals_the_point_kernel_bit_for_bit(small):
             same = bits(gl) == bits(gp)
             both_nan = np.isnan(gl) & np.isnan(gp)
             assert (same | both_nan).all(), (depth, start, dims, int((~(same | both_nan)).sum()))
+            # EVAL_EXACT goes the same way (k_lattice_columns_exact: the z-independent prefix of every term of the reference's literal
+            # sum is computed once per column): the reference-order point kernel is the yardstick
+            de, ge = gt.get_distance(q, gradient=True, eval_mode=S.EVAL_EXACT)
+            dle, gle = gt.get_distance_grid(org, stp, dims, gradient=True, eval_mode=S.EVAL_EXACT)
+            dve = gt.get_distance_grid(org, stp, dims, gradient=False, eval_mode=S.EVAL_EXACT)
+            assert np.array_equal(bits(dle), bits(de)) and np.array_equal(bits(dve), bits(de)), (depth, start, dims, int((bits(dle) != bits(de)).sum()))
+            same = bits(gle) == bits(ge)
+            both_nan = np.isnan(gle) & np.isnan(ge)
+            assert (same | both_nan).all(), (depth, start, dims, int((~(same | both_nan)).sum()))
 
 
 def test_sharded_build_emits_the_same_array(small, oracle):

@@ -15,7 +15,7 @@ bb = tree.get_grid_bounding_box(); size = float(bb[3] - bb[0])
 for n in [int(t) for t in os.environ.get('PROBE_N', '256,200,512').split(',')]:
     step = np.full(3, size / n, dtype=np.float32); origin = (bb[:3] + 0.5 * step).astype(np.float32)
     for grad in (True, False):
-        fn = lambda: tree.get_distance_grid(origin, step, (n, n, n), gradient=grad, eval_mode=S.EVAL_FAST, device_out=True)
+        fn = lambda: tree.get_distance_grid(origin, step, (n, n, n), gradient=grad, eval_mode=(S.EVAL_EXACT if os.environ.get('PROBE_EXACT') else S.EVAL_FAST), device_out=True)
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); first = (time.perf_counter() - t0) * 1e3
         for _ in range(3): fn()
         torch.cuda.synchronize()
