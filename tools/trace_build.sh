@@ -1,0 +1,18 @@
+#!/bin/bash
+# kernel trace of tools/gpu_build_probe.py: per-kernel totals divided by the number of builds (4)
+export TMPDIR=/tmp; REPO=$PWD; OUT=$REPO/gpurun_out/trace_build; mkdir -p $OUT; cd /tmp
+env "$@" timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/gpu_build_probe.py > $OUT/t.log 2>&1
+grep build $OUT/t.log
+python - <<PY
+import sqlite3,glob
+f=glob.glob("$OUT/t/**/*.db",recursive=True)
+db=sqlite3.connect(f[0])
+tabs=[r[0] for r in db.execute("select name from sqlite_master where type='table' or type='view'")]
+k=[t for t in tabs if t.startswith('kernels')][0]
+rows=list(db.execute(f"select name,count(*),sum(duration),max(duration) from {k} group by name order by sum(duration) desc"))
+tot=sum(r[2] for r in rows)
+print(f"GPU busy per build: {tot/4e6:.2f} ms in {sum(r[1] for r in rows)//4} launches")
+for n,c,s,mx in rows[:16]:
+    print(f"{n.split('(')[0][-44:]:46s} launches/build {c/4:6.1f}  ms/build {s/4e6:7.3f}  max {mx/1e6:6.3f} ms")
+PY
+rm -rf $OUT/t
