@@ -3,6 +3,7 @@
       the same mesh through the CONTINUITY builder (the exporter's default): whole 44.5 M-word array;
   C3  ExactOctreeSdf depth 7 / start 3 / min 128: nodes, written-flags, bit-packed sets, byte masks, 200 k queries with triangle ids;
   C5  256^3 lattice (cell centres, x fastest) value + gradient on the C2 tree: bit-exact in EVAL_EXACT, <= 1e-5 / 2e-4 in EVAL_FAST.
+  C4  (configs[3]) 1 310 720 triangles, depth 8 / start 3: nearest ids vs the oracle, four-device in-process sharded build == single build.
 The oracle runs under OpenMP on the box's host cores (canonical mode is thread-count invariant: tests/test_oracle_kats.py)."""
 import numpy as np
 import pytest
@@ -144,3 +145,48 @@ def test_non_star_shaped_geometry_torus_knot(oracle, gpu_ctx):
     inside = ((allp >= ge.get_grid_bounding_box()[:3]) & (allp < ge.get_grid_bounding_box()[3:])).all(axis=1)
     e0, t0 = oe.query(allp, tri=True); e1, t1 = ge.get_distance(allp, triangle=True)
     assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0[inside], t1[inside])
+
+
+def test_c4_one_million_triangles_sharded_equals_single_and_ids_match_the_oracle(oracle, gpu_ctx):
+    """BASELINE configs[3] at full size: 1 310 720 triangles, OctreeSdf depth 8 / start 3 / 1e-3.  (a) the nearest-triangle ids of
+    150 k random points equal the oracle's (planner + two-phase search at that scale); (b) the in-process multi-device build
+    (sdfhip_multi_*, four logical devices on this GPU: shards by start cell, all-gather-v, one replica per device) gives, on every
+    device, the array of the single-device build; (c) the single build's size is the one the bench reports."""
+    import ctypes as C
+    import sdflib_amd as S
+    from sdflib_amd._lib import lib, check, OctreeParams, OctreeInfo
+    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin, random_points_in_box
+    v, f = bumpy_icosphere(8)
+    assert len(f) == 1310720
+    box = box_with_margin(v)
+    gm, om = S.Mesh(v, f, gpu_ctx), oracle.Mesh(v, f)
+    pts = random_points_in_box(box, 150000, seed=99)
+    assert np.array_equal(gm.nearest_triangle(pts), om.nearest(pts))
+    single = S.OctreeSdf(gm, box, 8, 3, 1e-3, num_threads=2)
+    words = single.get_octree_data()
+    assert len(words) == 20058064 and int(single.info.num_leaves) == 307910
+    L = lib()
+    devs = (C.c_int * 4)(0, 0, 0, 0)
+    M = C.c_void_p()
+    check(L.sdfhip_multi_create(devs, 4, C.byref(M)))
+    try:
+        p = OctreeParams()
+        for k in range(3): p.box_min[k] = box[k]; p.box_max[k] = box[3 + k]
+        p.depth, p.start_depth, p.rule, p.algorithm, p.layout, p.fit_mode = 8, 3, S.RULE_TRAPEZOIDAL, S.ALG_NO_CONTINUITY, S.LAYOUT_SUBTREES, S.FIT_EXACT
+        p.rule_params[0] = 1e-3
+        trees = (C.c_void_p * 4)()
+        vv = np.ascontiguousarray(v, np.float32); ff = np.ascontiguousarray(f, np.uint32)
+        check(L.sdfhip_multi_octree_build(M, vv.ctypes.data_as(C.c_void_p), len(vv), ff.ctypes.data_as(C.c_void_p), len(ff), None, C.byref(p), None, trees))
+        try:
+            for r in (0, 3):
+                info = OctreeInfo()
+                check(L.sdfhip_octree_get_info(trees[r], C.byref(info)))
+                assert int(info.num_words) == len(words)
+                got = np.empty(len(words), np.uint32)
+                check(L.sdfhip_octree_download(trees[r], got.ctypes.data_as(C.c_void_p), 0))
+                assert np.array_equal(got, words), r
+        finally:
+            for r in range(4):
+                if trees[r]: L.sdfhip_octree_destroy(trees[r])
+    finally:
+        L.sdfhip_multi_destroy(M)
