@@ -39,6 +39,35 @@ __global__ void __launch_bounds__(256) k_gather_blocks(const uint32_t* __restric
     out[i] = acc;
 }
 
+// The same gather with the blocks fetched COOPERATIVELY: sixteen lanes read one lane's 256-byte block as one contiguous segment (an
+// instruction touches 8 cache lines instead of 64), the rows go through LDS to their owners, 16 source lanes at a time.
+constexpr int COOP_ROW = 68;                 // floats per LDS row: 64 + 4 of padding (b128 accesses of consecutive rows fall on different banks)
+__global__ void __launch_bounds__(256) k_gather_blocks_coop(const uint32_t* __restrict__ data, const uint32_t* __restrict__ block, uint64_t n, float* __restrict__ out) {
+    __shared__ float s_rows[4][16 * COOP_ROW];
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane >> 4, sub = lane & 15;
+    const bool live = i < n;
+    const uint32_t mine = live ? block[i] : 0u;
+    float acc = 0.f;
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + grp, srcLane = 16 * c + row;
+            const uint32_t blk = __shfl(mine, srcLane);
+            const float4 v = reinterpret_cast<const float4*>(data + 64ull * blk)[sub];
+            *reinterpret_cast<float4*>(&s_rows[w][row * COOP_ROW + 4 * sub]) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (grp == c) {
+            const float4* rowp = reinterpret_cast<const float4*>(&s_rows[w][sub * COOP_ROW]);
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const float4 v = rowp[q]; acc += (v.x + v.y) + (v.z + v.w); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (live) out[i] = acc;
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -50,7 +79,8 @@ int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const u
     SDF_REQUIRE(ctx && dev_data && dev_block_ids && dev_out, "NULL argument");
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
-    k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
+    if (getenv("SDFHIP_GATHER_COOP")) k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
+    else k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
     SDF_API_END
