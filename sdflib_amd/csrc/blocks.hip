@@ -79,8 +79,8 @@ int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const u
     SDF_REQUIRE(ctx && dev_data && dev_block_ids && dev_out, "NULL argument");
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
-    if (getenv("SDFHIP_GATHER_COOP")) k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
-    else k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);
+    if (getenv("SDFHIP_QUERY_LANE_LOADS")) k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);       // the pattern of k_octree_query
+    else k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);                                      // the pattern of k_octree_query_coop (default)
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
     SDF_API_END

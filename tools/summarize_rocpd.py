@@ -20,7 +20,7 @@ def short(name):
     return name[:90]
 
 
-SPLIT_BY_GRID = ("k_octree_query<", "k_gather_blocks")     # the same kernel is launched on different workloads: keep them apart
+SPLIT_BY_GRID = ("k_octree_query<", "k_octree_query_coop<", "k_gather_blocks")     # the same kernel is launched on different workloads: keep them apart
 
 
 def keyed(name, grid):
