@@ -679,6 +679,36 @@ def test_scalar_and_small_host_batches_are_answered_like_the_device(small, oracl
             assert np.array_equal(bits(dd), bits(d0)) and np.array_equal(bits(gd), bits(g0))
 
 
+def test_cooperative_fetch_kernel_on_ragged_batches(small, oracle):
+    """k_octree_query_coop shares every coefficient fetch among 16 lanes and passes the rows through LDS: batches whose size is not a
+    multiple of 16 / 64 / 256, batches that are entirely outside the grid, and batches where only some lanes of a wave are inside must
+    give the oracle's bits in every lane (device-resident points: no host shortcut)."""
+    import torch
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    gt = S.OctreeSdf(small["gm"], small["box"], 6, 3, 1e-3, num_threads=2)
+    ot = oracle.Octree(small["om"], small["box"], 6, 3, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    base = random_points_in_box(small["box"], 3000, seed=31)
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1023, 3000):
+        for variant in range(3):
+            pts = base[:n].copy()
+            if variant == 1: pts *= 3.0                                        # (almost) everything outside the grid
+            if variant == 2: pts[::3] = pts[::3] * 2.2 + 0.1                   # inside and outside lanes interleaved
+            d0, g0 = ot.query(pts, grad=True)
+            tp = torch.from_numpy(pts).cuda()
+            for mode in (S.EVAL_EXACT, S.EVAL_FAST):
+                d1, g1 = gt.get_distance(tp, gradient=True, eval_mode=mode)
+                d2 = gt.get_distance(tp, gradient=False, eval_mode=mode)
+                d1, g1, d2 = d1.cpu().numpy(), g1.cpu().numpy(), d2.cpu().numpy()
+                assert np.array_equal(bits(d1), bits(d2)), (n, variant, mode)
+                if mode == S.EVAL_EXACT:
+                    assert np.array_equal(bits(d1), bits(d0)), (n, variant)
+                    same = (bits(g1) == bits(g0)) | (np.isnan(g1) & np.isnan(g0))
+                    assert same.all(), (n, variant)
+                else:
+                    np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-5)
+
+
 def test_large_host_pointer_queries_are_pipelined_and_identical(small):
     """Host arrays of 3 M points (beyond the 32 MiB threshold): pinned piece by piece, uploaded / evaluated / downloaded in a pipeline.
     Same bits as the device-resident path; misaligned views of larger arrays (the pieces are page aligned, the arrays need not be)."""
