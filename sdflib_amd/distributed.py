@@ -5,7 +5,8 @@ The reference's own OpenMP decomposition makes every start-grid cell an independ
 builds its range on its GPU, and ONE exchange reassembles the node array:
     all-gather(body sizes) -> prefix sums give every rank's absolute body offset
     rank r emits its start-grid words and bodies with ABSOLUTE indices (no rebase pass needed afterwards)
-    all-gather(padded bodies), all-gather(padded grid slices)  [RCCL over xGMI; gloo in the CPU tests]
+    in-place all-gather-v of bodies and grid slices (rank r's segments broadcast from r at their final offsets: no padding)
+                                                               [RCCL over xGMI; gloo in the CPU tests]
     max-reduce(valueRange), min-reduce(minBorderValue)         (OctreeSdfDepthFirst.h:505-509)
 Every rank ends with the full, identical array (queries are then embarrassingly parallel).
 The partition / assembly logic is backend-agnostic torch code so that it is covered by world_size-2 gloo tests.
@@ -68,7 +69,7 @@ def _collective_device(dev, group=None):
 
 def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, group=None, stats=None):
     """Collective part: returns the full node array (int32 view of the u32 words) on every rank.
-    `stats` (dict, optional) receives ranks_seen and bytes_all_gathered (what the two padded all-gathers delivered to THIS rank).
+    `stats` (dict, optional) receives ranks_seen and bytes_all_gathered (the size of the assembled array: what the exchange left on THIS rank).
 
     grid_local: this rank's start-grid words (len = cells[1]-cells[0]); body_local: its bodies with ABSOLUTE indices
     already applied for offset = num_cells + sum(body_words of lower ranks)."""
@@ -80,24 +81,28 @@ def exchange_and_assemble(grid_local, body_local, body_words, cells, num_cells, 
     dist.all_gather(meta, mine, group=group)
     meta = torch.stack(meta).cpu().numpy()
     sizes = meta[:, 0]; begins = meta[:, 1]; ends = meta[:, 2]
-    max_body = int(sizes.max()); max_cells = int((ends - begins).max())
-    pb = torch.zeros(max(max_body, 1), dtype=torch.int32, device=dev); pb[:int(body_words)] = body_local[:int(body_words)]
-    pg = torch.zeros(max_cells, dtype=torch.int32, device=dev); pg[:cells[1] - cells[0]] = grid_local[:cells[1] - cells[0]]
-    gb = torch.empty(world * max(max_body, 1), dtype=torch.int32, device=dev)
-    gg = torch.empty(world * max_cells, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gb, pb, group=group)
-    dist.all_gather_into_tensor(gg, pg, group=group)
     total = num_cells + int(sizes.sum())
     if total >= (1 << 30):
         raise ValueError(f"assembled node array has {total} words: beyond the 30-bit node index of the reference layout")
-    if stats is not None:
-        stats["ranks_seen"] = int(len(meta)); stats["bytes_all_gathered"] = int(4 * (gb.numel() + gg.numel()))
+    # In-place all-gather-v (the construction of csrc/multi.hip): every rank writes its grid slice and its bodies at their FINAL
+    # position in the full array, then rank r's two segments are broadcast from r.  No padding to the largest shard (start cells are
+    # balanced by an estimate; bodies can differ by 2x), no reassembly copies; with RCCL the broadcasts are enqueued back to back.
     full = torch.empty(total, dtype=torch.int32, device=dev)
-    off = num_cells
+    offs = num_cells + np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    me = dist.get_rank(group)
+    full[int(begins[me]):int(ends[me])] = grid_local[:cells[1] - cells[0]]
+    full[int(offs[me]):int(offs[me]) + int(body_words)] = body_local[:int(body_words)]
+    work = []
     for r in range(world):
-        full[int(begins[r]):int(ends[r])] = gg[r * max_cells: r * max_cells + int(ends[r] - begins[r])]
-        full[off: off + int(sizes[r])] = gb[r * max(max_body, 1): r * max(max_body, 1) + int(sizes[r])]
-        off += int(sizes[r])
+        src = dist.get_global_rank(group, r) if group is not None else r
+        if ends[r] > begins[r]:
+            work.append(dist.broadcast(full[int(begins[r]):int(ends[r])], src=src, group=group, async_op=True))
+        if sizes[r] > 0:
+            work.append(dist.broadcast(full[int(offs[r]):int(offs[r]) + int(sizes[r])], src=src, group=group, async_op=True))
+    for w in work:
+        w.wait()
+    if stats is not None:
+        stats["ranks_seen"] = int(len(meta)); stats["bytes_all_gathered"] = int(4 * total)
     return full
 
 
