@@ -150,7 +150,7 @@ constexpr int NEAR_CHUNK = 32;              // queries a wave takes per atomic  
 // cand: [NEAR_K][numReps] ids; candCount[r] = number of ids written or NEAR_OVERFLOW.  counters: 8 u32, zero before the launch.
 // LDS: references u32 [stackDepth][BLOCK], queue u32 [NEAR_QUEUE][BLOCK], bounds u16 [stackDepth][BLOCK].
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand,
+__global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
                                                            uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
                                                            uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
                                                            unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk) {
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
         }
         if (__ballot(have) == 0ull) break;
         if (have) stIter++;
+        if (stats) { const uint64_t aliveNow = __ballot(have); if (lane == 0u) { atomicAdd(stats + 10, 1ull); atomicAdd(stats + 11, (unsigned long long)__popcll(aliveNow)); } }
         // ---- one pop per walking lane: a 4-wide node (one 64-byte line) or a triangle
         if (have && mode == 2 && nq == 0) { mode = 0; stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // seeded: the root, bound = -65504
         const bool walking = have && sp > 0 && mode != 2;
@@ -250,14 +251,18 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                     if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; }
                     if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
                         if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
+                            if (stats) atomicAdd(stats + 9, 1ull);
                             uint32_t keep = 0;
+                            // (against the STORED lower bounds: re-evaluating sixteen triangles here, in one lane while the other 63 wait, was
+                            // measured to happen for every third query and to cost the wave as much as everything else it does)
                             for (uint32_t i = 0; i < nc; i++) {
                                 const uint32_t id = cand[(size_t)i * numReps + r];
-                                if (triBounds32(b, id, p).lo <= U2) { cand[(size_t)keep * numReps + r] = id; keep++; }
+                                const float lo = candLo[(size_t)i * numReps + r];
+                                if (lo <= U2) { cand[(size_t)keep * numReps + r] = id; candLo[(size_t)keep * numReps + r] = lo; keep++; }
                             }
                             nc = keep;
                         }
-                        if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; nc++; } else overflow = true;
+                        if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; candLo[(size_t)nc * numReps + r] = tb.lo; nc++; } else overflow = true;
                     }
                 }
             }
@@ -499,7 +504,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
     if (!mine) return SDFHIP_OK;
     NearPlainAlloc plain;
-    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
+    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candLo.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
     if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(12)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 48, st)); S.counterReady = true; }
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 36, st));     // and so are the work counters of the persistent waves and the long list
@@ -518,14 +523,14 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     static const int drainLanes = getenv("SDFHIP_NEAR_DRAIN") ? atoi(getenv("SDFHIP_NEAR_DRAIN")) : NEAR_DRAIN_LANES;
     DevBuf<unsigned long long> stats;
     if (wantStats) { SDF_TRY(stats.reserve(16)); SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 128, st)); }
-    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
+    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
                                                             wantStats ? stats.p : nullptr, drainLanes, chunk);
     if (wantStats) {
-        unsigned long long h[9];
+        unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
         const double q = (double)(h[0] ? h[0] : 1);
-        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f\n",
-                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q);
+        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration\n",
+                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1));
     }
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candCount.p);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);

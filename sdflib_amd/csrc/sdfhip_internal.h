@@ -223,7 +223,8 @@ struct sdfhip_stage {
 // Scratch of the two-phase nearest-triangle search (dev_bvh_fast.h), kept with the context: plain device allocations that grow and
 // are reused by every build (they are the largest transient buffers of a build: 64 B per query).  Used under the context's buildLock.
 struct sdfhip_near_scratch {
-    sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList; sdfhip::DevBuf<uint8_t> candCount;   // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters, [10]: long list length
+    sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList; sdfhip::DevBuf<uint8_t> candCount; sdfhip::DevBuf<float> candLo;   // candLo: the candidates' lower bounds (k_near_candidates)
+      // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters, [10]: long list length
     bool counterReady = false;
 };
 
