@@ -511,7 +511,10 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
     // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
     const int worst = 3 * (stackDepth / 2 + 1) + 2;
-    static const int cap = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 32;
+    // measured: 32 entries for trees up to 2^20 triangles (C2, torus knot: 34 is 5 % slower, fewer waves per CU), 34 above (1.31 M triangles:
+    // one more 4-wide level, and with 32 entries 2.3 % of a level's queries overflowed into the low-occupancy long kernel: 0.039 -> 0.032 s)
+    static const int capEnv = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 0;
+    const int cap = capEnv ? capEnv : (bvh.numTriangles > (1u << 20) ? 34 : 32);
     const int sd = worst < cap ? worst : cap;
     const size_t lds = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (size_t)sd * 128 * 2;
     static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 8u;
@@ -528,9 +531,11 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     if (wantStats) {
         unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
+        uint32_t nLong = 0;
+        SDF_HIP_CHECK(hipMemcpyAsync(&nLong, S.fbCount.p + 10, 4, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
         const double q = (double)(h[0] ? h[0] : 1);
-        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration\n",
-                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1));
+        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration; %u queries handed to k_near_long\n",
+                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1), nLong);
     }
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candCount.p);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);

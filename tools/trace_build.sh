@@ -13,6 +13,7 @@ rows=list(db.execute(f"select name,count(*),sum(duration),max(duration) from {k}
 tot=sum(r[2] for r in rows)
 print(f"GPU busy per build: {tot/4e6:.2f} ms in {sum(r[1] for r in rows)//4} launches")
 for n,c,s,mx in rows[:16]:
-    print(f"{n.split('(')[0][-44:]:46s} launches/build {c/4:6.1f}  ms/build {s/4e6:7.3f}  max {mx/1e6:6.3f} ms")
+    nm = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-44:]
+    print(f"{nm:46s} launches/build {c/4:6.1f}  ms/build {s/4e6:7.3f}  max {mx/1e6:6.3f} ms")
 PY
 rm -rf $OUT/t
