@@ -252,14 +252,19 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                     if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
                         if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
                             if (stats) atomicAdd(stats + 9, 1ull);
-                            uint32_t keep = 0;
                             // (against the STORED lower bounds: re-evaluating sixteen triangles here, in one lane while the other 63 wait, was
-                            // measured to happen for every third query and to cost the wave as much as everything else it does)
-                            for (uint32_t i = 0; i < nc; i++) {
-                                const uint32_t id = cand[(size_t)i * numReps + r];
-                                const float lo = candLo[(size_t)i * numReps + r];
-                                if (lo <= U2) { cand[(size_t)keep * numReps + r] = id; candLo[(size_t)keep * numReps + r] = lo; keep++; }
-                            }
+                            // measured to happen for every third query and to cost the wave as much as everything else it does).  The sixteen
+                            // bounds are fetched by independent loads (one memory latency, not sixteen); entries move only behind the first gap.
+                            uint32_t keepMask = 0;
+#pragma unroll
+                            for (uint32_t i = 0; i < (uint32_t)NEAR_K; i++) keepMask |= (candLo[(size_t)i * numReps + r] <= U2) ? (1u << i) : 0u;
+                            uint32_t keep = (uint32_t)__builtin_ctz(~keepMask);             // the leading run of kept entries stays where it is
+                            for (uint32_t i = keep + 1u; i < (uint32_t)NEAR_K; i++)
+                                if ((keepMask >> i) & 1u) {
+                                    cand[(size_t)keep * numReps + r] = cand[(size_t)i * numReps + r];
+                                    candLo[(size_t)keep * numReps + r] = candLo[(size_t)i * numReps + r];
+                                    keep++;
+                                }
                             nc = keep;
                         }
                         if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; candLo[(size_t)nc * numReps + r] = tb.lo; nc++; } else overflow = true;
