@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <unordered_map>
+#include <sys/mman.h>
 #include <algorithm>
 #include <cstdlib>
 
@@ -555,6 +556,7 @@ struct LeafMap {
         while (keys[i] != NONE32) { if (keys[i] == k) return; i = (i + 1) & mask; }
         keys[i] = k; vals[i] = v; count++;
     }
+    void reserveFor(size_t more) { size_t cap = keys.size(); while (2 * (count + more + 1) > cap) cap *= 2; if (cap != keys.size()) rehash(cap); }
     void prefetch(uint32_t k) const { const size_t i = mix(k) & mask; __builtin_prefetch(&keys[i]); __builtin_prefetch(&vals[i]); }
     const LeafRef* find(uint32_t k) const {
         size_t i = mix(k) & mask;
@@ -563,26 +565,30 @@ struct LeafMap {
     }
 };
 
-// Host mirror of the node array: grows by realloc (mremap for large blocks: no copy) and never touches the 64-word payload
-// regions it merely reserves, so appending ~100 MB of leaf blocks during a post-pass costs neither page faults nor an upload.
+// Host mirror of the node array.  The planner touches 8 words of every 2 KB it appends (a child block, then eight reserved 256-byte
+// leaf payloads), i.e. EVERY page of the appended range once: with 4 KB pages that was a page fault per two subdivisions, a third of
+// the planner's time.  The mirror is therefore one reservation of address space for the largest possible array (30-bit index = 4 GB,
+// MAP_NORESERVE: untouched pages cost nothing), 2 MB aligned with a huge-page hint, so growing is free and a fault brings in 2 MB.
 struct HostWords {
-    uint32_t* p = nullptr; size_t n = 0, cap = 0;
+    uint32_t* p = nullptr; size_t n = 0; void* base = nullptr; size_t mapped = 0;
     HostWords() = default;
     HostWords(const HostWords&) = delete;
     HostWords& operator=(const HostWords&) = delete;
-    ~HostWords() { std::free(p); }
+    ~HostWords() { if (base) munmap(base, mapped); }
     size_t size() const { return n; }
     uint32_t* data() { return p; }
     uint32_t& operator[](size_t i) { return p[i]; }
     const uint32_t& operator[](size_t i) const { return p[i]; }
-    bool grow(size_t newSize) {                   // contents of the new part are unspecified
-        if (newSize > cap) {
-            size_t c = cap ? cap : (size_t)1 << 22;
-            while (c < newSize) c *= 2;
-            uint32_t* q = (uint32_t*)std::realloc(p, c * sizeof(uint32_t));
-            if (!q) return false;
-            p = q; cap = c;
+    bool grow(size_t newSize) {                   // contents of the new part are unspecified (zero, in fact)
+        if (!p) {
+            const size_t want = ((size_t)INDEX_MASK + 1u) * sizeof(uint32_t) + (2u << 20);
+            void* q = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (q == MAP_FAILED) return false;
+            base = q; mapped = want;
+            p = (uint32_t*)(((uintptr_t)q + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));
+            if (!getenv("SDFHIP_NO_THP")) madvise(p, (size_t)(INDEX_MASK + 1ull) * sizeof(uint32_t), MADV_HUGEPAGE);
         }
+        if (newSize > (size_t)INDEX_MASK + 1u) return false;
         n = newSize;
         return true;
     }
@@ -839,6 +845,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         std::vector<std::vector<OpDev>> gens;
         auto addOp = [&](uint32_t gen, const OpDev& op) { if (gens.size() <= gen) gens.resize(gen + 1); gens[gen].push_back(op); };
         std::vector<PNode> cache; std::vector<uint32_t> genOf;      // work list of one scheduled leaf, reused
+        cache.reserve(4096); genOf.reserve(4096);
+        if (pl.pool.capacity() < pl.pool.size() + 5ull * numCand) pl.pool.reserve(2 * (pl.pool.size() + 5ull * numCand));      // (growth by doubling would copy the pool several times per level)
+        pl.leaves.reserveFor(5ull * numCand);                 // one rehash up front instead of several in the middle of the pass
         for (uint32_t si = 0; si < numCand; si++) {
             // the planner is bound by host cache misses (random reads of the leaf table, the level mirrors and the word mirror):
             // run two prefetch stages ahead of the candidate being processed
@@ -952,6 +961,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                         k.srcLevel = NONE32; k.srcSlot = (uint32_t)pl.pool.size();
                         pl.pool.push_back(k);
                         cache.push_back(k); genOf.push_back(gen + 1);
+                        pl.leaves.prefetch(childIndex + ch);          // where the child registers itself when it is finalised (a table of tens of MB: a miss otherwise)
                         for (int q = 0; q < 6; q++) { const uint32_t ix = k.nIdx[q] & INDEX_MASK; if (ix < pl.hoc.size()) __builtin_prefetch(&pl.hoc[ix]); }
                     }
                     addOp(gen, op);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel trace of tools/gpu_build_probe.py: per-kernel totals divided by the number of builds (4)
 export TMPDIR=/tmp; REPO=$PWD; OUT=$REPO/gpurun_out/trace_build; mkdir -p $OUT; cd /tmp
-env "$@" timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/gpu_build_probe.py > $OUT/t.log 2>&1
+env "$@" timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/${PROBE_SCRIPT:-gpu_build_probe.py} > $OUT/t.log 2>&1
 grep build $OUT/t.log
 python - <<PY
 import sqlite3,glob
