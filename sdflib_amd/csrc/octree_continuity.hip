@@ -831,7 +831,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_TRY(sampleBatchBegin(st, md, B, SS, stackBytes, T->info.num_traversals));      // ended at the top of the next iteration
             N->sampled = true;
         }
+        pl.leaves.reserveFor(n);                     // sized once for the level; the slots of the entries sixteen ahead are prefetched
         for (uint32_t i = 0; i < n; i++) {
+            if (i + 16 < n) pl.leaves.prefetch(L->hWord[i + 16]);
             const bool leaf = (cd >= maxDepth) || L->hTerminal[i];
             if (leaf) pl.leaves.emplace(L->hWord[i], LeafRef{cd, i});
         }
