@@ -570,25 +570,33 @@ struct LeafMap {
 // the planner's time.  The mirror is therefore one reservation of address space for the largest possible array (30-bit index = 4 GB,
 // MAP_NORESERVE: untouched pages cost nothing), 2 MB aligned with a huge-page hint, so growing is free and a fault brings in 2 MB.
 struct HostWords {
-    uint32_t* p = nullptr; size_t n = 0; void* base = nullptr; size_t mapped = 0;
+    uint32_t* p = nullptr; size_t n = 0; void* base = nullptr; size_t mapped = 0; size_t heapCap = 0;
     HostWords() = default;
     HostWords(const HostWords&) = delete;
     HostWords& operator=(const HostWords&) = delete;
-    ~HostWords() { if (base) munmap(base, mapped); }
+    ~HostWords() { if (base) munmap(base, mapped); else std::free(p); }
     size_t size() const { return n; }
     uint32_t* data() { return p; }
     uint32_t& operator[](size_t i) { return p[i]; }
     const uint32_t& operator[](size_t i) const { return p[i]; }
-    bool grow(size_t newSize) {                   // contents of the new part are unspecified (zero, in fact)
+    bool grow(size_t newSize) {                   // contents of the new part are unspecified
+        if (newSize > (size_t)INDEX_MASK + 1u) return false;
         if (!p) {
             const size_t want = ((size_t)INDEX_MASK + 1u) * sizeof(uint32_t) + (2u << 20);
             void* q = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-            if (q == MAP_FAILED) return false;
-            base = q; mapped = want;
-            p = (uint32_t*)(((uintptr_t)q + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));
-            if (!getenv("SDFHIP_NO_THP")) madvise(p, (size_t)(INDEX_MASK + 1ull) * sizeof(uint32_t), MADV_HUGEPAGE);
+            if (q != MAP_FAILED) {
+                base = q; mapped = want;
+                p = (uint32_t*)(((uintptr_t)q + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));
+                if (!getenv("SDFHIP_NO_THP")) madvise(p, (size_t)(INDEX_MASK + 1ull) * sizeof(uint32_t), MADV_HUGEPAGE);
+            }
         }
-        if (newSize > (size_t)INDEX_MASK + 1u) return false;
+        if (!base && newSize > heapCap) {          // the reservation was refused (strict overcommit): an ordinary growing block
+            size_t c = heapCap ? heapCap : (size_t)1 << 22;
+            while (c < newSize) c *= 2;
+            uint32_t* q = (uint32_t*)std::realloc(p, c * sizeof(uint32_t));
+            if (!q) return false;
+            p = q; heapCap = c;
+        }
         n = newSize;
         return true;
     }
