@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
 // LDS with their lower bounds and filtered against the FINAL bound before they are written out.
 constexpr int NEAR_LONG_STACK = 6144, NEAR_LONG_CAND = 1024;
 __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ longList,
-                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, uint8_t* __restrict__ candCount) {
+                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, float* __restrict__ candLo, uint8_t* __restrict__ candCount) {
     __shared__ uint2 s_stack[NEAR_LONG_STACK];
     __shared__ uint2 s_cand[NEAR_LONG_CAND];
     const uint32_t lane = threadIdx.x;
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
                 const bool k = in && __uint_as_float(c.y) <= U2;
                 const uint64_t km = __ballot(k);
                 const uint32_t at = out + (uint32_t)__popcll(km & below);
-                if (k && at < (uint32_t)NEAR_K) cand[(size_t)at * numReps + r] = c.x;
+                if (k && at < (uint32_t)NEAR_K) { cand[(size_t)at * numReps + r] = c.x; candLo[(size_t)at * numReps + r] = __uint_as_float(c.y); }
                 out += (uint32_t)__popcll(km);
             }
             if (out > (uint32_t)NEAR_K) overflow = true;
@@ -453,7 +453,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand,
+__global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
                                                         const uint8_t* __restrict__ candCount, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
                                                         uint32_t* __restrict__ fbCount, uint32_t rank, uint32_t world) {
     __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK], s_frames[4 * (NEAR_MAX_TIES - 1) * BLOCK];
@@ -473,7 +473,8 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
             int n2 = 0;
             for (uint32_t i = 0; i < nc; i++) {
                 const uint32_t id = cand[(size_t)i * numReps + r];
-                if (triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
+                // (the fp32 lower bound recorded with the candidate rules most of them out of the tied set without a second fp64 evaluation)
+                if ((double)candLo[(size_t)i * numReps + r] <= thr && triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
             }
             if (n2 == 1) res = ids[0];
             else if (n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x);
@@ -542,8 +543,8 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
         fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration; %u queries handed to k_near_long\n",
                 h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1), nLong);
     }
-    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candCount.p);
-    k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
+    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p);
+    k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out);
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
