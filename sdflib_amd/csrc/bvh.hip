@@ -33,6 +33,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <pthread.h>
 #include <chrono>
 #include <sys/mman.h>
 #include <stdlib.h>
@@ -49,6 +50,8 @@ namespace sdfhip {
 // cannot starve each other however few workers there are.  Three classes of tasks — SHORT (a chunk of a data-parallel phase), MEDIUM
 // (a sub-range of a sort, a centre sum), LONG (a subtree) — and a waiter only helps with classes up to that of what it waits for:
 // a phase that picked up somebody's subtree would stall everything queued behind that phase for the length of the subtree.
+// (a fork()ed child inherits the pool object but none of its threads: it runs everything inline)
+static std::atomic<bool> g_plannerPoolForked{false};
 class PlannerPool {
 public:
     struct Group { std::atomic<int> left{0}; };
@@ -103,11 +106,12 @@ private:
         }
         if (getenv("SDFHIP_BVH_POOL_THREADS")) workers = std::max(0, atoi(getenv("SDFHIP_BVH_POOL_THREADS")));
         for (int i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
+        pthread_atfork(nullptr, nullptr, [] { g_plannerPoolForked.store(true); });
     }
 public:
     static PlannerPool& get() { static PlannerPool* p = new PlannerPool(); return *p; }
     void spawn(Group& grp, std::function<void()> fn, Class c) {
-        if (workers == 0) { fn(); return; }
+        if (workers == 0 || g_plannerPoolForked.load(std::memory_order_relaxed)) { fn(); return; }
         grp.left.fetch_add(1, std::memory_order_acq_rel);
         { std::lock_guard<std::mutex> g(m); q[c].push_back(Task{std::move(fn), &grp}); pending[c].fetch_add(1, std::memory_order_acq_rel); }
         if (sleepers.load(std::memory_order_acquire) > 0) cv.notify_one();
@@ -134,7 +138,7 @@ public:
     }
     // fn(0 .. parts-1), the caller included
     void run(int parts, const std::function<void(int)>& fn) {
-        if (parts <= 1 || workers == 0) { for (int i = 0; i < parts; i++) fn(i); return; }
+        if (parts <= 1 || workers == 0 || g_plannerPoolForked.load(std::memory_order_relaxed)) { for (int i = 0; i < parts; i++) fn(i); return; }
         Group grp;
         for (int i = 1; i < parts; i++) spawn(grp, [&fn, i]() { fn(i); }, SHORT);
         fn(0);

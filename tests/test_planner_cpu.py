@@ -85,3 +85,29 @@ def test_planner_result_does_not_depend_on_its_threading():
                 if val is None: os.environ.pop(k, None)
                 else: os.environ[k] = val
         assert np.array_equal(got[0].view(np.uint64), ref[0].view(np.uint64)) and np.array_equal(got[1], ref[1]), env
+
+
+def test_planner_works_in_a_forked_child():
+    """The planner's worker pool is created on first use and a fork()ed child inherits the pool object without its threads: the child
+    must plan inline (same tree) instead of waiting for workers that do not exist."""
+    from sdflib_amd import meshgen
+    v, f = meshgen.bumpy_icosphere(5)                        # 20 480 triangles: parallel phases are used in the parent
+    ref = planned(v, f)
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            got = planned(v, f)
+            code = 0 if (np.array_equal(got[0].view(np.uint64), ref[0].view(np.uint64)) and np.array_equal(got[1], ref[1])) else 4
+        finally:
+            os._exit(code)
+    import signal, time
+    deadline = time.time() + 60
+    while True:
+        done, status = os.waitpid(pid, os.WNOHANG)
+        if done: break
+        if time.time() > deadline:
+            os.kill(pid, signal.SIGKILL); os.waitpid(pid, 0)
+            raise AssertionError("the forked child hung in the planner")
+        time.sleep(0.05)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
