@@ -343,6 +343,16 @@ SDF_DEV bool sortedContains(const uint32_t* __restrict__ l, uint32_t len, uint32
     while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (l[mid] < v) lo = mid + 1; else hi = mid; }
     return lo < len && l[lo] == v;
 }
+// first position >= from with l[pos] >= v (l ascending): gallop from `from`, then bisect — cheap when the answer is near `from`
+SDF_DEV uint32_t lowerBoundFrom(const uint32_t* __restrict__ l, uint32_t len, uint32_t from, uint32_t v) {
+    if (from >= len || l[from] >= v) return from;
+    uint32_t lo = from, step = 1;                    // invariant: l[lo] < v
+    while (lo + step < len && l[lo + step] < v) { lo += step; step <<= 1; }
+    uint32_t hi = (lo + step < len) ? lo + step : len;          // l[hi] >= v or hi == len
+    lo++;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (l[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
 struct MergeArgs {
     uint32_t n; const uint32_t* inner; const uint32_t* childBase;
     const uint32_t* list; const uint32_t* listOff; const uint32_t* listLen;                 // this level's filtered lists
@@ -363,12 +373,20 @@ __global__ void __launch_bounds__(256) k_merge_union(MergeArgs a) {
     if (node >= a.n || !a.inner[node]) return;
     const uint32_t off = a.listOff[node], len = a.listLen[node], cb = a.childBase[node];
     uint32_t kept = 0;
+    // Both lists ascend, so the part of a child's list that can hold the 64 values of a chunk is a window that only moves forward:
+    // lanes 0..7 keep the window of child `lane` (a galloping search from where it was), and an element is then looked up in windows of
+    // a few dozen entries instead of in whole lists of thousands (dependent loads per element: ~38 -> ~10)
+    const uint32_t* wl = nullptr; uint32_t wlen = 0, wLo = 0, wHi = 0;
+    if (lane < 8) childFinal(a, cb + (uint32_t)lane, wl, wlen);
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t k = base + lane;
+        const uint32_t vmin = a.list[off + base], vmax = a.list[off + ((base + 63u < len) ? base + 63u : len - 1u)];
+        if (lane < 8) { wLo = lowerBoundFrom(wl, wlen, wLo, vmin); wHi = (vmax == 0xFFFFFFFFu) ? wlen : lowerBoundFrom(wl, wlen, wLo, vmax + 1u); }
         bool keep = false; uint32_t v = 0;
-        if (k < len) {
-            v = a.list[off + k];
-            for (uint32_t c = 0; c < 8 && !keep; c++) { const uint32_t* l; uint32_t ll; childFinal(a, cb + c, l, ll); keep = sortedContains(l, ll, v); }
+        if (k < len) v = a.list[off + k];
+        for (uint32_t c = 0; c < 8; c++) {
+            const uint32_t lo = __shfl(wLo, (int)c), hi = __shfl(wHi, (int)c);
+            if (k < len && !keep && hi > lo) { const uint32_t* l; uint32_t ll; childFinal(a, cb + c, l, ll); keep = sortedContains(l + lo, hi - lo, v); }
         }
         const unsigned long long mask = __ballot(keep);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
