@@ -137,6 +137,20 @@ static std::vector<std::pair<uint32_t, uint32_t>> partition(const std::vector<do
     const uint32_t n = (uint32_t)w.size();
     std::vector<double> cum(n); double t = 0; for (uint32_t i = 0; i < n; i++) { t += w[i] + 1e-9; cum[i] = t; }
     std::vector<uint32_t> cuts{0};
+    // SDFHIP_MULTI_CUTS="c1,c2,..." (world - 1 ascending cell indices) replaces the balanced cuts: tests use it to reassemble
+    // deliberately lopsided shards.  Ignored unless it is a valid cut list for this build.
+    if (const char* e = getenv("SDFHIP_MULTI_CUTS")) {
+        std::vector<uint32_t> given;
+        for (const char* q = e; *q;) { char* end; const unsigned long c = strtoul(q, &end, 10); if (end == q) break; given.push_back((uint32_t)c); q = *end == ',' ? end + 1 : end; }
+        bool ok = (int)given.size() == world - 1;
+        for (size_t i = 0; ok && i < given.size(); i++) ok = given[i] > (i ? given[i - 1] : 0u) && given[i] < n;
+        if (ok) {
+            std::vector<std::pair<uint32_t, uint32_t>> out;
+            given.insert(given.begin(), 0u); given.push_back(n);
+            for (int r = 0; r < world; r++) out.emplace_back(given[r], given[r + 1]);
+            return out;
+        }
+    }
     for (int r = 1; r < world; r++) {
         const double target = t * r / world;
         uint32_t c = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), target) - cum.begin()) + 1;

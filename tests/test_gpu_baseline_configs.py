@@ -149,9 +149,11 @@ def test_non_star_shaped_geometry_torus_knot(oracle, gpu_ctx):
 
 def test_c4_one_million_triangles_sharded_equals_single_and_ids_match_the_oracle(oracle, gpu_ctx):
     """BASELINE configs[3] at full size: 1 310 720 triangles, OctreeSdf depth 8 / start 3 / 1e-3.  (a) the nearest-triangle ids of
-    150 k random points equal the oracle's (planner + two-phase search at that scale); (b) the in-process multi-device build
-    (sdfhip_multi_*, four logical devices on this GPU: shards by start cell, all-gather-v, one replica per device) gives, on every
-    device, the array of the single-device build; (c) the single build's size is the one the bench reports."""
+    150 k random points equal the oracle's (planner + two-phase search at that scale); (b) the single-device build's WHOLE node
+    array, value range and min border value equal the oracle's (its OpenMP build over the start cells, canonical mode); (c) the
+    in-process multi-device build (sdfhip_multi_*, four logical devices on this GPU: shards by start cell, all-gather-v, one replica
+    per device) gives that array on every device — with the balanced cuts and with deliberately lopsided ones (SDFHIP_MULTI_CUTS)."""
+    import os
     import ctypes as C
     import sdflib_amd as S
     from sdflib_amd._lib import lib, check, OctreeParams, OctreeInfo
@@ -164,12 +166,19 @@ def test_c4_one_million_triangles_sharded_equals_single_and_ids_match_the_oracle
     assert np.array_equal(gm.nearest_triangle(pts), om.nearest(pts))
     single = S.OctreeSdf(gm, box, 8, 3, 1e-3, num_threads=2)
     words = single.get_octree_data()
-    assert len(words) == 20058064 and int(single.info.num_leaves) == 307910
+    ot = oracle.Octree(om, box, 8, 3, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
+    assert np.array_equal(ot.data(), words), "C4 node array differs from the oracle's"
+    assert np.float32(single.info.value_range) == np.float32(ot.value_range) and np.float32(single.info.min_border_value) == np.float32(ot.min_border)
+    assert len(words) == 20058064 and int(single.info.num_leaves) == 307910          # the size the bench reports
+    del ot
     L = lib()
     devs = (C.c_int * 4)(0, 0, 0, 0)
     M = C.c_void_p()
     check(L.sdfhip_multi_create(devs, 4, C.byref(M)))
-    try:
+    for cuts in (None, "1,2,500", "300,301,302"):
+      if cuts is None: os.environ.pop("SDFHIP_MULTI_CUTS", None)
+      else: os.environ["SDFHIP_MULTI_CUTS"] = cuts
+      try:
         p = OctreeParams()
         for k in range(3): p.box_min[k] = box[k]; p.box_max[k] = box[3 + k]
         p.depth, p.start_depth, p.rule, p.algorithm, p.layout, p.fit_mode = 8, 3, S.RULE_TRAPEZOIDAL, S.ALG_NO_CONTINUITY, S.LAYOUT_SUBTREES, S.FIT_EXACT
@@ -184,9 +193,28 @@ def test_c4_one_million_triangles_sharded_equals_single_and_ids_match_the_oracle
                 assert int(info.num_words) == len(words)
                 got = np.empty(len(words), np.uint32)
                 check(L.sdfhip_octree_download(trees[r], got.ctypes.data_as(C.c_void_p), 0))
-                assert np.array_equal(got, words), r
+                assert np.array_equal(got, words), (cuts, r)
         finally:
             for r in range(4):
                 if trees[r]: L.sdfhip_octree_destroy(trees[r])
-    finally:
-        L.sdfhip_multi_destroy(M)
+      finally:
+        os.environ.pop("SDFHIP_MULTI_CUTS", None)
+    L.sdfhip_multi_destroy(M)
+
+
+def test_nearest_ids_equal_the_real_reference_at_full_size(gpu_ctx):
+    """tests/golden/ref_nearest_large.npz holds ids returned by the REFERENCE's own tmd::TriangleMeshDistance (compiled as it is
+    from /root/reference in the build container: oracle/ref_tmd.cpp, tests/golden/make_golden.py) for 124 k seeded points per mesh —
+    random, far-field, near-surface and exactly ON vertices / edges / faces — on the meshes of the BASELINE configs (327 680-triangle
+    bumpy sphere and torus knot, 1 310 720-triangle sphere).  The product's host planner + two-phase device search must return them."""
+    import os
+    import sdflib_amd as S
+    from conftest import ROOT
+    from refpoints import ref_fixture_cases, points_digest
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_nearest_large.npz"))
+    assert str(g["source"]) == "reference:TriangleMeshDistance.h"
+    for name, v, f, pts in ref_fixture_cases():
+        assert points_digest(pts) == int(g[name + "_digest"]), f"{name}: the seeded points are not the ones the fixture was recorded for"
+        got = S.Mesh(v, f, gpu_ctx).nearest_triangle(pts)
+        bad = np.nonzero(got != g[name + "_ids"])[0]
+        assert len(bad) == 0, f"{name}: {len(bad)} of {len(pts)} ids differ from the reference, first at point {bad[0]} {pts[bad[0]]}"

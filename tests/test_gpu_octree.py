@@ -98,7 +98,11 @@ def test_gpu_matches_committed_golden_vectors(gpu_ctx):
     gm = S.Mesh(g["vertices"], g["triangles"], gpu_ctx)
     td = gm.triangle_data()
     assert np.array_equal(bits(td[:, :28]), bits(g["triangle_data"][:, :28]))
+    # nearest ids are REFERENCE outputs (oracle/_ref: the reference's TriangleMeshDistance.h compiled as it is, make_golden.py),
+    # incl. points exactly on vertices / edges / faces where several triangles tie and the visiting order decides
+    assert str(g["nearest_ids_source"]) == "reference:TriangleMeshDistance.h"
     assert np.array_equal(gm.nearest_triangle(g["points"]), g["nearest_ids"])
+    assert np.array_equal(gm.nearest_triangle(g["tie_points"]), g["tie_nearest_ids"])
     t = S.OctreeSdf(gm, g["box"], int(g["depth"]), int(g["start_depth"]), 1e-3, num_threads=2)
     assert np.array_equal(t.get_octree_data(), g["octree_words"])
     assert np.float32(t.info.value_range) == g["octree_value_range"] and np.float32(t.info.min_border_value) == g["octree_min_border"]

@@ -197,7 +197,17 @@ def test_golden_vectors(oracle):
     assert np.array_equal(v, g["vertices"]) and np.array_equal(f, g["triangles"])
     m = oracle.Mesh(v, f)
     assert np.array_equal(bits(m.triangle_data()), bits(g["triangle_data"]))
+    # reference outputs (recorded from oracle/_ref = the reference's own TriangleMeshDistance.h, see make_golden.py): ids of
+    # random points, ids / distances of points exactly on vertices, edges and faces, and the reference's whole BVH
+    assert str(g["nearest_ids_source"]) == "reference:TriangleMeshDistance.h"
     assert np.array_equal(m.nearest(g["points"]), g["nearest_ids"])
+    tid, td = m.nearest(g["tie_points"], with_dist=True)
+    assert np.array_equal(tid, g["tie_nearest_ids"])
+    assert np.array_equal(td.view(np.uint64), np.abs(g["tie_distances"]).view(np.uint64))
+    sph, lr = m.bvh_export()
+    assert np.array_equal(lr, g["bvh_children"])
+    inner = lr[:, 0] != -1
+    assert np.array_equal(np.asarray(sph)[inner].view(np.uint64), g["bvh_spheres"][inner].view(np.uint64))
     oc = oracle.Octree(m, g["box"], int(g["depth"]), int(g["start_depth"]), 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES)
     assert np.array_equal(oc.data(), g["octree_words"])
     d, gr = oc.query(g["points"], grad=True)
@@ -206,6 +216,18 @@ def test_golden_vectors(oracle):
     nodes, has, sets, masks = ex.data()
     assert np.array_equal(nodes[:, 0], g["exact_nodes"][:, 0]) and np.array_equal(sets, g["exact_sets"]) and np.array_equal(masks, g["exact_masks"])
     assert np.array_equal(bits(ex.query(g["points"])), bits(g["exact_dist"]))
+
+
+def test_oracle_ids_equal_the_reference_fixture_at_full_size(oracle):
+    """tests/golden/ref_nearest_large.npz = ids recorded from the REAL reference (oracle/_ref, make_golden.py) on the BASELINE
+    configs' meshes; needs no /root/reference, so it also guards the oracle on the GPU box."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from refpoints import ref_fixture_cases, points_digest
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_nearest_large.npz"))
+    assert str(g["source"]) == "reference:TriangleMeshDistance.h"
+    for name, v, f, pts in ref_fixture_cases()[:2]:            # the 1.31 M-triangle case is covered by test_oracle_ref_pin.py and the GPU suite
+        assert points_digest(pts) == int(g[name + "_digest"])
+        assert np.array_equal(oracle.Mesh(v, f).nearest(pts), g[name + "_ids"]), name
 
 
 def _leaf_histogram(data, G3, start):
