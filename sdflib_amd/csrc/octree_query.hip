@@ -765,7 +765,10 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     const uintptr_t PAGE = 4096, PIECE = 8u << 20;
     struct Reg { void* p; };
     std::vector<Reg> regs;
-    auto pin = [&](uintptr_t b, uintptr_t e) { if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
+    // SDFHIP_TEST_PIN_FAIL_AFTER=k: the (k+1)-th registration of a call is refused (tests drive the partial-fallback path with it)
+    const char* failEnv = getenv("SDFHIP_TEST_PIN_FAIL_AFTER");
+    const long failAfter = failEnv ? atol(failEnv) : -1;
+    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
     auto unpinAll = [&]() { for (const Reg& r : regs) (void)hipHostUnregister(r.p); regs.clear(); };
     const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = inB & ~(PAGE - 1), end = (inE + PAGE - 1) & ~(PAGE - 1);
     const uint64_t pieces = (end - base + PIECE - 1) / PIECE;
@@ -860,7 +863,7 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
             if (prc < 0) return prc;
             if (done == n) return SDFHIP_OK;
             if (done > 0) {        // a later piece could not be pinned: the rest through the plain path
-                own.unlock();
+                if (own.owns_lock()) own.unlock();          // held only for calls of at most kStageKeepBytes whose try_lock succeeded
                 return sdfhip_octree_query(T, xyz + 3 * done, n - done, out_dist + done, out_grad ? out_grad + 3 * done : nullptr, where, eval_mode);
             }
         }

@@ -16,5 +16,13 @@ timeout 700 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_
 timeout 700 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU -d $OUT/pmc_sq -o bench -- $CMD > $OUT/bench_pmc_sq.log 2>&1
 cd $REPO
 python tools/summarize_rocpd.py gpurun_out/prof_$TAG gpurun_out/prof_$TAG/summary > gpurun_out/prof_$TAG/summary.txt 2>&1
+# what ties the counters to the code: hashes of the sources the profiled library was built from (bench.py refuses a profile whose hashes
+# differ from the files it is run with; the GPU box has no .git, so the commit id is added when the summaries are copied to profiles/)
+python - <<PY > gpurun_out/prof_$TAG/summary_meta.json
+import json, sys, time
+sys.path.insert(0, "$REPO")
+import bench
+print(json.dumps({"tag": "$TAG", "command": "$CMD", "recorded_unix": int(time.time()), "source_hashes": bench.source_hashes()}, indent=1))
+PY
 rm -f gpurun_out/prof_$TAG/*/bench_results.db          # keep only the text summaries (gpurun_out is capped at 64 MiB)
 ls gpurun_out/prof_$TAG
