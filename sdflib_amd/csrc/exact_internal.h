@@ -27,7 +27,7 @@ struct ExLevel {
 
 // scratch of the leaf-sorted batched query, kept with the tree (grow-only) so that a call costs no hipMalloc / hipFree
 struct sdfhip_exact_scratch {
-    sdfhip::DevBuf<uint32_t> key, keyS, qi, qiS, qctx; sdfhip::DevBuf<unsigned char> tmp; std::mutex lock;
+    sdfhip::DevBuf<uint32_t> key, keyS, qi, qiS; sdfhip::DevBuf<unsigned char> tmp; std::mutex lock;
 };
 
 struct sdfhip_exact {
@@ -40,6 +40,9 @@ struct sdfhip_exact {
     const float* frames() const { return ownFrames.p ? ownFrames.p : mesh->dFrames.p; }
     sdfhip_exact_info info{};
     float cellSize = 0.f;
+    // per node that a query can end in: {set index, first mask offset, second mask offset, entries of the set} — what the walk from the
+    // start grid finds on its way (exact_query.hip, ensureLeafCtx): made once, on the first batched query, 16 bytes per node
+    sdfhip::DevBuf<uint32_t> leafCtx; bool leafCtxReady = false; std::mutex leafCtxLock;
     sdfhip::DevBuf<uint32_t> nodes;        // 2 words per node
     sdfhip::DevBuf<uint8_t> hasTri;
     sdfhip::DevBuf<uint32_t> sets;

@@ -16,6 +16,8 @@ struct ExactView {
     const uint32_t* nodes; const uint32_t* sets; const uint8_t* masks; const float* td; const float* frames;
     float bminx, bminy, bminz, bmaxx, bmaxy, bmaxz, cellSize;
     int G; uint32_t startDepth, bitEnc, bits;
+    uint32_t numNodes;                     // also the sort key of a query outside the grid (sorts behind every node)
+    uint64_t maskBytes, setWords;          // array lengths (both arrays carry padding behind them): the batched decode clamps its look-ahead loads
 };
 
 SDF_HD uint32_t unpackIndex(const uint32_t* __restrict__ set, uint32_t bIdx, uint32_t bits) {
@@ -111,17 +113,13 @@ static int ensureHostCopy(sdfhip_exact* T) {
 }
 
 // ---- leaf-sorted, wave-cooperative path (large batches) ------------------------------------------------------------------
-// k_exact_locate walks every query down to its leaf and records (leaf id, set / mask positions); queries are then
-// radix-sorted by leaf id so that the queries of one leaf sit next to each other.  k_exact_sorted gives each wave 64
-// consecutive sorted queries: for every distinct leaf in them the wave decodes the leaf's triangle list ONCE (bit-packed
-// set filtered through the byte masks with __ballot/popcount ranks), stages the surviving triangles' 80-byte frames in LDS
-// (each triangle fetched once per wave instead of once per query lane) and all lanes of that leaf scan the staged tile
-// in list order — so the first-minimum rule of the reference is preserved.  The lanes of the wave that do not hold a query of
-// the current leaf help with its triangles (see the comment in the kernel).
+// k_exact_locate walks every query down to the node it ends in and records that node's id; queries are then radix-sorted by it so that
+// the queries of one leaf sit next to each other, and k_exact_tiles (below) gives each wave 64 consecutive sorted queries: for every
+// distinct leaf in them the wave decodes the leaf's triangle list ONCE and all of the leaf's queries share the staged triangles.
 constexpr uint32_t QNONE = 0xFFFFFFFFu;
 
 __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
-                                                      uint32_t* __restrict__ tri, uint32_t* __restrict__ key, uint32_t* __restrict__ qidx, uint32_t* __restrict__ qctx) {
+                                                      uint32_t* __restrict__ tri, uint32_t* __restrict__ key, uint32_t* __restrict__ qidx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     qidx[i] = (uint32_t)i;
@@ -138,7 +136,7 @@ __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* 
         const F3 qm = F3{gmax(q.x, 0.f), gmax(q.y, 0.f), gmax(q.z, 0.f)};
         dist[i] = (length(qm) + gmin(gmax(q.x, gmax(q.y, q.z)), 0.0f)) + sqrtf(3.0f) * size.x;
         if (tri) tri[i] = 0;
-        key[i] = QNONE;
+        key[i] = v.numNodes;
         return;
     }
     uint32_t node = (uint32_t)((iz * v.G + iy) * v.G + ix);
@@ -150,117 +148,261 @@ __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* 
     };
     uint32_t depth = v.startDepth;
     while (!isLeaf(node) && depth < v.bitEnc) { node = descend(node); depth++; }
-    const uint32_t setIdx = v.nodes[2 * (size_t)node + 1];
-    uint32_t m1 = QNONE, m2 = QNONE;
     if (!isLeaf(node)) {
-        node = descend(node); m1 = v.nodes[2 * (size_t)node + 1];
-        if (!isLeaf(node)) { node = descend(node); m2 = v.nodes[2 * (size_t)node + 1]; }
+        node = descend(node);
+        if (!isLeaf(node)) node = descend(node);
     }
-    key[i] = node;
-    qctx[3 * i] = setIdx; qctx[3 * i + 1] = m1; qctx[3 * i + 2] = m2;
+    key[i] = node;          // what the node means for the query (set, masks) is in the tree's leafCtx table
+}
+
+// leafCtx (see exact_internal.h): the tree is walked level by level from the start grid, exactly as a query walks it — down to the
+// bit-encoding depth (or a leaf above it) for the packed set, then at most two more levels for the byte masks.
+struct CtxItem { uint32_t node, stage, set, m1; };
+__global__ void __launch_bounds__(256) k_exact_ctx_level(ExactView v, const CtxItem* __restrict__ in, uint32_t nIn, uint32_t depth, CtxItem* __restrict__ out,
+                                                         uint32_t* __restrict__ outCount, uint32_t* __restrict__ ctx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nIn) return;
+    CtxItem it = in[i];
+    const uint32_t w0 = v.nodes[2 * (size_t)it.node], aux = v.nodes[2 * (size_t)it.node + 1];
+    const bool leaf = (w0 & 0x80000000u) != 0u;
+    uint32_t m2 = QNONE;
+    bool final = false;
+    if (it.stage == 0) {
+        if (leaf || depth >= v.bitEnc) { it.set = aux; it.m1 = QNONE; it.stage = 1; final = leaf; }      // the node whose packed set a query decodes
+    } else if (it.stage == 1) { it.m1 = aux; it.stage = 2; final = leaf; }                                // first mask level
+    else { m2 = aux; final = true; }                                                                      // second mask level: the walk ends here
+    if (final) {
+        uint32_t* c = ctx + 4 * (size_t)it.node;
+        c[0] = it.set; c[1] = it.m1; c[2] = m2; c[3] = v.sets[it.set];
+        return;
+    }
+    const uint32_t base = atomicAdd(outCount, 8u);
+    const uint32_t child = w0 & 0x7FFFFFFFu;
+#pragma unroll
+    for (uint32_t k = 0; k < 8; k++) out[base + k] = CtxItem{child + k, it.stage, it.set, it.m1};
+}
+
+
+
+// ---- k_exact_tiles ------------------------------------------------------------------------------------------------------------------
+// A chunk of 64 set entries keeps a quarter of them on average, so survivors are compacted over the WHOLE set before any distance is
+// evaluated (evaluating chunk by chunk filled half the wave: 47 % of the lanes per VALU instruction in round 2's kernel).  Per run of
+// queries of one leaf:
+//   1. DECODE: the whole set streams through the two mask levels (ballot ranks) and the surviving triangle ids are COMPACTED into a
+//      per-wave LDS list (EX_IDS entries per round; longer lists take several rounds);
+//   2. EVALUATE: the list is walked in FULL tiles of 64 frames (80-byte packed frames gathered into LDS, one triangle per lane, stored as
+//      32 PAIRS with the two triangles' floats interleaved); lane (g, i) works for query i of the run on the tile's pairs g, g + G, ...;
+//      runs of more than 21 queries are cut into equal parts of 11..21 queries so that G x part fills at least 80 % of the wave; the
+//      distance of a point to BOTH triangles of a pair is one pass of packed fp32 instructions (sqDistPointTrianglePair: branch-free,
+//      every operation on two floats, the scalar routine's values bit for bit);
+//   3. REDUCE: the partial minima are 64-bit keys (distance bits << 32 | position in the leaf's list): the smallest key is the first
+//      minimum in list order, the reference's `d < best` rule, whatever the order of the ids — merged over g by a shuffle tree and handed
+//      to the query's own lane, which looks the triangle id up in the LDS list;
+//   4. once per WAVE, after its last run, all 64 lanes compute the signed distance (and gradient) of their own query's triangle.
+// One wave per block (64 threads): no block-level barriers, LDS per wave = ids + one frame tile.
+constexpr int EX_BATCH = 8;                   // chunks of 64 set entries decoded per round
+constexpr int EX_IDS = 64 * EX_BATCH;        // survivors of a round (LDS list)
+constexpr int EX_WORDS = (64 * EX_BATCH * 32 / 32 + 2 + 63) / 64;        // packed-set words a lane fetches per round at 32 bits per index (9)
+constexpr int EX_REC = 42;                   // floats per staged PAIR of frames: 40 + 2 so that the 32 records start in different banks
+constexpr unsigned long long EX_KEY_NONE = ((unsigned long long)0x7F800000u << 32);     // +inf at position 0: no candidate is smaller unless its distance is (`best = INFINITY`)
+
+SDF_DEV unsigned long long shflKey(unsigned long long k, int src) {
+    const uint32_t lo = __shfl((uint32_t)k, src), hi = __shfl((uint32_t)(k >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 template <bool GRAD>
-__global__ void __launch_bounds__(256) k_exact_sorted(ExactView v, const float* __restrict__ pts, uint64_t n, const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx,
-                                                      const uint32_t* __restrict__ qctx, float* __restrict__ dist, float* __restrict__ grad, uint32_t* __restrict__ tri) {
-    __shared__ float s_frames[4][64 * FRAME_FLOATS];
-    __shared__ uint32_t s_tri[4][64];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t e = (uint64_t)xcdLogicalBlock() * blockDim.x + threadIdx.x;       // queries are sorted by leaf: a contiguous range of leaves per XCD
-    uint32_t myKey = QNONE, q = 0;
+__global__ void __launch_bounds__(64) k_exact_tiles(ExactView v, const float* __restrict__ pts, uint64_t n, const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx,
+                                                    const uint4* __restrict__ leafCtx, float* __restrict__ dist, float* __restrict__ grad, uint32_t* __restrict__ tri) {
+    __shared__ __attribute__((aligned(16))) float s_pairs[32 * EX_REC];
+    __shared__ uint32_t s_ids[EX_IDS];
+    uint32_t* s_words = reinterpret_cast<uint32_t*>(s_pairs);          // the round's packed-set words live in the frame tile's space while it is idle
+    static_assert(64 * EX_WORDS <= 32 * EX_REC, "the frame tile must hold a round's set words");
+    const int lane = threadIdx.x;
+    const uint64_t e = (uint64_t)xcdLogicalBlock() * 64u + (uint64_t)lane;       // queries are sorted by leaf: a contiguous range of leaves per XCD
+    uint32_t myKey = v.numNodes, q = 0;
     if (e < n) { myKey = skey[e]; q = sidx[e]; }
-    const bool active = myKey != QNONE;
+    const bool active = myKey < v.numNodes;
     F3 p = F3{0.f, 0.f, 0.f};
     uint32_t cSet = 0, cM1 = QNONE, cM2 = QNONE;
-    if (active) { p = F3{pts[3 * (size_t)q], pts[3 * (size_t)q + 1], pts[3 * (size_t)q + 2]}; cSet = qctx[3 * (size_t)q]; cM1 = qctx[3 * (size_t)q + 1]; cM2 = qctx[3 * (size_t)q + 2]; }
+    uint32_t cCnt = 0;
+    if (active) {          // the lanes of a run read the same 16 bytes of the table: one request per run, not one per query
+        const uint4 c = leafCtx[myKey];
+        cSet = c.x; cM1 = c.y; cM2 = c.z; cCnt = c.w;
+        p = F3{pts[3 * (size_t)q], pts[3 * (size_t)q + 1], pts[3 * (size_t)q + 2]};
+    }
     bool done = !active;
+    unsigned long long acc = EX_KEY_NONE;                // this lane's own query: (distance bits, list position) of the nearest so far ...
+    uint32_t accTri = 0;                                 // ... and its triangle (0 while nothing was nearer than +inf, as in the reference)
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     for (;;) {
         const unsigned long long pending = __ballot(!done);
         if (pending == 0ull) break;
         const int leader = __ffsll((long long)pending) - 1;
         const uint32_t k = __shfl(myKey, leader);
-        const bool inRun = !done && myKey == k;
-        const uint32_t setIdx = __shfl(cSet, leader), m1i = __shfl(cM1, leader), m2i = __shfl(cM2, leader);
-        const uint32_t* set = v.sets + setIdx;
-        const uint32_t cnt = set[0];
-        const uint8_t* m1 = (m1i != QNONE) ? v.masks + m1i : nullptr;
-        const uint8_t* m2 = (m2i != QNONE) ? v.masks + m2i : nullptr;
-        // The run's queries sit in consecutive lanes [leader, leader + r).  Runs are short (about 10 queries per leaf at 10 M
-        // queries), so the (query, triangle) pairs of a tile are spread over the WHOLE wave: lane j works for the query of lane
-        // leader + j % r on the staged triangles g, g + G, ... with g = j / r, G = 64 / r, and the partial minima are merged
-        // afterwards by (distance, list position) — the first minimum in list order wins, exactly like the sequential scan.
+        const bool inRun = !done && myKey == k;          // sorted: the run's queries sit in lanes [leader, leader + r)
         const uint32_t r = (uint32_t)__popcll(__ballot(inRun));
-        const uint32_t G = 64u / r, g = (uint32_t)lane / r;
-        const int owner = leader + (int)((uint32_t)lane % r);
-        const F3 po = F3{__shfl(p.x, owner), __shfl(p.y, owner), __shfl(p.z, owner)};
-        float best = INFINITY; uint32_t bestTri = 0, bestPos = 0xFFFFFFFFu;
-        uint32_t r1 = 0, staged = 0;
-        for (uint32_t base = 0; base < cnt; base += 64) {
-            const uint32_t t = base + (uint32_t)lane;
-            const bool valid = t < cnt;
-            const bool pass1 = valid && (m1 ? maskBit(m1, t) : true);
-            const unsigned long long b1 = __ballot(pass1);
-            const uint32_t k1 = r1 + (uint32_t)__popcll(b1 & ltMask);
-            const bool pass = pass1 && (m2 ? maskBit(m2, k1) : true);
-            r1 += (uint32_t)__popcll(b1);
-            const unsigned long long b = __ballot(pass);
-            const uint32_t nk = (uint32_t)__popcll(b);
-            if (nk == 0) continue;
-            if (pass) {
-                const uint32_t slot = (uint32_t)__popcll(b & ltMask);
-                const uint32_t ti = unpackIndex(set + 1, t * v.bits, v.bits);
-                s_tri[w][slot] = ti;
-                const float4* src = reinterpret_cast<const float4*>(v.frames) + 5 * (size_t)ti;
-                float4* dst = reinterpret_cast<float4*>(&s_frames[w][slot * FRAME_FLOATS]);
-#pragma unroll
-                for (int c = 0; c < 5; c++) dst[c] = src[c];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (g < G) {
-                for (uint32_t sIdx = g; sIdx < nk; sIdx += G) {
-                    const float4* fp = reinterpret_cast<const float4*>(&s_frames[w][sIdx * FRAME_FLOATS]);
-                    const float4 a = fp[0], bq = fp[1], c = fp[2], d4 = fp[3], e4 = fp[4];
-                    TriFrame fr;
-                    fr.origin = F3{a.x, a.y, a.z};
-                    fr.m[0] = a.w; fr.m[1] = bq.x; fr.m[2] = bq.y; fr.m[3] = bq.z; fr.m[4] = bq.w; fr.m[5] = c.x; fr.m[6] = c.y; fr.m[7] = c.z; fr.m[8] = c.w;
-                    fr.b = F2{d4.x, d4.y}; fr.c = F2{d4.z, d4.w}; fr.v2 = e4.x; fr.v3 = F2{e4.y, e4.z};
-                    const float d = sqDistPointTriangle(po, fr);
-                    if (d < best) { best = d; bestTri = s_tri[w][sIdx]; bestPos = staged + sIdx; }
+        const uint32_t setIdx = __shfl(cSet, leader), m1i = __shfl(cM1, leader), m2i = __shfl(cM2, leader);
+        const uint32_t cnt = __shfl(cCnt, leader);
+        const bool m1 = m1i != QNONE, m2 = m2i != QNONE;
+        const uint32_t nsub = (r + 20u) / 21u, part = (r + nsub - 1u) / nsub;
+        uint32_t base = 0, r1 = 0, posBase = 0;
+        while (base < cnt) {
+            // 1. decode a round of survivors into s_ids: up to EX_BATCH chunks of 64 set entries per round.  Everything the round needs
+            // from memory is fetched by ONE set of independent, coalesced loads — lane l takes byte l of the first mask from the round's
+            // first entry on, bytes l and l + 1 of the second mask from the current rank on, and the packed-set words 64 j + l — so the
+            // round costs one memory latency (it was three per chunk: mask byte, second mask byte at the rank the first gives, set words;
+            // the waves spent most of their time waiting for that chain).  The words go through LDS, the mask bytes through shuffles.
+            uint32_t nIds = 0;
+            {
+                const uint32_t left = cnt - base;
+                const uint32_t nch = (left + 63u) / 64u < (uint32_t)EX_BATCH ? (left + 63u) / 64u : (uint32_t)EX_BATCH;
+                const uint32_t endEntry = (base + 64u * nch < cnt) ? base + 64u * nch : cnt;
+                const uint32_t firstWord = (base * v.bits) >> 5;
+                const uint32_t nWords = ((endEntry * v.bits + 31u) >> 5) + 1u - firstWord;          // + 1: unpacking reads word w + 1 as well
+                const uint32_t r1start = r1;
+                uint32_t B1 = 0xFFu, B2 = 0xFFFFu;
+                if (m1) { const uint64_t at = (uint64_t)m1i + (base >> 3) + (uint32_t)lane; B1 = v.masks[at < v.maskBytes ? at : v.maskBytes]; }
+                if (m2) {
+                    const uint64_t at = (uint64_t)m2i + (r1start >> 3) + (uint32_t)lane;
+                    B2 = (uint32_t)v.masks[at < v.maskBytes ? at : v.maskBytes] | ((uint32_t)v.masks[at + 1 < v.maskBytes ? at + 1 : v.maskBytes] << 8);
                 }
+                uint32_t W[EX_WORDS];
+#pragma unroll
+                for (int j = 0; j < EX_WORDS; j++) {
+                    const uint64_t at = (uint64_t)setIdx + 1u + firstWord + 64u * j + (uint32_t)lane;
+                    W[j] = (64u * j < nWords) ? v.sets[at <= v.setWords ? at : v.setWords] : 0u;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int j = 0; j < EX_WORDS; j++) if (64u * j < nWords) s_words[64 * j + lane] = W[j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                for (uint32_t c = 0; c < nch; c++) {
+                    const uint32_t t = base + 64u * c + (uint32_t)lane;
+                    const uint32_t b1 = (uint32_t)__shfl((int)B1, (int)(8u * c) + (lane >> 3));
+                    const bool pass1 = t < cnt && (b1 & (0x80u >> (lane & 7))) != 0u;
+                    const unsigned long long bal1 = __ballot(pass1);
+                    const uint32_t rel = (r1start & 7u) + (r1 - r1start) + (uint32_t)__popcll(bal1 & ltMask);      // bit offset from the first second-mask byte fetched
+                    r1 += (uint32_t)__popcll(bal1);
+                    const uint32_t two = (uint32_t)__shfl((int)B2, (int)((rel >> 3) < 63u ? (rel >> 3) : 63u));
+                    const uint32_t b2 = ((rel >> 3) == 64u) ? (two >> 8) : (two & 0xFFu);
+                    const bool pass = pass1 && (m2 ? (b2 & (0x80u >> (rel & 7u))) != 0u : true);
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) {
+                        const uint32_t bIdx = t * v.bits - (firstWord << 5), w = bIdx >> 5, bit = bIdx & 31u;
+                        const uint32_t w0 = s_words[w], w1 = s_words[w + 1];
+                        s_ids[nIds + (uint32_t)__popcll(bal & ltMask)] = ((w0 << bit) >> (32u - v.bits)) | (uint32_t)((unsigned long long)w1 >> (64u - (bit + v.bits)));
+                    }
+                    nIds += (uint32_t)__popcll(bal);
+                }
+                base += 64u * nch;
             }
-            staged += nk;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        {   // merge the G partial results of every query into its own lane
-            const uint32_t i = inRun ? (uint32_t)(lane - leader) : 0u;
-            float mb = INFINITY; uint32_t mt = 0, mp = 0xFFFFFFFFu;
-            for (uint32_t gg = 0; gg < G; gg++) {
-                const int src = (int)(i + r * gg);
-                const float cd = __shfl(best, src); const uint32_t ct = __shfl(bestTri, src), cp = __shfl(bestPos, src);
-                if (cd < mb || (cd == mb && cp < mp)) { mb = cd; mt = ct; mp = cp; }
+            if (nIds == 0) continue;
+            // 2. evaluate: part by part of the run, tile by tile of the list
+            for (uint32_t sub = 0; sub < nsub; sub++) {
+                const uint32_t lo = sub * part, sz = (r - lo < part) ? r - lo : part;
+                const uint32_t G = 64u / sz, g = (uint32_t)lane / sz, i = (uint32_t)lane - g * sz;
+                const int owner = leader + (int)(lo + i);
+                const F3 po = F3{__shfl(p.x, owner), __shfl(p.y, owner), __shfl(p.z, owner)};
+                unsigned long long best = EX_KEY_NONE;
+                for (uint32_t tb = 0; tb < nIds; tb += 64) {
+                    const uint32_t nk = (nIds - tb < 64u) ? nIds - tb : 64u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if ((uint32_t)lane < nk) {
+                        // frames are staged as PAIRS of triangles (2j, 2j + 1), float c of both next to each other: one 64-bit operand of a packed instruction
+                        const float4* src = reinterpret_cast<const float4*>(v.frames) + 5 * (size_t)s_ids[tb + (uint32_t)lane];
+                        float* dst = s_pairs + (lane >> 1) * EX_REC + (lane & 1);
+#pragma unroll
+                        for (int c = 0; c < 5; c++) { const float4 x = src[c]; dst[8 * c] = x.x; dst[8 * c + 2] = x.y; dst[8 * c + 4] = x.z; dst[8 * c + 6] = x.w; }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (g < G) {
+                        const uint32_t npairs = (nk + 1u) >> 1;
+                        for (uint32_t j = g; j < npairs; j += G) {
+                            const v2f* rec = reinterpret_cast<const v2f*>(s_pairs + j * EX_REC);
+                            v2f f[19];
+#pragma unroll
+                            for (int m = 0; m < 19; m++) f[m] = rec[m];
+                            const v2f d = sqDistPointTrianglePair(po, f);
+                            const uint32_t pos = posBase + tb + 2u * j;
+                            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | pos;
+                            const unsigned long long k1 = (2u * j + 1u < nk) ? (((unsigned long long)__float_as_uint(d.y) << 32) | (pos + 1u)) : EX_KEY_NONE;
+                            const unsigned long long kk = k1 < k0 ? k1 : k0;
+                            best = kk < best ? kk : best;
+                        }
+                    }
+                }
+                // 3. reduce over g (lanes i, i + sz, i + 2 sz, ...), result in lanes [0, sz); hand it to the queries' own lanes
+                if (g >= G) best = EX_KEY_NONE;
+                for (uint32_t span = 1; span < G; span <<= 1) {
+                    const int src = lane + (int)(span * sz);
+                    const unsigned long long other = shflKey(best, src < 64 ? src : lane);
+                    if (src < 64 && other < best) best = other;
+                }
+                const int from = lane - leader - (int)lo;              // lane of query (lo + from) holds it after the reduction
+                const unsigned long long mine = shflKey(best, (from >= 0 && from < (int)sz) ? from : lane);
+                if (inRun && from >= 0 && from < (int)sz && mine < acc) { acc = mine; accTri = s_ids[(uint32_t)mine - posBase]; }
             }
-            best = mb; bestTri = mt;
+            posBase += nIds;
         }
-        if (inRun) {
-            if (GRAD) {
-                F3 g;
-                dist[q] = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, g);
-                grad[3 * (size_t)q] = g.x; grad[3 * (size_t)q + 1] = g.y; grad[3 * (size_t)q + 2] = g.z;
-            } else dist[q] = signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
-            if (tri) tri[q] = bestTri;
-            done = true;
-        }
+        if (inRun) done = true;
+    }
+    // 4. every lane finishes its own query
+    if (active) {
+        const uint32_t bestTri = accTri;
+        if (GRAD) {
+            F3 gr;
+            dist[q] = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, gr);
+            grad[3 * (size_t)q] = gr.x; grad[3 * (size_t)q + 1] = gr.y; grad[3 * (size_t)q + 2] = gr.z;
+        } else dist[q] = signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
+        if (tri) tri[q] = bestTri;
     }
 }
 
 }  // namespace sdfhip
 
 using namespace sdfhip;
+
+// The per-node table of the batched query (exact_internal.h): one level-synchronous walk of the tree, once per tree.
+static int ensureLeafCtx(sdfhip_exact* T, const ExactView& v) {
+    std::lock_guard<std::mutex> own(T->leafCtxLock);
+    if (T->leafCtxReady) return SDFHIP_OK;
+    hipStream_t st = T->ctx->stream;
+    const sdfhip_exact_info& I = T->info;
+    const uint64_t nn = I.num_nodes;
+    SDF_REQUIRE(nn < (1ull << 31), "tree too large for the batched query");
+    SDF_TRY(T->leafCtx.reserve(4 * nn));
+    SDF_HIP_CHECK(hipMemsetAsync(T->leafCtx.p, 0xFF, 16 * nn, st));
+    DevBuf<uint32_t> fa, fb, cnt;                      // two frontiers of {node, stage, set, first mask} and the size of the next one
+    SDF_TRY(fa.reserve(4 * nn)); SDF_TRY(fb.reserve(4 * nn)); SDF_TRY(cnt.reserve(1));
+    const uint32_t G = (uint32_t)I.start_grid_size, g3 = G * G * G;
+    std::vector<uint32_t> seed(4 * (size_t)g3);
+    for (uint32_t i = 0; i < g3; i++) { seed[4 * i] = i; seed[4 * i + 1] = 0; seed[4 * i + 2] = QNONE; seed[4 * i + 3] = QNONE; }
+    SDF_HIP_CHECK(hipMemcpyAsync(fa.p, seed.data(), 16 * (size_t)g3, hipMemcpyHostToDevice, st));
+    uint32_t nIn = g3;
+    for (uint32_t depth = I.start_depth; nIn > 0; depth++) {
+        SDF_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, st));
+        k_exact_ctx_level<<<gridFor(nIn, 256), 256, 0, st>>>(v, reinterpret_cast<const CtxItem*>(fa.p), nIn, depth, reinterpret_cast<CtxItem*>(fb.p), cnt.p, T->leafCtx.p);
+        SDF_HIP_CHECK(hipGetLastError());
+        uint32_t nOut = 0;
+        SDF_HIP_CHECK(hipMemcpyAsync(&nOut, cnt.p, 4, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_REQUIRE(nOut <= nn, "node array is not a tree");
+        std::swap(fa, fb);
+        nIn = nOut;
+        SDF_REQUIRE(depth < 64, "node array is not a tree");
+    }
+    T->leafCtxReady = true;
+    return SDFHIP_OK;
+}
 
 extern "C" {
 
@@ -285,7 +427,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         SDF_TRY(ensureHostCopy(T));
         const sdfhip_exact_info& I = T->info;
         const ExactView hv{T->hNodes.data(), T->hSets.data(), T->hMasks.data(), T->hTri.data(), nullptr, I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
-                           T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
+                           T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index, (uint32_t)I.num_nodes, I.num_mask_bytes, I.num_set_words};
         for (uint64_t i = 0; i < n; i++) {
             const F3 p = F3{xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
             uint32_t t = 0;
@@ -311,7 +453,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     }
     const sdfhip_exact_info& I = T->info;
     ExactView v{T->nodes.p, T->sets.p, T->masks.p, T->tri(), T->frames(), I.box_min[0], I.box_min[1], I.box_min[2], I.box_max[0], I.box_max[1], I.box_max[2],
-                T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index};
+                T->cellSize, I.start_grid_size, I.start_depth, I.bit_encoding_start_depth, I.bits_per_index, (uint32_t)I.num_nodes, I.num_mask_bytes, I.num_set_words};
     if (n < 16384) {
         if (g) k_exact_query<true><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t);
         else k_exact_query<false><<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, nullptr, t);
@@ -321,17 +463,20 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         std::unique_lock<std::mutex> own(T->scratch.lock, std::try_to_lock);
         sdfhip_exact_scratch priv;
         sdfhip_exact_scratch& S = own.owns_lock() ? T->scratch : priv;
-        DevBuf<uint32_t>&key = S.key, &keyS = S.keyS, &qi = S.qi, &qiS = S.qiS, &qctx = S.qctx; DevBuf<unsigned char>& tmp = S.tmp;
-        SDF_TRY(key.reserve(n)); SDF_TRY(keyS.reserve(n)); SDF_TRY(qi.reserve(n)); SDF_TRY(qiS.reserve(n)); SDF_TRY(qctx.reserve(3 * n));
-        k_exact_locate<<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t, key.p, qi.p, qctx.p);
+        DevBuf<uint32_t>&key = S.key, &keyS = S.keyS, &qi = S.qi, &qiS = S.qiS; DevBuf<unsigned char>& tmp = S.tmp;
+        SDF_TRY(ensureLeafCtx(T, v));
+        SDF_TRY(key.reserve(n)); SDF_TRY(keyS.reserve(n)); SDF_TRY(qi.reserve(n)); SDF_TRY(qiS.reserve(n));
+        k_exact_locate<<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t, key.p, qi.p);
+        // keys are node ids, num_nodes for a query outside the grid (sorted last, skipped): only the bits such keys have are sorted on
+        // (21 instead of 32 at a million nodes: three radix passes instead of four)
         int keyBits = 1; while (keyBits < 32 && (1ull << keyBits) <= T->info.num_nodes) keyBits++;
         size_t tb = 0;
-        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, 32, st));
+        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, keyBits, st));
         SDF_TRY(tmp.reserve(tb));
-        (void)keyBits;   // outside-the-grid queries carry key 0xFFFFFFFF: sort on all 32 bits so that they end up last
-        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, 32, st));
-        if (g) k_exact_sorted<true><<<xcdGrid(gridFor(n, 256)), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, g, t);
-        else k_exact_sorted<false><<<xcdGrid(gridFor(n, 256)), 256, 0, st>>>(v, p, n, keyS.p, qiS.p, qctx.p, d, nullptr, t);
+        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, keyBits, st));
+        const uint4* lc = reinterpret_cast<const uint4*>(T->leafCtx.p);
+        if (g) k_exact_tiles<true><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, lc, d, g, t);
+        else k_exact_tiles<false><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, lc, d, nullptr, t);
         SDF_HIP_CHECK(hipGetLastError());
         if (!own.owns_lock()) SDF_HIP_CHECK(hipStreamSynchronize(st));      // the private scratch dies with this scope
     }
