@@ -9,10 +9,15 @@ from oracle import pyoracle as O
 from sdflib_amd.meshgen import icosphere, bumpy_icosphere, cube_mesh, box_with_margin
 
 MODE = os.environ.get("FUZZ_MODE", "")      # "continuity": always the CONTINUITY builder, deeper trees; "exact": deeper ExactOctreeSdf; "big": larger meshes
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
-ctx = S.Context(0)
+ctx = None          # made on first use: the module is also imported by tests/test_gpu_fuzz.py
+
+
+def _ctx():
+    global ctx
+    if ctx is None:
+        ctx = S.Context(0)
+    return ctx
 
 
 def random_mesh(rng):
@@ -44,6 +49,7 @@ def random_mesh(rng):
 
 
 def one(seed):
+    ctx = _ctx()
     rng = np.random.default_rng(seed)
     if os.environ.get("FUZZ_VERBOSE"): print(f"  seed {seed} start", flush=True)
     v, f = random_mesh(rng)
@@ -162,13 +168,16 @@ def one(seed):
     return f"T={len(f)} cont={int(cont)} rule={rule} d={depth}/{start} words={len(ot.data())} exact d={edepth}/{estart} min={mint}{extra}"
 
 
-fails = 0; t00 = time.time()
-for s in range(seed0, seed0 + iters):
-    try:
-        print(f"seed {s}: {one(s)}", flush=True)
-    except AssertionError as e:
-        fails += 1; print(f"seed {s}: MISMATCH {e}", flush=True)
-    except Exception as e:      # noqa: BLE001
-        fails += 1; print(f"seed {s}: ERROR {type(e).__name__}: {e}", flush=True)
-print(f"{iters} cases, {fails} failures, {time.time() - t00:.0f} s")
-sys.exit(1 if fails else 0)
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    fails = 0; t00 = time.time()
+    for s in range(seed0, seed0 + iters):
+        try:
+            print(f"seed {s}: {one(s)}", flush=True)
+        except AssertionError as e:
+            fails += 1; print(f"seed {s}: MISMATCH {e}", flush=True)
+        except Exception as e:      # noqa: BLE001
+            fails += 1; print(f"seed {s}: ERROR {type(e).__name__}: {e}", flush=True)
+    print(f"{iters} cases, {fails} failures, {time.time() - t00:.0f} s")
+    sys.exit(1 if fails else 0)
