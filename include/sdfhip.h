@@ -98,6 +98,11 @@ void sdfhip_abi_sizes(uint64_t out[3]);
 int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx** out);
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
+/* Device memory the context keeps for reuse (transient blocks of past builds in per-stream caches, the nearest search's candidate
+ * lists, host-pointer staging buffers).  Kept automatically below a high-water mark (SDFHIP_CACHE_KEEP_MB, default 512, applied when a
+ * build returns); sdfhip_ctx_trim waits for the context's stream and frees what exceeds keep_bytes (0: everything). */
+int sdfhip_ctx_trim(sdfhip_ctx* ctx, uint64_t keep_bytes);
+int sdfhip_ctx_cached_bytes(sdfhip_ctx* ctx, uint64_t* out_bytes);
 void* sdfhip_ctx_stream(sdfhip_ctx* ctx);
 
 /* Multi-GPU CONTINUITY build: the breadth-first builder couples neighbouring start cells in its serial
@@ -218,6 +223,13 @@ int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out);
 /* copy the node array (getOctreeData(): u32 words, leaf bit31, 64 float coefficients per leaf) */
 int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where);
 const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree);
+/* Device footprint.  Queries run on a packed layout of the tree (node words breadth-first + 256-byte-aligned coefficient blocks) that is
+ * made from the node array on the first query and holds everything the array holds; sdfhip_octree_compact makes it and RELEASES the
+ * array (half the footprint); download / device_words rebuild it from the layout, bit for bit, when asked.  Arrays of
+ * SDFHIP_COMPACT_ABOVE_MB (default 1024) and more are compacted automatically by their first query.  Not applied to an array with
+ * words that belong to no node or coefficient block (it keeps its array). */
+int sdfhip_octree_compact(sdfhip_octree* tree);
+int sdfhip_octree_device_bytes(sdfhip_octree* tree, uint64_t* out_bytes);
 
 /* batched getDistance: xyz = n points (3 floats each); out_grad may be NULL (normalised gradient otherwise) */
 int sdfhip_octree_query(sdfhip_octree* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int where, int eval_mode);

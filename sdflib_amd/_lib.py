@@ -61,6 +61,8 @@ SIGNATURES = {
     "sdfhip_ctx_create": (_int, [_int, _vp, _int, C.POINTER(_vp)]),
     "sdfhip_ctx_destroy": (_int, [_vp]),
     "sdfhip_ctx_synchronize": (_int, [_vp]),
+    "sdfhip_ctx_trim": (_int, [_vp, C.c_uint64]), "sdfhip_ctx_cached_bytes": (_int, [_vp, _vp]),
+    "sdfhip_octree_compact": (_int, [_vp]), "sdfhip_octree_device_bytes": (_int, [_vp, _vp]),
     "sdfhip_ctx_stream": (_vp, [_vp]),
     "sdfhip_ctx_set_exchange": (_int, [_vp, C.POINTER(Exchange)]),
     "sdfhip_mesh_create": (_int, [_vp, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),

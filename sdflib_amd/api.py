@@ -69,6 +69,15 @@ class Context:
     def synchronize(self):
         check(lib().sdfhip_ctx_synchronize(self.h))
 
+    def trim(self, keep_bytes=0):
+        """Free the device memory the context keeps for reuse beyond keep_bytes (sdfhip_ctx_trim)."""
+        check(lib().sdfhip_ctx_trim(self.h, int(keep_bytes)))
+
+    def cached_bytes(self):
+        n = C.c_uint64(0)
+        check(lib().sdfhip_ctx_cached_bytes(self.h, C.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "h", None):
             lib().sdfhip_ctx_destroy(self.h); self.h = None
@@ -259,6 +268,15 @@ class OctreeSdf:
         i = self.info
         serialization.save_octree(path, self.get_grid_bounding_box(), i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, self.get_octree_data())
         return True
+
+    def compact(self):
+        """Keep only the packed query layout on the device (sdfhip_octree_compact); get_octree_data() rebuilds the array when asked."""
+        check(lib().sdfhip_octree_compact(self.h))
+
+    def device_bytes(self):
+        n = C.c_uint64(0)
+        check(lib().sdfhip_octree_device_bytes(self.h, C.byref(n)))
+        return int(n.value)
 
     def get_octree_data(self):
         """getOctreeData(): the flat u32 node array (host copy)."""

@@ -800,11 +800,17 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
         SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
         p = dp.p; o = dout.p;
     }
-    if (nearestExactOnly() || n >= (1ull << 31)) k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
+    if (nearestExactOnly()) k_nearest<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), p, n, o);
     else {
         std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);      // the context's scratch is shared with the builders
         int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
-        SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), p, (uint32_t)n, o, mesh->ctx->nearScratch, depth + 2, 0u, 1u));
+        // the search keeps ~140 B of candidate lists per query in the context's scratch: batches go through in pieces of 4 M queries
+        // (0.6 GB), whatever their size
+        constexpr uint64_t kPiece = 1ull << 22;
+        for (uint64_t off = 0; off < n; off += kPiece) {
+            const uint64_t m = n - off < kPiece ? n - off : kPiece;
+            SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), p + 3 * off, (uint32_t)m, o + off, mesh->ctx->nearScratch, depth + 2, 0u, 1u));
+        }
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
     SDF_HIP_CHECK(hipGetLastError());

@@ -232,12 +232,9 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
     sdfhip_ctx* c = new sdfhip_ctx();
     c->device = device_id;
     SDF_HIP_CHECK(hipGetDeviceProperties(&c->prop, device_id));
-    {   // stream-ordered allocations (AllocScope) are served from the device's default pool: keep freed blocks for reuse
-        hipMemPool_t pool = nullptr; uint64_t keep = ~0ull;
-        if (hipDeviceGetDefaultMemPool(&pool, device_id) == hipSuccess && pool) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-    }
     if (stream_mode == SDFHIP_STREAM_BORROWED) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
     else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
+    BigBlockCache::get().addRef(c->device, c->stream);
     *out = c;
     return SDFHIP_OK;
     SDF_API_END
@@ -247,12 +244,37 @@ int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
     SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
     if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
-    if (ctx->ownsStream && ctx->stream) {
-        (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
-        BigBlockCache::get().trimStream(ctx->device, ctx->stream);           // the cached big blocks of this context's stream
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
+    // the cached blocks of this context's stream, once its last context goes (a borrowed stream can serve several contexts)
+    if (BigBlockCache::get().dropRef(ctx->device, ctx->stream) <= 0) BigBlockCache::get().trimStream(ctx->device, ctx->stream);
+    if (ctx->ownsStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_ctx_trim(sdfhip_ctx* ctx, uint64_t keep_bytes) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(ctx != nullptr, "ctx is NULL");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    SDF_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BigBlockCache::get().trimTo(ctx->device, ctx->stream, (size_t)keep_bytes);
+    {   // the context's own grow-only scratch: the nearest search's candidate lists and the host-pointer staging buffers
+        std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
+        if (ctx->nearScratch.bytes() > keep_bytes) ctx->nearScratch.release();
+        std::lock_guard<std::mutex> staging(ctx->stage.lock);
+        if (4 * (ctx->stage.pts.n + ctx->stage.dist.n + ctx->stage.grad.n + ctx->stage.ids.n) > keep_bytes) { ctx->stage.pts.release(); ctx->stage.dist.release(); ctx->stage.grad.release(); ctx->stage.ids.release(); }
+    }
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_ctx_cached_bytes(sdfhip_ctx* ctx, uint64_t* out_bytes) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(ctx != nullptr && out_bytes != nullptr, "NULL argument");
+    std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
+    *out_bytes = BigBlockCache::get().cachedBytes(ctx->device, ctx->stream) + ctx->nearScratch.bytes()
+               + 4 * (ctx->stage.pts.n + ctx->stage.dist.n + ctx->stage.grad.n + ctx->stage.ids.n);
     return SDFHIP_OK;
     SDF_API_END
 }

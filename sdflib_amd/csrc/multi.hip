@@ -256,7 +256,8 @@ int sdfhip_multi_octree_build(sdfhip_multi* M, const float* xyz, uint32_t nv, co
             const double t1 = nowSeconds();
             sdfhip_octree_info i0; sdfhip_octree_get_info(tree[0], &i0);
             std::vector<DevBuf<uint32_t>> full(n); std::vector<void*> buf(n);
-            buf[0] = tree[0]->data.p;
+            buf[0] = const_cast<uint32_t*>(sdfhip_octree_device_words(tree[0]));
+            if (!buf[0]) return cleanup(SDFHIP_E_HIP);
             for (int r = 1; r < n && rc == SDFHIP_OK; r++) { if (hipSetDevice(M->devices[r]) != hipSuccess) rc = SDFHIP_E_HIP; else { rc = full[r].reserve(i0.num_words); buf[r] = full[r].p; } }
             if (rc == SDFHIP_OK) rc = allGatherV(M, buf, {Segment{0, 0, i0.num_words}}, 4);
             for (int r = 1; r < n && rc == SDFHIP_OK; r++) {

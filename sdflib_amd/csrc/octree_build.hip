@@ -265,6 +265,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     SDF_REQUIRE(ctx && mesh && P && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
     std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
+    NearScratchMark nearMark(ctx);
     if (P->algorithm == SDFHIP_ALG_CONTINUITY) {
         SDF_REQUIRE(!shardOnly, "the CONTINUITY builder is not sharded (Iter 2 couples neighbouring start cells)");
         return continuityBuildImpl(ctx, mesh, P, out);
@@ -633,12 +634,15 @@ int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where) 
     SDF_API_BEGIN
     SDF_REQUIRE(tree && out_words, "NULL argument");
     SDF_REQUIRE(tree->hasData, "tree has no assembled node array (sharded build: emit + from_data first)");
-    SDF_HIP_CHECK(hipMemcpyAsync(out_words, tree->data.p, 4ull * tree->info.num_words, where == SDFHIP_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, tree->ctx->stream));
-    SDF_HIP_CHECK(hipStreamSynchronize(tree->ctx->stream));
-    return SDFHIP_OK;
+    SDF_HIP_CHECK(hipSetDevice(tree->ctx->device));
+    return octreeDownload(tree, out_words, where);
     SDF_API_END
 }
 
-const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) { return (tree && tree->hasData) ? tree->data.p : nullptr; }
+const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) {
+    if (!tree || !tree->hasData) return nullptr;
+    if (!tree->data.p && (hipSetDevice(tree->ctx->device) != hipSuccess || octreeMaterialize(tree) != SDFHIP_OK)) return nullptr;
+    return tree->data.p;
+}
 
 }  // extern "C"

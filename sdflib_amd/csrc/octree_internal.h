@@ -35,11 +35,13 @@ struct sdfhip_octree {
     sdfhip_octree_info info{};
     sdfhip_octree_params params{};
     sdfhip::DevBuf<uint32_t> data;          // full node array (when available): the reference's mOctreeData layout, what download / emit return
-    bool hasData = false;
+    bool hasData = false;                   // an assembled array EXISTS; it need not be resident: a compacted tree (sdfhip_octree_compact, or
+                                            // automatically above SDFHIP_COMPACT_ABOVE_MB) keeps the query layout only and rebuilds it on demand
     // Query-side layout, derived from `data` on the first query (octree_query.hip, ensureQueryLayout): the node words alone, packed
     // breadth-first (a few MB: the dependent loads of the walk stay in L2), and the leaves' coefficients as 256-byte-ALIGNED blocks
     // (a block is exactly two 128-byte lines; in `data` a block starts at any multiple of 4 bytes and straddles three).
     sdfhip::DevBuf<uint32_t> qTopo;         // [G^3 start cells][level 1 blocks]...: inner word = index of the 8-word child block, leaf word = LEAF_BIT | block id
+    sdfhip::DevBuf<uint32_t> qOrig;         // the nodes' words as `data` holds them, qTopo order: with qCoef, everything `data` holds
     sdfhip::DevBuf<float> qCoef;            // 64 floats per leaf, block id order
     uint64_t qNodes = 0, qLeaves = 0;
     bool qReady = false;
@@ -67,3 +69,9 @@ struct sdfhip_octree {
     bool built = false;
     float cellSize = 0.f;
 };
+
+namespace sdfhip {
+// octree_query.hip: the node array of a tree whose resident copy may have been released in favour of the query layout
+int octreeMaterialize(sdfhip_octree* tree);                                   // makes tree->data resident again
+int octreeDownload(sdfhip_octree* tree, uint32_t* out_words, int where);      // without keeping it resident
+}

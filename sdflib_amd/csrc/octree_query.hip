@@ -207,13 +207,15 @@ __global__ void k_ql_level(const uint32_t* __restrict__ data, uint64_t numWords,
     }
 }
 __global__ void k_ql_fill(const uint32_t* __restrict__ data, const uint32_t* __restrict__ src, const uint32_t* __restrict__ rank, uint32_t count,
-                          uint32_t* __restrict__ topoLevel, uint32_t nextLevelBase, float* __restrict__ coef) {
+                          uint32_t* __restrict__ topoLevel, uint32_t* __restrict__ origLevel, uint32_t nextLevelBase, float* __restrict__ coef) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const uint32_t r = rank[j];
+    const uint32_t word = data[src ? src[j] : j];
+    origLevel[j] = word;               // the node's word as the reference's array holds it: what octreeMaterialize rebuilds that array from
     if (!(r & LEAF_BIT)) { topoLevel[j] = nextLevelBase + 8u * r; return; }
     topoLevel[j] = r;
-    const uint32_t* from = data + (data[src ? src[j] : j] & INDEX_MASK);
+    const uint32_t* from = data + (word & INDEX_MASK);
     float4* to = reinterpret_cast<float4*>(coef + 64ull * (r & INDEX_MASK));
 #pragma unroll
     for (int q = 0; q < 16; q++) to[q] = make_float4(__uint_as_float(from[4 * q]), __uint_as_float(from[4 * q + 1]), __uint_as_float(from[4 * q + 2]), __uint_as_float(from[4 * q + 3]));
@@ -257,16 +259,82 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     }
     SDF_REQUIRE(total < (1ull << 30), "tree too large for the query layout");
     const uint64_t leaves = h[1];
-    SDF_TRY(T->qTopo.reserve(total)); SDF_TRY(T->qCoef.reserve(64ull * (leaves ? leaves : 1)));
+    SDF_TRY(T->qTopo.reserve(total)); SDF_TRY(T->qOrig.reserve(total)); SDF_TRY(T->qCoef.reserve(64ull * (leaves ? leaves : 1)));
     uint64_t base = 0;
     for (size_t i = 0; i < levels.size(); i++) {
         Level& L = *levels[i];
-        k_ql_fill<<<gridFor(L.count, 256), 256, 0, st>>>(T->data.p, i == 0 ? nullptr : L.src.p, L.rank.p, L.count, T->qTopo.p + base, (uint32_t)(base + L.count), T->qCoef.p);
+        k_ql_fill<<<gridFor(L.count, 256), 256, 0, st>>>(T->data.p, i == 0 ? nullptr : L.src.p, L.rank.p, L.count, T->qTopo.p + base, T->qOrig.p + base, (uint32_t)(base + L.count), T->qCoef.p);
         base += L.count;
     }
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));           // the level buffers are released below
     T->qNodes = total; T->qLeaves = leaves; T->qLevelNodes = levelNodes; T->qLevelLeafBase = levelLeafBase; T->qReady = true;
+    // The layout holds everything the array holds (node words + coefficient blocks), so a LARGE array need not stay on the device beside
+    // it: above SDFHIP_COMPACT_ABOVE_MB (default 1024) it is released here and rebuilt on demand (octreeMaterialize).
+    static const uint64_t compactAbove = (getenv("SDFHIP_COMPACT_ABOVE_MB") ? strtoull(getenv("SDFHIP_COMPACT_ABOVE_MB"), nullptr, 10) : 1024ull) << 20;
+    if (4ull * numWords >= compactAbove && total + 64ull * leaves == numWords) T->data.release();
+    return SDFHIP_OK;
+}
+
+// One level of the inverse of k_ql_fill: node words back to their positions, coefficient blocks back behind their leaves' indices.
+__global__ void k_ql_restore(const uint32_t* __restrict__ topoLevel, const uint32_t* __restrict__ origLevel, const uint32_t* __restrict__ posLevel, uint32_t count,
+                             uint32_t nextLevelBase, uint32_t* __restrict__ posNext, const float* __restrict__ coef, uint32_t* __restrict__ data) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const uint32_t word = origLevel[j], t = topoLevel[j];
+    data[posLevel ? posLevel[j] : j] = word;
+    const uint32_t idx = word & INDEX_MASK;
+    if (t & LEAF_BIT) {
+        const float4* from = reinterpret_cast<const float4*>(coef + 64ull * (t & INDEX_MASK));
+        uint32_t* to = data + idx;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const float4 x = from[q]; to[4 * q] = __float_as_uint(x.x); to[4 * q + 1] = __float_as_uint(x.y); to[4 * q + 2] = __float_as_uint(x.z); to[4 * q + 3] = __float_as_uint(x.w); }
+    } else {
+        const uint32_t child = t - nextLevelBase;
+#pragma unroll
+        for (uint32_t c = 0; c < 8u; c++) posNext[child + c] = idx + c;
+    }
+}
+
+// The reference's node array into `out` (num_words words on the device), from the resident copy or, for a compacted tree, from the layout.
+static int octreeWordsInto(sdfhip_octree* T, uint32_t* out) {
+    hipStream_t st = T->ctx->stream;
+    if (T->data.p) { SDF_HIP_CHECK(hipMemcpyAsync(out, T->data.p, 4ull * T->info.num_words, hipMemcpyDeviceToDevice, st)); return SDFHIP_OK; }
+    SDF_REQUIRE(T->qReady, "tree has neither its node array nor a query layout");
+    DevBuf<uint32_t> posA, posB;
+    uint32_t widest = 0; for (uint32_t c : T->qLevelNodes) widest = c > widest ? c : widest;
+    SDF_TRY(posA.reserve(widest)); SDF_TRY(posB.reserve(widest));
+    uint64_t base = 0;
+    for (size_t i = 0; i < T->qLevelNodes.size(); i++) {
+        const uint32_t count = T->qLevelNodes[i];
+        k_ql_restore<<<gridFor(count, 256), 256, 0, st>>>(T->qTopo.p + base, T->qOrig.p + base, i == 0 ? nullptr : posA.p, count, (uint32_t)(base + count), posB.p, T->qCoef.p, out);
+        std::swap(posA, posB);
+        base += count;
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));           // posA / posB are released below
+    return SDFHIP_OK;
+}
+
+int octreeMaterialize(sdfhip_octree* T) {
+    std::lock_guard<std::mutex> own(T->qLock);
+    if (T->data.p) return SDFHIP_OK;
+    DevBuf<uint32_t> d;
+    SDF_TRY(d.reserve(T->info.num_words));
+    SDF_TRY(octreeWordsInto(T, d.p));
+    T->data = std::move(d);
+    return SDFHIP_OK;
+}
+
+int octreeDownload(sdfhip_octree* T, uint32_t* out_words, int where) {
+    hipStream_t st = T->ctx->stream;
+    std::lock_guard<std::mutex> own(T->qLock);
+    if (where == SDFHIP_DEVICE) { SDF_TRY(octreeWordsInto(T, out_words)); SDF_HIP_CHECK(hipStreamSynchronize(st)); return SDFHIP_OK; }
+    DevBuf<uint32_t> tmp;                              // a compacted tree is rebuilt in a transient block: its footprint stays what it was
+    const uint32_t* src = T->data.p;
+    if (!src) { SDF_TRY(tmp.reserve(T->info.num_words)); SDF_TRY(octreeWordsInto(T, tmp.p)); src = tmp.p; }
+    SDF_HIP_CHECK(hipMemcpyAsync(out_words, src, 4ull * T->info.num_words, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
     return SDFHIP_OK;
 }
 
@@ -879,6 +947,29 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         if (out_grad) SDF_HIP_CHECK(hipMemcpyAsync(out_grad, g, 12 * n, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipStreamSynchronize(st));
     }
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_octree_compact(sdfhip_octree* T) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(T && T->hasData, "NULL argument or tree without an assembled node array");
+    SDF_HIP_CHECK(hipSetDevice(T->ctx->device));
+    SDF_TRY(ensureQueryLayout(T));
+    std::lock_guard<std::mutex> own(T->qLock);
+    // the layout reproduces the array only if every word of it is a node word or a coefficient of exactly one leaf (true for every array
+    // a builder of this library or the reference emits); anything else keeps its array
+    if (T->data.p && T->qNodes + 64ull * T->qLeaves == T->info.num_words) { SDF_HIP_CHECK(hipStreamSynchronize(T->ctx->stream)); T->data.release(); }
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_octree_device_bytes(sdfhip_octree* T, uint64_t* out_bytes) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(T && out_bytes, "NULL argument");
+    std::lock_guard<std::mutex> own(T->qLock);
+    const sdfhip_octree::LatticePlan& P = T->lattice;
+    *out_bytes = 4ull * (T->data.n + T->qTopo.n + T->qOrig.n + T->qCoef.n + T->qLeafCell.n + P.F.n + P.groupWaveBase.n + P.groupLeafBase.n + P.sortedLeaf.n + P.waveDesc.n) + 2ull * P.ranges.n;
     return SDFHIP_OK;
     SDF_API_END
 }

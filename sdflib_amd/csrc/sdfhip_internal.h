@@ -48,36 +48,67 @@ static inline double nowSeconds() {
 inline double& g_allocSeconds() { static thread_local double v = 0; return v; }
 inline long& g_allocCalls() { static thread_local long v = 0; return v; }
 
-// Stream-ordered allocation.  A build creates and drops a few hundred device buffers (hipMalloc / hipFree cost ~40 us each
-// and hipFree synchronises the device: 10 ms of a 60 ms build in the first measurements).  Inside an AllocScope the buffers of
-// the calling thread come from the device's default memory pool on the given stream instead (hipMallocAsync / hipFreeAsync: no
-// synchronisation, freed blocks are reused by later requests on the stream).  Outside a scope DevBuf falls back to hipMalloc /
-// hipFree, which is also how long-lived buffers (trees, meshes) are released later.
+// Transient device memory.  A build creates and drops a few hundred device buffers (hipMalloc / hipFree cost ~40 us each and hipFree
+// synchronises the device: 10 ms of a 60 ms build in the first measurements).  Inside an AllocScope the buffers of the calling thread
+// come from BlockCache (below) instead: blocks are handed out and taken back in the order of ONE stream, so a block released by its
+// owner can go to the next request on that stream at once — the reuse semantics of hipMallocAsync / hipFreeAsync without a runtime call.
+// Outside a scope DevBuf uses hipMalloc / hipFree, which is also how long-lived buffers (trees, meshes) are released later.
+//
+// Why not HIP's own stream-ordered pool (hipMallocAsync): it corrupts memory with this image's runtime.  Rounds 1-2 saw builds that took
+// large blocks from it produce, once in 5-30 runs, a wrong array or a fault in a later kernel, and worked around it for large blocks
+// only.  Round 3 reproduced it WITHOUT this library: tools/pool_repro/pool_repro.hip (100 lines of plain HIP: blocks of one stream
+// filled by a kernel, checked by a kernel, freed with hipFreeAsync, the next iteration's blocks allocated with hipMallocAsync) finds
+// hundreds of millions of wrong words from the second iteration on — most of them ZERO, in blocks that are still owned, also with the
+// stream idle at every hipFreeAsync, with the release threshold at its default or at its maximum, for blocks of 64 KB as for 170 MB —
+// and none with hipMalloc / hipFree in the same program.  The pool hands out address ranges whose earlier contents (or mapping) it
+// still manipulates.  No entry point of the library calls hipMallocAsync / hipFreeAsync any more.
 struct AllocState { hipStream_t stream = nullptr; bool active = false; };
 inline AllocState& tlsAlloc() { static thread_local AllocState s; return s; }
 struct AllocScope {
     AllocState prev;
     explicit AllocScope(hipStream_t s) { prev = tlsAlloc(); tlsAlloc().stream = s; tlsAlloc().active = !getenv("SDFHIP_NO_POOL"); }
-    ~AllocScope() { tlsAlloc() = prev; }
+    inline ~AllocScope();           // restores the previous state and applies the cache's high-water mark (below)
     AllocScope(const AllocScope&) = delete;
     AllocScope& operator=(const AllocScope&) = delete;
 };
 
-// LARGE transient blocks (>= kBigBlock) do not come from HIP's stream-ordered pool but from this cache of plain allocations, one free list
-// per (device, stream): a block released by its owner goes back to the list of the stream it was used on and is handed to a later
-// request on the SAME stream, so reuse is ordered by the stream exactly like hipMallocAsync / hipFreeAsync, without their cost or a
-// device synchronisation.  Why not the HIP pool for these: with the system runtime of this image (C / C++ hosts; Python binds torch's
-// older runtime) a build that requested a large block from the pool in mid-flight — 167 MB of culling scratch, 31 MB of candidate
-// lists — intermittently produced wrong arrays or faulted in a LATER kernel, deterministically gone with plain allocations; small
-// blocks (hundreds per build) stay with the pool.  Cached blocks are freed when their context is destroyed (trimStream).
+// Per (device, stream): LARGE blocks (>= kBigBlock) are plain allocations kept in one list and matched by "fits within 2x"; SMALL blocks
+// (a build asks for ~250 of them) are carved out of 64 MB slabs in power-of-two size classes, a released block waits in its class — a
+// context's first build costs a handful of hipMalloc calls, later ones none (250 runtime calls of ~14 us each before).
+// How long cached memory lives: (i) a HIGH-WATER MARK — when an API call that allocated through the cache returns (~AllocScope) and the
+// (device, stream) lists hold more than keepBytes() (SDFHIP_CACHE_KEEP_MB, default 512), the largest blocks, then idle slabs, are freed
+// until they do not: a process that built one huge tree does not sit on that build's peak scratch for ever; (ii) sdfhip_ctx_trim(ctx,
+// keep_bytes) on request; (iii) when the last context of a (device, stream) is destroyed (trimStream) — blocks released after that are
+// freed at once; (iv) when an allocation fails, everything cached on the device is freed and the request retried once (trimDevice).
 struct BigBlockCache {
-    struct Block { void* p; size_t bytes; bool fromPool; };
+    struct Block { void* p; size_t bytes; };
+    struct Slab { char* base; size_t bytes, used; long live; };       // live = blocks handed out and not yet released
     struct Key { int device; hipStream_t stream; bool operator<(const Key& o) const { return device != o.device ? device < o.device : stream < o.stream; } };
-    // per (device, stream): the large blocks in one list (few, matched by "fits within 2x"), the small ones in power-of-two size classes
-    struct Lists { std::vector<Block> big; std::vector<Block> small[24]; };
+    struct Lists { std::vector<Block> big; std::vector<Block> small[24]; std::vector<Slab> slabs; };
     std::mutex m; std::vector<std::pair<Key, Lists>> lists;
+    std::vector<std::pair<Key, int>> refs;            // live contexts per (device, stream)
+    static constexpr size_t kSlabBytes = 64u << 20;
     static BigBlockCache& get() { static BigBlockCache c; return c; }
+    static size_t keepBytes() { static const size_t v = (size_t)(getenv("SDFHIP_CACHE_KEEP_MB") ? strtoull(getenv("SDFHIP_CACHE_KEEP_MB"), nullptr, 10) : 512ull) << 20; return v; }
     Lists& listOf(Key k) { for (auto& e : lists) if (!(e.first < k) && !(k < e.first)) return e.second; lists.emplace_back(k, Lists()); return lists.back().second; }
+    void addRef(int dev, hipStream_t st) { std::lock_guard<std::mutex> g(m); for (auto& r : refs) if (r.first.device == dev && r.first.stream == st) { r.second++; return; } refs.emplace_back(Key{dev, st}, 1); }
+    int dropRef(int dev, hipStream_t st) {           // returns the contexts left on that stream
+        std::lock_guard<std::mutex> g(m);
+        for (size_t i = 0; i < refs.size(); i++) if (refs[i].first.device == dev && refs[i].first.stream == st) { const int left = --refs[i].second; if (left <= 0) { refs[i] = refs.back(); refs.pop_back(); } return left; }
+        return 0;
+    }
+    static size_t heldBytes(const Lists& L) { size_t t = 0; for (const Block& b : L.big) t += b.bytes; for (const Slab& s : L.slabs) t += s.bytes; return t; }
+    size_t cachedBytes(int dev, hipStream_t st) {     // device memory the cache holds for (device, stream) that no live buffer uses
+        std::lock_guard<std::mutex> g(m);
+        for (auto& e : lists) if (e.first.device == dev && e.first.stream == st) return heldBytes(e.second) - liveSmallBytes(e.second);
+        return 0;
+    }
+    static size_t liveSmallBytes(const Lists& L) {    // bytes of slab memory currently handed out = carved - waiting in the classes
+        size_t carved = 0, waiting = 0;
+        for (const Slab& s : L.slabs) carved += s.used;
+        for (auto& S : L.small) for (const Block& b : S) waiting += b.bytes;
+        return carved - waiting;
+    }
     hipError_t alloc(void** out, size_t bytes, hipStream_t st, size_t* got) {
         int dev = 0; (void)hipGetDevice(&dev);
         {
@@ -89,36 +120,101 @@ struct BigBlockCache {
         }
         const size_t rounded = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
         *got = rounded;
-        return hipMalloc(out, rounded);
+        hipError_t e = hipMalloc(out, rounded);
+        if (e != hipSuccess) { trimDevice(dev); e = hipMalloc(out, rounded); }       // stale cached blocks of other sizes must not make a build that fits fail
+        return e;
     }
-    // SMALL transient blocks (< kBigBlock; a build asks for ~250 of them): the first request of a size class goes to HIP's stream-ordered
-    // pool, a released block waits in its class for the next request on the same stream — a build after the first one makes no
-    // allocation call at all (250 x ~14 us = 3.5 ms of a 26 ms build before).
     static int classOf(size_t bytes) { int c = 8; while (((size_t)1 << c) < bytes) c++; return c - 8; }       // 256 B .. 2 GB
     hipError_t allocSmall(void** out, size_t bytes, hipStream_t st, size_t* got) {
         int dev = 0; (void)hipGetDevice(&dev);
         const int c = classOf(bytes);
-        *got = (size_t)1 << (c + 8);
+        const size_t sz = (size_t)1 << (c + 8);
+        *got = sz;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            {
+                std::lock_guard<std::mutex> g(m);
+                Lists& L = listOf(Key{dev, st});
+                if (!L.small[c].empty()) { *out = L.small[c].back().p; L.small[c].pop_back(); slabOf(L, *out)->live++; return hipSuccess; }
+                for (size_t i = L.slabs.size(); i-- > 0;) { Slab& s = L.slabs[i]; if (s.used + sz <= s.bytes) { *out = s.base + s.used; s.used += sz; s.live++; return hipSuccess; } }
+            }
+            void* base = nullptr;
+            const size_t slabBytes = sz > kSlabBytes ? sz : kSlabBytes;
+            hipError_t e = hipMalloc(&base, slabBytes);
+            if (e != hipSuccess) { trimDevice(dev); e = hipMalloc(&base, slabBytes); }
+            if (e != hipSuccess) return e;
+            std::lock_guard<std::mutex> g(m);
+            listOf(Key{dev, st}).slabs.push_back(Slab{(char*)base, slabBytes, 0, 0});
+        }
+        return hipErrorOutOfMemory;
+    }
+    static Slab* slabOf(Lists& L, void* p) { for (Slab& s : L.slabs) if ((char*)p >= s.base && (char*)p < s.base + s.bytes) return &s; return nullptr; }
+    void release(void* p, size_t bytes, int dev, hipStream_t st, bool small) {
         {
             std::lock_guard<std::mutex> g(m);
-            std::vector<Block>& L = listOf(Key{dev, st}).small[c];
-            if (!L.empty()) { *out = L.back().p; L.pop_back(); return hipSuccess; }
+            bool live = false;
+            for (auto& r : refs) if (r.first.device == dev && r.first.stream == st) { live = true; break; }
+            Lists& L = listOf(Key{dev, st});
+            if (small) {             // a slab block always goes back to its slab's class list: the slab is freed as a whole once it is idle
+                Slab* s = slabOf(L, p);
+                if (s) { s->live--; L.small[classOf(bytes)].push_back(Block{p, bytes}); if (live) return; }
+            } else if (live) { L.big.push_back(Block{p, bytes}); return; }
         }
-        return hipMallocAsync(out, *got, st);
+        // the stream's last context is gone (an object outlived it): nothing would ever reuse the block
+        if (small) freeIdleSlabs(dev, st); else (void)hipFree(p);
     }
-    void release(void* p, size_t bytes, int dev, hipStream_t st, bool fromPool) {
-        std::lock_guard<std::mutex> g(m);
-        Lists& L = listOf(Key{dev, st});
-        if (fromPool) L.small[classOf(bytes)].push_back(Block{p, bytes, true}); else L.big.push_back(Block{p, bytes, false});
+    // removes slabs without live blocks (and their waiting blocks) from L; returns them for hipFree outside the lock
+    static void takeIdleSlabs(Lists& L, std::vector<void*>& drop, size_t* total, size_t keep) {
+        for (size_t i = 0; i < L.slabs.size();) {
+            if (L.slabs[i].live > 0 || (total && *total <= keep)) { i++; continue; }
+            const Slab s = L.slabs[i];
+            for (auto& S : L.small) { size_t w = 0; for (size_t k = 0; k < S.size(); k++) if (!((char*)S[k].p >= s.base && (char*)S[k].p < s.base + s.bytes)) S[w++] = S[k]; S.resize(w); }
+            drop.push_back(s.base); if (total) *total -= s.bytes;
+            L.slabs[i] = L.slabs.back(); L.slabs.pop_back();
+        }
     }
-    void trimStream(int dev, hipStream_t st) {
-        Lists drop;
-        { std::lock_guard<std::mutex> g(m); std::swap(drop, listOf(Key{dev, st})); }
-        for (const Block& b : drop.big) (void)hipFree(b.p);
-        for (auto& L : drop.small) for (const Block& b : L) if (hipFreeAsync(b.p, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(b.p); }
+    void freeIdleSlabs(int dev, hipStream_t st) {
+        std::vector<void*> drop;
+        { std::lock_guard<std::mutex> g(m); takeIdleSlabs(listOf(Key{dev, st}), drop, nullptr, 0); }
+        for (void* p : drop) (void)hipFree(p);
+    }
+    // Frees cached memory of (device, stream) — the largest big blocks first, then idle slabs — until at most `keep` bytes stay.  hipFree
+    // waits for the device, so a block still referenced by queued work of that stream is safe to drop here.
+    void trimTo(int dev, hipStream_t st, size_t keep) {
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            Lists& L = listOf(Key{dev, st});
+            size_t total = heldBytes(L);
+            while (total > keep && !L.big.empty()) {
+                size_t bi = 0;
+                for (size_t i = 1; i < L.big.size(); i++) if (L.big[i].bytes > L.big[bi].bytes) bi = i;
+                drop.push_back(L.big[bi].p); total -= L.big[bi].bytes; L.big[bi] = L.big.back(); L.big.pop_back();
+            }
+            takeIdleSlabs(L, drop, &total, keep);
+        }
+        for (void* p : drop) (void)hipFree(p);
+    }
+    void trimStream(int dev, hipStream_t st) { trimTo(dev, st, 0); }
+    void trimDevice(int dev) {                       // everything idle on the device, all streams (an allocation failed)
+        std::vector<void*> drop;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (auto& e : lists) if (e.first.device == dev) { for (const Block& b : e.second.big) drop.push_back(b.p); e.second.big.clear(); takeIdleSlabs(e.second, drop, nullptr, 0); }
+        }
+        (void)hipGetLastError();
+        for (void* p : drop) (void)hipFree(p);
     }
 };
 constexpr size_t kBigBlock = 4u << 20;
+inline AllocScope::~AllocScope() {
+    const AllocState mine = tlsAlloc();
+    tlsAlloc() = prev;
+    if (mine.active && !prev.active) {               // the outermost scope of an API call
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && BigBlockCache::get().cachedBytes(dev, mine.stream) > BigBlockCache::keepBytes())
+            BigBlockCache::get().trimTo(dev, mine.stream, BigBlockCache::keepBytes());
+    }
+}
 
 // diagnostic (SDFHIP_ALLOC_CHECK): registry of the live device blocks; a new block overlapping a live one is reported
 struct AllocRegistry {
@@ -160,10 +256,9 @@ struct DevBuf {
         if (!p) return;
         if (AllocRegistry::on()) AllocRegistry::get().remove(p);
         const double t0 = nowSeconds();
-        // a block of the stream-ordered pool goes back through hipFreeAsync on the stream it came from, also when its owner (a tree, a mesh)
-        // is destroyed long after the build; a cached big block returns to its stream's free list
+        // a cached block returns to the free list of the stream it was handed out on, also when its owner (a tree, a mesh) is destroyed
+        // long after the build
         if (cachedBytes) { BigBlockCache::get().release(p, cachedBytes, cachedDevice, poolStream, cachedSmall); cachedBytes = 0; }
-        else if (pooled) { if (hipFreeAsync(p, poolStream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); } }
         else (void)hipFree(p);
         g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
         p = nullptr; n = 0;
@@ -181,12 +276,14 @@ struct DevBuf {
             if (e != hipSuccess) cachedBytes = 0;
         }
         else if (tlsAlloc().active) {
-            static const bool noSmallCache = getenv("SDFHIP_NO_SMALL_CACHE") != nullptr;
-            if (noSmallCache) { e = hipMallocAsync((void**)&p, count * sizeof(T), tlsAlloc().stream); cachedBytes = 0; }
-            else { e = BigBlockCache::get().allocSmall((void**)&p, count * sizeof(T), tlsAlloc().stream, &cachedBytes); cachedSmall = true; (void)hipGetDevice(&cachedDevice); if (e != hipSuccess) cachedBytes = 0; }
+            e = BigBlockCache::get().allocSmall((void**)&p, count * sizeof(T), tlsAlloc().stream, &cachedBytes); cachedSmall = true; (void)hipGetDevice(&cachedDevice);
+            if (e != hipSuccess) cachedBytes = 0;
             pooled = true; poolStream = tlsAlloc().stream;
         }
-        else { e = hipMalloc((void**)&p, count * sizeof(T)); pooled = false; }
+        else {
+            e = hipMalloc((void**)&p, count * sizeof(T)); pooled = false;
+            if (e != hipSuccess) { int dev = 0; (void)hipGetDevice(&dev); BigBlockCache::get().trimDevice(dev); e = hipMalloc((void**)&p, count * sizeof(T)); }
+        }
         g_allocSeconds() += nowSeconds() - t0; g_allocCalls()++;
         if (e != hipSuccess) { p = nullptr; setError("device allocation of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e)); return SDFHIP_E_HIP; }
         n = count;
@@ -226,6 +323,8 @@ struct sdfhip_near_scratch {
     sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList; sdfhip::DevBuf<uint8_t> candCount; sdfhip::DevBuf<float> candLo;   // candLo: the candidates' lower bounds (k_near_candidates)
       // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters, [10]: long list length
     bool counterReady = false;
+    size_t bytes() const { return 4 * (cand.n + fbList.n + fbCount.n + longList.n + candLo.n) + candCount.n; }
+    void release() { cand.release(); fbList.release(); fbCount.release(); longList.release(); candCount.release(); candLo.release(); counterReady = false; }
 };
 
 struct sdfhip_ctx {
@@ -241,6 +340,16 @@ struct sdfhip_ctx {
     // with an exchange installed, must stay in collective order.  Queries take no part in this and run concurrently.
     std::recursive_mutex buildLock;
     sdfhip_exchange exchange{};           // world >= 1: the CONTINUITY build shares out its traversals (sdfhip.h)
+};
+
+// Declared by a builder right after it takes the context's buildLock: when the build returns, the nearest search's candidate lists
+// (128 B per sample of the largest batch: gigabytes after a depth-9 build) are released if they exceed the caches' high-water mark.
+struct NearScratchMark {
+    sdfhip_ctx* ctx;
+    explicit NearScratchMark(sdfhip_ctx* c) : ctx(c) {}
+    ~NearScratchMark() {
+        if (ctx->nearScratch.bytes() > sdfhip::BigBlockCache::keepBytes()) { (void)hipStreamSynchronize(ctx->stream); ctx->nearScratch.release(); }
+    }
 };
 
 struct sdfhip_mesh {
