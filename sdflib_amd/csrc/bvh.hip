@@ -639,7 +639,40 @@ int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh) {
 
 // Upload a planned tree (8 doubles + 2 ints per inner node, host or device memory) and derive what the traversal needs besides:
 // the fp32 copy of the spheres, the coordinate scale bounding its rounding, and the per-triangle vertex records.
-static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where) {
+// The two-phase nearest search navigates the tree WITHOUT loading it (k_tri_ranks, k_wide_nodes, resolveTies): it assumes what the planner
+// produces — inner nodes numbered in pre-order, a node over the sorted range [b, e) split at (b + e) / 2, one-triangle ranges stored as
+// ~triangle.  An imported tree of any other shape would silently give wrong ids, so an import is checked against that shape (host walk
+// of the child array, O(T), overlapped with the device-side derivations) and refused otherwise.
+static bool isPlannerShaped(const int* kids, uint32_t T) {
+    if (T < 2) return true;
+    std::vector<uint8_t> seen(T, 0);
+    struct Item { uint32_t node, b, e; };
+    std::vector<Item> stack; stack.push_back(Item{0u, 0u, T});
+    uint64_t leaves = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (it.node >= T - 1) return false;
+        const uint32_t mid = (uint32_t)(0.5 * ((double)it.b + (double)it.e));
+        const uint32_t ranges[2][2] = {{it.b, mid}, {mid, it.e}};
+        const uint32_t expectInner[2] = {it.node + 1u, it.node + (mid - it.b)};
+        for (int side = 0; side < 2; side++) {
+            const int k = kids[2 * (size_t)it.node + side];
+            const uint32_t n = ranges[side][1] - ranges[side][0];
+            if (n == 1) {
+                if (k >= 0) return false;
+                const uint32_t t = (uint32_t)~k;
+                if (t >= T || seen[t]) return false;
+                seen[t] = 1; leaves++;
+            } else {
+                if (k < 0 || (uint32_t)k != expectInner[side]) return false;
+                stack.push_back(Item{(uint32_t)k, ranges[side][0], ranges[side][1]});
+            }
+        }
+    }
+    return leaves == T;
+}
+
+static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where, bool validate = false) {
     const uint32_t T = mesh->numTriangles;
     const uint64_t nn = T - 1;
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
@@ -667,7 +700,19 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     k_wide_nodes<<<gridFor(16ull * T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), reinterpret_cast<const float4*>(mesh->dTriVerts.p),
                                                triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
     SDF_HIP_CHECK(hipGetLastError());
+    bool shapeOk = true;
+    if (validate) {              // while the device derives its records
+        std::vector<int> hostKids;
+        const int* hk = kids;
+        if (where != SDFHIP_HOST) { hostKids.resize(nKids); SDF_HIP_CHECK(hipMemcpy(hostKids.data(), kids, nKids * sizeof(int), hipMemcpyDeviceToHost)); hk = hostKids.data(); }
+        shapeOk = isPlannerShaped(hk, T);
+    }
     SDF_HIP_CHECK(hipStreamSynchronize(st));
+    if (!shapeOk) {
+        mesh->hasBvh = false;
+        setError("imported BVH is not a midpoint-split tree numbered in pre-order (what sdfhip_mesh_bvh_export / the planner produce): refused");
+        return SDFHIP_E_INVALID;
+    }
     mesh->numBvhNodes = nn;
     mesh->hasBvh = true;
     return SDFHIP_OK;
@@ -782,7 +827,7 @@ int sdfhip_mesh_bvh_import(sdfhip_mesh* mesh, const double* spheres, const int32
     SDF_REQUIRE(mesh && spheres && children, "NULL argument");
     std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
-    return installBvh(mesh, spheres, children, where);
+    return installBvh(mesh, spheres, children, where, true);
     SDF_API_END
 }
 

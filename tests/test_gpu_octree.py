@@ -751,3 +751,27 @@ def test_pipelined_host_query_finishes_through_the_plain_path_when_a_later_piece
             finally:
                 os.environ.pop("SDFHIP_TEST_PIN_FAIL_AFTER", None)
             assert np.array_equal(bits(d), bits(want)), (n, after)
+
+
+def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
+    """The two-phase nearest search navigates the planner's tree by arithmetic (pre-order numbering, midpoint splits); an import that
+    is not of that shape would silently give wrong ids (round-2 advisor finding), so it is refused; the planner's own export is accepted."""
+    import sdflib_amd as S
+    from sdflib_amd._lib import SdfHipError
+    from sdflib_amd.meshgen import bumpy_icosphere, random_points_in_box, box_with_margin
+    v, f = bumpy_icosphere(3)
+    a = S.Mesh(v, f, gpu_ctx); a.build_bvh()
+    sph, kids = a.bvh_arrays()
+    b = S.Mesh(v, f, gpu_ctx)
+    b.set_bvh(sph, kids)                                    # the planner's tree: accepted
+    pts = random_points_in_box(box_with_margin(v), 5000, seed=2)
+    assert np.array_equal(a.nearest_triangle(pts), b.nearest_triangle(pts))
+    kids2 = kids.copy().reshape(-1, 2)
+    kids2[0] = kids2[0][::-1]                               # root's children swapped: still a valid binary tree, not the planner's numbering
+    c = S.Mesh(v, f, gpu_ctx)
+    with pytest.raises(SdfHipError):
+        c.set_bvh(sph, kids2.ravel())
+    kids3 = kids.copy(); leaf = np.nonzero(kids3 < 0)[0]
+    kids3[leaf[0]] = kids3[leaf[1]]                         # one triangle twice, another never
+    with pytest.raises(SdfHipError):
+        c.set_bvh(sph, kids3)
