@@ -291,7 +291,9 @@ int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* 
  * reassembles the array(s) on EVERY device with one in-place all-gather-v (ncclBroadcast per shard inside one group, over xGMI).  The same
  * device id listed several times (one-GPU test boxes) selects device-to-device copies instead of RCCL.  Outputs: out_trees[rank] (and
  * out_meshes[rank]) live on device_ids[rank]; all trees are identical and identical to the single-device build.
- * NO_CONTINUITY and ExactOctreeSdf builds are sharded; a CONTINUITY tree is built on the first device and broadcast. */
+ * NO_CONTINUITY and ExactOctreeSdf builds are sharded by start cell; a CONTINUITY tree (not separable by start cell) is built by every device
+ * with the BVH traversals of each sample batch shared out and completed by one sum all-reduce per batch (ncclAllReduce; staged copies on
+ * the copy transport), as sdflib_amd/distributed.py does across processes: identical trees everywhere, nothing broadcast afterwards. */
 typedef struct sdfhip_multi sdfhip_multi;
 typedef struct sdfhip_multi_stats {
     int32_t ranks, uses_rccl;

@@ -21,6 +21,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <thread>
+#include <condition_variable>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -34,6 +35,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool load() {
         if (ok) return true;
@@ -46,7 +48,8 @@ struct Rccl {
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart"); GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         Broadcast = (decltype(Broadcast))sym("ncclBroadcast"); GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && GetErrorString;
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && AllReduce && GetErrorString;
         return ok;
     }
 };
@@ -110,6 +113,67 @@ static int allGatherV(sdfhip_multi* M, const std::vector<void*>& buf, const std:
     for (const Segment& s : segs) M->bytesExchanged += s.count * elemSize;
     return SDFHIP_OK;
 }
+
+// ---- CONTINUITY builds on several devices of one process ---------------------------------------------------------------------------------
+// The breadth-first builder is not separable by start cell (its second iteration couples neighbouring cells, its post-pass is serial host
+// code), so every device builds the WHOLE tree and what is shared out is what costs the time: the BVH traversals of every deduplicated
+// sample batch (sdfhip_exchange, sdfhip.h: rank r traverses the 128-sample blocks b with b % world == r, one sum all-reduce of the id
+// buffer completes the batch everywhere).  sdflib_amd/distributed.py does this across processes; here the ranks are host threads:
+// the all-reduce is ncclAllReduce on the devices' communicators, or — one physical device listed several times, tests — staged copies
+// and adds between barriers of the threads.
+__global__ void k_add_u32(uint32_t* __restrict__ acc, const uint32_t* __restrict__ other, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += other[i];
+}
+struct ThreadBarrier {                     // all `n` threads, or none: a rank that fails releases the others with an error
+    std::mutex m; std::condition_variable cv; int n = 0, waiting = 0; uint64_t phase = 0; bool failed = false;
+    bool arrive() {
+        std::unique_lock<std::mutex> g(m);
+        if (failed) return false;
+        const uint64_t ph = phase;
+        if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); return true; }
+        cv.wait(g, [&] { return phase != ph || failed; });
+        return !failed;
+    }
+    void fail() { std::lock_guard<std::mutex> g(m); failed = true; cv.notify_all(); }
+};
+struct InProcessExchange {
+    sdfhip_multi* M = nullptr; int rank = 0; ThreadBarrier* bar = nullptr; std::vector<InProcessExchange>* all = nullptr;
+    DevBuf<uint32_t> buf, stage, acc; uint64_t bytes = 0; double seconds = 0;
+    static uint32_t* acquire(void* user, uint64_t count) {
+        InProcessExchange* X = (InProcessExchange*)user;
+        if (hipSetDevice(X->M->devices[X->rank]) != hipSuccess || X->buf.reserve(count ? count : 1) != SDFHIP_OK) return nullptr;
+        if (hipMemsetAsync(X->buf.p, 0, 4 * count, X->M->ctx[X->rank]->stream) != hipSuccess) return nullptr;
+        return X->buf.p;
+    }
+    static int allReduceSum(void* user, uint64_t count) {
+        InProcessExchange* X = (InProcessExchange*)user;
+        sdfhip_multi* M = X->M; const int n = (int)M->ctx.size(), r = X->rank;
+        hipStream_t st = M->ctx[r]->stream;
+        const double t0 = nowSeconds();
+        X->bytes += 4 * count;
+        if (M->useRccl) {
+            SDF_NCCL(rccl().AllReduce(X->buf.p, X->buf.p, count, ncclUint32, ncclSum, M->comm[r], st));
+            X->seconds += nowSeconds() - t0;
+            return SDFHIP_OK;
+        }
+        // copy transport: everybody's buffer complete -> sum of all into a private accumulator -> everybody done reading -> back into the buffer
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        if (!X->bar->arrive()) { setError("another device's CONTINUITY build failed"); return SDFHIP_E_HIP; }
+        SDF_TRY(X->acc.reserve(count ? count : 1)); SDF_TRY(X->stage.reserve(count ? count : 1));
+        SDF_HIP_CHECK(hipMemcpyAsync(X->acc.p, X->buf.p, 4 * count, hipMemcpyDeviceToDevice, st));
+        for (int k = 0; k < n; k++) {
+            if (k == r) continue;
+            SDF_HIP_CHECK(hipMemcpyAsync(X->stage.p, (*X->all)[k].buf.p, 4 * count, hipMemcpyDeviceToDevice, st));
+            k_add_u32<<<gridFor(count, 256), 256, 0, st>>>(X->acc.p, X->stage.p, count);
+        }
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        if (!X->bar->arrive()) { setError("another device's CONTINUITY build failed"); return SDFHIP_E_HIP; }
+        SDF_HIP_CHECK(hipMemcpyAsync(X->buf.p, X->acc.p, 4 * count, hipMemcpyDeviceToDevice, st));
+        X->seconds += nowSeconds() - t0;
+        return SDFHIP_OK;
+    }
+};
 
 // work estimate per start cell: vertices in the cell and its 26 neighbours (surface cells subdivide), as distributed.py::cell_weights
 static std::vector<double> cellWeights(const float* xyz, uint32_t nv, const float box_min[3], const float box_max[3], uint32_t startDepth) {
@@ -246,8 +310,28 @@ int sdfhip_multi_octree_build(sdfhip_multi* M, const float* xyz, uint32_t nv, co
     const uint32_t numCells = 1u << (3 * params->start_depth);
     const bool sharded = params->algorithm == SDFHIP_ALG_NO_CONTINUITY && n > 1 && numCells >= (uint32_t)n;
     int rc = SDFHIP_OK;
-    if (!sharded) {
-        // CONTINUITY (its second iteration couples neighbouring cells) or a single device: device 0 builds, the array is broadcast
+    if (!sharded && n > 1 && params->algorithm == SDFHIP_ALG_CONTINUITY) {
+        // every device builds the whole tree from identical inputs, the traversals are shared out (InProcessExchange above): the trees
+        // are bit-identical, nothing is broadcast afterwards
+        const double t0 = nowSeconds();
+        ThreadBarrier bar; bar.n = n;
+        std::vector<InProcessExchange> X(n);
+        for (int r = 0; r < n; r++) { X[r].M = M; X[r].rank = r; X[r].bar = &bar; X[r].all = &X; }
+        rc = perRank(n, [&](int r) {
+            SDF_HIP_CHECK(hipSetDevice(M->devices[r]));
+            sdfhip_exchange x{&X[r], &InProcessExchange::acquire, &InProcessExchange::allReduceSum, r, n};
+            SDF_TRY(sdfhip_ctx_set_exchange(M->ctx[r], &x));
+            const int brc = sdfhip_octree_build(M->ctx[r], mesh[r], params, &tree[r]);
+            (void)sdfhip_ctx_set_exchange(M->ctx[r], nullptr);
+            if (brc != SDFHIP_OK) bar.fail();
+            return brc;
+        });
+        for (int r = 0; r < n; r++) { (void)hipSetDevice(M->devices[r]); X[r].buf.release(); X[r].stage.release(); X[r].acc.release(); }
+        M->lastShardSeconds = nowSeconds() - t0;
+        M->lastExchangeSeconds = X[0].seconds; M->bytesExchanged = X[0].bytes;
+        if (rc != SDFHIP_OK) { for (int r = 0; r < n; r++) if (tree[r]) { sdfhip_octree_destroy(tree[r]); tree[r] = nullptr; } return cleanup(rc); }
+    } else if (!sharded) {
+        // a single device (or too few start cells to shard): device 0 builds, the array is broadcast
         const double t0 = nowSeconds();
         rc = sdfhip_octree_build(M->ctx[0], mesh[0], params, &tree[0]);
         if (rc != SDFHIP_OK) return cleanup(rc);

@@ -173,3 +173,8 @@ def test_in_process_multi_gpu_builds_equal_the_single_device_ones(tmp_path, devi
     assert len(lines) == 3 and all("mismatches 0 scalars_equal 1" in l for l in lines), r.stdout
     if devices != "0":
         assert "bytes_exchanged 0" not in lines[0], r.stdout
+        # CONTINUITY on several devices: every device builds the tree, only the shared traversals' ids are exchanged (far less than the
+        # array a broadcast would move), and the arrays are identical all the same
+        import re
+        m = re.search(r"words (\d+) .* bytes_exchanged (\d+)", lines[1])
+        assert m and 0 < int(m.group(2)) < 4 * int(m.group(1)) // 4, lines[1]
