@@ -528,7 +528,7 @@ def exact_query_roofline(ex, pts, ms, prof, sample=20000):
     return r
 
 
-EXACT_KERNEL = "sdfhip::k_exact_sorted<false>"
+EXACT_KERNEL = "sdfhip::k_exact_tiles<false>"
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
