@@ -287,12 +287,18 @@ struct IntroSortLike {
     }
 };
 
+struct BvhTask { int innerId; uint32_t begin, end, parentSlot; };      // a range left to the device; parentSlot: index of the subtree's sphere in units of 4 doubles
+
 struct HostBvhBuilder {
     const float* verts; const uint32_t* idx;
     double* sph;       // 8 doubles per inner node: spheres of the left and of the right child
     int* kids;         // 2 ints per inner node: child references (>= 0 inner node, < 0 ~triangle)
     std::vector<int> order;
     int maxParallelDepth = 0;
+    // offload (planBvhHost): ranges of at most offloadMax triangles are not planned here but listed for k_bvh_subtrees; the inner nodes
+    // that ARE planned here are listed too (their records are scattered into the device arrays)
+    uint32_t offloadMax = 0;
+    std::vector<BvhTask> tasks; std::vector<int> hostNodes; std::mutex listLock;
 
     struct D { double x, y, z; };
     KeyTri* scratchKeys = nullptr; float* scratchLoc = nullptr; uint32_t* scratchL = nullptr; uint32_t* scratchR = nullptr;      // T entries / 9 T floats, uninitialised, sliced by range
@@ -312,6 +318,12 @@ struct HostBvhBuilder {
     // `innerId` = pre-order index this subtree's root gets if it is an inner node (n > 1).
     int build(int innerId, double* out, int begin, int end, int depth) {
         const int n = end - begin;
+        if (offloadMax && n > 1 && (uint32_t)n <= offloadMax && out >= sph) {      // (`out` outside the array: the root's own sphere, which nobody reads)
+            std::lock_guard<std::mutex> g(listLock);
+            tasks.push_back(BvhTask{innerId, (uint32_t)begin, (uint32_t)end, (uint32_t)((out - sph) / 4)});
+            return innerId;
+        }
+        if (offloadMax && n > 1) { std::lock_guard<std::mutex> g(listLock); hostNodes.push_back(innerId); }
         if (n == 1) {
             const int t = order[begin];
             const D a = vtx(t, 0), b = vtx(t, 1), c = vtx(t, 2);
@@ -446,6 +458,198 @@ struct HostBvhBuilder {
         return innerId;
     }
 };
+
+// ---- the bottom of the tree on the device ---------------------------------------------------------------------------------------------
+// OPT-IN (SDFHIP_BVH_DEVICE_SUBTREES=1).  The host planner hands every range of at most kDevSubtreeMax triangles to the device (planBvhHost
+// with offload): those ranges are the bottom twelve of the tree's twenty levels, 45 % of the planner's CPU time.  The trees are identical
+// (tests/test_gpu_octree.py::test_hybrid_bvh_plan_equals_the_oracles_tree) but the build is not faster, see sdfhip_mesh_build_bvh.
+// One workgroup builds one such subtree, level by level, its {key, triangle} array in LDS:
+//   * a node is ONE lane's work for everything whose result depends on an order: the vertices are summed in range order in fp64 (the
+//     reference's centre), AABB -> split axis, radius, keys; the same expressions as HostBvhBuilder::build, operand for operand;
+//   * the range is then sorted by libstdc++'s introsort, restated once more (IntroSortLike above is the host's): median of three to the
+//     front, unguarded Hoare partition, ranges of at most 16 finished by insertion sort — a partition is one lane's work, the two
+//     parts it leaves are independent tasks of the next round, so a level's sorts cost about 3 n sequential steps, not n log n.  The
+//     permutation among tied keys is the sequential algorithm's because every comparison and swap is.  A range that exhausts
+//     introsort's depth limit (heap sort in libstdc++) raises a flag and the whole tree is planned on the host instead;
+//   * node ids follow from the pre-order numbering (left child = id + 1, right child = id + (mid - begin)), so the subtree writes its
+//     records straight into the device arrays, and its own sphere into its parent's record (planned on the host).
+struct BvhDevNode { int id; uint32_t b, e, slot; };
+constexpr uint32_t kDevSubtreeMax = 4096;
+constexpr uint32_t kDevSortTasks = 512;
+
+SDF_DEV void devInsertionSort(KeyTri* a, int first, int last) {
+    for (int i = first + 1; i < last; i++) {
+        const KeyTri val = a[i];
+        if (val.key < a[first].key) { for (int k = i; k > first; k--) a[k] = a[k - 1]; a[first] = val; }
+        else { int pos = i; while (val.key < a[pos - 1].key) { a[pos] = a[pos - 1]; pos--; } a[pos] = val; }
+    }
+}
+SDF_DEV void devSwap(KeyTri* a, int i, int j) { const KeyTri t = a[i]; a[i] = a[j]; a[j] = t; }
+// libstdc++'s __move_median_to_first(result, a, b, c)
+SDF_DEV void devMedianToFirst(KeyTri* k, int result, int a, int b, int c) {
+    if (k[a].key < k[b].key) {
+        if (k[b].key < k[c].key) devSwap(k, result, b);
+        else if (k[a].key < k[c].key) devSwap(k, result, c);
+        else devSwap(k, result, a);
+    } else if (k[a].key < k[c].key) devSwap(k, result, a);
+    else if (k[b].key < k[c].key) devSwap(k, result, c);
+    else devSwap(k, result, b);
+}
+// libstdc++'s __unguarded_partition(first, last, pivot)
+SDF_DEV int devPartition(KeyTri* k, int first, int last, int pivot) {
+    const float pk = k[pivot].key;
+    for (;;) {
+        while (k[first].key < pk) ++first;
+        --last;
+        while (pk < k[last].key) --last;
+        if (!(first < last)) return first;
+        devSwap(k, first, last);
+        ++first;
+    }
+}
+struct DevV3 { float x, y, z; };
+SDF_DEV void devTriVerts(const float4* __restrict__ triV, int t, DevV3& a, DevV3& b, DevV3& c) {
+    const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+    a = DevV3{q0.x, q0.y, q0.z}; b = DevV3{q0.w, q1.x, q1.y}; c = DevV3{q1.z, q1.w, q2.x};
+}
+SDF_DEV float devComp(const DevV3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
+
+__global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict__ tasks, const uint32_t* __restrict__ order, const float4* __restrict__ triV,
+                                                      double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed) {
+    extern __shared__ unsigned char s_bvh_raw[];
+    KeyTri* keys = reinterpret_cast<KeyTri*>(s_bvh_raw);
+    uint32_t* sortA = reinterpret_cast<uint32_t*>(s_bvh_raw + sizeof(KeyTri) * kDevSubtreeMax);        // {first, last, depth limit} x 3 words
+    uint32_t* sortB = sortA + 3 * kDevSortTasks;
+    __shared__ uint32_t s_count[4];                  // [0] nodes of the next level, [1] sort tasks of the next round, [2] overflow / depth-limit flag
+    const BvhTask T = tasks[blockIdx.x];
+    const uint32_t n = T.end - T.begin;
+    const int tid = threadIdx.x;
+    BvhDevNode* cur = nodeScratch + (size_t)blockIdx.x * 2u * (kDevSubtreeMax / 2u + 1u);
+    BvhDevNode* nxt = cur + (kDevSubtreeMax / 2u + 1u);
+    for (uint32_t i = tid; i < n; i += 256) keys[i] = KeyTri{0.f, (int)order[T.begin + i]};
+    if (tid == 0) { cur[0] = BvhDevNode{T.innerId, T.begin, T.end, T.parentSlot}; s_count[2] = 0; }
+    uint32_t nCur = 1;
+    __syncthreads();
+    while (nCur > 0) {
+        if (tid == 0) { s_count[0] = 0; s_count[1] = 0; }
+        __syncthreads();
+        // ---- A. one lane per node: centre (ordered fp64 sum), AABB -> axis, radius, keys; short ranges sorted at once
+        for (uint32_t j = tid; j < nCur; j += 256) {
+            const BvhDevNode nd = cur[j];
+            const int lo = (int)(nd.b - T.begin), nn = (int)(nd.e - nd.b);
+            double sx = 0.0, sy = 0.0, sz = 0.0;
+            const float fhi = 3.402823466e+38f;
+            float tx = -fhi, ty = -fhi, tz = -fhi, bx = fhi, by = fhi, bz = fhi;
+            for (int i = 0; i < nn; i++) {
+                DevV3 v[3]; devTriVerts(triV, keys[lo + i].tri, v[0], v[1], v[2]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    sx += (double)v[k].x; sy += (double)v[k].y; sz += (double)v[k].z;
+                    tx = v[k].x > tx ? v[k].x : tx; bx = v[k].x < bx ? v[k].x : bx; ty = v[k].y > ty ? v[k].y : ty; by = v[k].y < by ? v[k].y : by;
+                    tz = v[k].z > tz ? v[k].z : tz; bz = v[k].z < bz ? v[k].z : bz;
+                }
+            }
+            const double cnt = (double)(3 * nn);
+            const double cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
+            const double d0 = (double)tx - (double)bx, d1 = (double)ty - (double)by, d2 = (double)tz - (double)bz;
+            int dim = 0; double dm = d0;                       // std::max_element: the first of equal maxima
+            if (dm < d1) { dim = 1; dm = d1; }
+            if (dm < d2) dim = 2;
+            double r2 = 0.0;
+            for (int i = 0; i < nn; i++) {
+                DevV3 v[3]; devTriVerts(triV, keys[lo + i].tri, v[0], v[1], v[2]);
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double dx = cx - (double)v[k].x, dy = cy - (double)v[k].y, dz = cz - (double)v[k].z;
+                    const double q = dx * dx + dy * dy + dz * dz;
+                    r2 = r2 < q ? q : r2;
+                }
+                keys[lo + i].key = devComp(v[0], dim);
+            }
+            if (nd.slot != 0xFFFFFFFFu) { double* o = sph + 4 * (size_t)nd.slot; o[0] = cx; o[1] = cy; o[2] = cz; o[3] = sqrt(r2); }
+            if (nn <= 16) devInsertionSort(keys, lo, lo + nn);
+            else {
+                int lg = 0; for (int m = nn; m > 1; m >>= 1) lg++;
+                const uint32_t at = atomicAdd(&s_count[1], 1u);
+                if (at < kDevSortTasks) { sortA[3 * at] = (uint32_t)lo; sortA[3 * at + 1] = (uint32_t)(lo + nn); sortA[3 * at + 2] = (uint32_t)(2 * lg); }
+                else atomicOr(&s_count[2], 1u);
+            }
+        }
+        __syncthreads();
+        // ---- B. introsort rounds: every pending range is partitioned by one lane; parts of at most 16 are finished on the spot
+        uint32_t nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
+        uint32_t* in = sortA; uint32_t* out = sortB;
+        __syncthreads();
+        while (nSort > 0) {
+            if (tid == 0) s_count[1] = 0;
+            __syncthreads();
+            for (uint32_t t = tid; t < nSort; t += 256) {
+                const int first = (int)in[3 * t], last = (int)in[3 * t + 1]; const int depth = (int)in[3 * t + 2];
+                if (depth == 0) { atomicOr(&s_count[2], 2u); continue; }             // libstdc++ switches to heap sort here: the host plans this tree
+                devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
+                const int cut = devPartition(keys, first + 1, last, first);
+                const int parts[2][2] = {{first, cut}, {cut, last}};
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int f = parts[h][0], l = parts[h][1];
+                    if (l - f > 16) {
+                        const uint32_t at = atomicAdd(&s_count[1], 1u);
+                        if (at < kDevSortTasks) { out[3 * at] = (uint32_t)f; out[3 * at + 1] = (uint32_t)l; out[3 * at + 2] = (uint32_t)(depth - 1); }
+                        else atomicOr(&s_count[2], 4u);
+                    } else devInsertionSort(keys, f, l);
+                }
+            }
+            __syncthreads();
+            nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
+            uint32_t* sw = in; in = out; out = sw;
+            __syncthreads();
+        }
+        // ---- C. one lane per node: the children (leaves get their sphere here, inner children at the next level)
+        for (uint32_t j = tid; j < nCur; j += 256) {
+            const BvhDevNode nd = cur[j];
+            const uint32_t mid = (nd.b + nd.e) >> 1;           // (int)(0.5 * (begin + end))
+            const uint32_t rb[2] = {nd.b, mid}, re[2] = {mid, nd.e};
+            const int childId[2] = {nd.id + 1, nd.id + (int)(mid - nd.b)};
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint32_t slot = 2u * (uint32_t)nd.id + (uint32_t)side;
+                if (re[side] - rb[side] == 1u) {
+                    const int t = keys[rb[side] - T.begin].tri;
+                    DevV3 a, b, c; devTriVerts(triV, t, a, b, c);
+                    const double sx = ((double)a.x + (double)b.x) + (double)c.x, sy = ((double)a.y + (double)b.y) + (double)c.y, sz = ((double)a.z + (double)b.z) + (double)c.z;
+                    const double cx = sx / 3.0, cy = sy / 3.0, cz = sz / 3.0;
+                    auto dist = [&](const DevV3& p) { const double dx = (double)p.x - cx, dy = (double)p.y - cy, dz = (double)p.z - cz; return sqrt(dx * dx + dy * dy + dz * dz); };
+                    const double da = dist(a), db = dist(b), dc = dist(c);
+                    const double m1 = da < db ? db : da;
+                    double* o = sph + 4 * (size_t)slot; o[0] = cx; o[1] = cy; o[2] = cz; o[3] = m1 < dc ? dc : m1;
+                    kids[slot] = ~t;
+                } else {
+                    kids[slot] = childId[side];
+                    const uint32_t at = atomicAdd(&s_count[0], 1u);
+                    nxt[at] = BvhDevNode{childId[side], rb[side], re[side], slot};
+                }
+            }
+        }
+        __syncthreads();
+        nCur = s_count[0];
+        BvhDevNode* sw = cur; cur = nxt; nxt = sw;
+        __syncthreads();
+    }
+    if (tid == 0 && s_count[2]) atomicOr(failed, s_count[2]);
+}
+
+// the records the host planned (the top of the tree), scattered to their pre-order positions; a half whose child is a device subtree is
+// left alone (the subtree writes its own sphere there)
+__global__ void k_bvh_scatter_top(const int* __restrict__ ids, const double* __restrict__ sph8, const int* __restrict__ kids2, const unsigned char* __restrict__ halfOwned, uint32_t count,
+                                  double* __restrict__ sph, int* __restrict__ kids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int id = ids[i];
+    for (int h = 0; h < 2; h++) {
+        kids[2 * (size_t)id + h] = kids2[2 * (size_t)i + h];
+        if (halfOwned[2 * (size_t)i + h]) for (int k = 0; k < 4; k++) sph[8 * (size_t)id + 4 * h + k] = sph8[8 * (size_t)i + 4 * h + k];
+    }
+}
 
 __global__ void k_sph32(const double* __restrict__ sph, uint64_t n, float* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -672,7 +876,12 @@ static bool isPlannerShaped(const int* kids, uint32_t T) {
     return leaves == T;
 }
 
-static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where, bool validate = false) {
+// The device's share of a hybrid plan (planBvhHost with offload): the host-planned records go to their places, then one workgroup per
+// listed range builds its subtree (k_bvh_subtrees).  SDFHIP_E_UNSUPPORTED: a sort ran into introsort's depth limit — the caller plans on the host.
+struct PlannedBvh;
+static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st);
+
+static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where, bool validate = false, const PlannedBvh* hybrid = nullptr) {
     const uint32_t T = mesh->numTriangles;
     const uint64_t nn = T - 1;
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
@@ -681,8 +890,12 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     AllocScope allocScope(st);
     const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph, nSph * sizeof(double), kind, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids, nKids * sizeof(int), kind, st));
+    if (!hybrid) {
+        SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph, nSph * sizeof(double), kind, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids, nKids * sizeof(int), kind, st));
+    }
+    k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
+    if (hybrid) SDF_TRY(finishOnDevice(mesh, *hybrid, st));
     {
         float scale = 0.f;
         for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
@@ -690,7 +903,6 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
         SDF_TRY(mesh->dBvhSph32.reserve(nSph));
         k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
-    k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
     SDF_TRY(mesh->dTriRank.reserve(T));
     k_tri_ranks<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), T, mesh->dTriRank.p);
     DevBuf<uint32_t> triAtRank;
@@ -738,9 +950,14 @@ static void* plannerAlloc(size_t bytes) {
     });
     return p;
 }
-struct PlannedBvh { std::unique_ptr<double, FreeDeleter> sph; std::unique_ptr<int, FreeDeleter> kids; double gatherSeconds = 0, planSeconds = 0; int sortThreads = 0, parallelDepth = 0; };
-static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_t T) {
+struct PlannedBvh {
+    std::unique_ptr<double, FreeDeleter> sph; std::unique_ptr<int, FreeDeleter> kids; double gatherSeconds = 0, planSeconds = 0; int sortThreads = 0, parallelDepth = 0;
+    std::vector<BvhTask> tasks; std::vector<int> hostNodes; std::vector<int> order;       // offload only: what is left to the device, what was planned here, the triangle order so far
+};
+// offloadMax > 0: ranges of at most that many triangles are left to the device (k_bvh_subtrees); the arrays then hold the top of the tree only
+static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_t T, uint32_t offloadMax = 0) {
     PlannedBvh R;
+    if (T <= offloadMax) offloadMax = 0;
     const double t0 = nowSeconds();
     const uint64_t nn = T - 1;                                   // inner nodes
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
@@ -770,10 +987,52 @@ static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_
     if (getenv("SDFHIP_BVH_PAR_DEPTH")) b.maxParallelDepth = atoi(getenv("SDFHIP_BVH_PAR_DEPTH"));
     if (getenv("SDFHIP_BVH_SORT_THREADS")) b.sortThreads = atoi(getenv("SDFHIP_BVH_SORT_THREADS"));
     double rootSphere[4];
+    b.offloadMax = offloadMax;
     b.build(0, rootSphere, 0, (int)T, 0);
+    if (offloadMax) { R.tasks = std::move(b.tasks); R.hostNodes = std::move(b.hostNodes); R.order = std::move(b.order); }
     R.gatherSeconds = tGather - t0; R.planSeconds = nowSeconds() - tGather; R.sortThreads = b.sortThreads; R.parallelDepth = b.maxParallelDepth;
     return R;
 }
+
+}  // extern "C"
+
+static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st) {
+    const uint32_t T = mesh->numTriangles;
+    const size_t nt = P.tasks.size(), nh = P.hostNodes.size();
+    // the host's records, compacted: ids, 8 doubles, 2 child references, and per half whether the host owns that sphere
+    std::vector<double> s8(8 * nh); std::vector<int> k2(2 * nh); std::vector<unsigned char> own(2 * nh, 1);
+    {
+        std::vector<uint32_t> taskSlots(nt);
+        for (size_t i = 0; i < nt; i++) taskSlots[i] = P.tasks[i].parentSlot;
+        std::sort(taskSlots.begin(), taskSlots.end());
+        for (size_t i = 0; i < nh; i++) {
+            const int id = P.hostNodes[i];
+            memcpy(&s8[8 * i], P.sph.get() + 8 * (size_t)id, 64); k2[2 * i] = P.kids.get()[2 * (size_t)id]; k2[2 * i + 1] = P.kids.get()[2 * (size_t)id + 1];
+            for (int h = 0; h < 2; h++) if (std::binary_search(taskSlots.begin(), taskSlots.end(), 2u * (uint32_t)id + (uint32_t)h)) own[2 * i + h] = 0;
+        }
+    }
+    DevBuf<int> dIds, dK2; DevBuf<double> dS8; DevBuf<unsigned char> dOwn; DevBuf<uint32_t> dOrder, dFail; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
+    SDF_TRY(dIds.reserve(nh)); SDF_TRY(dK2.reserve(2 * nh)); SDF_TRY(dS8.reserve(8 * nh)); SDF_TRY(dOwn.reserve(2 * nh));
+    SDF_TRY(dOrder.reserve(T)); SDF_TRY(dFail.reserve(1)); SDF_TRY(dTasks.reserve(nt)); SDF_TRY(dScratch.reserve(nt * 2 * (kDevSubtreeMax / 2 + 1)));
+    SDF_HIP_CHECK(hipMemcpyAsync(dIds.p, P.hostNodes.data(), 4 * nh, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dK2.p, k2.data(), 8 * nh, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dS8.p, s8.data(), 64 * nh, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dOwn.p, own.data(), 2 * nh, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dOrder.p, P.order.data(), 4 * (size_t)T, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(dTasks.p, P.tasks.data(), sizeof(BvhTask) * nt, hipMemcpyHostToDevice, st));
+    SDF_HIP_CHECK(hipMemsetAsync(dFail.p, 0, 4, st));
+    k_bvh_scatter_top<<<gridFor(nh, 256), 256, 0, st>>>(dIds.p, dS8.p, dK2.p, dOwn.p, (uint32_t)nh, mesh->dBvhSph.p, mesh->dBvhKids.p);
+    const size_t lds = sizeof(KeyTri) * kDevSubtreeMax + 2 * 3 * 4 * kDevSortTasks;
+    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    uint32_t failed = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&failed, dFail.p, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));         // (the staging vectors above are released here)
+    if (failed && getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: device subtrees gave up (reason bits %u: 1 / 4 = sort task list full, 2 = introsort depth limit): planning on the host\n", failed);
+    return failed ? SDFHIP_E_UNSUPPORTED : SDFHIP_OK;
+}
+
+extern "C" {
 
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_API_BEGIN
@@ -782,9 +1041,19 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
-    PlannedBvh P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles);
-    const double tPlanned = nowSeconds();
-    SDF_TRY(installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST));
+    // SDFHIP_BVH_DEVICE_SUBTREES=1: ranges of at most 4096 triangles are built on the device (k_bvh_subtrees).  Off by default — measured on
+    // the 16-CPU box it does not shorten the build: the planner's wall time is the critical path through the TOP levels (the root's sort,
+    // then its children's ...), the bottom levels already run on otherwise idle pool threads, and the subtree kernel adds 7 ms.
+    static const uint32_t offload = getenv("SDFHIP_BVH_DEVICE_SUBTREES") ? kDevSubtreeMax : 0u;
+    PlannedBvh P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, offload);
+    double tPlanned = nowSeconds();
+    int rc = installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST, false, P.tasks.empty() ? nullptr : &P);
+    if (rc == SDFHIP_E_UNSUPPORTED && !P.tasks.empty()) {         // a device sort met introsort's depth limit: libstdc++'s heap sort decides that order
+        P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, 0);
+        tPlanned = nowSeconds();
+        rc = installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST);
+    }
+    SDF_TRY(rc);
     if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", P.gatherSeconds, P.planSeconds, P.sortThreads, P.parallelDepth, nowSeconds() - tPlanned);
     if (seconds) *seconds = nowSeconds() - t0;
     return SDFHIP_OK;

@@ -1,4 +1,5 @@
 """GPU parity: HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs."""
+import os
 import numpy as np
 import pytest
 
@@ -775,3 +776,49 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
     kids3[leaf[0]] = kids3[leaf[1]]                         # one triangle twice, another never
     with pytest.raises(SdfHipError):
         c.set_bvh(sph, kids3)
+
+
+def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx):
+    """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
+    k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
+    all 64 bits of every child sphere, every leaf's triangle.  Meshes chosen for what decides the tree: tied sort keys (symmetric meshes,
+    shared first vertices, duplicated triangles), degenerate triangles, scales, sizes around the hand-over threshold."""
+    import subprocess, sys
+    # the switch is read once per process: the hybrid plans run in a child
+    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._hybrid_cases_check()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "hybrid cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def _hybrid_cases():
+    from sdflib_amd import meshgen
+    rng = np.random.default_rng(11)
+    cases = []
+    for s_ in (5, 6):
+        cases.append(meshgen.icosphere(s_))                                   # symmetric: tied keys on every axis, 20 480 / 81 920 triangles
+    v, f = meshgen.bumpy_icosphere(6)
+    cases.append((v, f))
+    cases.append((v * np.array([1e-3, 7.0, 250.0], np.float32) + np.array([1e3, -2.0, 0.5], np.float32), f))
+    cases.append((v, np.concatenate([f, f[::3], f[::5]])))                    # duplicated triangles: fully tied pairs
+    cases.append((v, f[rng.permutation(len(f))]))
+    cases.append((v, f[:, [1, 2, 0]]))
+    cases.append((v, np.concatenate([f, np.array([[0, 0, 1], [2, 2, 2]], np.uint32)])))
+    v5, f5 = meshgen.bumpy_icosphere(5)
+    for n in (4095, 4096, 4097, 8191, 8193, 12289):                           # around the threshold: the root handed over whole, or split just above it
+        cases.append((v5, f5[:n]))
+    cases.append(meshgen.torus_knot(nu=512, nv=80))
+    cases.append(meshgen.bumpy_icosphere(7))
+    return cases
+
+
+def _hybrid_cases_check():
+    import sdflib_amd as S
+    from test_planner_cpu import same_tree
+    assert os.environ.get("SDFHIP_BVH_DEVICE_SUBTREES") == "1"
+    ctx = S.default_context(0)
+    for v, f in _hybrid_cases():
+        m = S.Mesh(v, f, ctx)
+        m.build_bvh()
+        assert same_tree(v, f, arrays=m.bvh_arrays())
+        m.close()
+    print("hybrid cases ok")

@@ -25,9 +25,10 @@ def planned(v, f):
     return sph, kids
 
 
-def same_tree(v, f):
+def same_tree(v, f, arrays=None):
+    """arrays = (spheres, children) of a tree planned elsewhere (the GPU tests pass what the device holds); default: the host planner's."""
     from oracle import pyoracle as O
-    sph, kids = planned(v, f)
+    sph, kids = arrays if arrays is not None else planned(v, f)
     om = O.Mesh(np.ascontiguousarray(v, np.float32), np.ascontiguousarray(f, np.uint32))
     osph, olr = om.bvh_export()
     osph = np.asarray(osph, np.float64).reshape(-1, 8); olr = np.asarray(olr, np.int32).reshape(-1, 2)
