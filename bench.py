@@ -35,11 +35,10 @@ def source_hashes():
 
 
 # the files a kernel's code comes from: a counter profile is accepted for a kernel only if none of them changed since it was recorded
-_COMMON = ["sdflib_amd/csrc/sdfhip_internal.h", "sdflib_amd/csrc/dev_math.h"]
-KERNEL_SOURCES = {
-    "octree_query": _COMMON + ["sdflib_amd/csrc/octree_query.hip", "sdflib_amd/csrc/octree_internal.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/blocks.hip"],
-    "exact_query": _COMMON + ["sdflib_amd/csrc/exact_query.hip", "sdflib_amd/csrc/exact_internal.h"],
-    "fit_mfma": _COMMON + ["sdflib_amd/csrc/dev_fit_mfma.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/octree_build.hip"],
+KERNEL_SOURCES = {          # (sdfhip_internal.h holds host-side plumbing — allocation, error handling — and no kernel code: not listed)
+    "octree_query": ["sdflib_amd/csrc/octree_query.hip", "sdflib_amd/csrc/octree_internal.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/blocks.hip"],
+    "exact_query": ["sdflib_amd/csrc/exact_query.hip", "sdflib_amd/csrc/exact_internal.h", "sdflib_amd/csrc/dev_math.h"],
+    "fit_mfma": ["sdflib_amd/csrc/dev_fit_mfma.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_build.hip"],
 }
 
 
