@@ -105,6 +105,55 @@ def triangle_soup(vertices, triangles):
     return v, f
 
 
+def scan_like_mesh(seed=0, subdivisions=4):
+    """What scanned / badly exported meshes bring and the analytic generators above do not, in one mesh (deterministic for a seed):
+      * SLIVERS: a band of triangles with aspect ratios 1e3 .. 1e5 (an edge split extremely close to one end);
+      * a HIGH-VALENCE vertex: a pole whose fan has 64 triangles;
+      * T-JUNCTIONS: edges split on one side only (the neighbour keeps the long edge: a crack with coincident geometry);
+      * SELF-INTERSECTION: a second, smaller sphere poking through the first (no boolean: both surfaces stay);
+      * UNWELDED SEAMS: part of the surface as a soup (private vertex copies), part of it with jittered duplicates (1e-7);
+      * a patch with FLIPPED winding, a few zero-area triangles and one isolated far-away triangle."""
+    rng = np.random.default_rng(seed)
+    v, f = bumpy_icosphere(subdivisions)
+    v = v.astype(np.float64); f = f.astype(np.int64)
+    verts = [v]; faces = []
+    nv = len(v)
+    tri = f.copy()
+    # T-junctions + slivers: split an edge of every 7th triangle at t (tiny for slivers), on THIS triangle only
+    keep = np.ones(len(tri), bool)
+    extra_v, extra_f = [], []
+    for k in range(0, len(tri), 7):
+        a, b, c = tri[k]
+        t = 10.0 ** -rng.uniform(3, 5) if (k // 7) % 2 == 0 else rng.uniform(0.3, 0.7)
+        m = nv + sum(len(x) for x in extra_v); extra_v.append(((1 - t) * v[a] + t * v[b])[None])
+        extra_f += [[a, m, c], [m, b, c]]
+        keep[k] = False
+    verts.append(np.concatenate(extra_v)); faces.append(tri[keep]); faces.append(np.array(extra_f, np.int64))
+    nv += len(verts[-1])
+    # high-valence pole: a 64-triangle fan capping a small circle above the north pole
+    ang = np.linspace(0, 2 * np.pi, 64, endpoint=False)
+    ring = np.stack([0.12 * np.cos(ang), 0.12 * np.sin(ang), np.full(64, 1.2)], 1); apex = np.array([[0.0, 0.0, 1.32]])
+    verts.append(np.concatenate([apex, ring])); faces.append(np.array([[nv, nv + 1 + i, nv + 1 + (i + 1) % 64] for i in range(64)], np.int64)); nv += 65
+    # self-intersection: a smaller sphere pushed through the surface
+    v2, f2 = icosphere(2)
+    verts.append(v2.astype(np.float64) * 0.35 + np.array([0.85, 0.1, 0.0])); faces.append(f2.astype(np.int64) + nv); nv += len(v2)
+    V = np.concatenate(verts); F = np.concatenate(faces)
+    # unwelded: a third of the triangles get private vertex copies, half of those jittered by 1e-7
+    sel = rng.random(len(F)) < 0.33
+    soup = V[F[sel].reshape(-1)].copy()
+    jit = rng.random(len(soup)) < 0.5
+    soup[jit] += rng.normal(0, 1e-7, (int(jit.sum()), 3))
+    Fs = np.arange(len(soup), dtype=np.int64).reshape(-1, 3) + len(V)
+    V = np.concatenate([V, soup]); F = np.concatenate([F[~sel], Fs])
+    # flipped patch, zero-area triangles, an isolated triangle far away
+    flip = V[F].mean(1)[:, 0] < -0.8
+    F[flip] = F[flip][:, [0, 2, 1]]
+    deg = F[rng.integers(0, len(F), 6)].copy(); deg[:, 2] = deg[:, 1]
+    far = np.array([[4.0, 4.0, 4.0], [4.1, 4.0, 4.0], [4.0, 4.1, 4.05]]); Ffar = np.array([[len(V), len(V) + 1, len(V) + 2]], np.int64)
+    V = np.concatenate([V, far]); F = np.concatenate([F, deg, Ffar])
+    return np.ascontiguousarray(V, np.float32), np.ascontiguousarray(F, np.uint32)
+
+
 def box_with_margin(vertices, margin=0.2):
     """(min xyz, max xyz) float32[6]: mesh bbox grown by margin * largest extent on every side."""
     lo = vertices.min(axis=0).astype(np.float32)

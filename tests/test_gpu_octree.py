@@ -822,3 +822,40 @@ def _hybrid_cases_check():
         assert same_tree(v, f, arrays=m.bvh_arrays())
         m.close()
     print("hybrid cases ok")
+
+
+@pytest.mark.parametrize("seed,subdiv", [(0, 3), (1, 4), (2, 5)])
+def test_scan_like_mesh_with_slivers_t_junctions_self_intersection(oracle, gpu_ctx, seed, subdiv):
+    """meshgen.scan_like_mesh: slivers (aspect 1e3..1e5), a valence-64 vertex, T-junctions, a self-intersecting component, unwelded and
+    jittered seams, a flipped patch, zero-area triangles, an isolated far triangle — with and without the loader's bounding box (seam
+    welding).  TriangleData, nearest ids, both OctreeSdf builders' arrays, the ExactOctreeSdf arrays and queries against the oracle."""
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import scan_like_mesh, box_with_margin, random_points_in_box
+    v, f = scan_like_mesh(seed, subdiv)
+    box = box_with_margin(v, margin=0.1)
+    pts = random_points_in_box(box, 40000, seed=seed + 5)
+    tri = v[f[::3]]
+    near = (tri.mean(1) + np.random.default_rng(seed).normal(0, 1e-3, (len(tri), 3))).astype(np.float32)       # points hugging the surface (slivers, seams)
+    pts = np.ascontiguousarray(np.concatenate([pts, near, v[::5]]), np.float32)
+    for bbox in (None, np.concatenate([v.min(0), v.max(0)]).astype(np.float32)):
+        om = oracle.Mesh(v, f, bbox=bbox) if bbox is not None else oracle.Mesh(v, f)
+        gm = S.Mesh(v, f, gpu_ctx, bbox=bbox) if bbox is not None else S.Mesh(v, f, gpu_ctx)
+        a, b = om.triangle_data(), gm.triangle_data()
+        assert np.array_equal(bits(a), bits(b)) or np.array_equal(a, b, equal_nan=True), "TriangleData"
+        assert np.array_equal(om.nearest(pts), gm.nearest_triangle(pts)), "nearest ids"
+        depth = 6 if subdiv < 5 else 7
+        for cont in (False, True):
+            ot = oracle.Octree(om, box, depth, 2, 1e-3, vertex_cache=False, layout=oracle.LAYOUT_SUBTREES, continuity=cont)
+            gt = S.OctreeSdf(gm, box, depth, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY if cont else S.ALG_NO_CONTINUITY, num_threads=2)
+            assert np.array_equal(ot.data(), gt.get_octree_data()), f"octree array (continuity={cont}, welded={bbox is not None})"
+            d0, g0 = ot.query(pts, grad=True); d1, g1 = gt.get_distance(pts, gradient=True)
+            assert np.array_equal(bits(d0), bits(d1)) and (np.array_equal(bits(g0), bits(g1)) or np.array_equal(g0, g1, equal_nan=True))
+        oe = oracle.Exact(om, box, 6, 2, 16, threads=0); ge = S.ExactOctreeSdf(gm, box, 6, 2, 16)
+        for name, x, y in zip(("nodes", "has", "sets", "masks"), oe.data(), ge.download()):
+            if name == "has": continue
+            if name == "nodes": x, y = x[:, 0], y[:, 0]
+            assert x.shape == y.shape and np.array_equal(x, y), f"exact {name}"
+        e0, t0 = oe.query(pts, tri=True); e1, t1 = ge.get_distance(pts, triangle=True)
+        assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0, t1.astype(np.uint32)), "exact queries"
+        eg0 = oe.query(pts, grad=True); eg1 = ge.get_distance(pts, gradient=True)
+        assert np.array_equal(bits(eg0[0]), bits(eg1[0])) and (np.array_equal(bits(eg0[1]), bits(eg1[1])) or np.array_equal(eg0[1], eg1[1], equal_nan=True)), "exact gradients"
