@@ -192,37 +192,6 @@ SDF_HD float sqDistPointTriangleSelect(F3 point, const TriFrame& d) {
     return (de1 >= 0) ? dA : ((de2 >= 0) ? dB : ((de3 >= 0) ? dC : zz));
 }
 
-// Two triangles at once for one point: every arithmetic operation of sqDistPointTriangleSelect on a pair of floats, i.e. on the packed
-// fp32 instructions of gfx950 (v_pk_mul_f32 / v_pk_add_f32: two IEEE results per issue slot, no fusion) — the same values bit for bit.
-// f[c] = {frame float c of triangle A, of triangle B}, c in the order of the packed frames (origin 0..2, m 3..11, b, c, v2, v3).
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__clang__)
-typedef float v2f __attribute__((ext_vector_type(2)));
-SDF_HD v2f sel2(bool c0, bool c1, v2f a, v2f b) { return v2f{c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-SDF_HD v2f sqDistPointTrianglePair(F3 point, const v2f* __restrict__ f) {
-    const v2f dx = point.x - f[0], dy = point.y - f[1], dz = point.z - f[2];
-    const v2f px = f[3] * dx + f[6] * dy + f[9] * dz;
-    const v2f py = f[4] * dx + f[7] * dy + f[10] * dz;
-    const v2f pz = f[5] * dx + f[8] * dy + f[11] * dz;
-    const v2f bx = f[12], by = f[13], cx = f[14], cy = f[15], v2 = f[16], v3x = f[17], v3y = f[18];
-    const v2f px2 = px - v2, qx3 = px - v3x, qy3 = py - v3y;
-    const v2f de2 = px2 * by - py * bx;
-    const v2f de3 = px * cy - py * cx;
-    const v2f xx = px * px, yy = py * py, zz = pz * pz;
-    const v2f dV1 = xx + yy + zz;
-    const v2f dV2 = px2 * px2 + yy + zz;
-    const v2f dV3 = qx3 * qx3 + qy3 * qy3 + zz;
-    const v2f dE1 = yy + zz;
-    const v2f dE2 = de2 * de2 + zz, dE3 = de3 * de3 + zz;
-    const v2f tb2 = px2 * bx + py * by, tb3 = qx3 * bx + qy3 * by;
-    const v2f tc1 = px * cx + py * cy, tc3 = qx3 * cx + qy3 * cy;
-    const v2f dA = sel2(px.x <= 0, px.y <= 0, dV1, sel2(px.x >= v2.x, px.y >= v2.y, dV2, dE1));
-    const v2f dB = sel2(tb2.x <= 0, tb2.y <= 0, dV2, sel2(tb3.x >= 0, tb3.y >= 0, dV3, dE2));
-    const v2f dC = sel2(tc1.x >= 0, tc1.y >= 0, dV1, sel2(tc3.x <= 0, tc3.y <= 0, dV3, dE3));
-    // de1 = -p.y: (de1 >= 0) is (-py >= 0)
-    return sel2(-py.x >= 0, -py.y >= 0, dA, sel2(de2.x >= 0, de2.y >= 0, dB, sel2(de3.x >= 0, de3.y >= 0, dC, zz)));
-}
-#endif
-
 // Pseudonormal that signs region r; q = the vector it is dotted with.
 SDF_HD float regionSign(const Proj& o, const TriFrame& d, const float* __restrict__ td) {
     const F3 p = o.p;

@@ -190,11 +190,11 @@ __global__ void __launch_bounds__(256) k_exact_ctx_level(ExactView v, const CtxI
 // queries of one leaf:
 //   1. DECODE: the whole set streams through the two mask levels (ballot ranks) and the surviving triangle ids are COMPACTED into a
 //      per-wave LDS list (EX_IDS entries per round; longer lists take several rounds);
-//   2. EVALUATE: the list is walked in FULL tiles of 64 frames (80-byte packed frames gathered into LDS, one triangle per lane, stored as
-//      32 PAIRS with the two triangles' floats interleaved); lane (g, i) works for query i of the run on the tile's pairs g, g + G, ...;
-//      runs of more than 21 queries are cut into equal parts of 11..21 queries so that G x part fills at least 80 % of the wave; the
-//      distance of a point to BOTH triangles of a pair is one pass of packed fp32 instructions (sqDistPointTrianglePair: branch-free,
-//      every operation on two floats, the scalar routine's values bit for bit);
+//   2. EVALUATE: the list is walked in FULL tiles of 64 frames (80-byte packed frames gathered into LDS, one triangle per lane); lane
+//      (g, i) works for query i of the run on the tile's triangles g, g + G, ...; runs of more than 21 queries are cut into equal parts
+//      of 11..21 queries so that G x part fills at least 80 % of the wave; the distance itself is branch-free
+//      (sqDistPointTriangleSelect).  A variant evaluating two triangles per step with packed fp32 instructions was measured and dropped:
+//      v_pk_mul_f32 / v_pk_add_f32 issue at half rate on gfx950 (no arithmetic gain) and its 107 registers cost occupancy (3.5 vs 3.2 ms);
 //   3. REDUCE: the partial minima are 64-bit keys (distance bits << 32 | position in the leaf's list): the smallest key is the first
 //      minimum in list order, the reference's `d < best` rule, whatever the order of the ids — merged over g by a shuffle tree and handed
 //      to the query's own lane, which looks the triangle id up in the LDS list;
@@ -203,7 +203,6 @@ __global__ void __launch_bounds__(256) k_exact_ctx_level(ExactView v, const CtxI
 constexpr int EX_BATCH = 8;                   // chunks of 64 set entries decoded per round
 constexpr int EX_IDS = 64 * EX_BATCH;        // survivors of a round (LDS list)
 constexpr int EX_WORDS = (64 * EX_BATCH * 32 / 32 + 2 + 63) / 64;        // packed-set words a lane fetches per round at 32 bits per index (9)
-constexpr int EX_REC = 42;                   // floats per staged PAIR of frames: 40 + 2 so that the 32 records start in different banks
 constexpr unsigned long long EX_KEY_NONE = ((unsigned long long)0x7F800000u << 32);     // +inf at position 0: no candidate is smaller unless its distance is (`best = INFINITY`)
 
 SDF_DEV unsigned long long shflKey(unsigned long long k, int src) {
@@ -214,10 +213,10 @@ SDF_DEV unsigned long long shflKey(unsigned long long k, int src) {
 template <bool GRAD>
 __global__ void __launch_bounds__(64) k_exact_tiles(ExactView v, const float* __restrict__ pts, uint64_t n, const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx,
                                                     const uint4* __restrict__ leafCtx, float* __restrict__ dist, float* __restrict__ grad, uint32_t* __restrict__ tri) {
-    __shared__ __attribute__((aligned(16))) float s_pairs[32 * EX_REC];
+    __shared__ float4 s_tile[64 * 5];                                  // one tile: 64 packed frames of 80 bytes
     __shared__ uint32_t s_ids[EX_IDS];
-    uint32_t* s_words = reinterpret_cast<uint32_t*>(s_pairs);          // the round's packed-set words live in the frame tile's space while it is idle
-    static_assert(64 * EX_WORDS <= 32 * EX_REC, "the frame tile must hold a round's set words");
+    uint32_t* s_words = reinterpret_cast<uint32_t*>(s_tile);           // the round's packed-set words live in the frame tile's space while it is idle
+    static_assert(64 * EX_WORDS <= 64 * 20, "the frame tile must hold a round's set words");
     const int lane = threadIdx.x;
     const uint64_t e = (uint64_t)xcdLogicalBlock() * 64u + (uint64_t)lane;       // queries are sorted by leaf: a contiguous range of leaves per XCD
     uint32_t myKey = v.numNodes, q = 0;
@@ -315,28 +314,25 @@ __global__ void __launch_bounds__(64) k_exact_tiles(ExactView v, const float* __
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if ((uint32_t)lane < nk) {
-                        // frames are staged as PAIRS of triangles (2j, 2j + 1), float c of both next to each other: one 64-bit operand of a packed instruction
                         const float4* src = reinterpret_cast<const float4*>(v.frames) + 5 * (size_t)s_ids[tb + (uint32_t)lane];
-                        float* dst = s_pairs + (lane >> 1) * EX_REC + (lane & 1);
+                        float4* dst = s_tile + 5 * lane;
 #pragma unroll
-                        for (int c = 0; c < 5; c++) { const float4 x = src[c]; dst[8 * c] = x.x; dst[8 * c + 2] = x.y; dst[8 * c + 4] = x.z; dst[8 * c + 6] = x.w; }
+                        for (int c = 0; c < 5; c++) dst[c] = src[c];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     if (g < G) {
-                        const uint32_t npairs = (nk + 1u) >> 1;
-                        for (uint32_t j = g; j < npairs; j += G) {
-                            const v2f* rec = reinterpret_cast<const v2f*>(s_pairs + j * EX_REC);
-                            v2f f[19];
-#pragma unroll
-                            for (int m = 0; m < 19; m++) f[m] = rec[m];
-                            const v2f d = sqDistPointTrianglePair(po, f);
-                            const uint32_t pos = posBase + tb + 2u * j;
-                            const unsigned long long k0 = ((unsigned long long)__float_as_uint(d.x) << 32) | pos;
-                            const unsigned long long k1 = (2u * j + 1u < nk) ? (((unsigned long long)__float_as_uint(d.y) << 32) | (pos + 1u)) : EX_KEY_NONE;
-                            const unsigned long long kk = k1 < k0 ? k1 : k0;
-                            best = kk < best ? kk : best;
+                        for (uint32_t sIdx = g; sIdx < nk; sIdx += G) {
+                            const float4* fp = s_tile + 5 * sIdx;
+                            const float4 a = fp[0], bq = fp[1], c = fp[2], d4 = fp[3], e4 = fp[4];
+                            TriFrame fr;
+                            fr.origin = F3{a.x, a.y, a.z};
+                            fr.m[0] = a.w; fr.m[1] = bq.x; fr.m[2] = bq.y; fr.m[3] = bq.z; fr.m[4] = bq.w; fr.m[5] = c.x; fr.m[6] = c.y; fr.m[7] = c.z; fr.m[8] = c.w;
+                            fr.b = F2{d4.x, d4.y}; fr.c = F2{d4.z, d4.w}; fr.v2 = e4.x; fr.v3 = F2{e4.y, e4.z};
+                            const float d = sqDistPointTriangleSelect(po, fr);
+                            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (posBase + tb + sIdx);
+                            best = key < best ? key : best;
                         }
                     }
                 }
