@@ -153,7 +153,7 @@ template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
                                                            uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
                                                            uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
-                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk) {
+                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk, bool seedFromNeighbour) {
     extern __shared__ uint32_t s_near_stack[];
     uint32_t stIter = 0, stPop = 0, stPruned = 0, stExpand = 0, stTri = 0, stSeed = 0, stDrain = 0;
     uint32_t* stkRef = s_near_stack + threadIdx.x;
@@ -174,6 +174,8 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
     uint32_t steps = 0;
     int mode = 0, seedRef = 0;        // 1: greedy first descent (nearest child only, nothing pushed) to get a bound; 2: waiting for its triangle
     bool have = false, done = false;
+    uint32_t lastTri = 0xFFFFFFFFu;   // the triangle that gave this lane's previous query its final bound: the next query (a Morton neighbour) is seeded with it
+    static_assert(NEAR_QUEUE >= 1, "the seed uses a queue slot");
     for (;;) {
         // ---- refill: the wave owns a chunk [chunkNext, chunkEnd) of its XCD's range and hands it out lane by lane; ONE atomic per chunk
         // (an atomic per refill was measured to serialise the whole launch on eight addresses)
@@ -200,6 +202,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                     // With no bound yet the first descent would push every sibling it passes (three per level): it is made
                     // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one triangle.
                     if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
+                    else if (seedFromNeighbour && lastTri != 0xFFFFFFFFu) { queue[0] = lastTri; nq = 1; sp = 0; mode = 2; }      // one triangle evaluation instead of a ten-step descent
                     else { sp = 1; mode = 1; seedRef = 0; }
                 }
             }
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                 const uint32_t t = queue[nq * BLOCK];
                 const TriBounds tb = triBounds32(b, t, p);
                 if (tb.lo <= U2) {
-                    if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; }
+                    if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; lastTri = t; }
                     if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
                         if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
                             if (stats) atomicAdd(stats + 9, 1ull);
@@ -532,8 +535,9 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     static const int drainLanes = getenv("SDFHIP_NEAR_DRAIN") ? atoi(getenv("SDFHIP_NEAR_DRAIN")) : NEAR_DRAIN_LANES;
     DevBuf<unsigned long long> stats;
     if (wantStats) { SDF_TRY(stats.reserve(16)); SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 128, st)); }
+    static const bool seedNeighbour = !(getenv("SDFHIP_NEAR_SEED") && !strcmp(getenv("SDFHIP_NEAR_SEED"), "descent"));       // A/B switch: the greedy descent of round 2
     k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                            wantStats ? stats.p : nullptr, drainLanes, chunk);
+                                                            wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour);
     if (wantStats) {
         unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
