@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(TPB) k_brute_nearest(ExMesh m, const float* __
     for (uint32_t k = threadIdx.x; k < len; k += TPB) {
         const uint32_t t = list[off + k];
         TriFrame f; loadFramePacked(m.frames, t, f);
-        const float d = sqDistPointTriangle(p, f);
+        const float d = sqDistPointTriangleSelect(p, f);
         if (d < best) { best = d; bestPos = k; }
     }
     waveArgMin(best, bestPos);
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const floa
                 f.origin = F3{a.x, a.y, a.z};
                 f.m[0] = a.w; f.m[1] = b.x; f.m[2] = b.y; f.m[3] = b.z; f.m[4] = b.w; f.m[5] = c.x; f.m[6] = c.y; f.m[7] = c.z; f.m[8] = c.w;
                 f.b = F2{d4.x, d4.y}; f.c = F2{d4.z, d4.w}; f.v2 = e4.x; f.v3 = F2{e4.y, e4.z};
-                const float d = sqDistPointTriangle(p, f);
+                const float d = sqDistPointTriangleSelect(p, f);
                 if (d < best) { best = d; bestPos = base + k; }
             }
         }
