@@ -91,6 +91,39 @@ __global__ void __launch_bounds__(TPB) k_brute_nearest(ExMesh m, const float* __
     if (threadIdx.x == 0) outTri[(size_t)node * pointsPerNode + pi] = (bestPos == NONE) ? (len ? list[off] : 0u) : list[off + bestPos];
 }
 
+// Near the root there are few (node, point) items with LONG lists (the root's 19 mid-points against all triangles: 19 waves marching
+// through 327 680 frames each was 4 ms of latency): the list of an item is cut into `slices` pieces, a block per (item, piece), and the
+// pieces' minima meet in a 64-bit atomic minimum on (distance bits << 32 | list position) — the first minimum in list order, as the
+// sequential scan finds it (an infinite or NaN distance never wins: `d < best` with best = +inf); k_brute_finish turns keys into ids.
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_brute_nearest_sliced(ExMesh m, const float* __restrict__ center, float half, uint32_t n, int pointsPerNode,
+                                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
+                                                              const uint32_t* __restrict__ skip, uint32_t slices, unsigned long long* __restrict__ keys) {
+    const uint32_t item = blockIdx.x / slices, piece = blockIdx.x - item * slices;
+    const uint32_t node = item / (uint32_t)pointsPerNode, pi = item - node * (uint32_t)pointsPerNode;
+    if (node >= n) return;
+    if (skip && skip[node]) return;
+    const F3 p = ldv(center, node) + ((pointsPerNode == 8) ? cornerRel((int)pi) : midRel((int)pi)) * half;
+    const uint32_t off = listOff[node], len = listLen[node];
+    const uint32_t per = (len + slices - 1u) / slices, k0 = piece * per, k1 = (k0 + per < len) ? k0 + per : len;
+    float best = INFINITY; uint32_t bestPos = NONE;
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += TPB) {
+        TriFrame f; loadFramePacked(m.frames, list[off + k], f);
+        const float d = sqDistPointTriangleSelect(p, f);
+        if (d < best) { best = d; bestPos = k; }
+    }
+    waveArgMin(best, bestPos);
+    if ((threadIdx.x & 63) == 0 && bestPos != NONE) atomicMin(keys + item, ((unsigned long long)__float_as_uint(best) << 32) | bestPos);
+}
+__global__ void k_brute_finish(uint32_t n, int pointsPerNode, const uint32_t* __restrict__ list, const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
+                               const uint32_t* __restrict__ skip, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ outTri) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t node = item / (uint32_t)pointsPerNode;
+    if (node >= n || (skip && skip[node])) return;
+    const uint32_t pos = (uint32_t)keys[item], off = listOff[node], len = listLen[node];
+    outTri[item] = (pos == NONE) ? (len ? list[off] : 0u) : list[off + pos];
+}
+
 // The 19 mid-points of a node against the node's own list, ONE block per node: the list's 80-byte frames are staged through LDS
 // once (64 per tile) and shared by the 19 points, instead of 19 blocks each streaming the list from L2 (the first version's
 // profile: 4.9 GB x2 of FETCH per launch).  Thread = (point m, slice s): the tile's triangles s, s + 13, ... ; partial minima
@@ -671,7 +704,16 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         SDF_HIP_CHECK(hipMemcpyAsync(L->pOff.p, hz.data(), hz.size() * 4, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipMemcpyAsync(L->pLen.p, hl.data(), hl.size() * 4, hipMemcpyHostToDevice, st));
         // 8 corners of every root: brute force over ALL usable triangles
-        k_brute_nearest<256><<<8 * L->n, 256, 0, st>>>(md, L->center.p, L->half, L->n, 8, allList.p, L->pOff.p, L->pLen.p, nullptr, L->cornerTri.p);
+        {
+            const uint32_t items = 8 * L->n;
+            uint32_t slices = allLen / (256u * 16u); if (slices < 1u) slices = 1u; if (slices > 256u) slices = 256u;
+            DevBuf<unsigned long long> keys;
+            SDF_TRY(keys.reserve(items));
+            SDF_HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, 8ull * items, st));
+            k_brute_nearest_sliced<256><<<items * slices, 256, 0, st>>>(md, L->center.p, L->half, L->n, 8, allList.p, L->pOff.p, L->pLen.p, nullptr, slices, keys.p);
+            k_brute_finish<<<gridFor(items, 256), 256, 0, st>>>(L->n, 8, allList.p, L->pOff.p, L->pLen.p, nullptr, keys.p, L->cornerTri.p);
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         LV[0] = std::move(L);
     }
@@ -749,7 +791,16 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             // few nodes with long lists near the root: a block per (node, point) keeps the chip busy; many nodes with short lists below:
             // a block per node shares the staged frames among the 19 points
             if (n >= 4096) k_brute_nearest_mids<<<n, 256, 0, st>>>(md, L->center.p, L->half, n, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
-            else k_brute_nearest<64><<<19 * n, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
+            else {
+                const uint32_t items = 19 * n;
+                const uint64_t avgLen = L->listTotal / (n ? n : 1u);
+                uint32_t slices = (uint32_t)(avgLen / (64u * 8u)); if (slices < 1u) slices = 1u; if (slices > 128u) slices = 128u;
+                DevBuf<unsigned long long> keys;
+                SDF_TRY(keys.reserve(items));
+                SDF_HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, 8ull * items, st));
+                k_brute_nearest_sliced<64><<<items * slices, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, slices, keys.p);
+                k_brute_finish<<<gridFor(items, 256), 256, 0, st>>>(n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, keys.p, L->midTri.p);
+            }
             std::unique_ptr<ExLevel> N(new ExLevel());
             N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
             SDF_TRY(N->center.reserve(3ull * N->n)); SDF_TRY(N->coord.reserve(N->n)); SDF_TRY(N->cornerTri.reserve(8ull * N->n));
