@@ -392,6 +392,29 @@ def cpu_baseline(v, f, box, args, pts):
             "host_hardware_threads": host_threads, "cpu_quota_cpus": quota}
 
 
+def reference_nearest(mesh, v, f, box, dev):
+    """Row a5 with the REAL reference timed beside it: tmd::TriangleMeshDistance (oracle/_ref/libtmd_ref.so, the reference's own header
+    compiled as it lies; test infrastructure) answers a bounded sample of nearest-triangle queries on the host cores, the engine
+    (sdfhip_mesh_nearest: two-phase search on the planner's tree) the same points on the GPU; ids must agree."""
+    try:
+        from oracle import pyref
+        if not pyref.available():
+            return {"skipped": "oracle/_ref/libtmd_ref.so not present"}
+    except Exception as e:      # noqa: BLE001
+        return {"skipped": f"oracle/_ref unavailable: {e}"}
+    from sdflib_amd.meshgen import random_points_in_box
+    t0 = time.perf_counter(); ref = pyref.RefMesh(v, f); ref_build = time.perf_counter() - t0
+    pts = random_points_in_box(box, 400_000, seed=4242)
+    t0 = time.perf_counter(); ids_ref = ref.nearest(pts); t_ref = time.perf_counter() - t0
+    big = random_points_in_box(box, 4_000_000, seed=4243)
+    mesh.nearest_triangle(big[:1000])
+    t0 = time.perf_counter(); mesh.nearest_triangle(big); t_gpu = time.perf_counter() - t0
+    same = bool(np.array_equal(ids_ref, mesh.nearest_triangle(pts)))
+    return {"kind": "reference", "reference_bvh_build_s": round(ref_build, 3), "reference_mqueries_s": round(len(pts) / t_ref / 1e6, 3), "reference_threads": os.cpu_count(),
+            "reference_sample": f"{len(pts)} uniform points of the box, tmd::TriangleMeshDistance::signed_distance under OpenMP (dynamic schedule)",
+            "engine_mqueries_s": round(len(big) / t_gpu / 1e6, 1), "engine_sample": f"{len(big)} points, host arrays in / out (PCIe inside)", "ids_identical": same}
+
+
 def _time_ms(fn, reps=5):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -468,6 +491,8 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, prof=None):
                            "decisions_rechecked_with_exact_fit": int(mi.fit_rechecks), "nodes": int(mi.num_nodes), "roofline": mfma_roofline(prof)}
     mt.close()
     r["host_pointer_api"] = host_pointer(tree, ex_for_scalar, pts, dev)
+    if rank == 0 and world == 1:
+        r["nearest_triangle_vs_reference"] = reference_nearest(mesh, np.asarray(mesh.vertices), np.asarray(mesh.indices), box, dev)
     ex_for_scalar.close()
     if len(mesh.indices) >= 300_000:
         r["torus_knot_328k"] = knot_workload(mesh.ctx, dev, pts.shape[0])
