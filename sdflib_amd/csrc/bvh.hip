@@ -710,8 +710,9 @@ __global__ void k_tri_at_rank(const uint32_t* __restrict__ triRank, uint32_t num
 // thin along it) and r', W measured against those decoded values here, so that nothing about the quantisation has to be bounded
 // analytically.  Subtrees above WIDE_SLAB_MAX triangles get no slab (W = +inf): it would not be thin, and the loops below are per thread.
 constexpr uint32_t WIDE_SLAB_MAX = 2048;
+constexpr uint32_t WIDE_SLAB_SPLIT = 192;          // children with more triangles get their slab from k_wide_slabs_big (a block each) instead of 16 lanes
 __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
-                             uint32_t numTriangles, uint4* __restrict__ wide) {
+                             uint32_t numTriangles, uint4* __restrict__ wide, uint4* __restrict__ bigList, uint32_t* __restrict__ bigCount, uint32_t bigCap) {
     // 16 lanes per node: they share the (cheap) header work and stride over the children's triangles for the two reductions
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid >> 4, sub = gid & 15u;
@@ -763,7 +764,11 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
             rh = halfRoundedUp(rf);                      // +inf when the radius exceeds the half range: the child is then always visited
             refs[c] = (uint32_t)ref[c];
             const uint32_t cnt = re[c] - rb[c];
-            if (cnt <= WIDE_SLAB_MAX) {
+            if (cnt > WIDE_SLAB_SPLIT && cnt <= WIDE_SLAB_MAX) {
+                // a long strided loop here would hold the 16 lanes (and the wave) for thousands of steps: listed for k_wide_slabs_big, which
+                // fills in the slab words of this child (until then: no slab, W = +inf)
+                if (sub == 0u) { const uint32_t at = atomicAdd(bigCount, 1u); if (at < bigCap) bigList[at] = make_uint4(i, (uint32_t)c, rb[c], re[c]); }
+            } else if (cnt <= WIDE_SLAB_MAX) {
                 double sx = 0, sy = 0, sz = 0;
                 for (uint32_t k = rb[c] + sub; k < re[c]; k += 16u) {
                     const uint32_t t = triAtRank[k];
@@ -797,6 +802,56 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
         if (sub == 0u) out[1 + c] = make_uint4(qx | (qy << 16), qz | ((uint32_t)rh << 16), mx | (my << 16), mz | ((uint32_t)wh << 16));
     }
     if (sub == 0u) out[5] = make_uint4(refs[0], refs[1], refs[2], refs[3]);
+}
+
+// The slab of one large child (WIDE_SLAB_SPLIT < triangles <= WIDE_SLAB_MAX): a block per listed (node, child).  Same construction as
+// in k_wide_nodes — direction = normalised sum of the subtree's area normals, quantised; W measured against the DECODED centre and
+// direction, rounded up — so the bound is conservative whatever the summation order; only the order of the fp64 sum differs.
+__global__ void __launch_bounds__(256) k_wide_slabs_big(const uint4* __restrict__ bigList, uint32_t count, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
+                                                        uint4* __restrict__ wide) {
+    __shared__ double s_a[3][4]; __shared__ double s_w[4];
+    const uint4 job = bigList[blockIdx.x];
+    if (blockIdx.x >= count) return;
+    uint4* out = wide + 8 * (size_t)job.x;
+    const uint4 hdr = out[0], rec = out[1 + job.y];
+    const float ox = __uint_as_float(hdr.x), oy = __uint_as_float(hdr.y), oz = __uint_as_float(hdr.z), scale = __uint_as_float(hdr.w);
+    const double dcx = (double)fmaf((float)(rec.x & 0xFFFFu), scale, ox), dcy = (double)fmaf((float)(rec.x >> 16), scale, oy), dcz = (double)fmaf((float)(rec.y & 0xFFFFu), scale, oz);
+    const int tid = threadIdx.x, w = tid >> 6;
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t k = job.z + (uint32_t)tid; k < job.w; k += 256u) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double ux = (double)q0.w - q0.x, uy = (double)q1.x - q0.y, uz = (double)q1.y - q0.z, vx = (double)q1.z - q0.x, vy = (double)q1.w - q0.y, vz = (double)q2.x - q0.z;
+        sx += uy * vz - uz * vy; sy += uz * vx - ux * vz; sz += ux * vy - uy * vx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sx += __shfl_xor(sx, o); sy += __shfl_xor(sy, o); sz += __shfl_xor(sz, o); }
+    if ((tid & 63) == 0) { s_a[0][w] = sx; s_a[1][w] = sy; s_a[2][w] = sz; }
+    __syncthreads();
+    sx = s_a[0][0] + s_a[0][1] + s_a[0][2] + s_a[0][3]; sy = s_a[1][0] + s_a[1][1] + s_a[1][2] + s_a[1][3]; sz = s_a[2][0] + s_a[2][1] + s_a[2][2] + s_a[2][3];
+    const double len = sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(len > 1e-300 && len < 1e300)) return;           // uniform: no slab, as k_wide_nodes leaves it
+    auto snorm = [&](double v) { double q = rint(v / len * 32767.0); if (q < -32767.0) q = -32767.0; if (q > 32767.0) q = 32767.0; return (int)q; };
+    const int ix = snorm(sx), iy = snorm(sy), iz = snorm(sz);
+    const double dmx = (double)((float)ix * (1.0f / 32767.0f)), dmy = (double)((float)iy * (1.0f / 32767.0f)), dmz = (double)((float)iz * (1.0f / 32767.0f));
+    double W = 0.0;
+    for (uint32_t k = job.z + (uint32_t)tid; k < job.w; k += 256u) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double px[3] = {q0.x, q0.w, q1.z}, py[3] = {q0.y, q1.x, q1.w}, pz[3] = {q0.z, q1.y, q2.x};
+        for (int j = 0; j < 3; j++) W = fmax(W, fabs(dmx * (px[j] - dcx) + dmy * (py[j] - dcy) + dmz * (pz[j] - dcz)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) W = fmax(W, __shfl_xor(W, o));
+    if ((tid & 63) == 0) s_w[w] = W;
+    __syncthreads();
+    if (tid == 0) {
+        W = fmax(fmax(s_w[0], s_w[1]), fmax(s_w[2], s_w[3]));
+        const double Winfl = W * (1.0 + 1e-9) + 1e-300;
+        float wf = (float)Winfl; if ((double)wf < Winfl) wf = nextafterf(wf, 3.0e38f);
+        const unsigned short wh = halfRoundedUp(wf);
+        out[1 + job.y] = make_uint4(rec.x, rec.y, (uint32_t)(ix & 0xFFFF) | ((uint32_t)(iy & 0xFFFF) << 16), (uint32_t)(iz & 0xFFFF) | ((uint32_t)wh << 16));
+    }
 }
 
 __global__ void __launch_bounds__(128) k_nearest(BvhDev bvh, const float* __restrict__ pts, uint64_t n, uint32_t* __restrict__ out) {
@@ -909,8 +964,19 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     SDF_TRY(triAtRank.reserve(T));
     k_tri_at_rank<<<gridFor(T, 256), 256, 0, st>>>(mesh->dTriRank.p, T, triAtRank.p);
     SDF_TRY(mesh->dBvhWide.reserve(32 * (size_t)(nn ? nn : 1)));
+    DevBuf<uint32_t> bigList, bigCount;                  // children too large for 16 lanes: at most T / WIDE_SLAB_SPLIT per level pair, 12 level pairs
+    const size_t bigCap = (size_t)T / WIDE_SLAB_SPLIT * 16 + 64;
+    SDF_TRY(bigList.reserve(4 * bigCap)); SDF_TRY(bigCount.reserve(1));
+    SDF_HIP_CHECK(hipMemsetAsync(bigCount.p, 0, 4, st));
     k_wide_nodes<<<gridFor(16ull * T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), reinterpret_cast<const float4*>(mesh->dTriVerts.p),
-                                               triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
+                                               triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p), reinterpret_cast<uint4*>(bigList.p), bigCount.p, (uint32_t)bigCap);
+    {
+        uint32_t nBig = 0;
+        SDF_HIP_CHECK(hipMemcpyAsync(&nBig, bigCount.p, 4, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_REQUIRE(nBig <= bigCap, "wide-node work list overflow");
+        if (nBig) k_wide_slabs_big<<<nBig, 256, 0, st>>>(reinterpret_cast<const uint4*>(bigList.p), nBig, reinterpret_cast<const float4*>(mesh->dTriVerts.p), triAtRank.p, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
+    }
     SDF_HIP_CHECK(hipGetLastError());
     bool shapeOk = true;
     if (validate) {              // while the device derives its records
