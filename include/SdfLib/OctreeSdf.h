@@ -157,9 +157,10 @@ private:
         } else {
             sdfhip_ctx* ctx = detail::defaultContext();
             sdfhip_mesh* m = nullptr;
-            detail::check(sdfhip_mesh_create_ex(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
-                                                mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
-                                                (mb.min.x <= mb.max.x) ? mbox : nullptr, &m));
+            // an OctreeSdf always needs the sphere BVH: it is planned on host threads while the device prepares the TriangleData
+            detail::check(sdfhip_mesh_create_opt(ctx, reinterpret_cast<const float*>(mesh.getVertices().data()), (uint32_t)mesh.getVertices().size(),
+                                                 mesh.getIndices().data(), (uint32_t)(mesh.getIndices().size() / 3),
+                                                 (mb.min.x <= mb.max.x) ? mbox : nullptr, SDFHIP_MESH_PLAN_BVH_EARLY, &m));
             int rc = sdfhip_octree_build(ctx, m, &p, &mTree);
             sdfhip_mesh_destroy(m);
             detail::check(rc);

@@ -134,6 +134,12 @@ int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices,
  * that is sdfhip_mesh_create. */
 int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
                           uint32_t num_triangles, const float* bbox6, sdfhip_mesh** out);
+/* Same with options.  SDFHIP_MESH_PLAN_BVH_EARLY: the sphere BVH is planned (host threads) WHILE the device prepares the TriangleData, for
+ * callers that know an OctreeSdf will be built from the mesh (the C++ OctreeSdf constructor, sdflib_amd.OctreeSdf): sdfhip_mesh_build_bvh
+ * — or the first build — then only installs it.  An ExactOctreeSdf never needs the BVH. */
+#define SDFHIP_MESH_PLAN_BVH_EARLY 1u
+int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
+                           uint32_t num_triangles, const float* bbox6, uint32_t flags, sdfhip_mesh** out);
 int sdfhip_mesh_destroy(sdfhip_mesh* mesh);
 /* edges owned by one triangle before welding / half-edges re-paired by the welding (either pointer may be NULL) */
 int sdfhip_mesh_edge_stats(sdfhip_mesh* mesh, uint32_t* unmatched_edges, uint32_t* welded_half_edges);

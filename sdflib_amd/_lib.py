@@ -67,6 +67,7 @@ SIGNATURES = {
     "sdfhip_ctx_set_exchange": (_int, [_vp, C.POINTER(Exchange)]),
     "sdfhip_mesh_create": (_int, [_vp, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
     "sdfhip_mesh_create_ex": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, C.POINTER(_vp)]),
+    "sdfhip_mesh_create_opt": (_int, [_vp, _vp, _u32, _vp, _u32, _vp, _u32, C.POINTER(_vp)]),
     "sdfhip_mesh_edge_stats": (_int, [_vp, C.POINTER(_u32), C.POINTER(_u32)]),
     "sdfhip_mesh_destroy": (_int, [_vp]),
     "sdfhip_mesh_triangle_data": (_int, [_vp, _vp]),

@@ -101,16 +101,18 @@ def default_context(device=0):
 class Mesh:
     """sdflib::Mesh(vertices, indices) + the per-mesh acceleration data (TriangleData, sphere BVH) on the device."""
 
-    def __init__(self, vertices, indices, ctx=None, bbox=None):
+    def __init__(self, vertices, indices, ctx=None, bbox=None, plan_bvh_early=False):
         """bbox (6 floats, optional) = the box the reference's file loader computes; it switches on the non-manifold seam
-        welding (TriangleUtils.cpp:292-420).  None = the raw-pointer constructor's behaviour (no welding)."""
+        welding (TriangleUtils.cpp:292-420).  None = the raw-pointer constructor's behaviour (no welding).
+        plan_bvh_early: the sphere BVH is planned on host threads while the device prepares the TriangleData (for a mesh an OctreeSdf
+        will be built from; SDFHIP_MESH_PLAN_BVH_EARLY)."""
         self.ctx = ctx or default_context()
         self.vertices = _np(vertices, np.float32).reshape(-1, 3)
         self.indices = _np(indices, np.uint32).reshape(-1, 3)
         self.bbox = None if bbox is None else _np(bbox, np.float32).reshape(6)
         h = C.c_void_p()
-        check(lib().sdfhip_mesh_create_ex(self.ctx.h, _ptr(self.vertices), len(self.vertices), _ptr(self.indices), len(self.indices),
-                                          None if self.bbox is None else _ptr(self.bbox), C.byref(h)))
+        check(lib().sdfhip_mesh_create_opt(self.ctx.h, _ptr(self.vertices), len(self.vertices), _ptr(self.indices), len(self.indices),
+                                           None if self.bbox is None else _ptr(self.bbox), 1 if plan_bvh_early else 0, C.byref(h)))
         self.h = h
 
     @classmethod

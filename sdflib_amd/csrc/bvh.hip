@@ -1062,6 +1062,24 @@ static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_
 
 }  // extern "C"
 
+static uint32_t bvhOffloadMax() {
+    // SDFHIP_BVH_DEVICE_SUBTREES=1: ranges of at most 4096 triangles are built on the device (k_bvh_subtrees).  Off by default — measured on
+    // the 16-CPU box it does not shorten the build: the planner's wall time is the critical path through the TOP levels (the root's sort,
+    // then its children's ...), the bottom levels already run on otherwise idle pool threads, and the subtree kernel adds 7 ms (see DESIGN.md).
+    static const uint32_t offload = getenv("SDFHIP_BVH_DEVICE_SUBTREES") ? kDevSubtreeMax : 0u;
+    return offload;
+}
+namespace sdfhip {
+void startEarlyBvhPlan(sdfhip_mesh* mesh) {
+    if (mesh->early.th.joinable() || mesh->early.plan) return;
+    mesh->early.drop = [](void* p) { delete static_cast<PlannedBvh*>(p); };
+    mesh->early.th = std::thread([mesh]() {
+        try { mesh->early.plan = new PlannedBvh(planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, bvhOffloadMax())); }
+        catch (...) { mesh->early.plan = nullptr; }          // (out of memory: sdfhip_mesh_build_bvh plans again and reports)
+    });
+}
+}
+
 static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st) {
     const uint32_t T = mesh->numTriangles;
     const size_t nt = P.tasks.size(), nh = P.hostNodes.size();
@@ -1107,11 +1125,11 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
-    // SDFHIP_BVH_DEVICE_SUBTREES=1: ranges of at most 4096 triangles are built on the device (k_bvh_subtrees).  Off by default — measured on
-    // the 16-CPU box it does not shorten the build: the planner's wall time is the critical path through the TOP levels (the root's sort,
-    // then its children's ...), the bottom levels already run on otherwise idle pool threads, and the subtree kernel adds 7 ms (see DESIGN.md).
-    static const uint32_t offload = getenv("SDFHIP_BVH_DEVICE_SUBTREES") ? kDevSubtreeMax : 0u;
-    PlannedBvh P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, offload);
+    const uint32_t offload = bvhOffloadMax();
+    PlannedBvh P;
+    if (mesh->early.th.joinable()) mesh->early.th.join();        // a plan started under the mesh preparation (sdfhip_mesh_create_opt)
+    if (mesh->early.plan) { P = std::move(*static_cast<PlannedBvh*>(mesh->early.plan)); delete static_cast<PlannedBvh*>(mesh->early.plan); mesh->early.plan = nullptr; }
+    else P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, offload);
     double tPlanned = nowSeconds();
     int rc = installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST, false, P.tasks.empty() ? nullptr : &P);
     if (rc == SDFHIP_E_UNSUPPORTED && !P.tasks.empty()) {         // a device sort met introsort's depth limit: libstdc++'s heap sort decides that order

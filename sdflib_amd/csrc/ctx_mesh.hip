@@ -308,6 +308,12 @@ int sdfhip_mesh_create(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uin
 
 int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, const float* bbox6, sdfhip_mesh** out) {
     SDF_API_BEGIN
+    return sdfhip_mesh_create_opt(ctx, xyz, nv, indices, nt, bbox6, 0u, out);
+    SDF_API_END
+}
+
+int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const uint32_t* indices, uint32_t nt, const float* bbox6, uint32_t flags, sdfhip_mesh** out) {
+    SDF_API_BEGIN
     SDF_REQUIRE(ctx && xyz && indices && out, "NULL argument");
     std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
@@ -321,6 +327,7 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const 
     m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;
     m->hVerts.assign(xyz, xyz + 3ull * nv);
     m->hIdx.assign(indices, indices + 3ull * nt);
+    if (flags & SDFHIP_MESH_PLAN_BVH_EARLY) sdfhip::startEarlyBvhPlan(m);      // the planner (host threads) runs under everything below
     hipStream_t st = ctx->stream;
     const uint32_t nhe = 3 * nt;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool

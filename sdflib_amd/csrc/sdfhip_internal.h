@@ -11,6 +11,7 @@
 #include <vector>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include "../../include/sdfhip.h"
 
 namespace sdfhip {
@@ -352,11 +353,19 @@ struct NearScratchMark {
     }
 };
 
+// A BVH plan started by sdfhip_mesh_create_opt (SDFHIP_MESH_PLAN_BVH_EARLY) on a host thread of its own, so that the planner runs under
+// the mesh preparation; sdfhip_mesh_build_bvh takes it over (bvh.hip).  Joined and dropped with the mesh if nobody did.
+struct EarlyBvhPlan {
+    std::thread th; void* plan = nullptr; void (*drop)(void*) = nullptr;
+    ~EarlyBvhPlan() { if (th.joinable()) th.join(); if (plan && drop) drop(plan); }
+};
+
 struct sdfhip_mesh {
     sdfhip_ctx* ctx = nullptr;
     uint32_t numVertices = 0, numTriangles = 0;
     std::vector<float> hVerts;            // host copies (BVH planner input)
     std::vector<uint32_t> hIdx;
+    EarlyBvhPlan early;
     sdfhip::DevBuf<float> dVerts;         // 3 floats per vertex
     sdfhip::DevBuf<uint32_t> dIdx;        // 3 per triangle
     sdfhip::DevBuf<float> dTri;           // 37 floats per triangle (TriangleData)
@@ -374,6 +383,8 @@ struct sdfhip_mesh {
     uint32_t unmatchedEdges = 0;          // edges owned by a single triangle (open / non-manifold mesh)
     uint32_t weldedEdges = 0;             // of those, half-edges re-paired by the seam welding
 };
+namespace sdfhip { void startEarlyBvhPlan(sdfhip_mesh* mesh); }      // bvh.hip: plans the BVH on a thread of its own (mesh->early)
+
 
 int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh);
 namespace sdfhip { int packFrames(hipStream_t st, const float* td, uint32_t numTriangles, float* frames); }
