@@ -999,14 +999,41 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
 extern "C" {
 
 // The planner proper: host memory in, host memory out, no device involved.  sph / kids as in HostBvhBuilder (8 doubles + 2 ints per inner
-// node; one dummy node for a one-triangle mesh).  Returns the arrays in 2 MB-aligned blocks (free()).
-struct FreeDeleter { void operator()(void* p) const { free(p); } };
+// node; one dummy node for a one-triangle mesh).
+// The planner's arrays — 8 doubles + 2 ints per node of output, 72 bytes per triangle of scratch: 200 MB at 1.31 M triangles — are 2 MB-aligned
+// blocks with a huge-page hint, touched up front by a few threads (first touch of a fresh mapping by all the planner's workers at once was
+// measured to stall single nodes for tens of milliseconds).  Allocating and faulting them in is a fifth of a plan's wall time, so blocks
+// given back are kept (up to SDFHIP_PLANNER_CACHE_MB, default 512) and handed to the next plan as they are.
+struct PlannerBlocks {
+    std::mutex m; std::vector<std::pair<void*, size_t>> idle, live; size_t idleBytes = 0;
+    static PlannerBlocks& get() { static PlannerBlocks* p = new PlannerBlocks(); return *p; }
+    static size_t cap() { static const size_t v = (size_t)(getenv("SDFHIP_PLANNER_CACHE_MB") ? strtoull(getenv("SDFHIP_PLANNER_CACHE_MB"), nullptr, 10) : 512ull) << 20; return v; }
+    void* take(size_t rounded) {
+        std::lock_guard<std::mutex> g(m);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < idle.size(); i++) if (idle[i].second >= rounded && idle[i].second <= 2 * rounded && (best == (size_t)-1 || idle[i].second < idle[best].second)) best = i;
+        if (best == (size_t)-1) return nullptr;
+        void* p = idle[best].first; live.push_back(idle[best]); idleBytes -= idle[best].second; idle[best] = idle.back(); idle.pop_back();
+        return p;
+    }
+    void track(void* p, size_t bytes) { std::lock_guard<std::mutex> g(m); live.emplace_back(p, bytes); }
+    void give(void* p) {
+        size_t bytes = 0;
+        {
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < live.size(); i++) if (live[i].first == p) { bytes = live[i].second; live[i] = live.back(); live.pop_back(); break; }
+            if (bytes && idleBytes + bytes <= cap()) { idle.emplace_back(p, bytes); idleBytes += bytes; return; }
+        }
+        free(p);
+    }
+};
+struct FreeDeleter { void operator()(void* p) const { if (p) PlannerBlocks::get().give(p); } };
 static void* plannerAlloc(size_t bytes) {
-    // 2 MB-aligned with a huge-page hint, touched up front by a few threads: first touch of a fresh mapping by all the planner's workers
-    // at once was measured to stall single nodes for tens of milliseconds
+    const size_t rounded0 = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    const size_t rounded = rounded0 ? rounded0 : (2u << 20);
+    if (void* cached = PlannerBlocks::get().take(rounded)) return cached;
     void* p = nullptr;
-    const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-    if (posix_memalign(&p, 2u << 20, rounded ? rounded : (2u << 20)) != 0) throw std::bad_alloc();
+    if (posix_memalign(&p, 2u << 20, rounded) != 0) throw std::bad_alloc();
     static const bool noThp = getenv("SDFHIP_BVH_NO_THP") != nullptr;
     if (!noThp) madvise(p, rounded, MADV_HUGEPAGE);
     int parts = (int)std::min<size_t>(16, rounded >> 21); if (parts < 1) parts = 1;
@@ -1014,6 +1041,7 @@ static void* plannerAlloc(size_t bytes) {
         char* q = (char*)p;
         for (size_t off = (rounded * (size_t)c / (size_t)parts) & ~(size_t)4095, e = rounded * (size_t)(c + 1) / (size_t)parts; off < e; off += 4096) q[off] = 0;
     });
+    PlannerBlocks::get().track(p, rounded);
     return p;
 }
 struct PlannedBvh {
@@ -1054,7 +1082,9 @@ static PlannedBvh planBvhHost(const float* hVerts, const uint32_t* hIdx, uint32_
     if (getenv("SDFHIP_BVH_SORT_THREADS")) b.sortThreads = atoi(getenv("SDFHIP_BVH_SORT_THREADS"));
     double rootSphere[4];
     b.offloadMax = offloadMax;
+    const double tBuild = nowSeconds();
     b.build(0, rootSphere, 0, (int)T, 0);
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh plan: output + gather %.4f s, scratch %.4f s, tree %.4f s\n", tGather - t0, tBuild - tGather, nowSeconds() - tBuild);
     if (offloadMax) { R.tasks = std::move(b.tasks); R.hostNodes = std::move(b.hostNodes); R.order = std::move(b.order); }
     R.gatherSeconds = tGather - t0; R.planSeconds = nowSeconds() - tGather; R.sortThreads = b.sortThreads; R.parallelDepth = b.maxParallelDepth;
     return R;
