@@ -157,6 +157,7 @@ int sdfhip_mesh_bvh_import(sdfhip_mesh* mesh, const double* spheres, const int32
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
 /* test hook, host only: mismatches between the BVH planner's threaded restatement of std::sort and std::sort itself on n keys */
 int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads);
+int sdfhip_test_heap_sort_matches_std(const double* keys, uint64_t n);     /* the restated libstdc++ heap sort vs std::make_heap + std::sort_heap */
 /* the BVH planner alone, host memory in and out (no device needed): 8 doubles + 2 ints per inner node, max(num_triangles - 1, 1) nodes.
  * Replaces the tree half of tmd::TriangleMeshDistance::construct (TriangleMeshDistance.h:421-490); CPU tests compare it with the oracle's. */
 int sdfhip_test_plan_bvh(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, double* out_spheres, int32_t* out_children, double* seconds);

@@ -474,8 +474,8 @@ struct HostBvhBuilder {
 //   * node ids follow from the pre-order numbering (left child = id + 1, right child = id + (mid - begin)), so the subtree writes its
 //     records straight into the device arrays, and its own sphere into its parent's record (planned on the host).
 struct BvhDevNode { int id; uint32_t b, e, slot; };
-constexpr uint32_t kDevSubtreeMax = 4096;
-constexpr uint32_t kDevSortTasks = 512;
+constexpr uint32_t kDevSubtreeMaxLimit = 16384;          // 128 KB of LDS for the keys + the sort task lists
+constexpr uint32_t kDevSortTasks = 1024;
 
 SDF_DEV void devInsertionSort(KeyTri* a, int first, int last) {
     for (int i = first + 1; i < last; i++) {
@@ -485,6 +485,34 @@ SDF_DEV void devInsertionSort(KeyTri* a, int first, int last) {
     }
 }
 SDF_DEV void devSwap(KeyTri* a, int i, int j) { const KeyTri t = a[i]; a[i] = a[j]; a[j] = t; }
+// libstdc++'s heap sort (what std::sort falls back to when a range exhausts introsort's depth limit: __partial_sort(first, last, last) =
+// __make_heap + __sort_heap), restated move for move: __push_heap, __adjust_heap, __pop_heap (bits/stl_heap.h).  Compiled for the host too:
+// sdfhip_test_heap_sort_matches_std compares it with std::make_heap / std::sort_heap on tie-heavy keys.
+SDF_HD void stdPushHeap(KeyTri* first, int holeIndex, int topIndex, KeyTri value) {
+    int parent = (holeIndex - 1) / 2;
+    while (holeIndex > topIndex && first[parent].key < value.key) { first[holeIndex] = first[parent]; holeIndex = parent; parent = (holeIndex - 1) / 2; }
+    first[holeIndex] = value;
+}
+SDF_HD void stdAdjustHeap(KeyTri* first, int holeIndex, int len, KeyTri value) {
+    const int topIndex = holeIndex;
+    int secondChild = holeIndex;
+    while (secondChild < (len - 1) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        if (first[secondChild].key < first[secondChild - 1].key) secondChild--;
+        first[holeIndex] = first[secondChild];
+        holeIndex = secondChild;
+    }
+    if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        first[holeIndex] = first[secondChild - 1];
+        holeIndex = secondChild - 1;
+    }
+    stdPushHeap(first, holeIndex, topIndex, value);
+}
+SDF_HD void stdHeapSort(KeyTri* first, int len) {
+    if (len >= 2) for (int parent = (len - 2) / 2;; parent--) { stdAdjustHeap(first, parent, len, first[parent]); if (parent == 0) break; }      // __make_heap
+    for (int last = len; last > 1;) { --last; const KeyTri value = first[last]; first[last] = first[0]; stdAdjustHeap(first, 0, last, value); }   // __sort_heap / __pop_heap
+}
 // libstdc++'s __move_median_to_first(result, a, b, c)
 SDF_DEV void devMedianToFirst(KeyTri* k, int result, int a, int b, int c) {
     if (k[a].key < k[b].key) {
@@ -515,7 +543,7 @@ SDF_DEV void devTriVerts(const float4* __restrict__ triV, int t, DevV3& a, DevV3
 SDF_DEV float devComp(const DevV3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
 __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict__ tasks, const uint32_t* __restrict__ order, const float4* __restrict__ triV,
-                                                      double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed) {
+                                                      double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed, uint32_t kDevSubtreeMax) {
     extern __shared__ unsigned char s_bvh_raw[];
     KeyTri* keys = reinterpret_cast<KeyTri*>(s_bvh_raw);
     uint32_t* sortA = reinterpret_cast<uint32_t*>(s_bvh_raw + sizeof(KeyTri) * kDevSubtreeMax);        // {first, last, depth limit} x 3 words
@@ -585,7 +613,7 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
             __syncthreads();
             for (uint32_t t = tid; t < nSort; t += 256) {
                 const int first = (int)in[3 * t], last = (int)in[3 * t + 1]; const int depth = (int)in[3 * t + 2];
-                if (depth == 0) { atomicOr(&s_count[2], 2u); continue; }             // libstdc++ switches to heap sort here: the host plans this tree
+                if (depth == 0) { stdHeapSort(keys + first, last - first); continue; }        // libstdc++ switches to heap sort here (it does happen: 1.31 M triangles)
                 devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
                 const int cut = devPartition(keys, first + 1, last, first);
                 const int parts[2][2] = {{first, cut}, {cut, last}};
@@ -1096,7 +1124,12 @@ static uint32_t bvhOffloadMax() {
     // SDFHIP_BVH_DEVICE_SUBTREES=1: ranges of at most 4096 triangles are built on the device (k_bvh_subtrees).  Off by default — measured on
     // the 16-CPU box it does not shorten the build: the planner's wall time is the critical path through the TOP levels (the root's sort,
     // then its children's ...), the bottom levels already run on otherwise idle pool threads, and the subtree kernel adds 7 ms.
-    static const uint32_t offload = getenv("SDFHIP_BVH_DEVICE_SUBTREES") ? kDevSubtreeMax : 0u;
+    static const uint32_t offload = [] {
+        const char* e = getenv("SDFHIP_BVH_DEVICE_SUBTREES");
+        if (!e) return 0u;
+        uint32_t v = (uint32_t)atoi(e); if (v <= 1u) v = 4096u;                 // =1: the default size; =N: ranges of at most N triangles
+        return v > kDevSubtreeMaxLimit ? kDevSubtreeMaxLimit : (v < 32u ? 32u : v);
+    }();
     return offload;
 }
 namespace sdfhip {
@@ -1112,6 +1145,7 @@ void startEarlyBvhPlan(sdfhip_mesh* mesh) {
 
 static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st) {
     const uint32_t T = mesh->numTriangles;
+    const uint32_t kDevSubtreeMax = bvhOffloadMax();
     const size_t nt = P.tasks.size(), nh = P.hostNodes.size();
     // the host's records, compacted: ids, 8 doubles, 2 child references, and per half whether the host owns that sphere
     std::vector<double> s8(8 * nh); std::vector<int> k2(2 * nh); std::vector<unsigned char> own(2 * nh, 1);
@@ -1137,7 +1171,9 @@ static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st
     SDF_HIP_CHECK(hipMemsetAsync(dFail.p, 0, 4, st));
     k_bvh_scatter_top<<<gridFor(nh, 256), 256, 0, st>>>(dIds.p, dS8.p, dK2.p, dOwn.p, (uint32_t)nh, mesh->dBvhSph.p, mesh->dBvhKids.p);
     const size_t lds = sizeof(KeyTri) * kDevSubtreeMax + 2 * 3 * 4 * kDevSortTasks;
-    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p);
+    static bool ldsRaised = false;
+    if (!ldsRaised && lds > (48u << 10)) { SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(KeyTri) * kDevSubtreeMaxLimit + 2 * 3 * 4 * kDevSortTasks))); ldsRaised = true; }
+    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, kDevSubtreeMax);
     SDF_HIP_CHECK(hipGetLastError());
     uint32_t failed = 0;
     SDF_HIP_CHECK(hipMemcpyAsync(&failed, dFail.p, 4, hipMemcpyDeviceToHost, st));
@@ -1171,6 +1207,21 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: gather %.3f s, planner %.3f s (%d sort threads, parallel depth %d), upload + device prep %.3f s\n", P.gatherSeconds, P.planSeconds, P.sortThreads, P.parallelDepth, nowSeconds() - tPlanned);
     if (seconds) *seconds = nowSeconds() - t0;
     return SDFHIP_OK;
+    SDF_API_END
+}
+
+// Test hook (no GPU needed): heap-sorts n {key, id} pairs with the restated libstdc++ heap sort (the device subtrees' fallback at introsort's
+// depth limit) and with std::make_heap + std::sort_heap; returns the number of positions where the permutations differ.
+int sdfhip_test_heap_sort_matches_std(const double* keys, uint64_t n) {
+    SDF_API_BEGIN
+    if (!keys) return -1;
+    std::vector<KeyTri> a(n), b(n);
+    for (uint64_t i = 0; i < n; i++) a[i] = b[i] = KeyTri{(float)keys[i], (int)i};
+    stdHeapSort(a.data(), (int)n);
+    std::make_heap(b.begin(), b.end(), keyLess); std::sort_heap(b.begin(), b.end(), keyLess);
+    int diff = 0;
+    for (uint64_t i = 0; i < n; i++) diff += (a[i].tri != b[i].tri || a[i].key != b[i].key) ? 1 : 0;
+    return diff;
     SDF_API_END
 }
 

@@ -90,6 +90,21 @@ def test_planner_sort_equals_std_sort():
                 assert lib().sdfhip_test_sort_matches_std(keys.ctypes.data_as(C.c_void_p), n, threads) == 0
 
 
+def test_restated_heap_sort_matches_libstdcxx():
+    """std::sort falls back to heap sort when a range exhausts introsort's depth limit (it happens in the 1.31 M-triangle tree); the device
+    subtree builder restates libstdc++'s __make_heap / __sort_heap move for move (bvh.hip, stdHeapSort: compiled for the host here)."""
+    import ctypes as C
+    import numpy as np
+    from sdflib_amd._lib import lib
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 2, 3, 4, 5, 16, 17, 31, 32, 33, 100, 1000, 4097, 16384):
+        inputs = [rng.random(n), rng.integers(0, max(1, n // 6 + 1), n).astype(np.float64), np.sort(rng.random(n)), np.sort(rng.random(n))[::-1].copy(),
+                  np.repeat(rng.random(max(1, n // 3 + 1)), 3)[:n].copy(), np.zeros(n), np.tile([1.0, 0.0], n // 2 + 1)[:n].copy()]
+        for keys in inputs:
+            keys = np.ascontiguousarray(keys, dtype=np.float64)
+            assert lib().sdfhip_test_heap_sort_matches_std(keys.ctypes.data_as(C.c_void_p), n) == 0, n
+
+
 def test_ctypes_struct_mirrors_have_the_c_sizes():
     import ctypes as C
     from sdflib_amd._lib import lib, OctreeInfo, OctreeParams, ExactInfo

@@ -778,7 +778,8 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
         c.set_bvh(sph, kids3)
 
 
-def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx):
+@pytest.mark.parametrize("subtree", ["1", "512", "16384"])
+def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree):
     """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
     k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
     all 64 bits of every child sphere, every leaf's triangle.  Meshes chosen for what decides the tree: tied sort keys (symmetric meshes,
@@ -786,7 +787,7 @@ def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx):
     import subprocess, sys
     # the switch is read once per process: the hybrid plans run in a child
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._hybrid_cases_check()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES="1"), capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "hybrid cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
@@ -808,13 +809,14 @@ def _hybrid_cases():
         cases.append((v5, f5[:n]))
     cases.append(meshgen.torus_knot(nu=512, nv=80))
     cases.append(meshgen.bumpy_icosphere(7))
+    cases.append(meshgen.bumpy_icosphere(8))                                  # 1.31 M triangles: ranges that exhaust introsort's depth limit (heap sort)
     return cases
 
 
 def _hybrid_cases_check():
     import sdflib_amd as S
     from test_planner_cpu import same_tree
-    assert os.environ.get("SDFHIP_BVH_DEVICE_SUBTREES") == "1"
+    assert os.environ.get("SDFHIP_BVH_DEVICE_SUBTREES")
     ctx = S.default_context(0)
     for v, f in _hybrid_cases():
         m = S.Mesh(v, f, ctx)
