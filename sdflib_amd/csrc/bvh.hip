@@ -474,26 +474,43 @@ struct HostBvhBuilder {
 //   * node ids follow from the pre-order numbering (left child = id + 1, right child = id + (mid - begin)), so the subtree writes its
 //     records straight into the device arrays, and its own sphere into its parent's record (planned on the host).
 struct BvhDevNode { int id; uint32_t b, e, slot; };
-constexpr uint32_t kDevSubtreeMaxLimit = 16384;          // 128 KB of LDS for the keys + the sort task lists
-constexpr uint32_t kDevSortTasks = 1024;
+constexpr uint32_t kDevSubtreeMaxLimit = 8192;           // 64 KB of LDS for the keys + the sort task lists + the per-node tables below
+constexpr uint32_t kCoopNodes = 128;                     // levels of at most this many nodes ...
+constexpr uint32_t kCoopMin = 32;                        // ... of more than this many triangles each are prepared by the whole workgroup
+SDF_DEV uint32_t devOrdKey(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // monotone float -> uint
+SDF_DEV float devOrdVal(uint32_t k) { return __uint_as_float(k ^ (0x80000000u | ~(uint32_t)((int32_t)k >> 31))); }      // (top bit set: clear it; else: all bits flipped)
+constexpr uint32_t kDevSortTasks = 512;           // (with the tables below: 72 KB at 4096 triangles, two workgroups per CU)
 
-SDF_DEV void devInsertionSort(KeyTri* a, int first, int last) {
+// LDS views with a skew: the ranges a workgroup's lanes work on start at regular strides (a level's nodes are 2560, 1280, ... 80, 40, 20
+// triangles apart), which without it puts every lane of a wave on the same two banks (measured: the sort rounds were 32-way conflicts).
+struct KeyArr {                      // 8-byte elements: one element of padding per 16
+    KeyTri* p; int base;
+    SDF_HD KeyTri& operator[](int i) const { const int j = base + i; return p[j + (j >> 4)]; }
+    SDF_HD KeyArr operator+(int o) const { return KeyArr{p, base + o}; }
+    static constexpr size_t bytes(uint32_t n) { return sizeof(KeyTri) * ((size_t)n + (n >> 4) + 1); }
+};
+struct IdxArr {                      // 2-byte elements: two elements of padding per 64
+    unsigned short* p;
+    SDF_HD unsigned short& operator[](int i) const { return p[i + 2 * (i >> 6)]; }
+    static constexpr size_t bytes(uint32_t n) { return (2 * ((size_t)n + 2 * (n >> 6) + 2) + 7) & ~(size_t)7; }
+};
+template <class A> SDF_DEV void devInsertionSort(A a, int first, int last) {
     for (int i = first + 1; i < last; i++) {
         const KeyTri val = a[i];
         if (val.key < a[first].key) { for (int k = i; k > first; k--) a[k] = a[k - 1]; a[first] = val; }
         else { int pos = i; while (val.key < a[pos - 1].key) { a[pos] = a[pos - 1]; pos--; } a[pos] = val; }
     }
 }
-SDF_DEV void devSwap(KeyTri* a, int i, int j) { const KeyTri t = a[i]; a[i] = a[j]; a[j] = t; }
+template <class A> SDF_DEV void devSwap(A a, int i, int j) { const KeyTri t = a[i]; a[i] = a[j]; a[j] = t; }
 // libstdc++'s heap sort (what std::sort falls back to when a range exhausts introsort's depth limit: __partial_sort(first, last, last) =
 // __make_heap + __sort_heap), restated move for move: __push_heap, __adjust_heap, __pop_heap (bits/stl_heap.h).  Compiled for the host too:
 // sdfhip_test_heap_sort_matches_std compares it with std::make_heap / std::sort_heap on tie-heavy keys.
-SDF_HD void stdPushHeap(KeyTri* first, int holeIndex, int topIndex, KeyTri value) {
+template <class A> SDF_HD void stdPushHeap(A first, int holeIndex, int topIndex, KeyTri value) {
     int parent = (holeIndex - 1) / 2;
     while (holeIndex > topIndex && first[parent].key < value.key) { first[holeIndex] = first[parent]; holeIndex = parent; parent = (holeIndex - 1) / 2; }
     first[holeIndex] = value;
 }
-SDF_HD void stdAdjustHeap(KeyTri* first, int holeIndex, int len, KeyTri value) {
+template <class A> SDF_HD void stdAdjustHeap(A first, int holeIndex, int len, KeyTri value) {
     const int topIndex = holeIndex;
     int secondChild = holeIndex;
     while (secondChild < (len - 1) / 2) {
@@ -509,12 +526,12 @@ SDF_HD void stdAdjustHeap(KeyTri* first, int holeIndex, int len, KeyTri value) {
     }
     stdPushHeap(first, holeIndex, topIndex, value);
 }
-SDF_HD void stdHeapSort(KeyTri* first, int len) {
+template <class A> SDF_HD void stdHeapSort(A first, int len) {
     if (len >= 2) for (int parent = (len - 2) / 2;; parent--) { stdAdjustHeap(first, parent, len, first[parent]); if (parent == 0) break; }      // __make_heap
     for (int last = len; last > 1;) { --last; const KeyTri value = first[last]; first[last] = first[0]; stdAdjustHeap(first, 0, last, value); }   // __sort_heap / __pop_heap
 }
 // libstdc++'s __move_median_to_first(result, a, b, c)
-SDF_DEV void devMedianToFirst(KeyTri* k, int result, int a, int b, int c) {
+template <class A> SDF_DEV void devMedianToFirst(A k, int result, int a, int b, int c) {
     if (k[a].key < k[b].key) {
         if (k[b].key < k[c].key) devSwap(k, result, b);
         else if (k[a].key < k[c].key) devSwap(k, result, c);
@@ -524,7 +541,7 @@ SDF_DEV void devMedianToFirst(KeyTri* k, int result, int a, int b, int c) {
     else devSwap(k, result, b);
 }
 // libstdc++'s __unguarded_partition(first, last, pivot)
-SDF_DEV int devPartition(KeyTri* k, int first, int last, int pivot) {
+SDF_DEV int devPartition(KeyArr k, int first, int last, int pivot) {
     const float pk = k[pivot].key;
     for (;;) {
         while (k[first].key < pk) ++first;
@@ -535,6 +552,95 @@ SDF_DEV int devPartition(KeyTri* k, int first, int last, int pivot) {
         ++first;
     }
 }
+// libstdc++'s __unguarded_partition(first, last, pivot) by its result instead of its scans (the construction of IntroSortLike::listPartition):
+// the t-th swap exchanges the t-th element from the left that is not less than the pivot with the t-th from the right that is not greater,
+// while they have not crossed.  One lane, no data-dependent branch in the pass over the keys; L / R: the lane's slices of the index lists.
+SDF_DEV int devListPartition(KeyArr k, IdxArr L, IdxArr R, int first, int last, int pivot) {
+    const float pk = k[pivot].key;
+    const int n = last - first;
+    int nl = 0, nr = 0;
+    for (int i = 0; i < n; i++) { const float key = k[first + i].key; L[first + nl] = (unsigned short)i; nl += !(key < pk); R[first + nr] = (unsigned short)i; nr += !(pk < key); }
+    int lo = 0, hi = nl < nr ? nl : nr;
+    while (lo < hi) { const int t = (lo + hi + 1) >> 1; if (L[first + t - 1] < R[first + nr - t]) lo = t; else hi = t - 1; }
+    const int m = lo;
+    for (int t = 1; t <= m; t++) devSwap(k, first + (int)L[first + t - 1], first + (int)R[first + nr - t]);
+    int stop = (m < nl) ? (int)L[first + m] : n;
+    if (m > 0 && (int)R[first + nr - m] < stop) stop = (int)R[first + nr - m];
+    return first + stop;
+}
+SDF_DEV void devWaveSync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+constexpr int kWaveSortLen = 160;        // pending ranges from this length on are partitioned by a whole wave
+// The introsort rounds of a workgroup (256 threads) over keys[] in LDS: `in` holds nSort pending ranges {first, last, depth limit}; every
+// round partitions each of them once — a long range by a whole wave (both index lists by ballots, 64 keys per step; the swaps in
+// parallel), a short one by one lane — and lists the parts for the next round; parts of at most 16 are finished by insertion sort, a
+// range out of depth by libstdc++'s heap sort.  Every comparison and exchange is the sequential algorithm's, so is the order among ties.
+// s_count[1] = next round's count, s_count[2] |= 4 when the lists (maxTasks entries) overflow.
+SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in, uint32_t* out, uint32_t* s_count, uint32_t nSort, uint32_t maxTasks, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    auto push = [&](int f, int l, int depth) {
+        const uint32_t at = atomicAdd(&s_count[1], 1u);
+        if (at < maxTasks) { out[3 * at] = (uint32_t)f; out[3 * at + 1] = (uint32_t)l; out[3 * at + 2] = (uint32_t)depth; }
+        else atomicOr(&s_count[2], 4u);
+    };
+    while (nSort > 0) {
+        if (tid == 0) s_count[1] = 0;
+        __syncthreads();
+        // long ranges: one wave each
+        for (uint32_t t = (uint32_t)wave; t < nSort; t += 4u) {
+            const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
+            if (last - first < kWaveSortLen) continue;
+            if (depth == 0) { if (lane == 0) stdHeapSort(keys + first, last - first); continue; }
+            if (lane == 0) devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
+            devWaveSync();
+            const float pk = keys[first].key;
+            const int f = first + 1, m = last - f;
+            int nl = 0, nr = 0;
+            for (int base = 0; base < m; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < m;
+                const float key = valid ? keys[f + i].key : 0.f;
+                const bool pl = valid && !(key < pk), pr = valid && !(pk < key);
+                const unsigned long long bl = __ballot(pl), br = __ballot(pr);
+                if (pl) listL[f + nl + (int)__popcll(bl & ltMask)] = (unsigned short)i;
+                if (pr) listR[f + nr + (int)__popcll(br & ltMask)] = (unsigned short)i;
+                nl += (int)__popcll(bl); nr += (int)__popcll(br);
+            }
+            devWaveSync();
+            int lo = 0, hi = nl < nr ? nl : nr;
+            while (lo < hi) { const int q = (lo + hi + 1) >> 1; if (listL[f + q - 1] < listR[f + nr - q]) lo = q; else hi = q - 1; }
+            const int ms = lo;
+            int stop = (ms < nl) ? (int)listL[f + ms] : m;
+            if (ms > 0 && (int)listR[f + nr - ms] < stop) stop = (int)listR[f + nr - ms];
+            for (int q = 1 + lane; q <= ms; q += 64) devSwap(keys, f + (int)listL[f + q - 1], f + (int)listR[f + nr - q]);
+            const int cut = f + stop;
+            if (lane == 0) {
+                if (cut - first > 1) push(first, cut, depth - 1);
+                if (last - cut > 1) push(cut, last, depth - 1);
+            }
+        }
+        // short ranges: one lane each
+        for (uint32_t t = (uint32_t)tid; t < nSort; t += 256u) {
+            const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
+            if (last - first >= kWaveSortLen) continue;
+            if (last - first <= 16) { devInsertionSort(keys, first, last); continue; }
+            if (depth == 0) { stdHeapSort(keys + first, last - first); continue; }        // libstdc++ switches to heap sort here (it does happen: 1.31 M triangles)
+            devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
+            const int cut = devListPartition(keys, listL, listR, first + 1, last, first);
+            const int parts[2][2] = {{first, cut}, {cut, last}};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int f = parts[h][0], l = parts[h][1];
+                if (l - f > 16) push(f, l, depth - 1);
+                else devInsertionSort(keys, f, l);
+            }
+        }
+        __syncthreads();
+        nSort = s_count[1] < maxTasks ? s_count[1] : maxTasks;
+        uint32_t* sw = in; in = out; out = sw;
+        __syncthreads();
+    }
+}
 struct DevV3 { float x, y, z; };
 SDF_DEV void devTriVerts(const float4* __restrict__ triV, int t, DevV3& a, DevV3& b, DevV3& c) {
     const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
@@ -543,12 +649,17 @@ SDF_DEV void devTriVerts(const float4* __restrict__ triV, int t, DevV3& a, DevV3
 SDF_DEV float devComp(const DevV3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
 __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict__ tasks, const uint32_t* __restrict__ order, const float4* __restrict__ triV,
-                                                      double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed, uint32_t kDevSubtreeMax) {
+                                                      double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed, uint32_t kDevSubtreeMax, unsigned long long* __restrict__ phaseClocks /* SDFHIP_TIMING: 100 MHz ticks of block 0 in A (workgroup), A (lane per node), B, C; else null */) {
     extern __shared__ unsigned char s_bvh_raw[];
-    KeyTri* keys = reinterpret_cast<KeyTri*>(s_bvh_raw);
-    uint32_t* sortA = reinterpret_cast<uint32_t*>(s_bvh_raw + sizeof(KeyTri) * kDevSubtreeMax);        // {first, last, depth limit} x 3 words
+    const KeyArr keys{reinterpret_cast<KeyTri*>(s_bvh_raw), 0};
+    const IdxArr listL{reinterpret_cast<unsigned short*>(s_bvh_raw + KeyArr::bytes(kDevSubtreeMax))};      // index lists of the partitions, by position
+    const IdxArr listR{reinterpret_cast<unsigned short*>(s_bvh_raw + KeyArr::bytes(kDevSubtreeMax) + IdxArr::bytes(kDevSubtreeMax))};
+    uint32_t* sortA = reinterpret_cast<uint32_t*>(s_bvh_raw + KeyArr::bytes(kDevSubtreeMax) + 2 * IdxArr::bytes(kDevSubtreeMax));        // {first, last, depth limit} x 3 words
     uint32_t* sortB = sortA + 3 * kDevSortTasks;
     __shared__ uint32_t s_count[4];                  // [0] nodes of the next level, [1] sort tasks of the next round, [2] overflow / depth-limit flag
+    // tables of a level prepared by the whole workgroup (see A below): first element, AABB (ordered-uint floats), centre, radius^2 bits, axis
+    __shared__ uint32_t s_nb[kCoopNodes + 1]; __shared__ uint32_t s_box[kCoopNodes][6]; __shared__ double s_ctr[kCoopNodes][3];
+    __shared__ unsigned long long s_r2[kCoopNodes]; __shared__ int s_dim[kCoopNodes];
     const BvhTask T = tasks[blockIdx.x];
     const uint32_t n = T.end - T.begin;
     const int tid = threadIdx.x;
@@ -556,13 +667,120 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
     BvhDevNode* nxt = cur + (kDevSubtreeMax / 2u + 1u);
     for (uint32_t i = tid; i < n; i += 256) keys[i] = KeyTri{0.f, (int)order[T.begin + i]};
     if (tid == 0) { cur[0] = BvhDevNode{T.innerId, T.begin, T.end, T.parentSlot}; s_count[2] = 0; }
-    uint32_t nCur = 1;
+    uint32_t nCur = 1, level = 0;
     __syncthreads();
+    const bool clocked = phaseClocks != nullptr && blockIdx.x == 0 && tid == 0;
+    unsigned long long tick = clocked ? wall_clock64() : 0ull;
+    auto lapClock = [&](int which) { if (clocked) { const unsigned long long now = wall_clock64(); phaseClocks[which] += now - tick; tick = now; } };
     while (nCur > 0) {
         if (tid == 0) { s_count[0] = 0; s_count[1] = 0; }
         __syncthreads();
+        // A level whose nodes are all large (the top levels of the subtree; sizes differ by at most one, the smallest is n >> level) is
+        // prepared by the whole workgroup: only the centre SUM depends on the order of its operands and stays one lane's chain per node
+        // (vertex loads eight triangles ahead); AABB, radius (maxima of identical expressions) and keys are taken per element.  cur[] is in
+        // left-to-right order on such levels (C keeps it so).  One lane per node was 2 x 4096 dependent global loads at the subtree's root.
+        const bool coop = level < 31u && (n >> level) > kCoopMin && nCur <= kCoopNodes;
+        if (coop) {
+            const float fhi = 3.402823466e+38f;
+            for (uint32_t j = tid; j < nCur; j += 256) {
+                s_nb[j] = cur[j].b - T.begin; s_r2[j] = 0ull;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { s_box[j][k] = devOrdKey(-fhi); s_box[j][3 + k] = devOrdKey(fhi); }
+            }
+            if (tid == 0) s_nb[nCur] = n;
+            __syncthreads();
+            const uint32_t per = (n + 255u) / 256u, i0 = (uint32_t)tid * per, i1 = (i0 + per < n) ? i0 + per : n;
+            uint32_t node0 = 0;
+            if (i0 < i1) { uint32_t lo_ = 0, hi_ = nCur - 1; while (lo_ < hi_) { const uint32_t m_ = (lo_ + hi_ + 1) >> 1; if (s_nb[m_] <= i0) lo_ = m_; else hi_ = m_ - 1; } node0 = lo_; }
+            {   // 1. AABB per node
+                uint32_t node = node0;
+                float tx = -fhi, ty = -fhi, tz = -fhi, bx = fhi, by = fhi, bz = fhi;
+                auto flush = [&]() {
+                    atomicMax(&s_box[node][0], devOrdKey(tx)); atomicMax(&s_box[node][1], devOrdKey(ty)); atomicMax(&s_box[node][2], devOrdKey(tz));
+                    atomicMin(&s_box[node][3], devOrdKey(bx)); atomicMin(&s_box[node][4], devOrdKey(by)); atomicMin(&s_box[node][5], devOrdKey(bz));
+                    tx = ty = tz = -fhi; bx = by = bz = fhi;
+                };
+                for (uint32_t i = i0; i < i1; i++) {
+                    while (i >= s_nb[node + 1]) { flush(); node++; }
+                    DevV3 v[3]; devTriVerts(triV, keys[i].tri, v[0], v[1], v[2]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {            // (a NaN coordinate is never taken, as in `v > t ? v : t`)
+                        tx = v[k].x > tx ? v[k].x : tx; bx = v[k].x < bx ? v[k].x : bx; ty = v[k].y > ty ? v[k].y : ty; by = v[k].y < by ? v[k].y : by;
+                        tz = v[k].z > tz ? v[k].z : tz; bz = v[k].z < bz ? v[k].z : bz;
+                    }
+                }
+                if (i0 < i1) flush();
+            }
+            __syncthreads();
+            // 2. one lane per node: split axis, centre = the vertices summed in range order
+            for (uint32_t j = tid; j < nCur; j += 256) {
+                const double d0 = (double)devOrdVal(s_box[j][0]) - (double)devOrdVal(s_box[j][3]), d1 = (double)devOrdVal(s_box[j][1]) - (double)devOrdVal(s_box[j][4]),
+                             d2 = (double)devOrdVal(s_box[j][2]) - (double)devOrdVal(s_box[j][5]);
+                int dim = 0; double dm = d0;
+                if (dm < d1) { dim = 1; dm = d1; }
+                if (dm < d2) dim = 2;
+                s_dim[j] = dim;
+                const int lo = (int)s_nb[j], nn = (int)(s_nb[j + 1] - s_nb[j]);
+                double sx = 0.0, sy = 0.0, sz = 0.0;
+                int i = 0;
+                for (; i + 8 <= nn; i += 8) {
+                    float4 q0[8], q1[8]; float q2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const size_t t = (size_t)keys[lo + i + u].tri;
+                        q0[u] = triV[3 * t]; q1[u] = triV[3 * t + 1]; q2[u] = reinterpret_cast<const float*>(triV)[12 * t + 8];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        sx += (double)q0[u].x; sy += (double)q0[u].y; sz += (double)q0[u].z;
+                        sx += (double)q0[u].w; sy += (double)q1[u].x; sz += (double)q1[u].y;
+                        sx += (double)q1[u].z; sy += (double)q1[u].w; sz += (double)q2[u];
+                    }
+                }
+                for (; i < nn; i++) {
+                    DevV3 v[3]; devTriVerts(triV, keys[lo + i].tri, v[0], v[1], v[2]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { sx += (double)v[k].x; sy += (double)v[k].y; sz += (double)v[k].z; }
+                }
+                const double cnt = (double)(3 * nn);
+                s_ctr[j][0] = sx / cnt; s_ctr[j][1] = sy / cnt; s_ctr[j][2] = sz / cnt;
+            }
+            __syncthreads();
+            {   // 3. radius and keys per element
+                uint32_t node = node0;
+                double r2 = 0.0;
+                double cx = 0, cy = 0, cz = 0; int dim = 0;
+                if (i0 < i1) { cx = s_ctr[node][0]; cy = s_ctr[node][1]; cz = s_ctr[node][2]; dim = s_dim[node]; }
+                for (uint32_t i = i0; i < i1; i++) {
+                    while (i >= s_nb[node + 1]) {
+                        atomicMax(&s_r2[node], (unsigned long long)__double_as_longlong(r2));
+                        node++; r2 = 0.0; cx = s_ctr[node][0]; cy = s_ctr[node][1]; cz = s_ctr[node][2]; dim = s_dim[node];
+                    }
+                    DevV3 v[3]; devTriVerts(triV, keys[i].tri, v[0], v[1], v[2]);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const double dx = cx - (double)v[k].x, dy = cy - (double)v[k].y, dz = cz - (double)v[k].z;
+                        const double q = dx * dx + dy * dy + dz * dz;
+                        r2 = r2 < q ? q : r2;                  // (never a NaN, never negative: the bits order like the values)
+                    }
+                    keys[i].key = devComp(v[0], dim);
+                }
+                if (i0 < i1) atomicMax(&s_r2[node], (unsigned long long)__double_as_longlong(r2));
+            }
+            __syncthreads();
+            // 4. spheres and the level's sort tasks (every range is longer than 16)
+            for (uint32_t j = tid; j < nCur; j += 256) {
+                const BvhDevNode nd = cur[j];
+                if (nd.slot != 0xFFFFFFFFu) { double* o = sph + 4 * (size_t)nd.slot; o[0] = s_ctr[j][0]; o[1] = s_ctr[j][1]; o[2] = s_ctr[j][2]; o[3] = sqrt(__longlong_as_double((long long)s_r2[j])); }
+                const int nn = (int)(nd.e - nd.b);
+                int lg = 0; for (int m = nn; m > 1; m >>= 1) lg++;
+                sortA[3 * j] = s_nb[j]; sortA[3 * j + 1] = s_nb[j] + (uint32_t)nn; sortA[3 * j + 2] = (uint32_t)(2 * lg);
+            }
+            if (tid == 0) s_count[1] = nCur;
+        }
+        lapClock(0);
         // ---- A. one lane per node: centre (ordered fp64 sum), AABB -> axis, radius, keys; short ranges sorted at once
-        for (uint32_t j = tid; j < nCur; j += 256) {
+        for (uint32_t j = tid; j < (coop ? 0u : nCur); j += 256) {
             const BvhDevNode nd = cur[j];
             const int lo = (int)(nd.b - T.begin), nn = (int)(nd.e - nd.b);
             double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -604,34 +822,14 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
             }
         }
         __syncthreads();
+        lapClock(1);
         // ---- B. introsort rounds: every pending range is partitioned by one lane; parts of at most 16 are finished on the spot
-        uint32_t nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
-        uint32_t* in = sortA; uint32_t* out = sortB;
-        __syncthreads();
-        while (nSort > 0) {
-            if (tid == 0) s_count[1] = 0;
+        {
+            const uint32_t nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
             __syncthreads();
-            for (uint32_t t = tid; t < nSort; t += 256) {
-                const int first = (int)in[3 * t], last = (int)in[3 * t + 1]; const int depth = (int)in[3 * t + 2];
-                if (depth == 0) { stdHeapSort(keys + first, last - first); continue; }        // libstdc++ switches to heap sort here (it does happen: 1.31 M triangles)
-                devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
-                const int cut = devPartition(keys, first + 1, last, first);
-                const int parts[2][2] = {{first, cut}, {cut, last}};
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int f = parts[h][0], l = parts[h][1];
-                    if (l - f > 16) {
-                        const uint32_t at = atomicAdd(&s_count[1], 1u);
-                        if (at < kDevSortTasks) { out[3 * at] = (uint32_t)f; out[3 * at + 1] = (uint32_t)l; out[3 * at + 2] = (uint32_t)(depth - 1); }
-                        else atomicOr(&s_count[2], 4u);
-                    } else devInsertionSort(keys, f, l);
-                }
-            }
-            __syncthreads();
-            nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
-            uint32_t* sw = in; in = out; out = sw;
-            __syncthreads();
+            devSortRounds(keys, listL, listR, sortA, sortB, s_count, nSort, kDevSortTasks, tid);
         }
+        lapClock(2);
         // ---- C. one lane per node: the children (leaves get their sphere here, inner children at the next level)
         for (uint32_t j = tid; j < nCur; j += 256) {
             const BvhDevNode nd = cur[j];
@@ -653,17 +851,340 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
                     kids[slot] = ~t;
                 } else {
                     kids[slot] = childId[side];
-                    const uint32_t at = atomicAdd(&s_count[0], 1u);
+                    const uint32_t at = coop ? 2u * j + (uint32_t)side : atomicAdd(&s_count[0], 1u);       // (a coop level's children are all inner nodes: left-to-right order is kept)
                     nxt[at] = BvhDevNode{childId[side], rb[side], re[side], slot};
                 }
             }
         }
         __syncthreads();
-        nCur = s_count[0];
+        lapClock(3);
+        nCur = coop ? 2u * nCur : s_count[0];
+        level++;
         BvhDevNode* sw = cur; cur = nxt; nxt = sw;
         __syncthreads();
     }
     if (tid == 0 && s_count[2]) atomicOr(failed, s_count[2]);
+}
+
+// ---- the top of the tree on the device too ------------------------------------------------------------------------------------------------
+// (The default; SDFHIP_BVH_BUILD=host switches it off.)  The levels whose nodes hold more than kDevSubtreeMax triangles are sorted in global memory, level by level, all
+// nodes of a level at once; k_bvh_subtrees then finishes every range.  The sort is libstdc++'s introsort once more, as ROUNDS: a round
+// partitions every pending range (> kDevSubtreeMax) once with the result of __unguarded_partition — the index lists of the elements not less /
+// not greater than the pivot, the t-th from the left exchanged with the t-th from the right while they have not crossed (see
+// IntroSortLike::parallelPartition) — on as many workgroups as the range has chunks; parts that fit in LDS are finished by k_sort_parts
+// (devSortRounds), parts of at most 16 by k_sort_tiny.  What depends on an order besides — the fp64 centre sums in range order — runs on a
+// second stream behind each level's sort: three lanes per node add x, y and z (k_top_sums), the rest of the wave gathers.
+struct GTask { uint32_t first, last, depth; };
+constexpr uint32_t kGsChunk = 2048;          // elements per workgroup in the round kernels (256 threads x 8)
+struct GsRound {
+    KeyTri* K; uint32_t* Ll; uint32_t* Rl;                          // keys; index lists by position
+    const GTask* tasks; const uint32_t* nTasksPtr; uint32_t maxTasks;
+    float* pk; uint32_t* chunkBase; uint32_t* totL; uint32_t* totR; uint32_t* swapped;       // per range
+    uint32_t* cntL; uint32_t* cntR;                                  // per chunk
+};
+SDF_DEV uint32_t gsTaskCount(const GsRound& R) { const uint32_t n = *R.nTasksPtr; return n < R.maxTasks ? n : R.maxTasks; }
+
+// one workgroup: pivots (median of three to the front), chunk layout of the round; zeroes the next round's counter
+__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) {
+    __shared__ uint32_t s_part[16]; __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nT = gsTaskCount(R);
+    if (tid == 0) { s_carry = 0; *nextCount = 0; if (*R.nTasksPtr > R.maxTasks) atomicOr(flags, 1u); }
+    __syncthreads();
+    for (uint32_t base = 0; base < nT; base += 1024u) {
+        const uint32_t t = base + (uint32_t)tid;
+        uint32_t nch = 0;
+        if (t < nT) {
+            const GTask task = R.tasks[t];
+            const int first = (int)task.first, last = (int)task.last;
+            if (task.depth == 0) atomicOr(flags, 2u);                 // heap sort of a range this long: left to the host planner
+            else devMedianToFirst(R.K, first, first + 1, first + (last - first) / 2, last - 1);
+            R.pk[t] = R.K[first].key;
+            nch = ((uint32_t)(last - first - 1) + kGsChunk - 1u) / kGsChunk;
+            R.totL[t] = 0; R.totR[t] = 0; R.swapped[t] = 0;
+        }
+        uint32_t incl = nch;                                          // inclusive scan over the workgroup
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < wave; w++) before += s_part[w];
+        if (t < nT) R.chunkBase[t] = s_carry + before + incl - nch;
+        __syncthreads();
+        if (tid == 1023) s_carry += before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) R.chunkBase[nT] = s_carry;
+}
+// which range and which of its chunks a workgroup of the round kernels works on
+struct GsChunk { uint32_t task; int f, m; uint32_t k; float pk; };
+SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c, uint32_t* s_task) {
+    const uint32_t nT = gsTaskCount(R);
+    if (block >= R.chunkBase[nT]) return false;                      // (uniform per workgroup)
+    if (threadIdx.x == 0) { uint32_t lo = 0, hi = nT - 1; while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (R.chunkBase[mid] <= block) lo = mid; else hi = mid - 1; } *s_task = lo; }
+    __syncthreads();
+    c.task = *s_task;
+    const GTask task = R.tasks[c.task];
+    c.f = (int)task.first + 1; c.m = (int)task.last - c.f; c.k = block - R.chunkBase[c.task]; c.pk = R.pk[c.task];
+    return true;
+}
+SDF_DEV uint32_t gsBlockSum(uint32_t v, uint32_t* s4) {               // sum over 256 threads, result in every thread
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+__global__ void __launch_bounds__(256) k_gs_count(GsRound R) {
+    __shared__ uint32_t s_task; __shared__ uint32_t s4[4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    const int i0 = (int)(c.k * kGsChunk) + 8 * (int)threadIdx.x;
+    uint32_t a = 0, b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (i0 + j < c.m) { const float key = R.K[c.f + i0 + j].key; a += !(key < c.pk); b += !(c.pk < key); }
+    const uint32_t A = gsBlockSum(a, s4), B = gsBlockSum(b, s4);
+    if (threadIdx.x == 0) { R.cntL[blockIdx.x] = A; R.cntR[blockIdx.x] = B; atomicAdd(&R.totL[c.task], A); atomicAdd(&R.totR[c.task], B); }
+}
+__global__ void __launch_bounds__(256) k_gs_fill(GsRound R) {
+    __shared__ uint32_t s_task; __shared__ uint32_t s4[4]; __shared__ uint32_t s_wave[2][4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // where this chunk's entries start in the range's lists: the counts of the range's chunks before it
+    uint32_t pa = 0, pb = 0;
+    for (uint32_t q = R.chunkBase[c.task] + (uint32_t)tid; q < blockIdx.x; q += 256u) { pa += R.cntL[q]; pb += R.cntR[q]; }
+    const uint32_t offL = gsBlockSum(pa, s4), offR = gsBlockSum(pb, s4);
+    const int i0 = (int)(c.k * kGsChunk) + 8 * tid;
+    uint32_t a = 0, b = 0; unsigned fl = 0, fr = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (i0 + j < c.m) { const float key = R.K[c.f + i0 + j].key; const bool l = !(key < c.pk), r = !(c.pk < key); fl |= (unsigned)l << j; fr |= (unsigned)r << j; a += l; b += r; }
+    uint32_t ia = a, ib = b;                                          // inclusive scans in thread (= element) order
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o); if (lane >= o) { ia += va; ib += vb; } }
+    if (lane == 63) { s_wave[0][wave] = ia; s_wave[1][wave] = ib; }
+    __syncthreads();
+    uint32_t ba = offL, bb = offR;
+    for (int w = 0; w < wave; w++) { ba += s_wave[0][w]; bb += s_wave[1][w]; }
+    uint32_t wa = ba + ia - a, wb = bb + ib - b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if ((fl >> j) & 1u) R.Ll[c.f + (int)wa++] = (uint32_t)(i0 + j);
+        if ((fr >> j) & 1u) R.Rl[c.f + (int)wb++] = (uint32_t)(i0 + j);
+    }
+}
+// the exchanges: pair t (1-based) is L_t and the t-th entry of R from its end; pairs that have crossed stay
+__global__ void __launch_bounds__(256) k_gs_swap(GsRound R) {
+    __shared__ uint32_t s_task; __shared__ uint32_t s4[4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    const uint32_t nl = R.totL[c.task], nr = R.totR[c.task], lim = nl < nr ? nl : nr;
+    const uint32_t q0 = c.k * kGsChunk + 8u * threadIdx.x + 1u;
+    uint32_t done = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j++) {
+        const uint32_t q = q0 + j;
+        if (q <= lim) {
+            const uint32_t a = R.Ll[c.f + (int)(q - 1)], b = R.Rl[c.f + (int)(nr - q)];
+            if (a < b) { devSwap(R.K, c.f + (int)a, c.f + (int)b); done++; }
+        }
+    }
+    const uint32_t D = gsBlockSum(done, s4);
+    if (threadIdx.x == 0 && D) atomicAdd(&R.swapped[c.task], D);
+}
+// the cut of every range and what becomes of its two parts
+__global__ void __launch_bounds__(256) k_gs_emit(GsRound R, GTask* __restrict__ next, uint32_t* __restrict__ nextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
+                                                 GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= gsTaskCount(R)) return;
+    const GTask task = R.tasks[t];
+    const int f = (int)task.first + 1, m = (int)task.last - f;
+    const uint32_t nl = R.totL[t], nr = R.totR[t], ms = R.swapped[t];
+    uint32_t stop = (ms < nl) ? R.Ll[f + (int)ms] : (uint32_t)m;
+    if (ms > 0) { const uint32_t r = R.Rl[f + (int)(nr - ms)]; if (r < stop) stop = r; }
+    const uint32_t cut = (uint32_t)f + stop;
+    const uint32_t pb[2] = {task.first, cut}, pe[2] = {cut, task.last};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t len = pe[h] - pb[h];
+        const GTask out{pb[h], pe[h], task.depth - 1u};
+        if (len > ldsMax) { const uint32_t at = atomicAdd(nextCount, 1u); if (at < R.maxTasks) next[at] = out; else atomicOr(flags, 1u); }
+        else if (len > 16u) { const uint32_t at = atomicAdd(partCount, 1u); if (at < maxParts) parts[at] = out; else atomicOr(flags, 1u); }
+        else if (len > 1u) { const uint32_t at = atomicAdd(tinyCount, 1u); if (at < maxTiny) tiny[at] = out; else atomicOr(flags, 1u); }
+    }
+}
+// a part that fits in LDS: the rest of its introsort in one workgroup
+__global__ void __launch_bounds__(256) k_sort_parts(KeyTri* __restrict__ K, const GTask* __restrict__ parts, uint32_t ldsMax, uint32_t* __restrict__ flags) {
+    extern __shared__ unsigned char s_bvh_raw[];
+    const KeyArr keys{reinterpret_cast<KeyTri*>(s_bvh_raw), 0};
+    const IdxArr listL{reinterpret_cast<unsigned short*>(s_bvh_raw + KeyArr::bytes(ldsMax))};
+    const IdxArr listR{reinterpret_cast<unsigned short*>(s_bvh_raw + KeyArr::bytes(ldsMax) + IdxArr::bytes(ldsMax))};
+    uint32_t* sortA = reinterpret_cast<uint32_t*>(s_bvh_raw + KeyArr::bytes(ldsMax) + 2 * IdxArr::bytes(ldsMax));
+    uint32_t* sortB = sortA + 3 * kDevSortTasks;
+    __shared__ uint32_t s_count[4];
+    const GTask part = parts[blockIdx.x];
+    const int n = (int)(part.last - part.first), tid = threadIdx.x;
+    for (int i = tid; i < n; i += 256) keys[i] = K[part.first + i];
+    if (tid == 0) { sortA[0] = 0; sortA[1] = (uint32_t)n; sortA[2] = part.depth; s_count[1] = 1; s_count[2] = 0; }
+    __syncthreads();
+    devSortRounds(keys, listL, listR, sortA, sortB, s_count, 1u, kDevSortTasks, tid);
+    for (int i = tid; i < n; i += 256) K[part.first + i] = keys[i];
+    if (tid == 0 && s_count[2]) atomicOr(flags, s_count[2]);
+}
+__global__ void k_sort_tiny(KeyTri* __restrict__ K, const GTask* __restrict__ tiny, uint32_t count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < count) devInsertionSort(K, (int)tiny[t].first, (int)tiny[t].last);
+}
+
+// ---- per level: AABB -> axis, keys; afterwards the centre sums and radii of its nodes
+struct TopNode { int id; uint32_t b, e, slot; };                    // slot: where the node's sphere goes, in units of 4 doubles (NONE32: the root's, nowhere)
+SDF_DEV uint32_t topNodeOf(const TopNode* __restrict__ nodes, uint32_t count, uint32_t i) {
+    uint32_t lo = 0, hi = count - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (nodes[mid].b <= i) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__global__ void k_top_init(uint32_t* __restrict__ box, unsigned long long* __restrict__ r2, uint32_t count) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const float fhi = 3.402823466e+38f;
+    for (int k = 0; k < 3; k++) { box[6 * j + k] = devOrdKey(-fhi); box[6 * j + 3 + k] = devOrdKey(fhi); }
+    r2[j] = 0ull;
+}
+__global__ void k_key_init(KeyTri* __restrict__ K, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) K[i] = KeyTri{0.f, (int)i}; }
+// 4 consecutive elements per thread; a wave whose lanes all sit in one node (the rule: nodes are longer than a workgroup's 1024 elements) reduces first
+__global__ void __launch_bounds__(256) k_top_aabb(const KeyTri* __restrict__ K, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, uint32_t n, uint32_t* __restrict__ box) {
+    const uint32_t i0 = 4u * (blockIdx.x * 256u + threadIdx.x);
+    const float fhi = 3.402823466e+38f;
+    float tx = -fhi, ty = -fhi, tz = -fhi, bx = fhi, by = fhi, bz = fhi;
+    uint32_t node = 0xFFFFFFFFu;
+    auto flush = [&]() {
+        atomicMax(&box[6 * node], devOrdKey(tx)); atomicMax(&box[6 * node + 1], devOrdKey(ty)); atomicMax(&box[6 * node + 2], devOrdKey(tz));
+        atomicMin(&box[6 * node + 3], devOrdKey(bx)); atomicMin(&box[6 * node + 4], devOrdKey(by)); atomicMin(&box[6 * node + 5], devOrdKey(bz));
+        tx = ty = tz = -fhi; bx = by = bz = fhi;
+    };
+    if (i0 < n) node = topNodeOf(nodes, count, i0);
+    const uint32_t nodeAtStart = node;
+    for (uint32_t i = i0; i < i0 + 4u && i < n; i++) {
+        while (i >= nodes[node].e) { flush(); node++; }
+        DevV3 v[3]; devTriVerts(triV, K[i].tri, v[0], v[1], v[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            tx = v[k].x > tx ? v[k].x : tx; bx = v[k].x < bx ? v[k].x : bx; ty = v[k].y > ty ? v[k].y : ty; by = v[k].y < by ? v[k].y : by;
+            tz = v[k].z > tz ? v[k].z : tz; bz = v[k].z < bz ? v[k].z : bz;
+        }
+    }
+    // a workgroup whose 1024 elements all lie in one node (most: nodes are longer than that) folds its box in LDS first: 6 atomics on the
+    // node's record instead of 24 (at the root every workgroup of the launch meets on the same six words)
+    __shared__ uint32_t s_fold[6];
+    const uint32_t nodeFirst = topNodeOf(nodes, count, 1024u * blockIdx.x);
+    const uint32_t lastEl = (1024u * blockIdx.x + 1023u < n) ? 1024u * blockIdx.x + 1023u : n - 1u;
+    const bool whole = lastEl < nodes[nodeFirst].e;                  // (uniform)
+    if (whole) {
+        if (threadIdx.x < 3) s_fold[threadIdx.x] = devOrdKey(-fhi); else if (threadIdx.x < 6) s_fold[threadIdx.x] = devOrdKey(fhi);
+        __syncthreads();
+    }
+    const uint32_t first = __shfl(nodeAtStart, 0);
+    if (__all(nodeAtStart == first && node == first && first != 0xFFFFFFFFu)) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float a = __shfl_xor(tx, o), b = __shfl_xor(ty, o), c = __shfl_xor(tz, o), d = __shfl_xor(bx, o), e = __shfl_xor(by, o), f = __shfl_xor(bz, o);
+            tx = a > tx ? a : tx; ty = b > ty ? b : ty; tz = c > tz ? c : tz; bx = d < bx ? d : bx; by = e < by ? e : by; bz = f < bz ? f : bz;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (whole) {
+                atomicMax(&s_fold[0], devOrdKey(tx)); atomicMax(&s_fold[1], devOrdKey(ty)); atomicMax(&s_fold[2], devOrdKey(tz));
+                atomicMin(&s_fold[3], devOrdKey(bx)); atomicMin(&s_fold[4], devOrdKey(by)); atomicMin(&s_fold[5], devOrdKey(bz));
+            } else flush();
+        }
+    } else if (node != 0xFFFFFFFFu) flush();
+    if (whole) {
+        __syncthreads();
+        if (threadIdx.x < 3) atomicMax(&box[6 * nodeFirst + threadIdx.x], s_fold[threadIdx.x]);
+        else if (threadIdx.x < 6) atomicMin(&box[6 * nodeFirst + threadIdx.x], s_fold[threadIdx.x]);
+    }
+}
+__global__ void k_top_dims(const uint32_t* __restrict__ box, uint32_t count, int* __restrict__ dims) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    double d[3];
+    for (int k = 0; k < 3; k++) d[k] = (double)devOrdVal(box[6 * j + k]) - (double)devOrdVal(box[6 * j + 3 + k]);
+    int dim = 0;                                       // std::max_element: the first of equal maxima
+    for (int k = 1; k < 3; k++) if (d[dim] < d[k]) dim = k;
+    dims[j] = dim;
+}
+__global__ void __launch_bounds__(256) k_top_keys(KeyTri* __restrict__ K, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, uint32_t n, const int* __restrict__ dims) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int dim = dims[topNodeOf(nodes, count, i)];
+    const size_t t = (size_t)K[i].tri;
+    const float4 q0 = triV[3 * t];
+    K[i].key = dim == 0 ? q0.x : (dim == 1 ? q0.y : q0.z);
+}
+__global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_t* __restrict__ snap) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) snap[i] = (uint32_t)K[i].tri; }
+// centre of a node = its vertices summed in range order, three chains (x, y, z) of 3 n additions each: one wave per node, all lanes gather 64
+// triangles and lay their coordinates out as doubles, lanes 0..2 add them in order (a workgroup per node: 256 triangles per step)
+__global__ void __launch_bounds__(256) k_top_sums(const uint32_t* __restrict__ order, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, double* __restrict__ centres) {
+    __shared__ double s_v[256][9];
+    const TopNode nd = nodes[blockIdx.x];
+    const int tid = threadIdx.x;
+    const uint32_t nn = nd.e - nd.b;
+    double sum = 0.0;
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f), q1 = q0; float q2 = 0.f;
+    auto load = [&](uint32_t base) { const uint32_t i = base + (uint32_t)tid; if (i < nn) { const size_t t = (size_t)order[nd.b + i]; q0 = triV[3 * t]; q1 = triV[3 * t + 1]; q2 = reinterpret_cast<const float*>(triV)[12 * t + 8]; } };
+    load(0);
+    for (uint32_t base = 0; base < nn; base += 256u) {
+        double* w = s_v[tid];
+        w[0] = (double)q0.x; w[1] = (double)q0.y; w[2] = (double)q0.z; w[3] = (double)q0.w; w[4] = (double)q1.x; w[5] = (double)q1.y; w[6] = (double)q1.z; w[7] = (double)q1.w; w[8] = (double)q2;
+        __syncthreads();
+        if (base + 256u < nn) load(base + 256u);                     // the next 256 triangles: two dependent gathers, in flight under the additions below
+        if (tid < 3) {
+            const uint32_t cnt = (nn - base < 256u) ? nn - base : 256u;
+            uint32_t i = 0;
+            for (; i + 8u <= cnt; i += 8u) {                         // the operands of eight triangles first, then their 24 dependent additions
+                double a[24];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { a[3 * u] = s_v[i + u][tid]; a[3 * u + 1] = s_v[i + u][3 + tid]; a[3 * u + 2] = s_v[i + u][6 + tid]; }
+#pragma unroll
+                for (int u = 0; u < 24; u++) sum += a[u];
+            }
+            for (; i < cnt; i++) { sum += s_v[i][tid]; sum += s_v[i][3 + tid]; sum += s_v[i][6 + tid]; }
+        }
+        __syncthreads();
+    }
+    if (tid < 3) centres[3 * (size_t)blockIdx.x + tid] = sum / (double)(3u * nn);
+}
+__global__ void __launch_bounds__(256) k_top_radius(const uint32_t* __restrict__ order, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, uint32_t n,
+                                                    const double* __restrict__ centres, unsigned long long* __restrict__ r2bits) {
+    const uint32_t i0 = 4u * (blockIdx.x * 256u + threadIdx.x);
+    uint32_t node = 0xFFFFFFFFu;
+    double cx = 0.0, cy = 0.0, cz = 0.0, r2 = 0.0;
+    if (i0 < n) { node = topNodeOf(nodes, count, i0); cx = centres[3 * (size_t)node]; cy = centres[3 * (size_t)node + 1]; cz = centres[3 * (size_t)node + 2]; }
+    const uint32_t nodeAtStart = node;
+    for (uint32_t i = i0; i < i0 + 4u && i < n; i++) {
+        while (i >= nodes[node].e) { atomicMax(&r2bits[node], (unsigned long long)__double_as_longlong(r2)); node++; r2 = 0.0; cx = centres[3 * (size_t)node]; cy = centres[3 * (size_t)node + 1]; cz = centres[3 * (size_t)node + 2]; }
+        DevV3 v[3]; devTriVerts(triV, (int)order[i], v[0], v[1], v[2]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double dx = cx - (double)v[k].x, dy = cy - (double)v[k].y, dz = cz - (double)v[k].z;
+            const double q = dx * dx + dy * dy + dz * dz;
+            r2 = r2 < q ? q : r2;                                     // (never a NaN, never negative: the bits order like the values)
+        }
+    }
+    const uint32_t first = __shfl(nodeAtStart, 0);
+    if (__all(nodeAtStart == first && node == first && first != 0xFFFFFFFFu)) {      // the whole wave in one node: one atomic
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const double other = __shfl_xor(r2, o); r2 = r2 < other ? other : r2; }
+        if ((threadIdx.x & 63) == 0) atomicMax(&r2bits[node], (unsigned long long)__double_as_longlong(r2));
+    } else if (node != 0xFFFFFFFFu) atomicMax(&r2bits[node], (unsigned long long)__double_as_longlong(r2));
+}
+// the records of a level's nodes: their sphere into the parent's record, their own child references (both children are inner nodes)
+__global__ void k_top_write(const TopNode* __restrict__ nodes, uint32_t count, const double* __restrict__ centres, const unsigned long long* __restrict__ r2bits, int haveSpheres,
+                            double* __restrict__ sph, int* __restrict__ kids) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const TopNode nd = nodes[j];
+    if (haveSpheres && nd.slot != 0xFFFFFFFFu) { double* o = sph + 4 * (size_t)nd.slot; o[0] = centres[3 * (size_t)j]; o[1] = centres[3 * (size_t)j + 1]; o[2] = centres[3 * (size_t)j + 2]; o[3] = sqrt(__longlong_as_double((long long)r2bits[j])); }
+    const uint32_t mid = (nd.b + nd.e) >> 1;
+    kids[2 * (size_t)nd.id] = nd.id + 1; kids[2 * (size_t)nd.id + 1] = nd.id + (int)(mid - nd.b);
 }
 
 // the records the host planned (the top of the tree), scattered to their pre-order positions; a half whose child is a device subtree is
@@ -964,7 +1485,8 @@ static bool isPlannerShaped(const int* kids, uint32_t T) {
 struct PlannedBvh;
 static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st);
 
-static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where, bool validate = false, const PlannedBvh* hybrid = nullptr) {
+static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st);
+static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int where, bool validate = false, const PlannedBvh* hybrid = nullptr, bool onDevice = false) {
     const uint32_t T = mesh->numTriangles;
     const uint64_t nn = T - 1;
     const size_t nSph = 8 * (size_t)(nn ? nn : 1), nKids = 2 * (size_t)(nn ? nn : 1);
@@ -973,12 +1495,13 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     AllocScope allocScope(st);
     const hipMemcpyKind kind = where == SDFHIP_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SDF_TRY(mesh->dBvhSph.reserve(nSph)); SDF_TRY(mesh->dBvhKids.reserve(nKids)); SDF_TRY(mesh->dTriVerts.reserve(12ull * T));
-    if (!hybrid) {
+    if (!hybrid && !onDevice) {
         SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhSph.p, sph, nSph * sizeof(double), kind, st));
         SDF_HIP_CHECK(hipMemcpyAsync(mesh->dBvhKids.p, kids, nKids * sizeof(int), kind, st));
     }
     k_tri_verts<<<gridFor(12ull * T, 256), 256, 0, st>>>(mesh->dVerts.p, mesh->dIdx.p, T, mesh->dTriVerts.p);
     if (hybrid) SDF_TRY(finishOnDevice(mesh, *hybrid, st));
+    if (onDevice) SDF_TRY(buildTreeOnDevice(mesh, st));
     {
         float scale = 0.f;
         for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
@@ -1127,20 +1650,195 @@ static uint32_t bvhOffloadMax() {
     static const uint32_t offload = [] {
         const char* e = getenv("SDFHIP_BVH_DEVICE_SUBTREES");
         if (!e) return 0u;
-        uint32_t v = (uint32_t)atoi(e); if (v <= 1u) v = 4096u;                 // =1: the default size; =N: ranges of at most N triangles
+        uint32_t v = (uint32_t)atoi(e); if (v == 0u) return 0u; if (v == 1u) v = 4096u;      // =0: off; =1: the default size; =N: ranges of at most N triangles
         return v > kDevSubtreeMaxLimit ? kDevSubtreeMaxLimit : (v < 32u ? 32u : v);
     }();
     return offload;
 }
 namespace sdfhip {
+static bool bvhBuildOnDevice() {
+    static const bool v = [] { const char* e = getenv("SDFHIP_BVH_BUILD"); return e == nullptr || strcmp(e, "host") != 0; }();      // the default; =host: the host planner
+    return v;
+}
 void startEarlyBvhPlan(sdfhip_mesh* mesh) {
-    if (mesh->early.th.joinable() || mesh->early.plan) return;
+    if (mesh->early.th.joinable() || mesh->early.plan || bvhBuildOnDevice()) return;      // (built on the device: nothing to plan)
     mesh->early.drop = [](void* p) { delete static_cast<PlannedBvh*>(p); };
     mesh->early.th = std::thread([mesh]() {
         try { mesh->early.plan = new PlannedBvh(planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, bvhOffloadMax())); }
         catch (...) { mesh->early.plan = nullptr; }          // (out of memory: sdfhip_mesh_build_bvh plans again and reports)
     });
 }
+}
+
+// The whole tree on the device (see k_gs_prepare); SDFHIP_BVH_BUILD=host plans on the host instead.  SDFHIP_E_UNSUPPORTED: a long range ran out of introsort's depth
+// limit or a work list overflowed — the caller plans on the host.
+static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
+    const uint32_t T = mesh->numTriangles;
+    uint32_t S = bvhOffloadMax(); if (S == 0) S = 4096u;
+    // a range leaves the rounds over global memory for k_sort_parts (LDS) at this length: a round costs ~50 us whatever its ranges, a workgroup's
+    // serial tail grows with the part (SDFHIP_BVH_PART, default 1024)
+    uint32_t partMax = 1024u; if (const char* e = getenv("SDFHIP_BVH_PART")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 32u) partMax = v; }
+    if (partMax > S) partMax = S;
+    const bool timing = getenv("SDFHIP_TIMING") != nullptr, debug = getenv("SDFHIP_BVH_DEBUG") != nullptr;
+    const double t0 = nowSeconds();
+    const float4* triV = reinterpret_cast<const float4*>(mesh->dTriVerts.p);
+    // the levels sorted in global memory: while some node is longer than S
+    std::vector<std::vector<TopNode>> levels;
+    std::vector<TopNode> cur{TopNode{0, 0u, T, 0xFFFFFFFFu}};
+    for (;;) {
+        uint32_t longest = 0; for (const TopNode& nd : cur) longest = std::max(longest, nd.e - nd.b);
+        if (longest <= S) break;
+        std::vector<TopNode> next; next.reserve(2 * cur.size());
+        for (const TopNode& nd : cur) {
+            const uint32_t mid = (nd.b + nd.e) >> 1;
+            next.push_back(TopNode{nd.id + 1, nd.b, mid, 2u * (uint32_t)nd.id});
+            next.push_back(TopNode{nd.id + (int)(mid - nd.b), mid, nd.e, 2u * (uint32_t)nd.id + 1u});
+        }
+        levels.push_back(std::move(cur)); cur = std::move(next);
+    }
+    const size_t nTop = levels.size();                  // cur: the subtrees' roots
+    size_t tableNodes = 0; std::vector<size_t> levelAt(nTop + 1, 0);
+    for (size_t l = 0; l < nTop; l++) { levelAt[l] = tableNodes; tableNodes += levels[l].size(); }
+    levelAt[nTop] = tableNodes;
+    const uint32_t maxTasks = 2u * (T / partMax) + 16u, maxParts = T / 16u + 16u, maxTiny = T / 2u + 16u;
+    const uint32_t maxChunks = T / kGsChunk + maxTasks + 1u;
+    DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, totL, totR, swapped, cntL, cntR, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
+    DevBuf<int> dims; DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
+    SDF_TRY(K.reserve(T)); SDF_TRY(snaps.reserve((size_t)T * (nTop ? nTop : 1))); SDF_TRY(ctr.reserve(8)); SDF_TRY(dFail.reserve(1));
+    if (nTop) {
+        SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(totL.reserve(maxTasks)); SDF_TRY(totR.reserve(maxTasks));
+        SDF_TRY(swapped.reserve(maxTasks)); SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
+        SDF_TRY(tiny.reserve(maxTiny)); SDF_TRY(dNodes.reserve(tableNodes)); SDF_TRY(dims.reserve(tableNodes)); SDF_TRY(centres.reserve(3 * tableNodes)); SDF_TRY(r2.reserve(tableNodes));
+        std::vector<TopNode> flat; flat.reserve(tableNodes);
+        for (size_t l = 0; l < nTop; l++) flat.insert(flat.end(), levels[l].begin(), levels[l].end());
+        SDF_HIP_CHECK(hipMemcpyAsync(dNodes.p, flat.data(), sizeof(TopNode) * tableNodes, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));        // (flat goes out of scope)
+        k_top_init<<<gridFor(tableNodes, 256), 256, 0, st>>>(box.p, r2.p, (uint32_t)tableNodes);
+    }
+    SDF_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 32, st)); SDF_HIP_CHECK(hipMemsetAsync(dFail.p, 0, 4, st));
+    k_key_init<<<gridFor(T, 256), 256, 0, st>>>(K.p, T);
+    const size_t lds = KeyArr::bytes(S) + 2 * IdxArr::bytes(S) + 2 * 3 * 4 * kDevSortTasks;
+    {
+        static bool raised = false;
+        if (!raised) {
+            const int most = (int)(KeyArr::bytes(kDevSubtreeMaxLimit) + 2 * IdxArr::bytes(kDevSubtreeMaxLimit) + 2 * 3 * 4 * kDevSortTasks);
+            SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, most));
+            SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_parts), hipFuncAttributeMaxDynamicSharedMemorySize, most));
+            raised = true;
+        }
+    }
+    struct EventHolder { hipEvent_t e = nullptr; ~EventHolder() { if (e) (void)hipEventDestroy(e); } };
+    std::vector<EventHolder> sorted(nTop);
+    // two side streams of the context: level 1 alone on the second (its two chains are as long as all deeper levels' together)
+    struct Side { hipStream_t s; } side{nullptr}, side1{nullptr};
+    const bool useSide = [] { const char* e = getenv("SDFHIP_BVH_SIDE"); return !(e && e[0] == '0'); }();      // SDFHIP_BVH_SIDE=0: everything on the context's stream
+    if (nTop && useSide) {
+        for (hipStream_t& s : mesh->ctx->bvhSide) if (!s) SDF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        side.s = mesh->ctx->bvhSide[0]; side1.s = mesh->ctx->bvhSide[1];
+    } else { side.s = st; side1.s = st; }
+    // whatever happens below, nothing of this call may still run on the side streams when its buffers are released
+    struct SideGuard { hipStream_t a, b; ~SideGuard() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } sideGuard{useSide ? side.s : nullptr, useSide ? side1.s : nullptr};
+    // ctr: [0], [1] = pending ranges of this / the next round (alternating), [2] = parts for k_sort_parts, [3] = for k_sort_tiny, [4] = flags
+    uint32_t hostCtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t rounds = 0;
+    std::vector<KeyTri> dbgPre, dbgPost;
+    for (size_t l = 0; l < nTop; l++) {
+        const std::vector<TopNode>& nodes = levels[l];
+        const uint32_t count = (uint32_t)nodes.size();
+        const TopNode* dN = dNodes.p + levelAt[l];
+        k_top_aabb<<<gridFor(T, 1024), 256, 0, st>>>(K.p, triV, dN, count, T, box.p + 6 * levelAt[l]);
+        k_top_dims<<<gridFor(count, 256), 256, 0, st>>>(box.p + 6 * levelAt[l], count, dims.p + levelAt[l]);
+        k_top_keys<<<gridFor(T, 256), 256, 0, st>>>(K.p, triV, dN, count, T, dims.p + levelAt[l]);
+        if (debug) { dbgPre.resize(T); SDF_HIP_CHECK(hipMemcpyAsync(dbgPre.data(), K.p, sizeof(KeyTri) * T, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); }
+        // the level's nodes are the first round's ranges
+        std::vector<GTask> first(count);
+        for (uint32_t j = 0; j < count; j++) { const uint32_t len = nodes[j].e - nodes[j].b; int lg = 0; for (uint32_t m = len; m > 1; m >>= 1) lg++; first[j] = GTask{nodes[j].b, nodes[j].e, (uint32_t)(2 * lg)}; }
+        SDF_REQUIRE(count <= maxTasks, "internal: more nodes on a level than ranges provided for");
+        int curBuf = 0;
+        hostCtr[0] = count; hostCtr[1] = 0; hostCtr[2] = 0; hostCtr[3] = 0;
+        SDF_HIP_CHECK(hipMemcpyAsync(tasks.p, first.data(), sizeof(GTask) * count, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemcpyAsync(ctr.p, hostCtr, 16, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        uint32_t pending = count;
+        while (pending > 0) {
+            // the host learns a round's outcome only by waiting for it: kRoundsPerSync rounds are queued at a time, sized for the most ranges they
+            // can have (a range leaves at most two); a round without ranges costs five empty launches
+            constexpr int kRoundsPerSync = 4;
+            uint32_t bound = pending;
+            for (int q = 0; q < kRoundsPerSync; q++) {
+                GsRound R{K.p, Ll.p, Rl.p, tasks.p + (size_t)curBuf * maxTasks, ctr.p + curBuf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p};
+                const unsigned chunkGrid = (unsigned)(T / kGsChunk + bound + 1u);
+                k_gs_prepare<<<1, 1024, 0, st>>>(R, ctr.p + (curBuf ^ 1), ctr.p + 4);
+                k_gs_count<<<chunkGrid, 256, 0, st>>>(R);
+                k_gs_fill<<<chunkGrid, 256, 0, st>>>(R);
+                k_gs_swap<<<chunkGrid, 256, 0, st>>>(R);
+                k_gs_emit<<<gridFor(bound, 256), 256, 0, st>>>(R, tasks.p + (size_t)(curBuf ^ 1) * maxTasks, ctr.p + (curBuf ^ 1), parts.p, ctr.p + 2, maxParts, tiny.p, ctr.p + 3, maxTiny, partMax, ctr.p + 4);
+                curBuf ^= 1;
+                rounds++;
+                bound = (bound > maxTasks / 2u) ? maxTasks : 2u * bound;
+            }
+            SDF_HIP_CHECK(hipMemcpyAsync(hostCtr, ctr.p, 20, hipMemcpyDeviceToHost, st));
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            if (hostCtr[4]) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: gave up at level %zu (flags %u: 1 = a work list overflowed, 2 = a long range out of introsort's depth)\n", l, hostCtr[4]); return SDFHIP_E_UNSUPPORTED; }
+            pending = hostCtr[curBuf];
+        }
+        if (hostCtr[2]) k_sort_parts<<<hostCtr[2], 256, KeyArr::bytes(partMax) + 2 * IdxArr::bytes(partMax) + 2 * 3 * 4 * kDevSortTasks, st>>>(K.p, parts.p, partMax, ctr.p + 4);
+        if (hostCtr[3]) k_sort_tiny<<<gridFor(hostCtr[3], 64), 64, 0, st>>>(K.p, tiny.p, hostCtr[3]);
+        uint32_t* snap = snaps.p + (size_t)T * l;
+        k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snap);
+        k_top_write<<<gridFor(count, 256), 256, 0, st>>>(dN, count, nullptr, nullptr, 0, mesh->dBvhSph.p, mesh->dBvhKids.p);
+        SDF_HIP_CHECK(hipGetLastError());
+        if (debug) {
+            dbgPost.resize(T);
+            SDF_HIP_CHECK(hipMemcpyAsync(dbgPost.data(), K.p, sizeof(KeyTri) * T, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
+            size_t bad = 0;
+            for (uint32_t j = 0; j < count && bad < 5; j++) {
+                IntroSortLike sorter; sorter.sort(dbgPre.data() + nodes[j].b, dbgPre.data() + nodes[j].e);
+                for (uint32_t i = nodes[j].b; i < nodes[j].e; i++) if (dbgPre[i].tri != dbgPost[i].tri || memcmp(&dbgPre[i].key, &dbgPost[i].key, 4) != 0) {
+                    fprintf(stderr, "[sdfhip] bvh debug: level %zu node %u [%u, %u): element %u is triangle %d (key %.9g) on the device, %d (%.9g) by std::sort\n", l, j, nodes[j].b, nodes[j].e, i, dbgPost[i].tri, dbgPost[i].key, dbgPre[i].tri, dbgPre[i].key);
+                    bad++; break;
+                }
+            }
+            fprintf(stderr, "[sdfhip] bvh debug: level %zu (%u nodes) %s, %u parts, %u tiny parts\n", l, count, bad ? "DIFFERS" : "sorted like std::sort", hostCtr[2], hostCtr[3]);
+        }
+        // behind this level's sort, on the side stream: centres (sums in this order), radii and sphere records of the NEXT level's nodes
+        if (l + 1 < nTop) {
+            hipStream_t ss = (l == 0) ? side1.s : side.s;
+            if (useSide) {
+                SDF_HIP_CHECK(hipEventCreateWithFlags(&sorted[l].e, hipEventDisableTiming));
+                SDF_HIP_CHECK(hipEventRecord(sorted[l].e, st));
+                SDF_HIP_CHECK(hipStreamWaitEvent(ss, sorted[l].e, 0));
+            }
+            const uint32_t nc = (uint32_t)levels[l + 1].size(); const size_t at = levelAt[l + 1];
+            k_top_sums<<<nc, 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, centres.p + 3 * at);
+            k_top_radius<<<gridFor(T, 1024), 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, T, centres.p + 3 * at, r2.p + at);
+            k_top_write<<<gridFor(nc, 256), 256, 0, ss>>>(dNodes.p + at, nc, centres.p + 3 * at, r2.p + at, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
+        }
+    }
+    const double tTop = nowSeconds();
+    // every remaining range: one workgroup each
+    const size_t nt = cur.size();
+    std::vector<BvhTask> ht(nt);
+    for (size_t i = 0; i < nt; i++) ht[i] = BvhTask{cur[i].id, cur[i].b, cur[i].e, cur[i].slot};
+    const uint32_t* order = snaps.p + (size_t)T * (nTop ? nTop - 1 : 0);
+    if (!nTop) k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snaps.p);
+    SDF_TRY(dTasks.reserve(nt)); SDF_TRY(dScratch.reserve(nt * 2 * (S / 2 + 1)));
+    SDF_HIP_CHECK(hipMemcpyAsync(dTasks.p, ht.data(), sizeof(BvhTask) * nt, hipMemcpyHostToDevice, st));
+    unsigned long long clk[4] = {0, 0, 0, 0};
+    if (timing) { SDF_TRY(dClk.reserve(4)); SDF_HIP_CHECK(hipMemsetAsync(dClk.p, 0, 32, st)); }
+    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, order, triV, mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, S, timing ? dClk.p : nullptr);
+    SDF_HIP_CHECK(hipGetLastError());
+    uint32_t failed = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&failed, dFail.p, 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(hostCtr, ctr.p, 20, hipMemcpyDeviceToHost, st));
+    if (timing) SDF_HIP_CHECK(hipMemcpyAsync(clk, dClk.p, 32, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    const double tSub = nowSeconds();
+    if (nTop && useSide) { SDF_HIP_CHECK(hipStreamSynchronize(side.s)); SDF_HIP_CHECK(hipStreamSynchronize(side1.s)); }
+    if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
+                        nTop, rounds, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
+    if (failed || hostCtr[4]) return SDFHIP_E_UNSUPPORTED;
+    return SDFHIP_OK;
 }
 
 static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st) {
@@ -1169,15 +1867,24 @@ static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st
     SDF_HIP_CHECK(hipMemcpyAsync(dOrder.p, P.order.data(), 4 * (size_t)T, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(dTasks.p, P.tasks.data(), sizeof(BvhTask) * nt, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemsetAsync(dFail.p, 0, 4, st));
+    const bool timing = getenv("SDFHIP_TIMING") != nullptr;
+    DevBuf<unsigned long long> dClk; unsigned long long clk[4] = {0, 0, 0, 0};
+    if (timing) { SDF_TRY(dClk.reserve(4)); SDF_HIP_CHECK(hipMemsetAsync(dClk.p, 0, 32, st)); }
+    const double tUp = nowSeconds();
+    if (timing) SDF_HIP_CHECK(hipStreamSynchronize(st));
+    const double tKer = nowSeconds();
     k_bvh_scatter_top<<<gridFor(nh, 256), 256, 0, st>>>(dIds.p, dS8.p, dK2.p, dOwn.p, (uint32_t)nh, mesh->dBvhSph.p, mesh->dBvhKids.p);
-    const size_t lds = sizeof(KeyTri) * kDevSubtreeMax + 2 * 3 * 4 * kDevSortTasks;
+    const size_t lds = KeyArr::bytes(kDevSubtreeMax) + 2 * IdxArr::bytes(kDevSubtreeMax) + 2 * 3 * 4 * kDevSortTasks;
     static bool ldsRaised = false;
-    if (!ldsRaised && lds > (48u << 10)) { SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(KeyTri) * kDevSubtreeMaxLimit + 2 * 3 * 4 * kDevSortTasks))); ldsRaised = true; }
-    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, kDevSubtreeMax);
+    if (!ldsRaised && lds > (48u << 10)) { SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KeyArr::bytes(kDevSubtreeMaxLimit) + 2 * IdxArr::bytes(kDevSubtreeMaxLimit) + 2 * 3 * 4 * kDevSortTasks))); ldsRaised = true; }
+    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, kDevSubtreeMax, timing ? dClk.p : nullptr);
     SDF_HIP_CHECK(hipGetLastError());
     uint32_t failed = 0;
+    if (timing) SDF_HIP_CHECK(hipMemcpyAsync(clk, dClk.p, 32, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipMemcpyAsync(&failed, dFail.p, 4, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));         // (the staging vectors above are released here)
+    if (timing) fprintf(stderr, "[sdfhip] bvh device subtrees: %zu ranges of <= %u, uploads %.4f s, kernels %.4f s; block 0: workgroup-prepared levels %.3f ms, lane-per-node levels %.3f ms, sorts %.3f ms, children %.3f ms\n",
+                        nt, kDevSubtreeMax, tKer - tUp, nowSeconds() - tKer, clk[0] * 1e-5, clk[1] * 1e-5, clk[2] * 1e-5, clk[3] * 1e-5);
     if (failed && getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: device subtrees gave up (reason bits %u: 1 / 4 = sort task list full, 2 = introsort depth limit): planning on the host\n", failed);
     return failed ? SDFHIP_E_UNSUPPORTED : SDFHIP_OK;
 }
@@ -1192,6 +1899,15 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
     const uint32_t offload = bvhOffloadMax();
+    if (bvhBuildOnDevice() && mesh->numTriangles >= 64u && !mesh->early.th.joinable() && !mesh->early.plan) {
+        const int rcDev = installBvh(mesh, nullptr, nullptr, SDFHIP_HOST, false, nullptr, true);
+        if (rcDev == SDFHIP_OK) {
+            if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] bvh: built on the device, %.3f s with the derived records\n", nowSeconds() - t0);
+            if (seconds) *seconds = nowSeconds() - t0;
+            return SDFHIP_OK;
+        }
+        if (rcDev != SDFHIP_E_UNSUPPORTED) return rcDev;
+    }
     PlannedBvh P;
     if (mesh->early.th.joinable()) mesh->early.th.join();        // a plan started under the mesh preparation (sdfhip_mesh_create_opt)
     if (mesh->early.plan) { P = std::move(*static_cast<PlannedBvh*>(mesh->early.plan)); delete static_cast<PlannedBvh*>(mesh->early.plan); mesh->early.plan = nullptr; }

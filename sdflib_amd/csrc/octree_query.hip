@@ -8,6 +8,7 @@
 // block (16 x dwordx4) -> 64-term polynomial.  HBM/L2-gather bound: ~292 B of algorithmic traffic per query.
 // EVAL_EXACT evaluates in the reference's literal order without FMA (bit-identical results); EVAL_FAST uses a
 // separable Horner scheme with FMA.  Compile with -ffp-contract=off.
+#include <sys/mman.h>
 #include "octree_internal.h"
 #include "dev_tricubic.h"
 #include <string.h>
@@ -825,6 +826,7 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     *done = 0;
     sdfhip_ctx* ctx = T->ctx;
     hipStream_t st = ctx->stream;
+    if (getenv("SDFHIP_DEBUG_PIN")) fprintf(stderr, "[sdfhip] pipelined query: xyz %p, n %llu, dist %p, grad %p, dp %p dd %p\n", (const void*)xyz, (unsigned long long)n, (void*)out_dist, (void*)out_grad, (void*)dp, (void*)dd);
     {
         std::lock_guard<std::mutex> g(ctx->copyStreamLock);
         if (!ctx->copyStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
@@ -836,7 +838,8 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     // SDFHIP_TEST_PIN_FAIL_AFTER=k: the (k+1)-th registration of a call is refused (tests drive the partial-fallback path with it)
     const char* failEnv = getenv("SDFHIP_TEST_PIN_FAIL_AFTER");
     const long failAfter = failEnv ? atol(failEnv) : -1;
-    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
+    const bool dbgPin = getenv("SDFHIP_DEBUG_PIN") != nullptr;
+    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); if (dbgPin) fprintf(stderr, "[sdfhip] pin [%p, %p)\n", (void*)b, (void*)e); return true; };
     auto unpinAll = [&]() { for (const Reg& r : regs) (void)hipHostUnregister(r.p); regs.clear(); };
     const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = inB & ~(PAGE - 1), end = (inE + PAGE - 1) & ~(PAGE - 1);
     const uint64_t pieces = (end - base + PIECE - 1) / PIECE;
@@ -853,8 +856,18 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
         const uint64_t avail = (e == inE) ? n : (e - inB) / 12;
         if (!outPinned) {          // the result arrays: pinned while the first piece is on the wire
             const uintptr_t ob = (uintptr_t)out_dist & ~(PAGE - 1), oe = ((uintptr_t)out_dist + 4 * n + PAGE - 1) & ~(PAGE - 1);
+            // The device WRITES these pages.  Memory the caller has allocated but never touched (np.empty, malloc) has no private pages yet, and
+            // registering it as it is was seen to leave the device a read-only mapping ("Memory access fault ... Write access to a read-only
+            // page" on the second page of a fresh 12 MB array at the top of the heap): fault the pages in for writing first.
+            auto populate = [&](uintptr_t b, uintptr_t e) {
+#ifdef MADV_POPULATE_WRITE
+                if (madvise((void*)(b & ~(PAGE - 1)), ((e + PAGE - 1) & ~(PAGE - 1)) - (b & ~(PAGE - 1)), MADV_POPULATE_WRITE) == 0) return;
+#endif
+                for (uintptr_t a = b; a < e; a = (a & ~(PAGE - 1)) + PAGE) { volatile char* c = (volatile char*)a; *c = *c; }      // (one byte of the caller's own array per page, content kept)
+            };
+            populate((uintptr_t)out_dist, (uintptr_t)out_dist + 4 * n);
             bool ok = pin(ob, oe);
-            if (ok && out_grad) { const uintptr_t gb = (uintptr_t)out_grad & ~(PAGE - 1), ge = ((uintptr_t)out_grad + 12 * n + PAGE - 1) & ~(PAGE - 1); ok = pin(gb, ge); }
+            if (ok && out_grad) { const uintptr_t gb = (uintptr_t)out_grad & ~(PAGE - 1), ge = ((uintptr_t)out_grad + 12 * n + PAGE - 1) & ~(PAGE - 1); populate((uintptr_t)out_grad, (uintptr_t)out_grad + 12 * n); ok = pin(gb, ge); }
             if (!ok) break;        // answered so far: nothing; the plain path takes over
             outPinned = true;
         }

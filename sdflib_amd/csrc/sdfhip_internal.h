@@ -336,6 +336,7 @@ struct sdfhip_ctx {
     bool ownsStream = false;
     hipStream_t copyStream = nullptr;      // results flow back on this one while the next piece of a large host-pointer query goes up (created on first use)
     std::mutex copyStreamLock;
+    hipStream_t bvhSide[2] = {nullptr, nullptr};      // the BVH build's centre sums run on these behind each level's sort (created on first use; builds are serialised by buildLock)
     hipDeviceProp_t prop;
     // Builds (mesh preparation, BVH, octrees) on one context run one at a time: they share the stream-ordered allocator's scope and,
     // with an exchange installed, must stay in collective order.  Queries take no part in this and run concurrently.

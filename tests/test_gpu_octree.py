@@ -778,8 +778,8 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
         c.set_bvh(sph, kids3)
 
 
-@pytest.mark.parametrize("subtree", ["1", "512", "16384"])
-def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree):
+@pytest.mark.parametrize("subtree,build", [("1", "host"), ("512", "host"), ("8192", "host"), ("4096", "device"), ("512", "device"), ("8192", "device")])
+def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build):
     """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
     k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
     all 64 bits of every child sphere, every leaf's triangle.  Meshes chosen for what decides the tree: tied sort keys (symmetric meshes,
@@ -787,8 +787,13 @@ def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree):
     import subprocess, sys
     # the switch is read once per process: the hybrid plans run in a child
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._hybrid_cases_check()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree), capture_output=True, text=True, timeout=900)
+    # build == "device": the top of the tree is sorted on the device as well (SDFHIP_BVH_BUILD=device: introsort as rounds over global memory,
+    # centre sums three lanes per node) — no host plan at all unless a long range exhausts introsort's depth limit
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree, SDFHIP_BVH_BUILD=build, SDFHIP_TIMING="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "hybrid cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    if build == "device":
+        built = r.stderr.count("bvh: built on the device")
+        assert built >= len(_hybrid_cases()) - 2, f"only {built} trees were built on the device:\n" + "\n".join(l for l in r.stderr.splitlines() if "gave up" in l)[-2000:]
 
 
 def _hybrid_cases():

@@ -5,7 +5,11 @@ os.environ.setdefault("SDFHIP_TIMING", "1")
 import sdflib_amd as S
 from sdflib_amd import meshgen
 sub = int(os.environ.get("PROBE_SUBDIV", "8"))
-v, f = meshgen.bumpy_icosphere(sub)
+if os.environ.get("PROBE_KNOT"):                     # PROBE_KNOT=nu:nv -> torus knot of 2 * nu * nv triangles
+    nu, nv = (int(x) for x in os.environ["PROBE_KNOT"].split(":"))
+    v, f = meshgen.torus_knot(nu=nu, nv=nv)
+else:
+    v, f = meshgen.bumpy_icosphere(sub)
 print("triangles", len(f), "hardware threads", os.cpu_count(), flush=True)
 for rep in range(int(os.environ.get('PROBE_REPS', '3'))):
     mesh = S.Mesh(v, f)
