@@ -572,8 +572,8 @@ SDF_DEV void devWaveSync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup
 constexpr int kWaveSortLen = 160;        // pending ranges from this length on are partitioned by a whole wave
 // The introsort rounds of a workgroup (256 threads) over keys[] in LDS: `in` holds nSort pending ranges {first, last, depth limit}; every
 // round partitions each of them once — a long range by a whole wave (both index lists by ballots, 64 keys per step; the swaps in
-// parallel), a short one by one lane — and lists the parts for the next round; parts of at most 16 are finished by insertion sort, a
-// range out of depth by libstdc++'s heap sort.  Every comparison and exchange is the sequential algorithm's, so is the order among ties.
+// parallel), a short one by sixteen lanes — and lists the parts for the next round; parts of at most 16 are finished by insertion sort (by
+// rank), a range out of depth by libstdc++'s heap sort.  Every comparison and exchange is the sequential algorithm's, so is the order among ties.
 // s_count[1] = next round's count, s_count[2] |= 4 when the lists (maxTasks entries) overflow.
 SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in, uint32_t* out, uint32_t* s_count, uint32_t nSort, uint32_t maxTasks, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -619,20 +619,67 @@ SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in
                 if (last - cut > 1) push(cut, last, depth - 1);
             }
         }
-        // short ranges: one lane each
-        for (uint32_t t = (uint32_t)tid; t < nSort; t += 256u) {
-            const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
-            if (last - first >= kWaveSortLen) continue;
-            if (last - first <= 16) { devInsertionSort(keys, first, last); continue; }
-            if (depth == 0) { stdHeapSort(keys + first, last - first); continue; }        // libstdc++ switches to heap sort here (it does happen: 1.31 M triangles)
-            devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
-            const int cut = devListPartition(keys, listL, listR, first + 1, last, first);
-            const int parts[2][2] = {{first, cut}, {cut, last}};
+        // short ranges: sixteen lanes each (four ranges per wave at a time; a lane of its own per range was a serial chain of ~450 cycles per
+        // element and step).  Partition as above with the group's 16 bits of the ballots; a part of at most 16 — what introsort leaves to its
+        // final insertion sort, a STABLE sort — is placed by rank: element i goes behind the elements before it that are not greater and the
+        // elements after it that are less (the same arrangement; keys that are not ordered at all, NaN, take the literal insertion sort).
+        {
+            const int gl = lane & 15, gshift = lane & 48;
+            auto groupBits = [&](unsigned long long b) { return (unsigned)((b >> gshift) & 0xFFFFull); };
+            const unsigned below = (1u << gl) - 1u;
+            auto rankSort = [&](int first, int last) {                 // 2 .. 16 elements, all lanes of the group
+                const int len = last - first;
+                if (len < 2) return;
+                const bool mine = gl < len;
+                const KeyTri e = mine ? (KeyTri)keys[first + gl] : KeyTri{0.f, 0};
+                const bool unordered = groupBits(__ballot(mine && e.key != e.key)) != 0u;
+                int rank = 0;
+                for (int j = 0; j < len; j++) { const float kj = keys[first + j].key; rank += (j < gl) ? !(e.key < kj) : (kj < e.key); }
+                devWaveSync();
+                if (unordered) { if (gl == 0) devInsertionSort(keys, first, last); }
+                else if (mine) keys[first + rank] = e;
+                devWaveSync();
+            };
+            for (uint32_t t = (uint32_t)(tid >> 4); t < nSort; t += 16u) {
+                const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
+                if (last - first >= kWaveSortLen) continue;
+                if (last - first <= 16) { rankSort(first, last); continue; }
+                if (depth == 0) { if (gl == 0) stdHeapSort(keys + first, last - first); continue; }        // libstdc++ switches to heap sort here (it does happen: 1.31 M triangles)
+                if (gl == 0) devMedianToFirst(keys, first, first + 1, first + (last - first) / 2, last - 1);
+                devWaveSync();
+                const float pk = keys[first].key;
+                const int f = first + 1, m = last - f;
+                int nl = 0, nr = 0;
+                for (int base = 0; base < m; base += 16) {
+                    const int i = base + gl;
+                    const bool valid = i < m;
+                    const float key = valid ? keys[f + i].key : 0.f;
+                    const bool pl = valid && !(key < pk), pr = valid && !(pk < key);
+                    const unsigned bl = groupBits(__ballot(pl)), br = groupBits(__ballot(pr));
+                    if (pl) listL[f + nl + (int)__popc(bl & below)] = (unsigned short)i;
+                    if (pr) listR[f + nr + (int)__popc(br & below)] = (unsigned short)i;
+                    nl += (int)__popc(bl); nr += (int)__popc(br);
+                }
+                devWaveSync();
+                const int lim = nl < nr ? nl : nr;
+                int ms = 0;                                           // pairs that have not crossed: a prefix of 1 .. lim
+                for (int base = 0; base < lim; base += 16) {
+                    const int q = base + gl + 1;
+                    const bool go = q <= lim && listL[f + q - 1] < listR[f + nr - q];
+                    ms += (int)__popc(groupBits(__ballot(go)));
+                }
+                int stop = (ms < nl) ? (int)listL[f + ms] : m;
+                if (ms > 0 && (int)listR[f + nr - ms] < stop) stop = (int)listR[f + nr - ms];
+                for (int q = 1 + gl; q <= ms; q += 16) devSwap(keys, f + (int)listL[f + q - 1], f + (int)listR[f + nr - q]);
+                devWaveSync();
+                const int cut = f + stop;
+                const int parts[2][2] = {{first, cut}, {cut, last}};
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int f = parts[h][0], l = parts[h][1];
-                if (l - f > 16) push(f, l, depth - 1);
-                else devInsertionSort(keys, f, l);
+                for (int h = 0; h < 2; h++) {
+                    const int pf = parts[h][0], pe = parts[h][1];
+                    if (pe - pf > 16) { if (gl == 0) push(pf, pe, depth - 1); }
+                    else rankSort(pf, pe);
+                }
             }
         }
         __syncthreads();

@@ -826,7 +826,6 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     *done = 0;
     sdfhip_ctx* ctx = T->ctx;
     hipStream_t st = ctx->stream;
-    if (getenv("SDFHIP_DEBUG_PIN")) fprintf(stderr, "[sdfhip] pipelined query: xyz %p, n %llu, dist %p, grad %p, dp %p dd %p\n", (const void*)xyz, (unsigned long long)n, (void*)out_dist, (void*)out_grad, (void*)dp, (void*)dd);
     {
         std::lock_guard<std::mutex> g(ctx->copyStreamLock);
         if (!ctx->copyStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
@@ -838,10 +837,15 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     // SDFHIP_TEST_PIN_FAIL_AFTER=k: the (k+1)-th registration of a call is refused (tests drive the partial-fallback path with it)
     const char* failEnv = getenv("SDFHIP_TEST_PIN_FAIL_AFTER");
     const long failAfter = failEnv ? atol(failEnv) : -1;
-    const bool dbgPin = getenv("SDFHIP_DEBUG_PIN") != nullptr;
-    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); if (dbgPin) fprintf(stderr, "[sdfhip] pin [%p, %p)\n", (void*)b, (void*)e); return true; };
+    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
     auto unpinAll = [&]() { for (const Reg& r : regs) (void)hipHostUnregister(r.p); regs.clear(); };
-    const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = inB & ~(PAGE - 1), end = (inE + PAGE - 1) & ~(PAGE - 1);
+    // Only pages that lie WHOLLY inside the caller's arrays are registered, and no direct copy starts or ends in a page the array shares
+    // with a neighbour on the heap: the bytes before the first and after the last whole page travel as small pageable copies.  (Seen on the
+    // GPU box: an output array that began in the last page of an array a previous call had registered — and the runtime had pinned for its
+    // own pageable copies — was registered "successfully", but the copy into it resolved to the stale pinned object and ran off its end:
+    // "Memory access fault ... Write access to a read-only page" one page into the new array.)
+    const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = (inB + PAGE - 1) & ~(PAGE - 1), end = inE & ~(PAGE - 1);
+    if (end <= base + PAGE) return 1;
     const uint64_t pieces = (end - base + PIECE - 1) / PIECE;
     auto pieceEnd = [&](uint64_t k) { const uintptr_t e = base + (k + 1) * PIECE; return e < end ? e : end; };
     if (!pin(base, pieceEnd(0))) return 1;
@@ -850,24 +854,29 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
     SDF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     int rc = SDFHIP_OK;
     uint64_t launched = 0; bool outPinned = false;
+    uintptr_t ob = 0, oe = 0, gb = 0, ge = 0;                   // registered interiors of out_dist / out_grad
+    // device -> host, split at the registered interior [lo, hi) of the destination array
+    auto down = [&](void* host, const void* dev, size_t bytes, uintptr_t lo, uintptr_t hi) {
+        const uintptr_t s = (uintptr_t)host, e = s + bytes;
+        const uintptr_t ms = s > lo ? s : lo, me = e < hi ? e : hi;
+        bool ok = true;
+        if (me > ms) {
+            if (s < ms) ok = ok && hipMemcpyAsync((void*)s, dev, ms - s, hipMemcpyDeviceToHost, back) == hipSuccess;
+            ok = ok && hipMemcpyAsync((void*)ms, (const char*)dev + (ms - s), me - ms, hipMemcpyDeviceToHost, back) == hipSuccess;
+            if (e > me) ok = ok && hipMemcpyAsync((void*)me, (const char*)dev + (me - s), e - me, hipMemcpyDeviceToHost, back) == hipSuccess;
+        } else ok = hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, back) == hipSuccess;      // wholly outside the interior (a head or tail of less than a page)
+        return ok;
+    };
     for (uint64_t k = 0; k < pieces && rc == SDFHIP_OK; k++) {
-        const uintptr_t b = k == 0 ? inB : base + k * PIECE, e = pieceEnd(k) < inE ? pieceEnd(k) : inE;
+        const uintptr_t b = base + k * PIECE, e = pieceEnd(k);
+        if (k == 0 && base > inB && hipMemcpyAsync(dp, (const void*)inB, base - inB, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
         if (hipMemcpyAsync((char*)dp + (b - inB), (const void*)b, e - b, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-        const uint64_t avail = (e == inE) ? n : (e - inB) / 12;
+        if (e == end && inE > end && hipMemcpyAsync((char*)dp + (end - inB), (const void*)end, inE - end, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+        const uint64_t avail = (e == end) ? n : (e - inB) / 12;
         if (!outPinned) {          // the result arrays: pinned while the first piece is on the wire
-            const uintptr_t ob = (uintptr_t)out_dist & ~(PAGE - 1), oe = ((uintptr_t)out_dist + 4 * n + PAGE - 1) & ~(PAGE - 1);
-            // The device WRITES these pages.  Memory the caller has allocated but never touched (np.empty, malloc) has no private pages yet, and
-            // registering it as it is was seen to leave the device a read-only mapping ("Memory access fault ... Write access to a read-only
-            // page" on the second page of a fresh 12 MB array at the top of the heap): fault the pages in for writing first.
-            auto populate = [&](uintptr_t b, uintptr_t e) {
-#ifdef MADV_POPULATE_WRITE
-                if (madvise((void*)(b & ~(PAGE - 1)), ((e + PAGE - 1) & ~(PAGE - 1)) - (b & ~(PAGE - 1)), MADV_POPULATE_WRITE) == 0) return;
-#endif
-                for (uintptr_t a = b; a < e; a = (a & ~(PAGE - 1)) + PAGE) { volatile char* c = (volatile char*)a; *c = *c; }      // (one byte of the caller's own array per page, content kept)
-            };
-            populate((uintptr_t)out_dist, (uintptr_t)out_dist + 4 * n);
-            bool ok = pin(ob, oe);
-            if (ok && out_grad) { const uintptr_t gb = (uintptr_t)out_grad & ~(PAGE - 1), ge = ((uintptr_t)out_grad + 12 * n + PAGE - 1) & ~(PAGE - 1); populate((uintptr_t)out_grad, (uintptr_t)out_grad + 12 * n); ok = pin(gb, ge); }
+            ob = ((uintptr_t)out_dist + PAGE - 1) & ~(PAGE - 1); oe = ((uintptr_t)out_dist + 4 * n) & ~(PAGE - 1);
+            bool ok = oe > ob && pin(ob, oe);
+            if (ok && out_grad) { gb = ((uintptr_t)out_grad + PAGE - 1) & ~(PAGE - 1); ge = ((uintptr_t)out_grad + 12 * n) & ~(PAGE - 1); ok = ge > gb && pin(gb, ge); }
             if (!ok) break;        // answered so far: nothing; the plain path takes over
             outPinned = true;
         }
@@ -875,8 +884,8 @@ static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, fl
             const uint64_t m = avail - launched;
             launchQuery(eval_mode, out_grad != nullptr, gridFor(m, 256), st, q, dp + 3 * launched, m, dd + launched, out_grad ? dg + 3 * launched : nullptr);
             if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(back, ev, 0) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-            if (hipMemcpyAsync(out_dist + launched, dd + launched, 4 * m, hipMemcpyDeviceToHost, back) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-            if (out_grad && hipMemcpyAsync(out_grad + 3 * launched, dg + 3 * launched, 12 * m, hipMemcpyDeviceToHost, back) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            if (!down(out_dist + launched, dd + launched, 4 * m, ob, oe)) { rc = SDFHIP_E_HIP; break; }
+            if (out_grad && !down(out_grad + 3 * launched, dg + 3 * launched, 12 * m, gb, ge)) { rc = SDFHIP_E_HIP; break; }
             launched = avail;
         }
         if (k + 1 < pieces && !pin(base + (k + 1) * PIECE, pieceEnd(k + 1))) break;      // refused: the plain path finishes the rest
