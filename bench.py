@@ -24,6 +24,9 @@ import sdflib_amd as S  # noqa: E402
 from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin  # noqa: E402
 from sdflib_amd import distributed as sdist  # noqa: E402
 
+# where sdfhip_mesh_build_bvh builds the tree: on the device (the default: introsort rounds over global memory + k_bvh_subtrees) or by the host planner
+BVH_BUILT_ON = "host" if os.environ.get("SDFHIP_BVH_BUILD") == "host" else "device"
+
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 
 
@@ -294,7 +297,7 @@ def main():
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
         "roofline": roof,
-        "build": {**(e2e if world == 1 else {}), "octree_build_s": round(build_s, 4), "octree_rebuild_s": (round(rebuild_s, 4) if rebuild_s is not None else None), "bvh_host_planner_s": round(bvh_s, 4), "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), "nearest_fallbacks": int(info.num_nearest_fallbacks), **_r4(binfo)},
+        "build": {**(e2e if world == 1 else {}), "octree_build_s": round(build_s, 4), "octree_rebuild_s": (round(rebuild_s, 4) if rebuild_s is not None else None), "bvh_build_s": round(bvh_s, 4), "bvh_built_on": BVH_BUILT_ON, "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), "nearest_fallbacks": int(info.num_nearest_fallbacks), **_r4(binfo)},
     }
 
     if world > 1:       # collective sanity: every rank contributes its rank + 1; the sum proves all N ranks were in the communicator
@@ -669,7 +672,7 @@ def knot_workload(ctx, dev, n):
     ex = S.ExactOctreeSdf(m, box, 7, 3, 128)
     torch.cuda.synchronize(); ebuild = time.perf_counter() - t0
     ems = _time_ms(lambda: ex.get_distance(pts, out=out), reps=3)
-    r = {"triangles": int(len(f)), "mesh_prep_s": round(prep, 4), "bvh_host_planner_s": round(bvh_s, 4), "octree_build_s": round(build_s, 4), "octree_first_build_s": round(builds[0], 4), "words": int(i.num_words), "leaves": int(i.num_leaves),
+    r = {"triangles": int(len(f)), "mesh_prep_s": round(prep, 4), "bvh_build_s": round(bvh_s, 4), "octree_build_s": round(build_s, 4), "octree_first_build_s": round(builds[0], 4), "words": int(i.num_words), "leaves": int(i.num_leaves),
          "bvh_traversals": int(i.num_traversals), "nearest_fallbacks": int(i.num_nearest_fallbacks), "query_ms": round(ms, 4), "mqueries_s": round(n / ms / 1e3, 1),
          "exact_build_s": round(ebuild, 4), "exact_nodes": int(ex.info.num_nodes), "exact_max_triangles_in_leafs": int(ex.info.max_triangles_in_leafs),
          "exact_query_ms": round(ems, 3), "exact_mqueries_s": round(n / ems / 1e3, 1)}
@@ -711,7 +714,7 @@ def build_1m(ctx, rank, world, dev):
         dist.barrier()
     dt = time.perf_counter() - t0
     i = tree.info
-    r = {"triangles": int(len(f)), "octree_build_s": round(dt, 4), "mesh_prep_s": round(prep, 4), "bvh_host_planner_s": round(bvh_s, 4),
+    r = {"triangles": int(len(f)), "octree_build_s": round(dt, 4), "mesh_prep_s": round(prep, 4), "bvh_build_s": round(bvh_s, 4), "bvh_built_on": BVH_BUILT_ON,
          "words": int(i.num_words), "leaves": int(i.num_leaves), **({"bvh_share_s": round(bvh_s, 4)} if world > 1 else {}), **_r4(binfo)}
     tree.close()
     if world == 1:
