@@ -604,8 +604,10 @@ def deep_tree(mesh, box, dev, prof):
 
 def host_pointer(tree, ex, pts, dev):
     """The drop-in boundary as the reference's callers use it: HOST arrays in, host arrays out (PCIe inside the call), and the scalar
-    getDistance.  Large calls are pipelined (caller's arrays pinned piece by piece, upload / kernel / download overlapped on two streams);
-    one-point calls are answered on host copies of the arrays.  The link ceilings are measured here with pinned torch tensors."""
+    getDistance.  Large calls take the DEFAULT path: plain copies between the caller's pageable arrays and the context's buffers around the
+    kernel.  (The pinned two-stream pipeline — 2.9-3.1 ms for these 10 M points in profiles/r03d_bench_n1.json / r03e — is opt-in since it was
+    seen to end in a GPU memory access fault, SDFHIP_HOST_PIPELINE=1; `path` says which one this process measured.)
+    One-point calls are answered on host copies of the arrays.  The link ceilings are measured here with pinned torch tensors."""
     import ctypes as C
     from sdflib_amd._lib import lib, check
     n = pts.shape[0]
@@ -642,7 +644,8 @@ def host_pointer(tree, ex, pts, dev):
         return b
     us_oct = scalar(lambda q: L.sdfhip_octree_query(tree.h, q, 1, dptr, None, 0, S.EVAL_EXACT))
     us_ex = scalar(lambda q: L.sdfhip_exact_query(ex.h, q, 1, dptr, None, None, 0))
-    return {"queries": int(n), "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
+    path = "pinned two-stream pipeline (SDFHIP_HOST_PIPELINE=1)" if (os.environ.get("SDFHIP_HOST_PIPELINE") == "1" and "SDFHIP_NO_PIPELINE" not in os.environ) else "plain pageable copies (default)"
+    return {"queries": int(n), "path": path, "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
             "pcie_pinned_h2d_gb_s": round(up_gbs, 1), "pcie_pinned_d2h_gb_s": round(down_gbs, 1), "pcie_bound_ms": round(bound_seq * 1e3, 3),
             "frac_of_pcie_bound": round(bound_seq / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),
             "note": "bound = pinned upload + pinned download of the same arrays, one after the other (measured on this box); scalar = one point per call through the C ABI from ctypes, mean over 64 random points of the box"}
