@@ -136,7 +136,8 @@ int sdfhip_mesh_create_ex(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertic
                           uint32_t num_triangles, const float* bbox6, sdfhip_mesh** out);
 /* Same with options.  SDFHIP_MESH_PLAN_BVH_EARLY: the sphere BVH is planned (host threads) WHILE the device prepares the TriangleData, for
  * callers that know an OctreeSdf will be built from the mesh (the C++ OctreeSdf constructor, sdflib_amd.OctreeSdf): sdfhip_mesh_build_bvh
- * — or the first build — then only installs it.  An ExactOctreeSdf never needs the BVH. */
+ * — or the first build — then only installs it.  An ExactOctreeSdf never needs the BVH.  Has an effect only under SDFHIP_BVH_BUILD=host: by default
+ * the tree is built on the device (bvh.hip::buildTreeOnDevice) and nothing is planned on the host. */
 #define SDFHIP_MESH_PLAN_BVH_EARLY 1u
 int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t num_vertices, const uint32_t* indices,
                            uint32_t num_triangles, const float* bbox6, uint32_t flags, sdfhip_mesh** out);
