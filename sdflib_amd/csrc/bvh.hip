@@ -1166,6 +1166,13 @@ __global__ void __launch_bounds__(256) k_top_keys(KeyTri* __restrict__ K, const 
     const float4 q0 = triV[3 * t];
     K[i].key = dim == 0 ? q0.x : (dim == 1 ? q0.y : q0.z);
 }
+// the nine coordinates of every triangle in the order of `order` (the first nine floats of its record): what a host thread sums for a long node
+__global__ void k_top_gather9(const uint32_t* __restrict__ order, const float* __restrict__ triV12, uint32_t n, float* __restrict__ out9) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9ull * n) return;
+    const uint32_t e = (uint32_t)(i / 9u), k = (uint32_t)(i % 9u);
+    out9[i] = triV12[12 * (size_t)order[e] + k];
+}
 __global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_t* __restrict__ snap) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) snap[i] = (uint32_t)K[i].tri; }
 // centre of a node = its vertices summed in range order, three chains (x, y, z) of 3 n additions each: one wave per node, all lanes gather 64
 // triangles and lay their coordinates out as doubles, lanes 0..2 add them in order (a workgroup per node: 256 triangles per step)
@@ -1783,8 +1790,27 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         for (hipStream_t& s : mesh->ctx->bvhSide) if (!s) SDF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         side.s = mesh->ctx->bvhSide[0]; side1.s = mesh->ctx->bvhSide[1];
     } else { side.s = st; side1.s = st; }
+    // Centre sums of LONG nodes (more than kHostSumMin = 200 000 triangles, SDFHIP_BVH_HOST_SUM_MIN: levels 1 - 2 at 1.31 M triangles, none at
+    // 327 680) on host threads instead of k_top_sums: a chain of dependent fp64 additions is what bounds them — 13 ms per 655 360 triangles on a
+    // lane, 2.3 ms on a CPU core INCLUDING the gather and the 47 MB download (measured) — and the device's side stream runs the levels one after
+    // the other.  Measured at 1.31 M triangles (profiles/r03_bvh_host_sums_thresholds.txt): nodes above 400 000 on the host (level 1 only) 20.4 ms,
+    // exactly as without — it was the deeper levels queued behind each other that the build waited 5.3 ms for, not level 1 —; above 200 000:
+    // 15.9 ms; above 100 000: 14.5 ms, but + 0.2 ms at 327 680 triangles, where there is no wait to remove.  A worker thread does everything for such a level on side1, so that the thread driving the rounds never waits for a pageable
+    // copy: gather of the level's coordinates in range order on the device, download, one adding thread per node (the planner's loop), centres
+    // back up, radii and records as for the other levels.  Declared BEFORE the guard below: the worker is joined, then the side streams are
+    // waited for, then the jobs' buffers go.  SDFHIP_BVH_HOST_SUMS=0: off.
+    const uint32_t kHostSumMin = [] { const char* e = getenv("SDFHIP_BVH_HOST_SUM_MIN"); const long v = e ? atol(e) : 0; return v >= 1000 ? (uint32_t)v : 200000u; }();
+    struct HostSumJob { size_t level = 0; DevBuf<float> dG; std::unique_ptr<float, FreeDeleter> hG; hipEvent_t sortedBefore = nullptr; std::vector<double> centres; };
+    struct HostSumQueue { std::mutex m; std::condition_variable cv; std::vector<std::unique_ptr<HostSumJob>> jobs; bool closed = false; } hostQueue;
     // whatever happens below, nothing of this call may still run on the side streams when its buffers are released
     struct SideGuard { hipStream_t a, b; ~SideGuard() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } sideGuard{useSide ? side.s : nullptr, useSide ? side1.s : nullptr};
+    const bool hostSumsOn = useSide && [] { const char* e = getenv("SDFHIP_BVH_HOST_SUMS"); return !(e && e[0] == '0'); }();
+    struct HostSumWorker {
+        std::thread th; int rc = SDFHIP_OK; double busy = 0; HostSumQueue* q = nullptr;
+        void finish() { if (q) { { std::lock_guard<std::mutex> g(q->m); q->closed = true; } q->cv.notify_all(); } if (th.joinable()) th.join(); }
+        ~HostSumWorker() { finish(); }
+    } hostWorker;
+    hostWorker.q = &hostQueue;
     // ctr: [0], [1] = pending ranges of this / the next round (alternating), [2] = parts for k_sort_parts, [3] = for k_sort_tiny, [4] = flags
     uint32_t hostCtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
@@ -1857,9 +1883,56 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
                 SDF_HIP_CHECK(hipStreamWaitEvent(ss, sorted[l].e, 0));
             }
             const uint32_t nc = (uint32_t)levels[l + 1].size(); const size_t at = levelAt[l + 1];
-            k_top_sums<<<nc, 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, centres.p + 3 * at);
-            k_top_radius<<<gridFor(T, 1024), 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, T, centres.p + 3 * at, r2.p + at);
-            k_top_write<<<gridFor(nc, 256), 256, 0, ss>>>(dNodes.p + at, nc, centres.p + 3 * at, r2.p + at, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
+            uint32_t shortest = 0xFFFFFFFFu; for (const TopNode& nd : levels[l + 1]) shortest = std::min(shortest, nd.e - nd.b);
+            if (hostSumsOn && shortest > kHostSumMin && nc <= 16u) {
+                std::unique_ptr<HostSumJob> job(new HostSumJob());
+                job->level = l + 1; job->sortedBefore = sorted[l].e;
+                SDF_TRY(job->dG.reserve(9 * (size_t)T));
+                job->hG.reset((float*)plannerAlloc(36 * (size_t)T));
+                SDF_REQUIRE(job->hG != nullptr, "out of host memory");
+                { std::lock_guard<std::mutex> g(hostQueue.m); hostQueue.jobs.push_back(std::move(job)); }
+                hostQueue.cv.notify_all();
+                if (!hostWorker.th.joinable()) {
+                    const int device = mesh->ctx->device; hipStream_t s1 = side1.s;
+                    hostWorker.th = std::thread([&, device, s1]() {
+                        auto fail = [&](int rc) { if (hostWorker.rc == SDFHIP_OK) hostWorker.rc = rc; };
+                        if (hipSetDevice(device) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
+                        for (size_t next = 0;;) {
+                            HostSumJob* jp = nullptr;
+                            { std::unique_lock<std::mutex> g(hostQueue.m); hostQueue.cv.wait(g, [&] { return next < hostQueue.jobs.size() || hostQueue.closed; }); if (next < hostQueue.jobs.size()) jp = hostQueue.jobs[next++].get(); }
+                            if (!jp) return;                           // closed and nothing left
+                            const double tj = nowSeconds();
+                            HostSumJob& job = *jp;
+                            const std::vector<TopNode>& nodes = levels[job.level];
+                            const uint32_t nc2 = (uint32_t)nodes.size(); const size_t at2 = levelAt[job.level];
+                            const uint32_t* snapPrev = snaps.p + (size_t)T * (job.level - 1);      // the order this level's parent left = this level's range order
+                            if (hipStreamWaitEvent(s1, job.sortedBefore, 0) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
+                            k_top_gather9<<<gridFor(9ull * T, 256), 256, 0, s1>>>(snapPrev, reinterpret_cast<const float*>(triV), T, job.dG.p);
+                            if (hipMemcpyAsync(job.hG.get(), job.dG.p, 36 * (size_t)T, hipMemcpyDeviceToHost, s1) != hipSuccess || hipStreamSynchronize(s1) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
+                            job.centres.assign(3 * (size_t)nc2, 0.0);
+                            std::vector<std::thread> adders;
+                            for (uint32_t j = 0; j < nc2; j++) adders.emplace_back([&, j]() {
+                                const float* q = job.hG.get() + 9 * (size_t)nodes[j].b;
+                                const size_t nv = 3 * (size_t)(nodes[j].e - nodes[j].b);
+                                double sx = 0.0, sy = 0.0, sz = 0.0;
+                                for (size_t v = 0; v < nv; v++) { sx += (double)q[3 * v]; sy += (double)q[3 * v + 1]; sz += (double)q[3 * v + 2]; }
+                                const double cnt = (double)nv;
+                                job.centres[3 * (size_t)j] = sx / cnt; job.centres[3 * (size_t)j + 1] = sy / cnt; job.centres[3 * (size_t)j + 2] = sz / cnt;
+                            });
+                            for (std::thread& a : adders) a.join();
+                            if (hipMemcpyAsync(centres.p + 3 * at2, job.centres.data(), 24 * (size_t)nc2, hipMemcpyHostToDevice, s1) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
+                            k_top_radius<<<gridFor(T, 1024), 256, 0, s1>>>(snapPrev, triV, dNodes.p + at2, nc2, T, centres.p + 3 * at2, r2.p + at2);
+                            k_top_write<<<gridFor(nc2, 256), 256, 0, s1>>>(dNodes.p + at2, nc2, centres.p + 3 * at2, r2.p + at2, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
+                            if (hipGetLastError() != hipSuccess) { fail(SDFHIP_E_HIP); return; }
+                            hostWorker.busy += nowSeconds() - tj;
+                        }
+                    });
+                }
+            } else {
+                k_top_sums<<<nc, 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, centres.p + 3 * at);
+                k_top_radius<<<gridFor(T, 1024), 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, T, centres.p + 3 * at, r2.p + at);
+                k_top_write<<<gridFor(nc, 256), 256, 0, ss>>>(dNodes.p + at, nc, centres.p + 3 * at, r2.p + at, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
+            }
         }
     }
     const double tTop = nowSeconds();
@@ -1881,7 +1954,10 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     if (timing) SDF_HIP_CHECK(hipMemcpyAsync(clk, dClk.p, 32, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const double tSub = nowSeconds();
+    hostWorker.finish();                             // (it enqueues on side1: joined before side1 is waited for)
+    if (hostWorker.rc != SDFHIP_OK) { setError("BVH build: the host centre sums failed"); return hostWorker.rc; }
     if (nTop && useSide) { SDF_HIP_CHECK(hipStreamSynchronize(side.s)); SDF_HIP_CHECK(hipStreamSynchronize(side1.s)); }
+    if (timing && !hostQueue.jobs.empty()) fprintf(stderr, "[sdfhip] bvh on the device: centre sums of %zu long level(s) on host threads, %.4f s from the level's sort being waited for to its records being queued\n", hostQueue.jobs.size(), hostWorker.busy);
     if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
                         nTop, rounds, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
     if (failed || hostCtr[4]) return SDFHIP_E_UNSUPPORTED;
