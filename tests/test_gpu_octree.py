@@ -810,7 +810,7 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
         c.set_bvh(sph, kids3)
 
 
-@pytest.mark.parametrize("subtree,build", [("1", "host"), ("512", "host"), ("8192", "host"), ("4096", "device"), ("512", "device"), ("8192", "device")])
+@pytest.mark.parametrize("subtree,build", [("1", "host"), ("512", "host"), ("8192", "host"), ("4096", "device"), ("512", "device"), ("8192", "device"), ("4096", "device-hostsums")])
 def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build):
     """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
     k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
@@ -821,9 +821,16 @@ def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._hybrid_cases_check()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     # build == "device": the top of the tree is sorted on the device as well (SDFHIP_BVH_BUILD=device: introsort as rounds over global memory,
     # centre sums three lanes per node) — no host plan at all unless a long range exhausts introsort's depth limit
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree, SDFHIP_BVH_BUILD=build, SDFHIP_TIMING="1"), capture_output=True, text=True, timeout=900)
+    # build == "device-hostsums": the device build with the centre sums of every level of at most 16 nodes of more than 1000 triangles on the
+    # host worker thread (SDFHIP_BVH_HOST_SUM_MIN=1000; the default, 200 000, reaches it only on the 1.31 M-triangle mesh)
+    env = dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree, SDFHIP_BVH_BUILD="device" if build.startswith("device") else build, SDFHIP_TIMING="1")
+    if build == "device-hostsums": env["SDFHIP_BVH_HOST_SUM_MIN"] = "1000"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "hybrid cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-    if build == "device":
+    if build == "device-hostsums":
+        jobs = sum(int(l.split("centre sums of ")[1].split()[0]) for l in r.stderr.splitlines() if "long level(s) on host threads" in l)
+        assert jobs >= 20, f"only {jobs} levels were summed on the host: the variant no longer exercises the worker"
+    if build.startswith("device"):
         built = r.stderr.count("bvh: built on the device")
         assert built >= len(_hybrid_cases()) - 2, f"only {built} trees were built on the device:\n" + "\n".join(l for l in r.stderr.splitlines() if "gave up" in l)[-2000:]
 
