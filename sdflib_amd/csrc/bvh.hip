@@ -2163,7 +2163,24 @@ int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, u
     DevBuf<float> dp; DevBuf<uint32_t> dout;
     SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dout.reserve(4 * n));
     SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
-    k_nearest_stats<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), dp.p, n, dout.p);
+    if (nearestExactOnly()) k_nearest_stats<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), dp.p, n, dout.p);
+    else {
+        // the two-phase search's own counters: [id, wide-node expansions, wave iterations alive, triangle evaluations]; with
+        // SDFHIP_NEAR_PRESEED=1 of a second run seeded with the first run's answers (the fewest visits any visiting order can need)
+        std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
+        SDF_REQUIRE(n < (1ull << 22), "stats: at most 4 M points");
+        int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
+        DevBuf<uint32_t> ids; SDF_TRY(ids.reserve(n));
+        SDF_HIP_CHECK(hipMemsetAsync(dout.p, 0, sizeof(uint32_t) * 4 * n, st));
+        SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), dp.p, (uint32_t)n, ids.p, mesh->ctx->nearScratch, depth + 2, 0u, 1u, dout.p, nullptr));
+        if (getenv("SDFHIP_NEAR_PRESEED")) {
+            SDF_HIP_CHECK(hipMemsetAsync(dout.p, 0, sizeof(uint32_t) * 4 * n, st));
+            DevBuf<uint32_t> ids2; SDF_TRY(ids2.reserve(n));
+            SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), dp.p, (uint32_t)n, ids2.p, mesh->ctx->nearScratch, depth + 2, 0u, 1u, dout.p, ids.p));
+        }
+        SDF_HIP_CHECK(hipMemcpy2DAsync(dout.p, 16, ids.p, 4, 4, n, hipMemcpyDeviceToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(out4, dout.p, sizeof(uint32_t) * 4 * n, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));

@@ -147,9 +147,9 @@ SDF_DEV bool sphereCloser(SphereTerms t, double best) {
 // children, defer the farther one, test the nearer one) or evaluate the validated triangle.
 struct TraversalLane {
     D3 p; F3 p32; double best; int bestTri; int sp; int ref; bool haveRef;
-    SDF_DEV void start(const BvhDev& b, F3 pf) {
+    SDF_DEV void start(const BvhDev& b, F3 pf, double best0 = BVH_NO_BOUND) {
         p = D3{(double)pf.x, (double)pf.y, (double)pf.z}; p32 = pf;
-        best = BVH_NO_BOUND; bestTri = (b.numTriangles == 1u) ? 0 : -1; sp = 0; ref = 0;
+        best = best0; bestTri = (b.numTriangles == 1u) ? 0 : -1; sp = 0; ref = 0;
         haveRef = b.numTriangles > 1u;           // the root is entered without a test (one-triangle mesh: nothing to traverse)
     }
     // step 1; returns true when the query is finished (nothing validated, nothing deferred)
@@ -200,10 +200,13 @@ struct TraversalLane {
 
 // Nearest triangle id for a float point (widened to double).  STRIDE = LDS stride between the lane's stack entries.
 // counts[0..2] (optional, dev probe): inner nodes entered, iterations of the WAVE's loop while this lane was in it, triangles evaluated.
+// best0: a bound STRICTLY above the nearest distance (default: none, as the reference starts).  The result is the same: until the
+// unbounded run adopts its first triangle below best0 its `best` is >= best0, so it enters every node and adopts that very triangle
+// too, and from there the two runs are in the same state; what the bounded run skipped adopts nothing below best0 (dev_bvh_fast.h).
 template <int STRIDE, bool STATS = false>
-SDF_DEV uint32_t bvhNearest(const BvhDev& b, F3 pf, uint32_t* __restrict__ stk, uint32_t* counts = nullptr) {
+SDF_DEV uint32_t bvhNearest(const BvhDev& b, F3 pf, uint32_t* __restrict__ stk, uint32_t* counts = nullptr, double best0 = BVH_NO_BOUND) {
     TraversalLane L;
-    L.start(b, pf);
+    L.start(b, pf, best0);
     // wave-synchronous form: every iteration runs the pop step, then the enter / triangle step, for the lanes that need them
     bool alive = true;
     while (__ballot(alive) != 0ull) {

@@ -80,8 +80,9 @@ SDF_DEV float pointTriangleSq32(F3 point, F3 v0, F3 v1, F3 v2, float& scale, flo
 
 // fp32 distance of one triangle record with its error bound: (lower, upper) bounds of the exact squared distance
 struct TriBounds { float lo, hi; };
-SDF_DEV TriBounds triBounds32(const BvhDev& b, uint32_t t, F3 p) {
-    const float4 q0 = b.triV[3 * (size_t)t], q1 = b.triV[3 * (size_t)t + 1], q2 = b.triV[3 * (size_t)t + 2];
+SDF_DEV TriBounds triBounds32(float4 q0, float4 q1, float4 q2, F3 p);
+SDF_DEV TriBounds triBounds32(const BvhDev& b, uint32_t t, F3 p) { return triBounds32(b.triV[3 * (size_t)t], b.triV[3 * (size_t)t + 1], b.triV[3 * (size_t)t + 2], p); }
+SDF_DEV TriBounds triBounds32(float4 q0, float4 q1, float4 q2, F3 p) {
     float scale, c;
     const float d2 = pointTriangleSq32(p, F3{q0.x, q0.y, q0.z}, F3{q0.w, q1.x, q1.y}, F3{q1.z, q1.w, q2.x}, scale, c);
     const float slack = 4e-6f * scale + 1e-37f;
@@ -110,7 +111,8 @@ SDF_DEV float halfBitsToFloat(unsigned short bits) { return (float)__builtin_bit
 // and at least |v| - r.  For a point "above" a smooth patch of the surface the sphere bound is loose by the patch's radius, the
 // slab's by its sagitta only; measured on the bumpy sphere it cuts the visits of a far-field query by three.
 // Every term is rounded in the conservative direction (|m| = 1 +- 1e-4, fp32 products within 2e-6 of |v|).
-SDF_DEV void wideBounds(const float4* __restrict__ nd, F3 p, float l[4], uint32_t cr[4]) {
+template <typename ND>
+SDF_DEV void wideBounds(ND nd, F3 p, float l[4], uint32_t cr[4]) {
     const float4 h = nd[0], rf = nd[5];
     cr[0] = __float_as_uint(rf.x); cr[1] = __float_as_uint(rf.y); cr[2] = __float_as_uint(rf.z); cr[3] = __float_as_uint(rf.w);
 #pragma unroll
@@ -140,8 +142,10 @@ SDF_DEV void wideBounds(const float4* __restrict__ nd, F3 p, float l[4], uint32_
 // of code of the search, and run per visit it would execute for the two or three lanes that happen to sit at a leaf.
 
 constexpr int NEAR_QUEUE = 4;              // pending triangle evaluations per lane
-constexpr int NEAR_DRAIN_LANES = 40;
-constexpr int NEAR_CHUNK = 32;              // queries a wave takes per atomic       // a drain round is worth its instructions once this many lanes have one pending
+constexpr int NEAR_DRAIN_LANES = 40;        // a drain round is worth its instructions once this many lanes have one pending
+constexpr int NEAR_CHUNK = 32;              // runs a wave takes per atomic
+constexpr int NEAR_RUN = 1;                 // consecutive queries a lane works through (each seeded by the one before; > 1 was measured to starve the launch: a batch has ~8 queries per resident lane)
+constexpr int NEAR_TWO_PASS_MIN = 32768;    // batches of this many queries and more run as leaders + followers
 
 // PERSISTENT waves: a lane that has finished its query takes the next one (one atomic per wave and refill), so a wave stays full
 // until the work runs out instead of idling behind its longest traversal (half the lanes of a wave, measured).  The queries are
@@ -149,24 +153,47 @@ constexpr int NEAR_CHUNK = 32;              // queries a wave takes per atomic  
 // moves on to the other eighths when its own is exhausted.
 // cand: [NEAR_K][numReps] ids; candCount[r] = number of ids written or NEAR_OVERFLOW.  counters: 8 u32, zero before the launch.
 // LDS: references u32 [stackDepth][BLOCK], queue u32 [NEAR_QUEUE][BLOCK], bounds u16 [stackDepth][BLOCK].
-template <int BLOCK>
+template <int BLOCK, bool PACKED, bool COOP>
 __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
-                                                           uint8_t* __restrict__ candCount, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
+                                                           uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
                                                            uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
-                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk, bool seedFromNeighbour) {
+                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk, bool seedFromNeighbour,
+                                                           uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, uint32_t run, int pass, uint32_t* __restrict__ best, uint32_t stageOff, uint32_t lead, bool directTri) {
     extern __shared__ uint32_t s_near_stack[];
     uint32_t stIter = 0, stPop = 0, stPruned = 0, stExpand = 0, stTri = 0, stSeed = 0, stDrain = 0;
     uint32_t* stkRef = s_near_stack + threadIdx.x;
     uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
-    unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;
+    unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;      // (not PACKED only)
+    // PACKED (trees of at most 2^21 triangles): one word per stack entry — the reference in 22 bits (two's complement), the bound as the
+    // top 10 bits of a non-negative half rounded down (5 bits of mantissa: a bound within 3 % above U is expanded instead of dropped) —
+    // 128 instead of 192 bytes of LDS per lane for 32 entries: 8 instead of 6 workgroups per CU
+    // COOP: the node / triangle records of a wave's lanes are fetched COOPERATIVELY — eight lanes read the 16-byte pieces of one lane's
+    // 128-byte node (four lanes those of a 48-byte triangle record) as one contiguous request, and the pieces reach their owner through
+    // a staging area in LDS (32 nodes of 7 x 16 B, or 64 triangle records of 3 x 16 B, per wave).  A lane-private fetch is six (three)
+    // dwordx4 instructions that each touch 64 different cache lines, and the texture addresser works through them a lane at a time:
+    // VMEM instructions x 64 lanes / 256 CUs came to the kernel's whole duration in the counters (tools/pmc_near.sh).
+    float4* stage = reinterpret_cast<float4*>(s_near_stack + stageOff) + (threadIdx.x >> 6) * (32 * 7);
+    auto stPush = [&](int at, uint32_t ref, float lb) {
+        if (PACKED) stkRef[at * BLOCK] = (ref & 0x3FFFFFu) | ((uint32_t)(halfRoundedDown(fmaxf(lb, 0.f)) >> 5) << 22);
+        else { stkRef[at * BLOCK] = ref; stkLb[at * BLOCK] = halfRoundedDown(lb); }
+    };
     // this rank's queries: the 128-query blocks blk with blk % world == rank, numbered consecutively
     const uint32_t allBlocks = (numReps + 127u) / 128u;
     const uint32_t mine = allBlocks > rank ? (allBlocks - rank + world - 1u) / world : 0u;
-    const uint32_t total = mine * 128u;
-    const uint32_t per = ((mine + 7u) / 8u) * 128u;             // queries per XCD range
+    // pass 0: every query in one sweep.  pass 1: two PHASES in one launch — first the LEADERS (every eighth query of the Morton order),
+    // then, as soon as no leader is left to hand out, the others, each seeded with the triangle its leader ended on (best[], 0xFFFFFFFF
+    // until the leader has finished: the lane's previous triangle seeds the query then) — the leader is at most seven positions back in
+    // the order, i.e. one or two lattice steps away.  (As two launches the leaders' launch ran one query per lane: 36 % of the time for
+    // an eighth of the queries.)  The followers are dealt from the start of the order, whose leaders were the first to be taken.
+    const uint32_t all = mine * 128u;
+    int phase = pass;                            // wave-uniform
+    uint32_t total = phase == 0 ? all : all / lead;
+    uint32_t per = (((total + 127u) / 128u + 7u) / 8u) * 128u;             // queries per XCD range
+    int qpass = 0;                               // the phase this lane's run belongs to
     const uint32_t lane = __lane_id();
     uint32_t xcd = blockIdx.x & 7u; uint32_t tried = 0;
     uint32_t chunkNext = 0, chunkEnd = 0;        // wave-uniform
+    uint32_t runNext = 0, runEnd = 0;            // this lane's run of consecutive queries
     uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
     float U = 3.0e38f, U2 = 3.0e38f;            // upper bounds of the minimum distance / squared distance
     uint32_t nc = 0; bool overflow = false;
@@ -177,23 +204,40 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
     uint32_t lastTri = 0xFFFFFFFFu;   // the triangle that gave this lane's previous query its final bound: the next query (a Morton neighbour) is seeded with it
     static_assert(NEAR_QUEUE >= 1, "the seed uses a queue slot");
     for (;;) {
-        // ---- refill: the wave owns a chunk [chunkNext, chunkEnd) of its XCD's range and hands it out lane by lane; ONE atomic per chunk
-        // (an atomic per refill was measured to serialise the whole launch on eight addresses)
+        // ---- refill: the wave owns a chunk [chunkNext, chunkEnd) of its XCD's range — ONE atomic per chunk (an atomic per refill was
+        // measured to serialise the whole launch on eight addresses) — and hands it out in RUNS of `run` consecutive queries per lane:
+        // a lane works through its run in order, so the triangle that bounded its previous query belongs to the Morton NEIGHBOUR of
+        // the next one and seeds it almost exactly (with single queries dealt lane by lane the lane's previous query lay 20-60
+        // positions back: measured 96 expansions + 27 triangle tests per query against 67 + 11 with a perfect seed).
         uint64_t idle = __ballot(!have && !done);
         while (idle != 0ull) {
-            if (chunkNext >= chunkEnd) {
-                if (tried >= 8u) { if (!have) done = true; break; }
-                const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
-                uint32_t base = 0;
-                if (lane == 0u) base = atomicAdd(counters + xcd, chunk);
-                base = __shfl(base, 0) + lo;
-                if (base >= hi) { tried++; xcd = (xcd + 1u) & 7u; continue; }       // this range is exhausted: the next XCD's, or stop after all eight
-                chunkNext = base; chunkEnd = (base + chunk < hi) ? base + chunk : hi;
+            const bool needRun = !have && !done && runNext >= runEnd;
+            const uint64_t need = __ballot(needRun);
+            if (need != 0ull) {
+                if (chunkNext >= chunkEnd) {
+                    if (tried >= 8u && phase == 1) {      // the leaders are all taken: on to the followers
+                        phase = 2; tried = 0; xcd = blockIdx.x & 7u;
+                        total = all - all / lead; per = (((total + 127u) / 128u + 7u) / 8u) * 128u;
+                        continue;
+                    }
+                    if (tried >= 8u) { if (needRun) done = true; idle = __ballot(!have && !done); continue; }
+                    const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
+                    uint32_t base = 0;
+                    if (lane == 0u) base = atomicAdd(counters + xcd + (phase == 2 ? 10u : 0u), chunk);
+                    base = __shfl(base, 0) + lo;
+                    if (base >= hi) { tried++; xcd = (xcd + 1u) & 7u; continue; }       // this range is exhausted: the next XCD's, or stop after all eight
+                    chunkNext = base; chunkEnd = (base + chunk < hi) ? base + chunk : hi;
+                }
+                const uint32_t availRuns = (chunkEnd - chunkNext + run - 1u) / run;
+                const uint32_t slot = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+                if (needRun && slot < availRuns) { runNext = chunkNext + slot * run; runEnd = (runNext + run < chunkEnd) ? runNext + run : chunkEnd; qpass = phase; }
+                const uint32_t want = (uint32_t)__popcll(need);
+                const uint32_t given = want < availRuns ? want : availRuns;
+                chunkNext = (chunkNext + given * run < chunkEnd) ? chunkNext + given * run : chunkEnd;
             }
-            const uint32_t avail = chunkEnd - chunkNext;
-            const uint32_t slot = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!have && !done && slot < avail) {
-                const uint32_t q = chunkNext + slot;
+            if (!have && !done && runNext < runEnd) {
+                const uint32_t j = runNext++;
+                const uint32_t q = qpass == 0 ? j : (qpass == 1 ? lead * j : j + j / (lead - 1u) + 1u);
                 const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
                 if (rr < numReps) {
                     r = rr; have = true;
@@ -202,54 +246,105 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                     // With no bound yet the first descent would push every sibling it passes (three per level): it is made
                     // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one triangle.
                     if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
+                    else if (seedTri) { queue[0] = seedTri[r]; nq = 1; sp = 0; mode = 2; }                                        // dev probe: the search seeded with its own answer
+                    else if (qpass == 2 && __builtin_nontemporal_load(best + (r & ~(lead - 1u))) < b.numTriangles) { queue[0] = __builtin_nontemporal_load(best + (r & ~(lead - 1u))); nq = 1; sp = 0; mode = 2; }
                     else if (seedFromNeighbour && lastTri != 0xFFFFFFFFu) { queue[0] = lastTri; nq = 1; sp = 0; mode = 2; }      // one triangle evaluation instead of a ten-step descent
                     else { sp = 1; mode = 1; seedRef = 0; }
                 }
             }
-            const uint32_t want = (uint32_t)__popcll(idle);
-            chunkNext += want < avail ? want : avail;
-            idle = __ballot(!have && !done);          // lanes that drew a query beyond numReps (the padded tail) draw again
+            idle = __ballot(!have && !done);          // lanes that drew a query beyond numReps (the padded tail) or no run yet draw again
         }
         if (__ballot(have) == 0ull) break;
         if (have) stIter++;
         if (stats) { const uint64_t aliveNow = __ballot(have); if (lane == 0u) { atomicAdd(stats + 10, 1ull); atomicAdd(stats + 11, (unsigned long long)__popcll(aliveNow)); } }
         // ---- one pop per walking lane: a 4-wide node (one 64-byte line) or a triangle
-        if (have && mode == 2 && nq == 0) { mode = 0; stkRef[0] = 0u; stkLb[0] = (unsigned short)0xFBFFu; sp = 1; }      // seeded: the root, bound = -65504
+        if (have && mode == 2 && nq == 0) { mode = 0; stPush(0, 0u, PACKED ? 0.f : -65504.f); sp = 1; }      // seeded: the root
         const bool walking = have && sp > 0 && mode != 2;
+        int expandRef = -1;          // the node this lane expands in this iteration
         if (walking && nq < NEAR_QUEUE) {
             int ref; float lbound;
             if (mode == 1) { ref = seedRef; lbound = -3.0e38f; stSeed++; }
+            else if (PACKED) { sp--; steps++; const uint32_t e = stkRef[sp * BLOCK]; ref = (int)(e << 10) >> 10; lbound = halfBitsToFloat((unsigned short)((e >> 22) << 5)); stPop++; }
             else { sp--; steps++; ref = (int)stkRef[sp * BLOCK]; lbound = halfBitsToFloat(stkLb[sp * BLOCK]); stPop++; }
             if (lbound > U) stPruned++;
             if (!(lbound > U)) {
                 if (ref >= 0 && sp + 4 > stackDepth) steps = 0xFFFFFFF0u;        // the (short) stack would overflow: a job for k_near_long
-                else if (ref >= 0) {
-                    float l[4]; uint32_t cr[4];
-                    wideBounds(b.wide + 8 * (size_t)ref, p, l, cr);
-                    stExpand++;
-                    // sort the four by bound (ascending), push the survivors farthest first: the nearest is popped next
-#define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
-                    SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
-#undef SDF_CE
-                    if (mode == 1) {
-                        seedRef = (int)cr[0];
-                        if (seedRef < 0) { queue[nq * BLOCK] = (uint32_t)~seedRef; nq++; mode = 2; }
-                    } else {
+                else if (ref >= 0) expandRef = ref;
+                else { queue[nq * BLOCK] = (uint32_t)~ref; nq++; }
+            }
+        }
+        float4 nd[6];
+        if (COOP) {
+            const uint64_t act = __ballot(expandRef >= 0);
+            if (act != 0ull) {
+                // all loads first (one memory round trip), then the two halves of the wave through the staging area
+                float4 v[8];
 #pragma unroll
-                        for (int c = 3; c >= 0; c--)
-                            if (!(l[c] > U)) { stkRef[sp * BLOCK] = cr[c]; stkLb[sp * BLOCK] = halfRoundedDown(l[c]); sp++; }
+                for (int s8 = 0; s8 < 8; s8++) {
+                    const int rsrc = __shfl(expandRef, 8 * s8 + (int)(lane >> 3));
+                    v[s8] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (((act >> (8 * s8)) & 0xFFull) != 0ull && rsrc >= 0 && (lane & 7u) < 6u) v[s8] = b.wide[8 * (size_t)rsrc + (lane & 7u)];
+                }
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    if (((act >> (32 * half)) & 0xFFFFFFFFull) == 0ull) continue;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++)
+                        if ((lane & 7u) < 6u) stage[(8 * s4 + (int)(lane >> 3)) * 7 + (int)(lane & 7u)] = v[4 * half + s4];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if ((int)(lane >> 5) == half && expandRef >= 0) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) nd[k] = stage[(int)(lane & 31u) * 7 + k];
                     }
-                } else { queue[nq * BLOCK] = (uint32_t)~ref; nq++; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+            }
+        }
+        if (expandRef >= 0) {
+            float l[4]; uint32_t cr[4];
+            if (COOP) wideBounds(&nd[0], p, l, cr);
+            else wideBounds(b.wide + 8 * (size_t)expandRef, p, l, cr);
+            stExpand++;
+            // sort the four by bound (ascending), push the survivors farthest first: the nearest is popped next
+#define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
+            SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
+#undef SDF_CE
+            if (mode == 1) {
+                seedRef = (int)cr[0];
+                if (seedRef < 0) { queue[nq * BLOCK] = (uint32_t)~seedRef; nq++; mode = 2; }
+            } else {
+#pragma unroll
+                for (int c = 3; c >= 0; c--)
+                    if (!(l[c] > U)) {
+                        // a surviving TRIANGLE goes straight to the queue while there is room (an iteration saved: popping it would only move it there)
+                        if (directTri && (int)cr[c] < 0 && nq < NEAR_QUEUE) { queue[nq * BLOCK] = ~cr[c]; nq++; }
+                        else { stPush(sp, cr[c], l[c]); sp++; }
+                    }
             }
         }
         // ---- one drain round when enough lanes have a triangle pending, a lane is stuck on a full queue, or nobody walks any more
         const uint64_t pend = __ballot(have && nq > 0);
         if (pend != 0ull && (__popcll(pend) >= drainLanes || __ballot(have && nq >= NEAR_QUEUE) != 0ull || __ballot(have && sp > 0 && mode != 2) == 0ull)) {
             if (have) stDrain++;
-            if (have && nq > 0) {
-                nq--; stTri++;
-                const uint32_t t = queue[nq * BLOCK];
-                const TriBounds tb = triBounds32(b, t, p);
+            const bool draining = have && nq > 0;
+            uint32_t t = 0xFFFFFFFFu;
+            if (draining) { nq--; stTri++; t = queue[nq * BLOCK]; }
+            float4 tq[3];
+            if (COOP) {
+                const uint64_t dact = __ballot(draining);
+                float4* tstage = stage;          // 64 records of 3 x 16 bytes: the node staging area's 3584 bytes hold them
+#pragma unroll
+                for (int s4 = 0; s4 < 4; s4++) {
+                    const uint32_t tsrc = (uint32_t)__shfl((int)t, 16 * s4 + (int)(lane >> 2));
+                    if (((dact >> (16 * s4)) & 0xFFFFull) != 0ull && tsrc != 0xFFFFFFFFu && (lane & 3u) < 3u)
+                        tstage[(16 * s4 + (int)(lane >> 2)) * 3 + (int)(lane & 3u)] = b.triV[3 * (size_t)tsrc + (lane & 3u)];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (draining) { tq[0] = tstage[(int)lane * 3]; tq[1] = tstage[(int)lane * 3 + 1]; tq[2] = tstage[(int)lane * 3 + 2]; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            if (draining) {
+                const TriBounds tb = COOP ? triBounds32(tq[0], tq[1], tq[2], p) : triBounds32(b, t, p);
                 if (tb.lo <= U2) {
                     if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; lastTri = t; }
                     if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
@@ -279,7 +374,9 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
         // handed to k_near_long, where a whole wave works on it: left to one lane, its dependent chain of pops alone outlasts the
         // rest of the launch (measured: the longest of 1.5 M traversals took as long as all the others together)
         if (have && sp == 0 && nq == 0 && mode == 0) {
-            candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); have = false;
+            candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); candU2[r] = U2; have = false;
+            if (qpass == 1) best[r] = lastTri;
+            if (perQuery) { perQuery[4 * (size_t)r + 1] = stExpand; perQuery[4 * (size_t)r + 2] = stIter; perQuery[4 * (size_t)r + 3] = stTri; }
             if (stats) {
                 atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)stIter); atomicAdd(stats + 2, (unsigned long long)stPop); atomicAdd(stats + 3, (unsigned long long)stPruned);
                 atomicAdd(stats + 4, (unsigned long long)stExpand); atomicAdd(stats + 5, (unsigned long long)stTri); atomicAdd(stats + 6, (unsigned long long)stSeed); atomicAdd(stats + 7, (unsigned long long)stDrain);
@@ -287,7 +384,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
             }
             stIter = stPop = stPruned = stExpand = stTri = stSeed = stDrain = 0;
         }
-        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; }
+        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; if (qpass == 1) best[r] = lastTri; }
     }
 }
 
@@ -297,7 +394,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
 // LDS with their lower bounds and filtered against the FINAL bound before they are written out.
 constexpr int NEAR_LONG_STACK = 6144, NEAR_LONG_CAND = 1024;
 __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ longList,
-                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, float* __restrict__ candLo, uint8_t* __restrict__ candCount) {
+                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, float* __restrict__ candLo, uint8_t* __restrict__ candCount, float* __restrict__ candU2) {
     __shared__ uint2 s_stack[NEAR_LONG_STACK];
     __shared__ uint2 s_cand[NEAR_LONG_CAND];
     const uint32_t lane = threadIdx.x;
@@ -384,7 +481,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
             }
             if (out > (uint32_t)NEAR_K) overflow = true;
         }
-        if (lane == 0) candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : out);
+        if (lane == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : out); candU2[r] = U2; }
     }
 }
 
@@ -457,7 +554,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
 
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
-                                                        const uint8_t* __restrict__ candCount, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
+                                                        const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
                                                         uint32_t* __restrict__ fbCount, uint32_t rank, uint32_t world) {
     __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK], s_frames[4 * (NEAR_MAX_TIES - 1) * BLOCK];
     const uint64_t r64 = ((uint64_t)blockIdx.x * world + rank) * BLOCK + threadIdx.x;
@@ -468,19 +565,39 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
     const uint32_t nc = candCount[r];
     uint32_t res = NEAR_UNRESOLVED;
     if (nc != NEAR_OVERFLOW && nc > 0u) {
-        double dmin2 = BVH_NO_BOUND;
-        for (uint32_t i = 0; i < nc; i++) { const double d2 = triangleSq(b, cand[(size_t)i * numReps + r], p); dmin2 = d2 < dmin2 ? d2 : dmin2; }
-        if (dmin2 >= 1e-200) {
-            const double thr = dmin2 * (1.0 + 4e-12);
-            uint32_t* ids = s_ids + threadIdx.x;
-            int n2 = 0;
+        // Only LIVE candidates — lower bound not above the search's final upper bound u2 — can be the minimum or tied with it (the
+        // minimum's own bounds enclose its distance, and a tie lies within 4e-12 of it): the others were recorded while the bound was
+        // still loose (6 candidates per query on average, 2-3 of them live) and cost no fp64 evaluation.  One live candidate with a
+        // positive lower bound IS the answer, unevaluated.
+        const float u2 = candU2[r];
+        double dmin2 = BVH_NO_BOUND; uint32_t argmin = NEAR_UNRESOLVED, live = 0, liveId = 0; float liveLo = 0.f;
+        for (uint32_t i = 0; i < nc; i++)
+            if (candLo[(size_t)i * numReps + r] <= u2) { live++; liveId = cand[(size_t)i * numReps + r]; liveLo = candLo[(size_t)i * numReps + r]; }
+        if (live == 1u && liveLo > 0.f) res = liveId;
+        else if (live >= 1u) {
             for (uint32_t i = 0; i < nc; i++) {
+                if (!(candLo[(size_t)i * numReps + r] <= u2)) continue;
                 const uint32_t id = cand[(size_t)i * numReps + r];
-                // (the fp32 lower bound recorded with the candidate rules most of them out of the tied set without a second fp64 evaluation)
-                if ((double)candLo[(size_t)i * numReps + r] <= thr && triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
+                const double d2 = triangleSq(b, id, p);
+                if (d2 < dmin2) { dmin2 = d2; argmin = id; }
             }
-            if (n2 == 1) res = ids[0];
-            else if (n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x);
+            if (dmin2 >= 1e-200) {
+                const double thr = dmin2 * (1.0 + 4e-12);
+                // (the fp32 lower bound recorded with a candidate rules most of them out of the tied set without a second fp64 evaluation)
+                uint32_t maybe = 0;
+                for (uint32_t i = 0; i < nc; i++) maybe += ((double)candLo[(size_t)i * numReps + r] <= thr) ? 1u : 0u;
+                if (maybe == 1u) res = argmin;           // nobody else can be within the tie threshold
+                else {
+                    uint32_t* ids = s_ids + threadIdx.x;
+                    int n2 = 0;
+                    for (uint32_t i = 0; i < nc; i++) {
+                        const uint32_t id = cand[(size_t)i * numReps + r];
+                        if ((double)candLo[(size_t)i * numReps + r] <= thr && triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
+                    }
+                    if (n2 == 1) res = ids[0];
+                    else if (n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x);
+                }
+            }
         }
     }
     out[r] = res;
@@ -490,13 +607,22 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
 // ---- phase 3 ---------------------------------------------------------------------------------------------------------
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* __restrict__ pos, const uint32_t* __restrict__ fbList, uint32_t* __restrict__ fbCount,
-                                                         uint32_t first, uint32_t* __restrict__ out) {
+                                                         uint32_t first, uint32_t* __restrict__ out, const float* __restrict__ candU2) {
     extern __shared__ uint32_t s_fb_stack[];
     const uint32_t count = *fbCount;
     if (blockIdx.x == 0 && threadIdx.x == 0 && first == 0u) atomicAdd(fbCount + 1, count);       // running total of a build (fbCount[0] restarts with every batch)
     for (uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
         const uint32_t r = fbList[i];
-        out[r] = bvhNearest<BLOCK>(b, F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]}, s_fb_stack + threadIdx.x);
+        // The traversal starts from the candidate search's bound (fp32 upper bound of the squared distance incl. its error margin, i.e.
+        // strictly above the minimum) instead of from infinity: the same answer (dev_bvh.h) without the visits that precede the first
+        // good triangle — the points that end up here sit among thousands of almost equidistant triangles (a tube's axis), and unbounded
+        // a handful of them took 3 ms per batch of the torus knot's build.
+        const F3 pf = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+        const float u2 = candU2 ? candU2[r] : 3.0e38f;
+        uint32_t t = 0xFFFFFFFFu;
+        if (u2 < 1.0e37f) t = bvhNearest<BLOCK>(b, pf, s_fb_stack + threadIdx.x, nullptr, sqrt((double)u2) * (1.0 + 1e-6));
+        if (t == 0xFFFFFFFFu) t = bvhNearest<BLOCK>(b, pf, s_fb_stack + threadIdx.x);
+        out[r] = t;
     }
 }
 
@@ -507,16 +633,17 @@ struct NearPlainAlloc { AllocState saved; NearPlainAlloc() { saved = tlsAlloc();
 static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
 
 // Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  stackDepth = BVH depth + 2.
-static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, uint32_t n, uint32_t* out, NearScratch& S, int stackDepth, uint32_t rank, uint32_t world) {
+static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, uint32_t n, uint32_t* out, NearScratch& S, int stackDepth, uint32_t rank, uint32_t world,
+                           uint32_t* perQuery = nullptr, const uint32_t* seedTri = nullptr) {
     if (n == 0) return SDFHIP_OK;
     const uint32_t blocks = gridFor(n, 128);
     const uint32_t mine = blocks > rank ? (blocks - rank + world - 1) / world : 0;
     if (!mine) return SDFHIP_OK;
     NearPlainAlloc plain;
-    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candLo.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
-    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(12)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 48, st)); S.counterReady = true; }
+    SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candLo.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.candU2.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
+    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(24)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 96, st)); S.counterReady = true; }
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
-    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 36, st));     // and so are the work counters of the persistent waves and the long list
+    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 88, st));     // and so are the work counters of the persistent waves ([2..9], second pass [12..19]) and the long list
     // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
     // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
     const int worst = 3 * (stackDepth / 2 + 1) + 2;
@@ -525,19 +652,37 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     static const int capEnv = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 0;
     const int cap = capEnv ? capEnv : (bvh.numTriangles > (1u << 20) ? 34 : 32);
     const int sd = worst < cap ? worst : cap;
-    const size_t lds = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (size_t)sd * 128 * 2;
-    static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 8u;
+    static const bool packedEnv = !(getenv("SDFHIP_NEAR_PACKED") && getenv("SDFHIP_NEAR_PACKED")[0] == '0');
+    const bool packed = packedEnv && bvh.numTriangles <= (1u << 21);
+    static const uint32_t lead = (getenv("SDFHIP_NEAR_LEAD") && atoi(getenv("SDFHIP_NEAR_LEAD")) >= 2) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LEAD")) : 8u;          // a power of two <= 128
+    static const bool directTri = !(getenv("SDFHIP_NEAR_DIRECT") && getenv("SDFHIP_NEAR_DIRECT")[0] == '0');
+    static const bool coop = !(getenv("SDFHIP_NEAR_COOP") && getenv("SDFHIP_NEAR_COOP")[0] == '0');
+    const size_t ldsBase = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (packed ? 0 : (size_t)sd * 128 * 2);
+    const size_t lds = ldsBase + (coop ? 2 * 32 * 7 * 16 : 0);           // + a staging area per wave
+    static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 12u;
     uint32_t grid = 256u * perCU;
     if (grid > mine) grid = mine;
     static const uint32_t maxSteps = getenv("SDFHIP_NEAR_LONG") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LONG")) : 1536u;
     static const bool wantStats = getenv("SDFHIP_NEAR_STATS") != nullptr;
-    static const uint32_t chunk = getenv("SDFHIP_NEAR_CHUNK") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_CHUNK")) : (uint32_t)NEAR_CHUNK;
+    static const uint32_t run = (getenv("SDFHIP_NEAR_RUN") && atoi(getenv("SDFHIP_NEAR_RUN")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_RUN")) : (uint32_t)NEAR_RUN;
+    static const uint32_t chunkRuns = (getenv("SDFHIP_NEAR_CHUNK") && atoi(getenv("SDFHIP_NEAR_CHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_CHUNK")) : (uint32_t)NEAR_CHUNK;
+    const uint32_t chunk = chunkRuns * run;         // queries a wave takes per atomic: whole runs
     static const int drainLanes = getenv("SDFHIP_NEAR_DRAIN") ? atoi(getenv("SDFHIP_NEAR_DRAIN")) : NEAR_DRAIN_LANES;
     DevBuf<unsigned long long> stats;
     if (wantStats) { SDF_TRY(stats.reserve(16)); SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 128, st)); }
     static const bool seedNeighbour = !(getenv("SDFHIP_NEAR_SEED") && !strcmp(getenv("SDFHIP_NEAR_SEED"), "descent"));       // A/B switch: the greedy descent of round 2
-    k_near_candidates<128><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                            wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour);
+    // Leaders first (batches of NEAR_TWO_PASS_MIN queries and more): every eighth query of the Morton order, then the rest, each seeded
+    // with the triangle its leader ended on.  A search seeded with its own answer needs 67 expansions + 11 triangle tests on the C2
+    // mesh's level-7 samples (tools/gpu_near_hist.py), seeded by the lane's previous query (20-60 positions back) 96 + 27; the leader is
+    // at most seven positions back.  
+    static const uint32_t twoPassMin = getenv("SDFHIP_NEAR_TWO_PASS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_TWO_PASS")) : (uint32_t)NEAR_TWO_PASS_MIN;
+    const bool twoPass = !seedTri && twoPassMin != 0u && n >= twoPassMin;
+    if (twoPass) { SDF_TRY(S.best.reserve(n)); SDF_HIP_CHECK(hipMemsetAsync(S.best.p, 0xFF, sizeof(uint32_t) * (size_t)n, st)); }
+#define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
+        S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)
+    if (packed) { if (coop) SDF_NEAR_LAUNCH(true, true); else SDF_NEAR_LAUNCH(true, false); }
+    else { if (coop) SDF_NEAR_LAUNCH(false, true); else SDF_NEAR_LAUNCH(false, false); }
+#undef SDF_NEAR_LAUNCH
     if (wantStats) {
         unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
@@ -547,9 +692,9 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
         fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration; %u queries handed to k_near_long\n",
                 h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1), nLong);
     }
-    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p);
-    k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, out, S.fbList.p, S.fbCount.p, rank, world);
-    k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out);
+    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p);
+    k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
+    k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out, S.candU2.p);
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
 }

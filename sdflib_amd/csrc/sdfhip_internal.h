@@ -321,11 +321,11 @@ struct sdfhip_stage {
 // Scratch of the two-phase nearest-triangle search (dev_bvh_fast.h), kept with the context: plain device allocations that grow and
 // are reused by every build (they are the largest transient buffers of a build: 64 B per query).  Used under the context's buildLock.
 struct sdfhip_near_scratch {
-    sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList; sdfhip::DevBuf<uint8_t> candCount; sdfhip::DevBuf<float> candLo;   // candLo: the candidates' lower bounds (k_near_candidates)
-      // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters, [10]: long list length
+    sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList, best; sdfhip::DevBuf<uint8_t> candCount; sdfhip::DevBuf<float> candLo, candU2;   // candU2: the final upper bound of every query's squared distance; candLo: the candidates' lower bounds (k_near_candidates)
+      // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters (leaders), [10]: long list length, [12..19]: work counters (followers); best: the leaders' triangles
     bool counterReady = false;
-    size_t bytes() const { return 4 * (cand.n + fbList.n + fbCount.n + longList.n + candLo.n) + candCount.n; }
-    void release() { cand.release(); fbList.release(); fbCount.release(); longList.release(); candCount.release(); candLo.release(); counterReady = false; }
+    size_t bytes() const { return 4 * (cand.n + fbList.n + fbCount.n + longList.n + candLo.n + best.n + candU2.n) + candCount.n; }
+    void release() { cand.release(); fbList.release(); fbCount.release(); longList.release(); best.release(); candCount.release(); candLo.release(); candU2.release(); counterReady = false; }
 };
 
 struct sdfhip_ctx {
