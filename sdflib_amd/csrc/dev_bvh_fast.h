@@ -111,27 +111,28 @@ SDF_DEV float halfBitsToFloat(unsigned short bits) { return (float)__builtin_bit
 // and at least |v| - r.  For a point "above" a smooth patch of the surface the sphere bound is loose by the patch's radius, the
 // slab's by its sagitta only; measured on the bumpy sphere it cuts the visits of a far-field query by three.
 // Every term is rounded in the conservative direction (|m| = 1 +- 1e-4, fp32 products within 2e-6 of |v|).
+// bound of ONE child record q of a wide node whose header is h
+SDF_DEV float childBound(float4 h, float4 q, F3 p) {
+    const uint32_t w0 = __float_as_uint(q.x), w1 = __float_as_uint(q.y), w2 = __float_as_uint(q.z), w3 = __float_as_uint(q.w);
+    const float vx = p.x - fmaf((float)(w0 & 0xFFFFu), h.w, h.x), vy = p.y - fmaf((float)(w0 >> 16), h.w, h.y), vz = p.z - fmaf((float)(w1 & 0xFFFFu), h.w, h.z);
+    const float rad = halfBitsToFloat((unsigned short)(w1 >> 16)), W = halfBitsToFloat((unsigned short)(w3 >> 16));
+    const float mx = (float)(short)(w2 & 0xFFFFu) * (1.0f / 32767.0f), my = (float)(short)(w2 >> 16) * (1.0f / 32767.0f), mz = (float)(short)(w3 & 0xFFFFu) * (1.0f / 32767.0f);
+    const float v2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
+    const float a = __builtin_amdgcn_sqrtf(v2);
+    const float ls = (a - rad) - 2e-6f * (a + rad);
+    const float hm = fabsf(fmaf(mx, vx, fmaf(my, vy, mz * vz)));
+    const float up = fmaxf(hm * 0.9999f - 3e-6f * a - W, 0.f) * 0.9999f;                       // (h - W) / |m|, rounded down
+    const float rho2 = fmaxf(v2 * 0.999996f - hm * hm * 1.0003f - 6e-6f * v2, 0.f);           // |v|^2 - h^2 / |m|^2, rounded down
+    const float lat = fmaxf(__builtin_amdgcn_sqrtf(rho2) * 0.999999f - rad, 0.f);
+    const float ld = __builtin_amdgcn_sqrtf(fmaf(up, up, lat * lat)) * 0.999998f;
+    return rad < 0.f ? 3.4e38f : fmaxf(ls, (W < 6.0e4f) ? ld : -3.4e38f);
+}
 template <typename ND>
 SDF_DEV void wideBounds(ND nd, F3 p, float l[4], uint32_t cr[4]) {
     const float4 h = nd[0], rf = nd[5];
     cr[0] = __float_as_uint(rf.x); cr[1] = __float_as_uint(rf.y); cr[2] = __float_as_uint(rf.z); cr[3] = __float_as_uint(rf.w);
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const float4 q = nd[1 + c];
-        const uint32_t w0 = __float_as_uint(q.x), w1 = __float_as_uint(q.y), w2 = __float_as_uint(q.z), w3 = __float_as_uint(q.w);
-        const float vx = p.x - fmaf((float)(w0 & 0xFFFFu), h.w, h.x), vy = p.y - fmaf((float)(w0 >> 16), h.w, h.y), vz = p.z - fmaf((float)(w1 & 0xFFFFu), h.w, h.z);
-        const float rad = halfBitsToFloat((unsigned short)(w1 >> 16)), W = halfBitsToFloat((unsigned short)(w3 >> 16));
-        const float mx = (float)(short)(w2 & 0xFFFFu) * (1.0f / 32767.0f), my = (float)(short)(w2 >> 16) * (1.0f / 32767.0f), mz = (float)(short)(w3 & 0xFFFFu) * (1.0f / 32767.0f);
-        const float v2 = fmaf(vx, vx, fmaf(vy, vy, vz * vz));
-        const float a = __builtin_amdgcn_sqrtf(v2);
-        const float ls = (a - rad) - 2e-6f * (a + rad);
-        const float hm = fabsf(fmaf(mx, vx, fmaf(my, vy, mz * vz)));
-        const float up = fmaxf(hm * 0.9999f - 3e-6f * a - W, 0.f) * 0.9999f;                       // (h - W) / |m|, rounded down
-        const float rho2 = fmaxf(v2 * 0.999996f - hm * hm * 1.0003f - 6e-6f * v2, 0.f);           // |v|^2 - h^2 / |m|^2, rounded down
-        const float lat = fmaxf(__builtin_amdgcn_sqrtf(rho2) * 0.999999f - rad, 0.f);
-        const float ld = __builtin_amdgcn_sqrtf(fmaf(up, up, lat * lat)) * 0.999998f;
-        l[c] = rad < 0.f ? 3.4e38f : fmaxf(ls, (W < 6.0e4f) ? ld : -3.4e38f);
-    }
+    for (int c = 0; c < 4; c++) l[c] = childBound(h, nd[1 + c], p);
 }
 
 // ---- phase 1 ---------------------------------------------------------------------------------------------------------
@@ -385,6 +386,186 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
             stIter = stPop = stPruned = stExpand = stTri = stSeed = stDrain = 0;
         }
         if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; if (qpass == 1) best[r] = lastTri; }
+    }
+}
+
+// ---- phase 1, QUAD form -------------------------------------------------------------------------------------------------
+// Four lanes per query: lane c of a quad tests child c of the popped wide node (one 16-byte record each: a quad reads the node's
+// 64 bytes of child records as one contiguous request), the survivors are ranked inside the quad (three DPP rotations) and pushed on
+// the QUAD's stack, nearest on top; surviving triangles go to the quad's queue and are evaluated four at a time, one per lane.
+// Against one lane per query: a quarter of the stack per lane (16 queries x 40 entries x 6 B = 3.8 KB per wave instead of 12 KB, so
+// the LDS no longer caps the occupancy at three waves per SIMD), no compare-exchange network, 55 instead of 214 instructions between
+// two dependent fetches, and the four lanes of a quad never diverge in the expansion.
+constexpr int QUAD_STACK = 40, QUAD_TQ = 8;
+template <int CTRL> SDF_DEV float quadPermF(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)); }
+template <int CTRL> SDF_DEV uint32_t quadPermU(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false); }
+SDF_DEV uint32_t quadBallot(bool pred, uint32_t lane) { return (uint32_t)(__ballot(pred) >> (lane & ~3u)) & 0xFu; }
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
+                                                      uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, uint32_t* __restrict__ counters,
+                                                      uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount, int drainQuads, uint32_t chunk,
+                                                      bool seedFromNeighbour, uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, int pass,
+                                                      uint32_t* __restrict__ best, uint32_t lead) {
+    __shared__ uint32_t s_ref[BLOCK / 64][QUAD_STACK][16];
+    __shared__ unsigned short s_lb[BLOCK / 64][QUAD_STACK][16];
+    __shared__ uint32_t s_tq[BLOCK / 64][QUAD_TQ][16];
+    const uint32_t lane = __lane_id(), c = lane & 3u, quad = lane >> 2, wv = threadIdx.x >> 6;
+    uint32_t (*stk)[16] = s_ref[wv]; unsigned short (*lbs)[16] = s_lb[wv]; uint32_t (*tq)[16] = s_tq[wv];
+    const uint32_t allBlocks = (numReps + 127u) / 128u;
+    const uint32_t mine = allBlocks > rank ? (allBlocks - rank + world - 1u) / world : 0u;
+    const uint32_t all = mine * 128u;
+    int phase = pass;                            // wave-uniform (k_near_candidates: leaders, then followers)
+    uint32_t total = phase == 0 ? all : all / lead;
+    uint32_t per = (((total + 127u) / 128u + 7u) / 8u) * 128u;
+    uint32_t xcd = blockIdx.x & 7u, tried = 0, chunkNext = 0, chunkEnd = 0;
+    // per query; identical in the four lanes of its quad
+    uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
+    float U = 3.0e38f, U2 = 3.0e38f;
+    uint32_t nc = 0, steps = 0, lastTri = 0xFFFFFFFFu, stExpand = 0, stIter = 0, stTri = 0;
+    int sp = 0, nq = 0, mode = 0, seedRef = 0, qpass = 0;
+    bool have = false, done = false, overflow = false;
+    for (;;) {
+        // ---- refill: quads without a query draw from the wave's chunk (one atomic per chunk)
+        uint64_t idle = __ballot(c == 0u && !have && !done);
+        while (idle != 0ull) {
+            if (chunkNext >= chunkEnd) {
+                if (tried >= 8u && phase == 1) {
+                    phase = 2; tried = 0; xcd = blockIdx.x & 7u;
+                    total = all - all / lead; per = (((total + 127u) / 128u + 7u) / 8u) * 128u;
+                    continue;
+                }
+                if (tried >= 8u) { if (!have) done = true; break; }
+                const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
+                uint32_t base = 0;
+                if (lane == 0u) base = atomicAdd(counters + xcd + (phase == 2 ? 10u : 0u), chunk);
+                base = __shfl(base, 0) + lo;
+                if (base >= hi) { tried++; xcd = (xcd + 1u) & 7u; continue; }
+                chunkNext = base; chunkEnd = (base + chunk < hi) ? base + chunk : hi;
+            }
+            const uint32_t avail = chunkEnd - chunkNext;
+            const uint32_t slot = (uint32_t)__popcll(idle & ((1ull << (lane & ~3u)) - 1ull));
+            if (!have && !done && slot < avail) {
+                const uint32_t j = chunkNext + slot;
+                const uint32_t q = phase == 0 ? j : (phase == 1 ? lead * j : j + j / (lead - 1u) + 1u);
+                const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
+                if (rr < numReps) {
+                    r = rr; have = true; qpass = phase;
+                    p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+                    U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; sp = 0; steps = 0; stExpand = stIter = stTri = 0;
+                    uint32_t seed = 0xFFFFFFFFu;
+                    if (seedTri) seed = seedTri[r];
+                    else if (qpass == 2) seed = __builtin_nontemporal_load(best + (r & ~(lead - 1u)));
+                    if (!(seed < b.numTriangles) && seedFromNeighbour) seed = lastTri;
+                    if (b.numTriangles == 1u) { if (c == 0u) tq[0][quad] = 0u; nq = 1; mode = 0; }
+                    else if (seed < b.numTriangles) { if (c == 0u) tq[0][quad] = seed; nq = 1; mode = 2; }       // one triangle evaluation gives the first bound
+                    else { mode = 1; seedRef = 0; }                                                              // a greedy descent does
+                }
+            }
+            const uint32_t want = (uint32_t)__popcll(idle);
+            chunkNext += want < avail ? want : avail;
+            idle = __ballot(c == 0u && !have && !done);
+        }
+        if (__ballot(have) == 0ull) break;
+        if (have) stIter++;
+        __builtin_amdgcn_wave_barrier();
+        // ---- one pop per walking quad (always an inner node: triangles never enter the stack)
+        if (have && mode == 2 && nq == 0) { mode = 0; if (c == 0u) { stk[0][quad] = 0u; lbs[0][quad] = (unsigned short)0xFBFFu; } sp = 1; }      // seeded: the root, bound = -65504
+        __builtin_amdgcn_wave_barrier();
+        int ref = -1;
+        if (have && mode != 2 && nq <= QUAD_TQ - 4) {
+            if (mode == 1) ref = seedRef;
+            else if (sp > 0) {
+                sp--; steps++;
+                const int e = (int)stk[sp][quad]; const float lbound = halfBitsToFloat(lbs[sp][quad]);
+                if (!(lbound > U)) { if (sp + 4 > QUAD_STACK) steps = 0xFFFFFFF0u; else ref = e; }        // (a stack about to overflow: a job for k_near_long)
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (ref >= 0) {
+            const float4* nd = b.wide + 8 * (size_t)ref;
+            const float4 h = nd[0], q = nd[1 + c];
+            const uint32_t cr = reinterpret_cast<const uint32_t*>(nd + 5)[c];
+            const float lb = childBound(h, q, p);
+            stExpand++;
+            if (mode == 1) {
+                float m = fminf(lb, quadPermF<0xB1>(lb)); m = fminf(m, quadPermF<0x4E>(m));
+                const uint32_t first = (uint32_t)__builtin_ctz(quadBallot(lb == m, lane) | 16u);
+                seedRef = (int)__shfl((int)cr, (int)((lane & ~3u) + (first & 3u)));
+                if (seedRef < 0) { if (c == 0u) tq[nq][quad] = (uint32_t)~seedRef; nq++; mode = 2; }
+            } else {
+                const bool surv = !(lb > U);
+                const bool isTri = surv && (int)cr < 0, isNode = surv && (int)cr >= 0;
+                const uint32_t nibT = quadBallot(isTri, lane), nibN = quadBallot(isNode, lane);
+                if (isTri) tq[nq + __popc(nibT & ((1u << c) - 1u))][quad] = ~cr;
+                nq += __popc(nibT);
+                // position from the bottom = the number of surviving nodes FARTHER than mine (ties: the higher lane counts as farther)
+                const float key = isNode ? lb : -3.4e38f;
+                const float k1 = quadPermF<0x39>(key), k2 = quadPermF<0x4E>(key), k3 = quadPermF<0x93>(key);
+                const uint32_t c1 = (c + 1u) & 3u, c2 = (c + 2u) & 3u, c3 = (c + 3u) & 3u;
+                const int farther = ((k1 > key || (k1 == key && c1 > c)) ? 1 : 0) + ((k2 > key || (k2 == key && c2 > c)) ? 1 : 0) + ((k3 > key || (k3 == key && c3 > c)) ? 1 : 0);
+                if (isNode) { stk[sp + farther][quad] = cr; lbs[sp + farther][quad] = halfRoundedDown(lb); }
+                sp += __popc(nibN);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- one drain round (up to four triangles per quad, one per lane) when enough quads have some pending, a quad has no room
+        // left for a node's four, or nobody walks any more
+        const uint64_t pendQ = __ballot(c == 0u && have && nq > 0);
+        if (pendQ != 0ull && (__popcll(pendQ) >= drainQuads || __ballot(have && nq > QUAD_TQ - 4) != 0ull || __ballot(have && mode != 2 && (mode == 1 || sp > 0)) == 0ull)) {
+            const int take = nq < 4 ? nq : 4;
+            const bool mineT = have && (int)c < take;
+            uint32_t t = 0u; TriBounds tb{3.4e38f, 3.4e38f};
+            if (mineT) { t = tq[nq - 1 - (int)c][quad]; tb = triBounds32(b, t, p); }
+            if (have) stTri += (uint32_t)take;
+            if (have && take > 0) {
+                nq -= take;
+                const float hi = mineT ? tb.hi : 3.4e38f;
+                float m = fminf(hi, quadPermF<0xB1>(hi)); m = fminf(m, quadPermF<0x4E>(m));
+                if (m < U2) {
+                    U2 = m; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f;
+                    const uint32_t first = (uint32_t)__builtin_ctz(quadBallot(mineT && hi == m, lane) | 16u);
+                    lastTri = (uint32_t)__shfl((int)t, (int)((lane & ~3u) + (first & 3u)));
+                }
+                if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
+                    const bool rec = mineT && tb.lo <= U2;
+                    const uint32_t nibR = quadBallot(rec, lane);
+                    const uint32_t k = (uint32_t)__popc(nibR);
+                    if (nc + k > (uint32_t)NEAR_K) {    // rare: drop the entries the bound has overtaken since they were recorded (lane 0 of the quad)
+                        uint32_t keep = nc;
+                        if (c == 0u) {
+                            uint32_t keepMask = 0;
+                            for (uint32_t i = 0; i < nc; i++) keepMask |= (candLo[(size_t)i * numReps + r] <= U2) ? (1u << i) : 0u;
+                            keep = 0;
+                            for (uint32_t i = 0; i < nc; i++)
+                                if ((keepMask >> i) & 1u) {
+                                    if (i != keep) { cand[(size_t)keep * numReps + r] = cand[(size_t)i * numReps + r]; candLo[(size_t)keep * numReps + r] = candLo[(size_t)i * numReps + r]; }
+                                    keep++;
+                                }
+                        }
+                        nc = quadPermU<0x00>(keep);
+                    }
+                    if (nc + k <= (uint32_t)NEAR_K) {
+                        if (rec) { const uint32_t at = nc + (uint32_t)__popc(nibR & ((1u << c) - 1u)); cand[(size_t)at * numReps + r] = t; candLo[(size_t)at * numReps + r] = tb.lo; }
+                        nc += k;
+                    } else overflow = true;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- finished queries; long ones go to k_near_long
+        if (have && sp == 0 && nq == 0 && mode == 0) {
+            if (c == 0u) {
+                candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); candU2[r] = U2;
+                if (qpass == 1) best[r] = lastTri;
+                if (perQuery) { perQuery[4 * (size_t)r + 1] = stExpand; perQuery[4 * (size_t)r + 2] = stIter; perQuery[4 * (size_t)r + 3] = stTri; }
+            }
+            have = false;
+        }
+        if (have && steps > maxSteps) {
+            if (c == 0u) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; if (qpass == 1) best[r] = lastTri; }
+            have = false;
+        }
     }
 }
 
@@ -678,11 +859,21 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     static const uint32_t twoPassMin = getenv("SDFHIP_NEAR_TWO_PASS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_TWO_PASS")) : (uint32_t)NEAR_TWO_PASS_MIN;
     const bool twoPass = !seedTri && twoPassMin != 0u && n >= twoPassMin;
     if (twoPass) { SDF_TRY(S.best.reserve(n)); SDF_HIP_CHECK(hipMemsetAsync(S.best.p, 0xFF, sizeof(uint32_t) * (size_t)n, st)); }
+    static const bool quads = !(getenv("SDFHIP_NEAR_KERNEL") && !strcmp(getenv("SDFHIP_NEAR_KERNEL"), "lanes"));
+    static const int drainQuads = getenv("SDFHIP_NEAR_DRAINQ") ? atoi(getenv("SDFHIP_NEAR_DRAINQ")) : 10;
+    if (quads) {
+        uint32_t qgrid = 256u * 8u;
+        const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
+        if (qgrid > needBlocks) qgrid = needBlocks;
+        k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
+                                                        drainQuads, chunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead);
+    } else {
 #define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
         S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)
     if (packed) { if (coop) SDF_NEAR_LAUNCH(true, true); else SDF_NEAR_LAUNCH(true, false); }
     else { if (coop) SDF_NEAR_LAUNCH(false, true); else SDF_NEAR_LAUNCH(false, false); }
 #undef SDF_NEAR_LAUNCH
+    }
     if (wantStats) {
         unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
