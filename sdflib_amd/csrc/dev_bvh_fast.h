@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
 // Against one lane per query: a quarter of the stack per lane (16 queries x 40 entries x 6 B = 3.8 KB per wave instead of 12 KB, so
 // the LDS no longer caps the occupancy at three waves per SIMD), no compare-exchange network, 55 instead of 214 instructions between
 // two dependent fetches, and the four lanes of a quad never diverge in the expansion.
-constexpr int QUAD_STACK = 40, QUAD_TQ = 8;
+constexpr int QUAD_STACK = 40, QUAD_TQ = 12;
 template <int CTRL> SDF_DEV float quadPermF(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false)); }
 template <int CTRL> SDF_DEV uint32_t quadPermU(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false); }
 SDF_DEV uint32_t quadBallot(bool pred, uint32_t lane) { return (uint32_t)(__ballot(pred) >> (lane & ~3u)) & 0xFu; }
@@ -509,9 +509,9 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- one drain round (up to four triangles per quad, one per lane) when enough quads have some pending, a quad has no room
+        // ---- one drain round (up to four triangles per quad, one per lane) when enough LANES would have one to test, a quad has no room
         // left for a node's four, or nobody walks any more
-        const uint64_t pendQ = __ballot(c == 0u && have && nq > 0);
+        const uint64_t pendQ = __ballot(have && (int)c < nq);         // the lanes a drain round would occupy (c < min(nq, 4))
         if (pendQ != 0ull && (__popcll(pendQ) >= drainQuads || __ballot(have && nq > QUAD_TQ - 4) != 0ull || __ballot(have && mode != 2 && (mode == 1 || sp > 0)) == 0ull)) {
             const int take = nq < 4 ? nq : 4;
             const bool mineT = have && (int)c < take;
@@ -860,13 +860,15 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     const bool twoPass = !seedTri && twoPassMin != 0u && n >= twoPassMin;
     if (twoPass) { SDF_TRY(S.best.reserve(n)); SDF_HIP_CHECK(hipMemsetAsync(S.best.p, 0xFF, sizeof(uint32_t) * (size_t)n, st)); }
     static const bool quads = !(getenv("SDFHIP_NEAR_KERNEL") && !strcmp(getenv("SDFHIP_NEAR_KERNEL"), "lanes"));
-    static const int drainQuads = getenv("SDFHIP_NEAR_DRAINQ") ? atoi(getenv("SDFHIP_NEAR_DRAINQ")) : 10;
+    static const int drainQuads = getenv("SDFHIP_NEAR_DRAINQ") ? atoi(getenv("SDFHIP_NEAR_DRAINQ")) : 40;          // lanes with a triangle to test that make a drain round worth its instructions
     if (quads) {
-        uint32_t qgrid = 256u * 8u;
+        static const uint32_t qPerCU = getenv("SDFHIP_NEAR_QBLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QBLOCKS_PER_CU")) : 6u;       // all resident (70 VGPRs: 7 waves per SIMD); measured 6 < 8 < 12: blocks that start late only add a tail
+        static const uint32_t qchunk = (getenv("SDFHIP_NEAR_QCHUNK") && atoi(getenv("SDFHIP_NEAR_QCHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QCHUNK")) : 16u;      // queries a wave (16 quads) takes per atomic: measured 16 < 32 < 64
+        uint32_t qgrid = 256u * qPerCU;
         const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
         if (qgrid > needBlocks) qgrid = needBlocks;
         k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                        drainQuads, chunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead);
+                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead);
     } else {
 #define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
         S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)
