@@ -164,6 +164,7 @@ def octree_query_roofline(info, start_depth, n, kernel_ms, gradient, prof, kerne
     fits = working_set < 256 * 2 ** 20
     compulsory = io_bytes + min(tree_bytes, int((256 + 4 * mean_loads) * n))
     r = roofline_block(kernel, kernel_ms, bytes_per_query * n, compulsory, prof.traffic("octree_query", kernel, n))
+    r["bound_regime"] = "fabric / Infinity Cache (working set below 256 MB: see roofline_hbm for the HBM-resident figure of this kernel)" if fits else "hbm"
     r.update({"bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "working_set_bytes": int(working_set),
               "infinity_cache_resident": bool(fits),
               "regime": ("L2-miss gather served by the 256 MB Infinity Cache (working set below it): the bytes counted cross the L2 -> fabric boundary, not the "
@@ -242,6 +243,7 @@ def main():
         t0 = time.perf_counter()
         again = S.OctreeSdf(mesh, box, args.depth, args.start_depth, 1e-3, num_threads=2)
         torch.cuda.synchronize(); rebuild_s = time.perf_counter() - t0
+        rebuild_info = again.info
         again.close()
         e2e = end_to_end_build(ctx, v, f, box, args.depth, args.start_depth, dev)
 
@@ -279,6 +281,7 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     prof = Profile(enabled=(args.subdiv == 7 and args.depth == 8 and args.start_depth == 3))
+    build_roof = build_roofline(rebuild_info, rebuild_s, len(v), len(f), prof) if world == 1 else None
     kname = f"sdfhip::k_octree_query_coop<{0 if args.eval == 'exact' else 1},{'true' if args.gradient else 'false'}>"
     roof = octree_query_roofline(info, args.start_depth, args.queries, kernel_ms, args.gradient, prof, kname)
 
@@ -297,7 +300,7 @@ def main():
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
         "roofline": roof,
-        "build": {**(e2e if world == 1 else {}), "octree_build_s": round(build_s, 4), "octree_rebuild_s": (round(rebuild_s, 4) if rebuild_s is not None else None), "bvh_build_s": round(bvh_s, 4), "bvh_built_on": BVH_BUILT_ON, "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), "nearest_fallbacks": int(info.num_nearest_fallbacks), **_r4(binfo)},
+        "build": {**(e2e if world == 1 else {}), **({"roofline": build_roof} if build_roof else {}), "octree_build_s": round(build_s, 4), "octree_rebuild_s": (round(rebuild_s, 4) if rebuild_s is not None else None), "bvh_build_s": round(bvh_s, 4), "bvh_built_on": BVH_BUILT_ON, "samples": int(info.num_samples), "bvh_traversals": int(info.num_traversals), "nearest_fallbacks": int(info.num_nearest_fallbacks), **_r4(binfo)},
     }
 
     if world > 1:       # collective sanity: every rank contributes its rank + 1; the sum proves all N ranks were in the communicator
@@ -311,11 +314,61 @@ def main():
         result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world, prof)
     if not args.no_build_1m:
         result["build_1m"] = build_1m(ctx, rank, world, dev)
+    # the HBM-honest figure of the headline kernel beside the headline (whose working set sits in the Infinity Cache): the depth-9 tree's block
+    deep = (result.get("extras") or {}).get("deep_tree_d9")
+    if deep and deep.get("roofline"):
+        result["roofline_hbm"] = {**deep["roofline"], "workload": f"same kernel, depth-9 tree ({deep['words'] * 4 / 1e9:.2f} GB, beyond the 256 MB Infinity Cache), {deep['queries']} uniform-random queries: extras.deep_tree_d9"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+NEAR_KERNEL = "sdfhip::k_near_quads<256>"
+KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip"]
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def build_roofline(info, build_s, nv, nt, prof):
+    """SURVEY.md 8(d) "B" for the build's dominant kernel, the fp32 candidate search of the nearest-triangle queries (k_near_quads, ~2/3 of a
+    NO_CONTINUITY build's GPU time).  Live: the kernel's device time inside the build just run (HIP events on the build's stream, summed over
+    its batches) and its work counters (wide-node expansions, triangle tests: counted by the kernel).  From the committed counter profile,
+    when its sources are unchanged: lanes active per VALU instruction, L2 -> fabric traffic per dispatch (an average over ALL dispatches of the
+    profiled bench run, whose meshes differ: indicative).  Algorithmic bytes per query = 12 (point) + 5 (candidate count, bound) + 96 per
+    expansion (header + four child records + references of a 128-byte node) + 48 per triangle test; they are gathered through the L2 (hit rate
+    above 90 %), so the HBM fraction says how far the kernel is from being byte bound: it is bound by instruction issue (valu_lanes_active,
+    expansions_per_query).  build_compulsory = 8(d)'s per-node bytes of the whole build over the build's wall time."""
+    q = int(info.num_traversals); t = float(info.seconds_near_candidates)
+    if q == 0 or t <= 0:
+        return None
+    ex, tr = int(info.near_expansions), int(info.near_triangle_tests)
+    alg = q * 17 + ex * 96 + tr * 48
+    nodes, leaves = int(info.num_nodes), int(info.num_leaves)
+    compulsory_build = 12 * nv + 12 * nt + 148 * nt + nodes * (8 * 36 + 19 * 36 + 20) + leaves * 256
+    r = {"bound": "hbm", "kernel": NEAR_KERNEL.split("::")[-1], "kernel_ms_per_build": round(t * 1e3, 3), "search_ms_per_build": round(float(info.seconds_near_search) * 1e3, 3),
+         "share_of_build": round(t / build_s, 3), "queries": q, "mqueries_s": round(q / t / 1e6, 1),
+         "expansions_per_query": round(ex / q, 1), "triangle_tests_per_query": round(tr / q, 1),
+         "algorithmic_bytes_per_build": int(alg), "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
+         "child_tests_per_s_g": round(4 * ex / t / 1e9, 1), "fp32_vector_frac": round((4 * ex * 55 + tr * 130) / t / 1e12 / FP32_VECTOR_PEAK_TFLOPS * 2, 4),
+         "build_compulsory_bytes": int(compulsory_build), "build_compulsory_gb_s": round(compulsory_build / build_s / 1e9, 1), "build_compulsory_frac": round(compulsory_build / build_s / 1e9 / HBM_PEAK_GBS, 4),
+         "note": "instruction bound (about 55 VALU instructions per child test, 130 per triangle test; fp32_vector_frac counts them as lane-instructions against the 2-flop-per-lane FMA peak), "
+                 "not byte bound: the records are gathered through the L2"}
+    why = prof.stale("near_search")
+    if why:
+        r["profile_refused"] = why
+    else:
+        sq, pm, st = prof.sq_row(NEAR_KERNEL), prof.pmc_row(NEAR_KERNEL), prof.stats_row(NEAR_KERNEL)
+        if sq and sq.get("SQ_THREAD_CYCLES_VALU_avg_per_dispatch"):
+            r["valu_lanes_active"] = round(float(sq["SQ_THREAD_CYCLES_VALU_avg_per_dispatch"]) / (64.0 * float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"])), 3)
+        if pm:
+            hit, miss = float(pm.get("TCC_HIT_sum_avg_per_dispatch") or 0), float(pm.get("TCC_MISS_sum_avg_per_dispatch") or 0)
+            r["traffic_per_dispatch_avg"] = int((float(pm["FETCH_SIZE_avg_per_dispatch"]) * 2.0 + float(pm["WRITE_SIZE_avg_per_dispatch"])) * 1024)
+            r["l2_hit"] = round(hit / (hit + miss), 4) if hit + miss > 0 else None
+        if st:
+            r["profile_avg_dispatch_ms"] = round(float(st["avg_ns"]) / 1e6, 3)
+        r["profile"] = prof.prefix
+    return r
 
 
 def end_to_end_build(ctx, v, f, box, depth, start_depth, dev):
@@ -604,9 +657,8 @@ def deep_tree(mesh, box, dev, prof):
 
 def host_pointer(tree, ex, pts, dev):
     """The drop-in boundary as the reference's callers use it: HOST arrays in, host arrays out (PCIe inside the call), and the scalar
-    getDistance.  Large calls take the DEFAULT path: plain copies between the caller's pageable arrays and the context's buffers around the
-    kernel.  (The pinned two-stream pipeline — 2.9-3.1 ms for these 10 M points in profiles/r03d_bench_n1.json / r03e — is opt-in since it was
-    seen to end in a GPU memory access fault, SDFHIP_HOST_PIPELINE=1; `path` says which one this process measured.)
+    getDistance.  Large calls are plain copies between the caller's pageable arrays and the context's buffers around the kernel (the
+    in-place-pinned two-stream pipeline of rounds 2-3 was removed in round 4: it ended in a GPU memory access fault whose cause was never found).
     One-point calls are answered on host copies of the arrays.  The link ceilings are measured here with pinned torch tensors."""
     import ctypes as C
     from sdflib_amd._lib import lib, check
@@ -644,7 +696,7 @@ def host_pointer(tree, ex, pts, dev):
         return b
     us_oct = scalar(lambda q: L.sdfhip_octree_query(tree.h, q, 1, dptr, None, 0, S.EVAL_EXACT))
     us_ex = scalar(lambda q: L.sdfhip_exact_query(ex.h, q, 1, dptr, None, None, 0))
-    path = "pinned two-stream pipeline (SDFHIP_HOST_PIPELINE=1)" if (os.environ.get("SDFHIP_HOST_PIPELINE") == "1" and "SDFHIP_NO_PIPELINE" not in os.environ) else "plain pageable copies (default)"
+    path = "plain pageable copies"
     return {"queries": int(n), "path": path, "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
             "pcie_pinned_h2d_gb_s": round(up_gbs, 1), "pcie_pinned_d2h_gb_s": round(down_gbs, 1), "pcie_bound_ms": round(bound_seq * 1e3, 3),
             "frac_of_pcie_bound": round(bound_seq / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),

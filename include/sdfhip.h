@@ -193,6 +193,11 @@ typedef struct sdfhip_octree_info {
     float reserved0;
     uint64_t num_nearest_fallbacks; /* of num_traversals: queries the two-phase nearest search (fp32 candidates + exact tie replay) handed to the
                                        order-exact fp64 traversal because it could not decide them with certainty */
+    /* the candidate search of those traversals (SURVEY.md 8(d) "B": the build's dominant kernel), counted and timed by the build itself */
+    uint64_t near_expansions;       /* 4-wide BVH nodes expanded (128-byte records fetched) */
+    uint64_t near_triangle_tests;   /* fp32 point/triangle evaluations (48-byte records fetched) */
+    double seconds_near_candidates; /* device time of the candidate kernel's launches (HIP events on the build's stream) */
+    double seconds_near_search;     /* ... of the whole search: candidates + long queries + exact resolution + fallback */
 } sdfhip_octree_info;
 
 typedef struct sdfhip_octree_params {
@@ -230,6 +235,8 @@ int sdfhip_octree_destroy(sdfhip_octree* tree);
 int sdfhip_octree_get_info(sdfhip_octree* tree, sdfhip_octree_info* out);
 /* copy the node array (getOctreeData(): u32 words, leaf bit31, 64 float coefficients per leaf) */
 int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where);
+/* device address of the node array (rebuilt first if the tree was compacted).  Valid until the tree is destroyed or
+ * sdfhip_octree_compact is called on it; the automatic compaction of large trees leaves an array alone once its address was handed out. */
 const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree);
 /* Device footprint.  Queries run on a packed layout of the tree (node words breadth-first + 256-byte-aligned coefficient blocks) that is
  * made from the node array on the first query and holds everything the array holds; sdfhip_octree_compact makes it and RELEASES the

@@ -22,7 +22,8 @@ class OctreeInfo(C.Structure):
                 ("num_nodes", C.c_uint64), ("num_samples", C.c_uint64), ("cell_begin", C.c_uint32), ("cell_end", C.c_uint32),
                 ("body_words", C.c_uint64), ("body_offset", C.c_uint64), ("seconds_samples", C.c_double), ("seconds_decide", C.c_double),
                 ("seconds_total", C.c_double), ("leaves_per_depth", C.c_uint64 * 16), ("fit_rechecks", C.c_uint64), ("num_traversals", C.c_uint64),
-                ("post_pass_scheduled", C.c_uint64), ("start_grid_cell_size", C.c_float), ("reserved0", C.c_float), ("num_nearest_fallbacks", C.c_uint64)]
+                ("post_pass_scheduled", C.c_uint64), ("start_grid_cell_size", C.c_float), ("reserved0", C.c_float), ("num_nearest_fallbacks", C.c_uint64),
+                ("near_expansions", C.c_uint64), ("near_triangle_tests", C.c_uint64), ("seconds_near_candidates", C.c_double), ("seconds_near_search", C.c_double)]
 
 
 class OctreeParams(C.Structure):

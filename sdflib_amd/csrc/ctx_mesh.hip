@@ -243,7 +243,6 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
     SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
-    if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     for (hipStream_t& s : ctx->bvhSide) if (s) { (void)hipStreamDestroy(s); s = nullptr; }
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
     // the cached blocks of this context's stream, once its last context goes (a borrowed stream can serve several contexts)

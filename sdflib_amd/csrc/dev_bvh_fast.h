@@ -162,6 +162,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                                                            uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, uint32_t run, int pass, uint32_t* __restrict__ best, uint32_t stageOff, uint32_t lead, bool directTri) {
     extern __shared__ uint32_t s_near_stack[];
     uint32_t stIter = 0, stPop = 0, stPruned = 0, stExpand = 0, stTri = 0, stSeed = 0, stDrain = 0;
+    unsigned long long accExpand = 0, accTri = 0;
     uint32_t* stkRef = s_near_stack + threadIdx.x;
     uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
     unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;      // (not PACKED only)
@@ -383,10 +384,14 @@ __global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float
                 atomicAdd(stats + 4, (unsigned long long)stExpand); atomicAdd(stats + 5, (unsigned long long)stTri); atomicAdd(stats + 6, (unsigned long long)stSeed); atomicAdd(stats + 7, (unsigned long long)stDrain);
                 atomicAdd(stats + 8, (unsigned long long)nc);
             }
+            accExpand += stExpand; accTri += stTri;
             stIter = stPop = stPruned = stExpand = stTri = stSeed = stDrain = 0;
         }
-        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; if (qpass == 1) best[r] = lastTri; }
+        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; if (qpass == 1) best[r] = lastTri; accExpand += stExpand; accTri += stTri; }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { accExpand += __shfl_xor(accExpand, o); accTri += __shfl_xor(accTri, o); }
+    if (lane == 0u) { atomicAdd(reinterpret_cast<unsigned long long*>(counters + 18), accExpand); atomicAdd(reinterpret_cast<unsigned long long*>(counters + 20), accTri); }
 }
 
 // ---- phase 1, QUAD form -------------------------------------------------------------------------------------------------
@@ -423,6 +428,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
     uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
     float U = 3.0e38f, U2 = 3.0e38f;
     uint32_t nc = 0, steps = 0, lastTri = 0xFFFFFFFFu, stExpand = 0, stIter = 0, stTri = 0;
+    uint32_t accExpand = 0, accTri = 0;          // this quad's totals over the launch (one atomic per wave at the end)
     int sp = 0, nq = 0, mode = 0, seedRef = 0, qpass = 0;
     bool have = false, done = false, overflow = false;
     for (;;) {
@@ -560,13 +566,20 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                 if (qpass == 1) best[r] = lastTri;
                 if (perQuery) { perQuery[4 * (size_t)r + 1] = stExpand; perQuery[4 * (size_t)r + 2] = stIter; perQuery[4 * (size_t)r + 3] = stTri; }
             }
+            accExpand += stExpand; accTri += stTri;
             have = false;
         }
         if (have && steps > maxSteps) {
             if (c == 0u) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; if (qpass == 1) best[r] = lastTri; }
+            accExpand += stExpand; accTri += stTri;
             have = false;
         }
     }
+    // the launch's work counters (sdfhip_octree_info.near_expansions / near_triangle_tests): a sum over the wave's quads, two atomics per wave
+    unsigned long long e = c == 0u ? accExpand : 0u, t = c == 0u ? accTri : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); t += __shfl_xor(t, o); }
+    if (lane == 0u) { atomicAdd(reinterpret_cast<unsigned long long*>(counters + 18), e); atomicAdd(reinterpret_cast<unsigned long long*>(counters + 20), t); }
 }
 
 // ---- phase 1b: one wave per long query ------------------------------------------------------------------------------------
@@ -822,9 +835,16 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     if (!mine) return SDFHIP_OK;
     NearPlainAlloc plain;
     SDF_TRY(S.cand.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candLo.reserve((size_t)NEAR_K * n)); SDF_TRY(S.candCount.reserve(n)); SDF_TRY(S.candU2.reserve(n)); SDF_TRY(S.fbList.reserve(n)); SDF_TRY(S.longList.reserve(n));
-    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(24)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 96, st)); S.counterReady = true; }
+    if (!S.counterReady) { SDF_TRY(S.fbCount.reserve(32)); SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 128, st)); S.counterReady = true; S.evUsed = 0; }
     SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p, 0, 4, st));          // the fallback list is per batch
-    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 88, st));     // and so are the work counters of the persistent waves ([2..9], second pass [12..19]) and the long list
+    SDF_HIP_CHECK(hipMemsetAsync(S.fbCount.p + 2, 0, 72, st));     // and so are the work counters of the persistent waves ([2..9], second pass [12..19]) and the long list
+    // device time of this batch's launches, summed up by nearTotals() when the build has finished
+    const bool timed = S.evUsed < sdfhip_near_scratch::kMaxTimed;
+    hipEvent_t* ev = S.ev + 3 * S.evUsed;
+    if (timed) {
+        while (S.evMade < 3 * (S.evUsed + 1)) { SDF_HIP_CHECK(hipEventCreate(&S.ev[S.evMade])); S.evMade++; }
+        S.evUsed++;
+    }
     // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
     // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
     const int worst = 3 * (stackDepth / 2 + 1) + 2;
@@ -859,6 +879,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     static const uint32_t twoPassMin = getenv("SDFHIP_NEAR_TWO_PASS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_TWO_PASS")) : (uint32_t)NEAR_TWO_PASS_MIN;
     const bool twoPass = !seedTri && twoPassMin != 0u && n >= twoPassMin;
     if (twoPass) { SDF_TRY(S.best.reserve(n)); SDF_HIP_CHECK(hipMemsetAsync(S.best.p, 0xFF, sizeof(uint32_t) * (size_t)n, st)); }
+    if (timed) SDF_HIP_CHECK(hipEventRecord(ev[0], st));
     static const bool quads = !(getenv("SDFHIP_NEAR_KERNEL") && !strcmp(getenv("SDFHIP_NEAR_KERNEL"), "lanes"));
     static const int drainQuads = getenv("SDFHIP_NEAR_DRAINQ") ? atoi(getenv("SDFHIP_NEAR_DRAINQ")) : 40;          // lanes with a triangle to test that make a drain round worth its instructions
     if (quads) {
@@ -876,6 +897,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     else { if (coop) SDF_NEAR_LAUNCH(false, true); else SDF_NEAR_LAUNCH(false, false); }
 #undef SDF_NEAR_LAUNCH
     }
+    if (timed) SDF_HIP_CHECK(hipEventRecord(ev[1], st));
     if (wantStats) {
         unsigned long long h[12];
         SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
@@ -889,6 +911,25 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out, S.candU2.p);
     SDF_HIP_CHECK(hipGetLastError());
+    if (timed) SDF_HIP_CHECK(hipEventRecord(ev[2], st));
+    return SDFHIP_OK;
+}
+
+// What the searches since the counters were reset (a build's start) amounted to; synchronises the stream.
+struct NearTotals { uint64_t fallbacks = 0, expansions = 0, triangleTests = 0; double candidateSeconds = 0, searchSeconds = 0; };
+static int nearTotals(hipStream_t st, NearScratch& S, NearTotals& out) {
+    out = NearTotals();
+    if (!S.counterReady) return SDFHIP_OK;
+    uint32_t h[24];
+    SDF_HIP_CHECK(hipMemcpyAsync(h, S.fbCount.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    out.fallbacks = h[1];
+    out.expansions = (uint64_t)h[20] | ((uint64_t)h[21] << 32); out.triangleTests = (uint64_t)h[22] | ((uint64_t)h[23] << 32);
+    for (int i = 0; i < S.evUsed; i++) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, S.ev[3 * i], S.ev[3 * i + 1]) == hipSuccess && hipEventElapsedTime(&b, S.ev[3 * i], S.ev[3 * i + 2]) == hipSuccess) { out.candidateSeconds += 1e-3 * a; out.searchSeconds += 1e-3 * b; }
+        else (void)hipGetLastError();
+    }
     return SDFHIP_OK;
 }
 

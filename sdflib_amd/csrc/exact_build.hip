@@ -884,10 +884,10 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         *out = E.release();
         return SDFHIP_OK;
     }
-    SDF_TRY(E->nodes.reserve(2 * I.num_nodes)); SDF_TRY(E->hasTri.reserve(I.num_nodes)); SDF_TRY(E->sets.reserve(I.num_set_words ? I.num_set_words : 1)); SDF_TRY(E->masks.reserve(I.num_mask_bytes ? I.num_mask_bytes : 1));
+    SDF_TRY(E->nodes.reserve(2 * I.num_nodes)); SDF_TRY(E->hasTri.reserve(I.num_nodes)); SDF_TRY(E->sets.reserve(I.num_set_words + 2)); SDF_TRY(E->masks.reserve(I.num_mask_bytes + 1));          // (+ the look-ahead padding k_exact_tiles reads, as the import paths add)
     SDF_HIP_CHECK(hipMemsetAsync(E->nodes.p, 0, 8ull * I.num_nodes, st)); SDF_HIP_CHECK(hipMemsetAsync(E->hasTri.p, 0, I.num_nodes, st));
-    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4ull * (I.num_set_words ? I.num_set_words : 1), st));
-    SDF_HIP_CHECK(hipMemsetAsync(E->masks.p, 0, I.num_mask_bytes ? I.num_mask_bytes : 1, st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->sets.p, 0, 4ull * (I.num_set_words + 2), st));
+    SDF_HIP_CHECK(hipMemsetAsync(E->masks.p, 0, I.num_mask_bytes + 1, st));
     SDF_TRY(exactEmit(E.get(), G3, 0u, 0u, E->nodes.p, E->hasTri.p, E->nodes.p + 2ull * G3, E->hasTri.p + G3, E->sets.p, E->masks.p));
     E->levels.clear();
     E->built = true;

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* 
 // bit-encoding depth (or a leaf above it) for the packed set, then at most two more levels for the byte masks.
 struct CtxItem { uint32_t node, stage, set, m1; };
 __global__ void __launch_bounds__(256) k_exact_ctx_level(ExactView v, const CtxItem* __restrict__ in, uint32_t nIn, uint32_t depth, CtxItem* __restrict__ out,
-                                                         uint32_t* __restrict__ outCount, uint32_t* __restrict__ ctx) {
+                                                         uint32_t* __restrict__ outCount, uint32_t* __restrict__ ctx, uint32_t capacity) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nIn) return;
     CtxItem it = in[i];
@@ -178,6 +178,9 @@ __global__ void __launch_bounds__(256) k_exact_ctx_level(ExactView v, const CtxI
     }
     const uint32_t base = atomicAdd(outCount, 8u);
     const uint32_t child = w0 & 0x7FFFFFFFu;
+    // a node array that is not a tree (shared or cyclic child links in imported data) grows the frontier beyond the node count: nothing is
+    // written past the buffer or read past the array, the count alone tells the host
+    if ((uint64_t)base + 8u > capacity || (uint64_t)child + 8u > capacity) return;
 #pragma unroll
     for (uint32_t k = 0; k < 8; k++) out[base + k] = CtxItem{child + k, it.stage, it.set, it.m1};
 }
@@ -386,7 +389,7 @@ static int ensureLeafCtx(sdfhip_exact* T, const ExactView& v) {
     uint32_t nIn = g3;
     for (uint32_t depth = I.start_depth; nIn > 0; depth++) {
         SDF_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, st));
-        k_exact_ctx_level<<<gridFor(nIn, 256), 256, 0, st>>>(v, reinterpret_cast<const CtxItem*>(fa.p), nIn, depth, reinterpret_cast<CtxItem*>(fb.p), cnt.p, T->leafCtx.p);
+        k_exact_ctx_level<<<gridFor(nIn, 256), 256, 0, st>>>(v, reinterpret_cast<const CtxItem*>(fa.p), nIn, depth, reinterpret_cast<CtxItem*>(fb.p), cnt.p, T->leafCtx.p, (uint32_t)nn);
         SDF_HIP_CHECK(hipGetLastError());
         uint32_t nOut = 0;
         SDF_HIP_CHECK(hipMemcpyAsync(&nOut, cnt.p, 4, hipMemcpyDeviceToHost, st));

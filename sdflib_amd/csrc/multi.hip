@@ -153,6 +153,8 @@ struct InProcessExchange {
         const double t0 = nowSeconds();
         X->bytes += 4 * count;
         if (M->useRccl) {
+            // all ranks agree on the host to enter the collective, or none does: a rank whose build failed would leave its peers in it for ever
+            if (!X->bar->arrive()) { setError("another device's CONTINUITY build failed"); return SDFHIP_E_HIP; }
             SDF_NCCL(rccl().AllReduce(X->buf.p, X->buf.p, count, ncclUint32, ncclSum, M->comm[r], st));
             X->seconds += nowSeconds() - t0;
             return SDFHIP_OK;
@@ -318,12 +320,14 @@ int sdfhip_multi_octree_build(sdfhip_multi* M, const float* xyz, uint32_t nv, co
         std::vector<InProcessExchange> X(n);
         for (int r = 0; r < n; r++) { X[r].M = M; X[r].rank = r; X[r].bar = &bar; X[r].all = &X; }
         rc = perRank(n, [&](int r) {
+            // every error exit releases the peers waiting at the barrier (a rank that never arrives would hold them for ever)
+            struct FailGuard { ThreadBarrier& b; bool armed = true; ~FailGuard() { if (armed) b.fail(); } } guard{bar};
             SDF_HIP_CHECK(hipSetDevice(M->devices[r]));
             sdfhip_exchange x{&X[r], &InProcessExchange::acquire, &InProcessExchange::allReduceSum, r, n};
             SDF_TRY(sdfhip_ctx_set_exchange(M->ctx[r], &x));
             const int brc = sdfhip_octree_build(M->ctx[r], mesh[r], params, &tree[r]);
             (void)sdfhip_ctx_set_exchange(M->ctx[r], nullptr);
-            if (brc != SDFHIP_OK) bar.fail();
+            if (brc == SDFHIP_OK) guard.armed = false;
             return brc;
         });
         for (int r = 0; r < n; r++) { (void)hipSetDevice(M->devices[r]); X[r].buf.release(); X[r].stage.release(); X[r].acc.release(); }
@@ -386,7 +390,8 @@ int sdfhip_multi_octree_build(sdfhip_multi* M, const float* xyz, uint32_t nv, co
             sdfhip_octree_info& I = tree[r]->info;
             for (int s = 0; s < n; s++) {
                 I.num_leaves += info[s].num_leaves; I.num_nodes += info[s].num_nodes; I.num_samples += info[s].num_samples; I.num_traversals += info[s].num_traversals;
-                I.num_nearest_fallbacks += info[s].num_nearest_fallbacks;
+                I.num_nearest_fallbacks += info[s].num_nearest_fallbacks; I.near_expansions += info[s].near_expansions; I.near_triangle_tests += info[s].near_triangle_tests;
+                I.seconds_near_candidates = std::max(I.seconds_near_candidates, info[s].seconds_near_candidates); I.seconds_near_search = std::max(I.seconds_near_search, info[s].seconds_near_search);
                 for (int d = 0; d < 16; d++) I.leaves_per_depth[d] += info[s].leaves_per_depth[d];
             }
             return SDFHIP_OK;

@@ -505,7 +505,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         T->hasData = true;
         T->levels.clear();
     }
-    SDF_TRY(sampleFallbacks(st, SS, T->info.num_nearest_fallbacks));
+    SDF_TRY(sampleFallbacks(st, SS, T->info));
     T->info.seconds_total = nowSeconds() - tStart;
     *out = T.release();
     return SDFHIP_OK;
@@ -641,7 +641,10 @@ int sdfhip_octree_download(sdfhip_octree* tree, uint32_t* out_words, int where) 
 
 const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) {
     if (!tree || !tree->hasData) return nullptr;
-    if (!tree->data.p && (hipSetDevice(tree->ctx->device) != hipSuccess || octreeMaterialize(tree) != SDFHIP_OK)) return nullptr;
+    if (hipSetDevice(tree->ctx->device) != hipSuccess || octreeMaterialize(tree) != SDFHIP_OK) return nullptr;       // (takes the tree's lock; a no-op when the array is resident)
+    std::lock_guard<std::mutex> own(tree->qLock);
+    if (!tree->data.p) return nullptr;                  // compacted by another thread in between
+    tree->dataPinned = true;                            // no automatic release behind the caller's back from now on
     return tree->data.p;
 }
 

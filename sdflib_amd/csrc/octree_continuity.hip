@@ -1114,7 +1114,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     T->hasData = true; T->built = true;
-    SDF_TRY(sampleFallbacks(st, SS, T->info.num_nearest_fallbacks));
+    SDF_TRY(sampleFallbacks(st, SS, T->info));
     T->info.seconds_total = nowSeconds() - tStart;
     *out = T.release();
     return SDFHIP_OK;

@@ -35,6 +35,7 @@ struct sdfhip_octree {
     sdfhip_octree_info info{};
     sdfhip_octree_params params{};
     sdfhip::DevBuf<uint32_t> data;          // full node array (when available): the reference's mOctreeData layout, what download / emit return
+    bool dataPinned = false;                // sdfhip_octree_device_words handed the array's address out: it is not released automatically any more
     bool hasData = false;                   // an assembled array EXISTS; it need not be resident: a compacted tree (sdfhip_octree_compact, or
                                             // automatically above SDFHIP_COMPACT_ABOVE_MB) keeps the query layout only and rebuilds it on demand
     // Query-side layout, derived from `data` on the first query (octree_query.hip, ensureQueryLayout): the node words alone, packed

@@ -273,7 +273,12 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     // The layout holds everything the array holds (node words + coefficient blocks), so a LARGE array need not stay on the device beside
     // it: above SDFHIP_COMPACT_ABOVE_MB (default 1024) it is released here and rebuilt on demand (octreeMaterialize).
     static const uint64_t compactAbove = (getenv("SDFHIP_COMPACT_ABOVE_MB") ? strtoull(getenv("SDFHIP_COMPACT_ABOVE_MB"), nullptr, 10) : 1024ull) << 20;
-    if (4ull * numWords >= compactAbove && total + 64ull * leaves == numWords) T->data.release();
+    // (not once sdfhip_octree_device_words has handed its address out; and the block goes back to the device, not to the stream's cache:
+    // a query runs outside any allocation scope, so nothing else would apply the cache's high-water mark)
+    if (4ull * numWords >= compactAbove && total + 64ull * leaves == numWords && !T->dataPinned) {
+        T->data.release();
+        BigBlockCache::get().trimTo(ctx->device, st, BigBlockCache::keepBytes());
+    }
     return SDFHIP_OK;
 }
 
@@ -816,94 +821,6 @@ static void launchQuery(int eval_mode, bool grad, unsigned blocks, hipStream_t s
     }
 }
 
-// Large host-pointer queries (the reference API hands over host arrays): a kernel of 0.05 ms per million points sits between two PCIe
-// hops, and copies from / to PAGEABLE memory run at 35-42 GB/s (measured, staged by the runtime) against 57 GB/s for pinned memory.
-// The caller's arrays are therefore pinned IN PLACE, piece by piece (hipHostRegister, 8 MiB at a time: ~0.1 ms, on the host, while the
-// previous piece is on the wire), each piece goes up asynchronously, the points it completes are evaluated at once and their results
-// flow back on a second stream while the next piece goes up.  Returns 1 when it did not run (registration refused: the plain path
-// answers), SDFHIP_OK or an error otherwise; *done = points answered.
-static int queryHostPipelined(sdfhip_octree* T, const float* xyz, uint64_t n, float* out_dist, float* out_grad, int eval_mode, float* dp, float* dd, float* dg, uint64_t* done) {
-    *done = 0;
-    sdfhip_ctx* ctx = T->ctx;
-    hipStream_t st = ctx->stream;
-    {
-        std::lock_guard<std::mutex> g(ctx->copyStreamLock);
-        if (!ctx->copyStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
-    }
-    hipStream_t back = ctx->copyStream;
-    const uintptr_t PAGE = 4096, PIECE = 8u << 20;
-    struct Reg { void* p; };
-    std::vector<Reg> regs;
-    // SDFHIP_TEST_PIN_FAIL_AFTER=k: the (k+1)-th registration of a call is refused (tests drive the partial-fallback path with it)
-    const char* failEnv = getenv("SDFHIP_TEST_PIN_FAIL_AFTER");
-    const long failAfter = failEnv ? atol(failEnv) : -1;
-    auto pin = [&](uintptr_t b, uintptr_t e) { if (failAfter >= 0 && (long)regs.size() >= failAfter) return false; if (hipHostRegister((void*)b, e - b, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return false; } regs.push_back(Reg{(void*)b}); return true; };
-    auto unpinAll = [&]() { for (const Reg& r : regs) (void)hipHostUnregister(r.p); regs.clear(); };
-    // Only pages that lie WHOLLY inside the caller's arrays are registered, and no direct copy starts or ends in a page the array shares
-    // with a neighbour on the heap: the bytes before the first and after the last whole page travel as small pageable copies.  (Seen on the
-    // GPU box: an output array that began in the last page of an array a previous call had registered — and the runtime had pinned for its
-    // own pageable copies — was registered "successfully", but the copy into it resolved to the stale pinned object and ran off its end:
-    // "Memory access fault ... Write access to a read-only page" one page into the new array.)
-    const uintptr_t inB = (uintptr_t)xyz, inE = inB + 12 * n, base = (inB + PAGE - 1) & ~(PAGE - 1), end = inE & ~(PAGE - 1);
-    if (end <= base + PAGE) return 1;
-    const uint64_t pieces = (end - base + PIECE - 1) / PIECE;
-    auto pieceEnd = [&](uint64_t k) { const uintptr_t e = base + (k + 1) * PIECE; return e < end ? e : end; };
-    if (!pin(base, pieceEnd(0))) return 1;
-    const QueryTree q = makeQueryTree(T);
-    hipEvent_t ev;
-    SDF_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    int rc = SDFHIP_OK;
-    uint64_t launched = 0; bool outPinned = false;
-    uintptr_t ob = 0, oe = 0, gb = 0, ge = 0;                   // registered interiors of out_dist / out_grad
-    // device -> host, split at the registered interior [lo, hi) of the destination array
-    // The bytes outside the interior (less than a page at either end of an array) are PAGEABLE copies: the runtime may hold the calling thread
-    // until such a copy has run, i.e. until the kernel before it has — issued inside the loop that stalls the upload of the next pieces
-    // (measured: 2.93 -> 3.26 ms for 10 M points).  They are listed here and issued after the loop; the device buffers live until then.
-    struct Edge { void* host; const void* dev; size_t bytes; };
-    std::vector<Edge> edges;
-    auto down = [&](void* host, const void* dev, size_t bytes, uintptr_t lo, uintptr_t hi) {
-        const uintptr_t s = (uintptr_t)host, e = s + bytes;
-        const uintptr_t ms = s > lo ? s : lo, me = e < hi ? e : hi;
-        if (me <= ms) { edges.push_back(Edge{host, dev, bytes}); return true; }      // wholly outside the interior
-        if (s < ms) edges.push_back(Edge{(void*)s, dev, (size_t)(ms - s)});
-        if (e > me) edges.push_back(Edge{(void*)me, (const char*)dev + (me - s), (size_t)(e - me)});
-        return hipMemcpyAsync((void*)ms, (const char*)dev + (ms - s), me - ms, hipMemcpyDeviceToHost, back) == hipSuccess;
-    };
-    for (uint64_t k = 0; k < pieces && rc == SDFHIP_OK; k++) {
-        const uintptr_t b = base + k * PIECE, e = pieceEnd(k);
-        if (k == 0 && base > inB && hipMemcpyAsync(dp, (const void*)inB, base - inB, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-        if (hipMemcpyAsync((char*)dp + (b - inB), (const void*)b, e - b, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-        if (e == end && inE > end && hipMemcpyAsync((char*)dp + (end - inB), (const void*)end, inE - end, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-        const uint64_t avail = (e == end) ? n : (e - inB) / 12;
-        if (!outPinned) {          // the result arrays: pinned while the first piece is on the wire
-            ob = ((uintptr_t)out_dist + PAGE - 1) & ~(PAGE - 1); oe = ((uintptr_t)out_dist + 4 * n) & ~(PAGE - 1);
-            bool ok = oe > ob && pin(ob, oe);
-            if (ok && out_grad) { gb = ((uintptr_t)out_grad + PAGE - 1) & ~(PAGE - 1); ge = ((uintptr_t)out_grad + 12 * n) & ~(PAGE - 1); ok = ge > gb && pin(gb, ge); }
-            if (!ok) break;        // answered so far: nothing; the plain path takes over
-            outPinned = true;
-        }
-        if (avail > launched) {
-            const uint64_t m = avail - launched;
-            launchQuery(eval_mode, out_grad != nullptr, gridFor(m, 256), st, q, dp + 3 * launched, m, dd + launched, out_grad ? dg + 3 * launched : nullptr);
-            if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(back, ev, 0) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-            if (!down(out_dist + launched, dd + launched, 4 * m, ob, oe)) { rc = SDFHIP_E_HIP; break; }
-            if (out_grad && !down(out_grad + 3 * launched, dg + 3 * launched, 12 * m, gb, ge)) { rc = SDFHIP_E_HIP; break; }
-            launched = avail;
-        }
-        if (k + 1 < pieces && !pin(base + (k + 1) * PIECE, pieceEnd(k + 1))) break;      // refused: the plain path finishes the rest
-    }
-    // the edges: only those of points that were evaluated (a refused registration leaves the rest to the plain path); `back` already waits for
-    // the last kernel it has a copy of
-    if (rc == SDFHIP_OK) for (const Edge& g : edges) if (hipMemcpyAsync(g.host, g.dev, g.bytes, hipMemcpyDeviceToHost, back) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-    const hipError_t e1 = hipStreamSynchronize(st), e2 = hipStreamSynchronize(back);
-    (void)hipEventDestroy(ev);
-    unpinAll();
-    if (rc == SDFHIP_OK && (e1 != hipSuccess || e2 != hipSuccess)) { setError("pipelined query failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); return SDFHIP_E_HIP; }
-    if (rc != SDFHIP_OK) { setError("pipelined query: HIP call failed"); return rc; }
-    *done = outPinned ? launched : 0;
-    return SDFHIP_OK;
-}
-
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -951,22 +868,10 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     if (where == SDFHIP_HOST) {
         SDF_TRY(dp.reserve(3 * n)); SDF_TRY(dd.reserve(n));
         if (out_grad) SDF_TRY(dg.reserve(3 * n));
-        // OPT-IN (SDFHIP_HOST_PIPELINE=1) since the end of round 3.  With queryHostPipelined in use the -m gpu suite died in 6 of 8 runs on the
-        // GPU box with "Memory access fault by GPU ... Write access to a read-only page" — seen one page into an output array the call had just
-        // registered (an array adjacent on the heap to one a previous call had registered and released), once on the next, unrelated copy — and
-        // in 0 of 3 runs without it.  The mechanism is NOT understood (two fixes that each passed once failed on the next run);
-        // a legal call must not be able to take the process down, so the plain path below answers unless the caller asks for the pipeline.
-        static const bool pipe = [] { const char* e = getenv("SDFHIP_HOST_PIPELINE"); return e != nullptr && e[0] == '1' && getenv("SDFHIP_NO_PIPELINE") == nullptr; }();
-        if (pipe && 12 * n >= (32ull << 20)) {
-            uint64_t done = 0;
-            const int prc = queryHostPipelined(T, xyz, n, out_dist, out_grad, eval_mode, dp.p, dd.p, out_grad ? dg.p : nullptr, &done);
-            if (prc < 0) return prc;
-            if (done == n) return SDFHIP_OK;
-            if (done > 0) {        // a later piece could not be pinned: the rest through the plain path
-                if (own.owns_lock()) own.unlock();          // held only for calls of at most kStageKeepBytes whose try_lock succeeded
-                return sdfhip_octree_query(T, xyz + 3 * done, n - done, out_dist + done, out_grad ? out_grad + 3 * done : nullptr, where, eval_mode);
-            }
-        }
+        // Plain copies between the caller's (pageable) arrays and the context's buffers around the kernel: 10 M points in 3.2 ms = 0.90 of
+        // the box's PCIe bound.  (Rounds 2-3 had a pipeline that pinned the caller's pages in place piece by piece and overlapped upload,
+        // kernel and download on two streams — 2.93-3.07 ms — but ended in a GPU memory access fault after mixed registration failures
+        // over the same arrays, cause never found; it was removed in round 4: a legal call must not be able to take the process down.)
         SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, 12 * n, hipMemcpyHostToDevice, st));
         p = dp.p; d = dd.p; g = out_grad ? dg.p : nullptr;
     }
@@ -991,7 +896,11 @@ int sdfhip_octree_compact(sdfhip_octree* T) {
     std::lock_guard<std::mutex> own(T->qLock);
     // the layout reproduces the array only if every word of it is a node word or a coefficient of exactly one leaf (true for every array
     // a builder of this library or the reference emits); anything else keeps its array
-    if (T->data.p && T->qNodes + 64ull * T->qLeaves == T->info.num_words) { SDF_HIP_CHECK(hipStreamSynchronize(T->ctx->stream)); T->data.release(); }
+    if (T->data.p && T->qNodes + 64ull * T->qLeaves == T->info.num_words) {
+        SDF_HIP_CHECK(hipStreamSynchronize(T->ctx->stream));
+        T->data.release(); T->dataPinned = false;          // an explicit request: pointers from sdfhip_octree_device_words are invalid from here on (sdfhip.h)
+        BigBlockCache::get().trimTo(T->ctx->device, T->ctx->stream, BigBlockCache::keepBytes());
+    }
     return SDFHIP_OK;
     SDF_API_END
 }

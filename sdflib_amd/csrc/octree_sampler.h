@@ -202,14 +202,14 @@ static int sampleBatch(hipStream_t st, const MeshDev& md, const SampleBatch& B, 
     SDF_TRY(sampleBatchBegin(st, md, B, S, stackBytes, traversals));
     return sampleBatchEnd(st, md, S);
 }
-// total of fallbacks since the scratch was created (synchronises the stream)
-static int sampleFallbacks(hipStream_t st, SampleScratch& S, uint64_t& out) {
-    out = 0;
-    if (!S.near || !S.near->counterReady) return SDFHIP_OK;
-    uint32_t h = 0;
-    SDF_HIP_CHECK(hipMemcpyAsync(&h, S.near->fbCount.p + 1, 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    out = h;
+// the search's totals of this build into the tree's info (synchronises the stream)
+static int sampleFallbacks(hipStream_t st, SampleScratch& S, sdfhip_octree_info& info) {
+    info.num_nearest_fallbacks = 0;
+    if (!S.near) return SDFHIP_OK;
+    NearTotals t;
+    SDF_TRY(nearTotals(st, *S.near, t));
+    info.num_nearest_fallbacks = t.fallbacks; info.near_expansions = t.expansions; info.near_triangle_tests = t.triangleTests;
+    info.seconds_near_candidates = t.candidateSeconds; info.seconds_near_search = t.searchSeconds;
     return SDFHIP_OK;
 }
 // the 19 mid-points of one level

@@ -323,7 +323,12 @@ struct sdfhip_stage {
 struct sdfhip_near_scratch {
     sdfhip::DevBuf<uint32_t> cand, fbList, fbCount, longList, best; sdfhip::DevBuf<uint8_t> candCount; sdfhip::DevBuf<float> candLo, candU2;   // candU2: the final upper bound of every query's squared distance; candLo: the candidates' lower bounds (k_near_candidates)
       // fbCount[0]: this batch's fallback list length, [1]: total since reset, [2..9]: work counters (leaders), [10]: long list length, [12..19]: work counters (followers); best: the leaders' triangles
+      // [20..21], [22..23]: u64 totals of wide-node expansions and triangle tests since the counters were reset
     bool counterReady = false;
+    // device time of the search's launches within a build: event triples (before the candidate kernel, after it, after the fallback) per batch
+    static constexpr int kMaxTimed = 24;
+    hipEvent_t ev[3 * kMaxTimed] = {}; int evMade = 0, evUsed = 0;
+    ~sdfhip_near_scratch() { for (int i = 0; i < evMade; i++) (void)hipEventDestroy(ev[i]); }
     size_t bytes() const { return 4 * (cand.n + fbList.n + fbCount.n + longList.n + candLo.n + best.n + candU2.n) + candCount.n; }
     void release() { cand.release(); fbList.release(); fbCount.release(); longList.release(); best.release(); candCount.release(); candLo.release(); candU2.release(); counterReady = false; }
 };
@@ -334,8 +339,6 @@ struct sdfhip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownsStream = false;
-    hipStream_t copyStream = nullptr;      // results flow back on this one while the next piece of a large host-pointer query goes up (created on first use)
-    std::mutex copyStreamLock;
     hipStream_t bvhSide[2] = {nullptr, nullptr};      // the BVH build's centre sums run on these behind each level's sort (created on first use; builds are serialised by buildLock)
     hipDeviceProp_t prop;
     // Builds (mesh preparation, BVH, octrees) on one context run one at a time: they share the stream-ordered allocator's scope and,

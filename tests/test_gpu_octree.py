@@ -715,8 +715,7 @@ def test_cooperative_fetch_kernel_on_ragged_batches(small, oracle):
 
 
 def _host_pointer_large_case(gm, box):
-    """Host arrays of 3 M points (beyond the pipeline's 32 MiB threshold): same bits as the device-resident path; misaligned views of larger
-    arrays (pinned pieces are page aligned, the caller's arrays need not be)."""
+    """Host arrays of 3 M points: same bits as the device-resident path; misaligned views of larger arrays."""
     import torch
     import sdflib_amd as S
     from sdflib_amd.meshgen import random_points_in_box
@@ -733,57 +732,24 @@ def _host_pointer_large_case(gm, box):
     assert np.array_equal(bits(d2), bits(d))
 
 
-def _host_pointer_pin_failure_case(gm, box):
-    """A later hipHostRegister piece is refused after part of the output was written (forced with SDFHIP_TEST_PIN_FAIL_AFTER): the rest
-    goes through the plain path.  23 M points = 276 MB of coordinates, above the 256 MB limit of the context's staging buffers, i.e. the
-    call does NOT hold the staging lock (round-2 advisor finding: unlocking it unconditionally threw std::system_error).  Only the
-    pipelined path reads the variable: on the default (plain) path this is a plain large-query check."""
+def _host_pointer_huge_case(gm, box):
+    """23 M points = 276 MB of coordinates, above the 256 MB limit of the context's staging buffers (the call does not hold the staging
+    lock and allocates its own buffers), and 3 M points (staged): same bits as the device-resident path."""
     import torch
     import sdflib_amd as S
     from sdflib_amd.meshgen import random_points_in_box
     gt = S.OctreeSdf(gm, box, 6, 3, 1e-3, num_threads=2)
-    for n in (23_000_000, 3_000_000):                     # without and with the staging lock
+    for n in (23_000_000, 3_000_000):
         pts = random_points_in_box(box, n, seed=29)
         want = gt.get_distance(torch.from_numpy(pts).cuda()).cpu().numpy()
-        for after in (3, 7):
-            os.environ["SDFHIP_TEST_PIN_FAIL_AFTER"] = str(after)
-            try:
-                d = gt.get_distance(pts)
-            finally:
-                os.environ.pop("SDFHIP_TEST_PIN_FAIL_AFTER", None)
-            assert np.array_equal(bits(d), bits(want)), (n, after)
+        d = gt.get_distance(pts)
+        assert np.array_equal(bits(d), bits(want)), n
 
 
 def test_large_host_pointer_queries_are_identical(small):
-    """The DEFAULT host-pointer path (plain copies through the context's buffers) on 3 M and 23 M points, misaligned views included."""
+    """The host-pointer path (plain copies through the context's buffers) on 3 M and 23 M points, misaligned views included."""
     _host_pointer_large_case(small["gm"], small["box"])
-    _host_pointer_pin_failure_case(small["gm"], small["box"])
-
-
-def _host_pipeline_child():
-    import sdflib_amd as S
-    from sdflib_amd.meshgen import bumpy_icosphere, box_with_margin
-    assert os.environ.get("SDFHIP_HOST_PIPELINE") == "1"
-    v, f = bumpy_icosphere(4)
-    gm = S.Mesh(v, f, S.default_context(0)); box = box_with_margin(v)
-    for _ in range(3):                                   # adjacent result arrays of successive calls are what was seen to fault
-        _host_pointer_large_case(gm, box)
-        _host_pointer_pin_failure_case(gm, box)
-    print("host pipeline ok")
-
-
-@pytest.mark.skipif(os.environ.get("SDFHIP_TEST_HOST_PIPELINE") != "1",
-                    reason="the pinned two-stream host pipeline is opt-in (SDFHIP_HOST_PIPELINE=1) and this test with it: with the pipeline in use the "
-                           "suite died with a GPU memory access fault (write to a read-only page of a freshly registered array) in 6 of 8 runs on the "
-                           "GPU box, cause not found (DESIGN.md section 5); set SDFHIP_TEST_HOST_PIPELINE=1 to run it in a child process")
-def test_pipelined_host_query_opt_in():
-    """The opt-in pipeline (pieces pinned in place, upload / evaluate / download overlapped) in a CHILD process, so that the GPU fault it has
-    been seen to end in fails this test instead of taking the suite down: same bits as the device-resident path, misaligned views, forced
-    registration failures finishing through the plain path."""
-    import subprocess, sys
-    code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._host_pipeline_child()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SDFHIP_HOST_PIPELINE="1"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "host pipeline ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    _host_pointer_huge_case(small["gm"], small["box"])
 
 
 def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
