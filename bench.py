@@ -227,7 +227,7 @@ def main():
     box = box_with_margin(v)
     ctx = S.Context(dev.index, use_torch_stream=True)
     mesh = S.Mesh(v, f, ctx)
-    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: planned once (rank 0, all cores), broadcast
+    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: every rank builds it on its own device (host planner: rank 0 + broadcast)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if world > 1:
@@ -755,7 +755,7 @@ def build_1m(ctx, rank, world, dev):
     t0 = time.perf_counter()
     mesh = S.Mesh(v, f, ctx)
     prep = time.perf_counter() - t0
-    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: planned once (rank 0, all cores), broadcast
+    bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: every rank builds it on its own device (host planner: rank 0 + broadcast)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -770,13 +770,25 @@ def build_1m(ctx, rank, world, dev):
     dt = time.perf_counter() - t0
     i = tree.info
     r = {"triangles": int(len(f)), "octree_build_s": round(dt, 4), "mesh_prep_s": round(prep, 4), "bvh_build_s": round(bvh_s, 4), "bvh_built_on": BVH_BUILT_ON,
-         "words": int(i.num_words), "leaves": int(i.num_leaves), **({"bvh_share_s": round(bvh_s, 4)} if world > 1 else {}), **_r4(binfo)}
+         "words": int(i.num_words), "leaves": int(i.num_leaves), **_r4(binfo)}
     tree.close()
     if world == 1:
         r["steady_state"] = end_to_end_build(ctx, v, f, box, 8, 3, dev)
         r["end_to_end_s"] = r["steady_state"]["end_to_end_s"]
     else:
-        r["end_to_end_s"] = round(prep + bvh_s + dt, 4)
+        # what north_star asks of the N-GPU build: seconds at N and where they go.  serial = what every rank repeats (mesh upload +
+        # TriangleData, the sphere BVH - built by every rank on its own device, or planned by rank 0 and broadcast under
+        # SDFHIP_BVH_BUILD=host); sharded = the slowest rank's shard of the start cells; exchange = sizes + all-gather-v + reductions
+        one_device = os.environ.get("SDFHIP_BENCH_ONE_DEVICE") == "1"
+        t = torch.tensor([prep, bvh_s, binfo.get("shard_build_s", 0.0), binfo.get("exchange_s", 0.0)], dtype=torch.float64, device=torch.device("cpu") if one_device else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        prep_m, bvh_m, shard_m, exch_m = (float(x) for x in t.tolist())
+        r["end_to_end_s"] = round(prep_m + bvh_m + dt, 4)
+        r["n_gpus"] = world
+        r["split"] = {"serial_s": round(prep_m + bvh_m, 4), "serial_mesh_prep_s": round(prep_m, 4), "serial_bvh_s": round(bvh_m, 4), "sharded_s": round(shard_m, 4),
+                      "exchange_s": round(exch_m, 4), "exchange_bytes_per_rank": int(binfo.get("exchange_bytes", 0)),
+                      "bvh": "every rank builds it on its own device" if BVH_BUILT_ON == "device" else "planned by rank 0, broadcast",
+                      "note": "max over ranks of every part; octree_build_s = sharded + exchange between two barriers"}
     return r
 
 

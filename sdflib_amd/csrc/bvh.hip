@@ -1710,7 +1710,7 @@ static uint32_t bvhOffloadMax() {
     return offload;
 }
 namespace sdfhip {
-static bool bvhBuildOnDevice() {
+bool bvhBuildOnDevice() {
     static const bool v = [] { const char* e = getenv("SDFHIP_BVH_BUILD"); return e == nullptr || strcmp(e, "host") != 0; }();      // the default; =host: the host planner
     return v;
 }

@@ -476,19 +476,244 @@ __global__ void __launch_bounds__(256) kc_pp_children(const OpDev* __restrict__ 
     }
 }
 
+// ---- post-pass, integer part ON THE DEVICE (round 4) ------------------------------------------------------------------------
+// The reference's post-pass (OctreeSdfBreadthFirstNoDelay.h:739-1181) is a serial loop: every scheduled leaf is subdivided by a local
+// breadth-first search that reads and appends to mOctreeData.  Two facts make it a decide -> scan -> write scheme:
+//  (1) WHAT a visited node does — split or stay a leaf — does not depend on the order in which the scheduled leaves are processed.  A
+//      node splits iff one of its neighbour look-ups lands on an inner node WITHOUT the mark bit, i.e. on a node subdivided by the
+//      regular iterations.  The post-pass itself only ever turns a leaf into a MARKED inner node and creates leaves / marked nodes
+//      below it: a word that is "leaf or marked" stays so for the rest of the build, a regular inner word never changes, and a
+//      neighbour walk that enters leaf-or-marked territory can only stay inside it and ends without a contribution whichever state
+//      it finds there.  So the walks are evaluated against the array as it was before the pass, every root by itself; a pointer that
+//      would lead into blocks the pass is about to create (the siblings of a node created by the pass) carries bit 30 — the
+//      reference's own "nothing there" marker, skipped by every look-up — instead of an index that does not exist yet;
+//  (2) WHERE things are allocated follows from the order alone: roots in list order (first occurrence of every still-leaf word),
+//      inside a root its nodes generation by generation in queue order; a split takes 8 words, a leaf 64 — except the first leaf
+//      of a root, which recycles the root's old coefficient block.  That is an exclusive scan over (root, generation, position).
+// Leaves are found through their coefficient block (a leaf word holds its index; blocks are allocated in units of 8 words after the
+// start grid, so (index - G^3) / 8 addresses a direct table): recOf[] = the level node or pool node owning the block.
+struct PPNode {
+    uint32_t path, pci, coord, depth;
+    uint32_t nIdx[6];
+    uint8_t nDepth[6]; uint8_t split, gen;
+    uint32_t srcLevel, srcSlot;       // level + slot of a level node, or NONE32 + pool slot
+    uint32_t root, parent;            // number of the root in this pass; index of the parent in the pass's node array (NONE32: a root)
+    uint32_t word;                    // roots: their node word
+    uint32_t samplesMask;
+    uint32_t oldCoeff;                // the coefficient block the root owned
+    uint32_t ignore;                  // a node finalised by an earlier post-pass (no Iter-1 data to recycle)
+    uint32_t childPool;               // splits: first of the 8 pool slots of the children
+};
+struct PoolRec { uint32_t path, pci, coord, depth; uint32_t nIdx[6]; uint8_t nDepth[6]; uint8_t pad[2]; };
+struct LevelInt { const uint8_t* path; const uint32_t* pci; const uint32_t* coord; const uint32_t* nIdx; const uint8_t* nDepth; };
+struct LevelIntTable { LevelInt lv[12]; };
+constexpr uint32_t PP_MAXGEN = 12;
+constexpr uint32_t REC_POOL = 1u << 31;
+
+SDF_DEV uint32_t coeffSlot(uint32_t leafWord, uint32_t G3) { return ((leafWord & INDEX_MASK) - G3) >> 3; }
+
+// level leaves own the blocks Iter 2 gave them
+__global__ void kc_register_leaves(CLevelDev L, uint32_t cd, uint32_t base, uint32_t G3, uint32_t* __restrict__ recOf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= L.n || L.inner[i]) return;
+    recOf[(base + L.allocOff[i] - G3) >> 3] = (cd << 27) | i;
+}
+__global__ void kpp_first(const uint32_t* __restrict__ clist, uint32_t n, const uint32_t* __restrict__ oc, uint32_t G3, uint32_t* __restrict__ firstOcc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = oc[clist[i]];
+    if (w & LEAF_BIT) atomicMin(&firstOcc[coeffSlot(w, G3)], i);
+}
+__global__ void kpp_rootflag(const uint32_t* __restrict__ clist, uint32_t n, const uint32_t* __restrict__ oc, uint32_t G3, const uint32_t* __restrict__ firstOcc, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t w = oc[clist[i]];
+    flag[i] = ((w & LEAF_BIT) && firstOcc[coeffSlot(w, G3)] == i) ? 1u : 0u;
+}
+__global__ void kpp_roots(const uint32_t* __restrict__ clist, uint32_t n, const uint32_t* __restrict__ oc, uint32_t G3, uint32_t* __restrict__ firstOcc, const uint32_t* __restrict__ flag,
+                          const uint32_t* __restrict__ scan, const uint32_t* __restrict__ recOf, LevelIntTable LI, const PoolRec* __restrict__ pool, PPNode* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint32_t W = clist[i], w = oc[W], slot = coeffSlot(w, G3);
+    firstOcc[slot] = NONE32;                    // the table is all ones again when the pass ends
+    const uint32_t ref = recOf[slot];
+    PPNode nd{};
+    if (ref & REC_POOL) {
+        const PoolRec r = pool[ref & ~REC_POOL];
+        nd.path = r.path; nd.pci = r.pci; nd.coord = r.coord; nd.depth = r.depth;
+        for (int k = 0; k < 6; k++) { nd.nIdx[k] = r.nIdx[k]; nd.nDepth[k] = r.nDepth[k]; }
+        nd.srcLevel = NONE32; nd.srcSlot = ref & ~REC_POOL; nd.ignore = 1u;
+    } else {
+        const uint32_t lvl = ref >> 27, s = ref & ((1u << 27) - 1u);
+        const LevelInt& l = LI.lv[lvl];
+        nd.path = l.path[s]; nd.pci = l.pci[s]; nd.coord = l.coord[s]; nd.depth = lvl;
+        for (int k = 0; k < 6; k++) { nd.nIdx[k] = l.nIdx[6 * (size_t)s + k]; nd.nDepth[k] = l.nDepth[6 * (size_t)s + k]; }
+        nd.srcLevel = lvl; nd.srcSlot = s; nd.ignore = 0u;
+    }
+    nd.root = scan[i]; nd.parent = NONE32; nd.word = W; nd.oldCoeff = w & INDEX_MASK; nd.gen = 0;
+    out[scan[i]] = nd;
+}
+// one node of the local searches: refresh its six outward pointers, collect the mid-points next to regularly subdivided
+// neighbours, decide (OctreeSdfBreadthFirstNoDelay.h:770-912; the planner's loop body above, reading the device array)
+__global__ void __launch_bounds__(128) kpp_decide(PPNode* __restrict__ nodes, uint32_t begin, uint32_t n, uint32_t cd, uint32_t startDepth, int G, MaskTable NM,
+                                                  const uint32_t* __restrict__ oc, uint32_t* __restrict__ splitFlag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    PPNode& nd = nodes[begin + i];
+    const bool first = nd.parent == NONE32;
+    const uint32_t depthN = nd.depth, c = nd.path & 7u, path = nd.path;
+    uint32_t nI[6]; uint32_t nD[6];
+    for (int k = 0; k < 6; k++) { nI[k] = nd.nIdx[k]; nD[k] = nd.nDepth[k]; }
+    auto leaf = [&](uint32_t at) { return (oc[at] & LEAF_BIT) != 0; };
+    auto leafish = [&](uint32_t at) { return (oc[at] & (LEAF_BIT | MARK_BIT)) != 0; };
+    uint32_t subdividedMask = 0;
+    if (depthN > startDepth) {
+        for (uint32_t nb = 1; nb <= 6; nb++) {
+            const uint32_t sign = ((((nb & c) >> 2) & 1u) << ((nb & 1u) | ((nb & 2u) >> 1))) + ((((nb & c) >> 1) & 1u) << (nb & 1u)) + (nb & c & 1u);
+            uint32_t ix = nI[nb - 1], dp = nD[nb - 1];
+            if (((ix >> 30) & 1u) != 0) continue;
+            if ((!first || (ix >> 31)) && leaf(ix & ~B31)) ix = B31 | ix;
+            else {
+                if (!first || (ix >> 31)) { ix = oc[ix & ~B31] & INDEX_MASK; dp++; }
+                while (dp < depthN && dp < cd) {
+                    const uint32_t dd = depthN - dp;
+                    const uint32_t cid = (3 * dd < 32) ? ((path >> (3 * dd)) & 7u) : 0u;
+                    ix += (nb ^ cid);
+                    if (leaf(ix & ~B31)) { ix = B31 | ix; break; }
+                    ix = oc[ix & ~B31] & INDEX_MASK; dp++;
+                }
+                if (cd >= depthN && !(ix >> 31)) subdividedMask |= leafish((ix & ~B31) + (nb ^ c)) ? 0u : NM.m[4 * (nb - 1) + sign];
+            }
+            nI[nb - 1] = ix; nD[nb - 1] = dp;
+        }
+    }
+    if (cd >= depthN) {
+        if (depthN > startDepth) {
+            const uint32_t nc = ~c;
+            auto upd = [&](uint32_t nid, uint32_t dir, uint32_t sign) {
+                const bool lf = (nid >> 31) || (nid >> 30) || leafish(nid + (dir ^ c));
+                subdividedMask |= lf ? 0u : NM.m[4 * (dir - 1) + sign];
+            };
+            // the six siblings: blocks created by the post-pass hold nothing but leaves and marked nodes
+            const uint32_t pci = first ? nd.pci : B30;
+            upd(pci, 1u, nc & 1u); upd(pci, 2u, (nc >> 1) & 1u); upd(pci, 4u, (nc >> 2) & 1u);
+            upd(pci, 3u, nc & 3u); upd(pci, 5u, ((nc >> 1) & 2u) + (nc & 1u)); upd(pci, 6u, (nc >> 1) & 3u);
+            upd(nI[0], 3u, 2u ^ (c & 3u)); upd(nI[0], 5u, ((nc >> 1) & 2u) + (c & 1u));
+            upd(nI[1], 3u, 1u ^ (c & 3u)); upd(nI[1], 6u, 2u ^ ((c >> 1) & 3u));
+            upd(nI[3], 5u, ((c >> 1) & 2u) + (nc & 1u)); upd(nI[3], 6u, 1u ^ ((c >> 1) & 3u));
+        } else if (depthN == startDepth) {
+            const int gx = (int)(nd.coord & 1023u), gy = (int)((nd.coord >> 10) & 1023u), gz = (int)(nd.coord >> 20);
+            forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) {
+                const int x = gx + dx, y = gy + dy, z = gz + dz;
+                if (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) subdividedMask |= leafish((uint32_t)(z * G * G + y * G + x)) ? 0u : NM.m[4 * (dir - 1) + sign];
+            });
+        }
+    }
+    const bool split = cd >= depthN && subdividedMask != 0u;
+    for (int k = 0; k < 6; k++) { nd.nIdx[k] = nI[k]; nd.nDepth[k] = (uint8_t)nD[k]; }
+    nd.samplesMask = ~subdividedMask; nd.split = split ? 1 : 0;
+    splitFlag[i] = split ? 1u : 0u;
+}
+// the eight children of every splitting node of a generation -> the next generation (queue order: parents in order, children 0..7)
+__global__ void kpp_expand(PPNode* __restrict__ nodes, uint32_t begin, uint32_t n, const uint32_t* __restrict__ splitFlag, const uint32_t* __restrict__ splitScan,
+                           uint32_t nextBegin, uint32_t poolBase, uint32_t startDepth, int G) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 3, ch = gid & 7u;
+    if (i >= n || !splitFlag[i]) return;
+    const PPNode& p = nodes[begin + i];
+    const uint32_t rank = splitScan[i], depthN = p.depth, c = p.path & 7u;
+    const uint32_t gx = p.coord & 1023u, gy = (p.coord >> 10) & 1023u, gz = p.coord >> 20;
+    PPNode k{};
+    k.path = (uint8_t)((p.path << 3) | ch); k.pci = NONE32; k.depth = depthN + 1;
+    k.coord = (2u * gx + (ch & 1u)) | ((2u * gy + ((ch >> 1) & 1u)) << 10) | ((2u * gz + (ch >> 2)) << 20);
+    uint32_t oN[6]; uint8_t oD[6];
+    if (depthN == startDepth) { neighboursInGrid(ch, (int)gx, (int)gy, (int)gz, G, oN); for (int q = 0; q < 6; q++) oD[q] = (uint8_t)depthN; }
+    else {
+        uint32_t pN[6]; uint8_t pD[6];
+        for (int q = 0; q < 6; q++) { pN[q] = p.nIdx[q]; pD[q] = p.nDepth[q]; }
+        // the parent's own block is real for a root; for a node the pass created it does not exist yet: "nothing there"
+        neighboursVector(ch, c, (p.parent == NONE32) ? p.pci : B30, depthN, pN, pD, oN, oD);
+    }
+    for (int q = 0; q < 6; q++) { k.nIdx[q] = oN[q]; k.nDepth[q] = oD[q]; }
+    k.srcLevel = NONE32; k.srcSlot = poolBase + 8u * rank + ch; k.root = p.root; k.parent = begin + i; k.oldCoeff = p.oldCoeff; k.gen = (uint8_t)(p.gen + 1);
+    nodes[nextBegin + 8u * rank + ch] = k;
+    if (ch == 0) nodes[begin + i].childPool = poolBase + 8u * rank;
+}
+__global__ void kpp_firstleaf(const PPNode* __restrict__ nodes, uint32_t N, uint32_t* __restrict__ firstLeaf) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N && !nodes[j].split) atomicMin(&firstLeaf[nodes[j].root], j);
+}
+__global__ void kpp_sizes(const PPNode* __restrict__ nodes, uint32_t N, const uint32_t* __restrict__ firstLeaf, uint32_t* __restrict__ size) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < N) size[j] = nodes[j].split ? 8u : (firstLeaf[nodes[j].root] == j ? 0u : 64u);
+}
+// segments (root, generation) are contiguous in the generation-major node array
+__global__ void kpp_bounds(const PPNode* __restrict__ nodes, uint32_t N, const uint32_t* __restrict__ size, const uint32_t* __restrict__ ex, uint32_t* __restrict__ segStart, uint32_t* __restrict__ segEnd) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t r = nodes[j].root, g = nodes[j].gen;
+    if (j == 0 || nodes[j - 1].root != r || nodes[j - 1].gen != g) segStart[PP_MAXGEN * (size_t)r + g] = ex[j];
+    if (j + 1 == N || nodes[j + 1].root != r || nodes[j + 1].gen != g) segEnd[PP_MAXGEN * (size_t)r + g] = ex[j] + size[j];
+}
+__global__ void kpp_roottot(uint32_t numRoots, const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segEnd, uint32_t* __restrict__ rootTot) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= numRoots) return;
+    uint32_t t = 0;
+    for (uint32_t g = 0; g < PP_MAXGEN; g++) t += segEnd[PP_MAXGEN * (size_t)r + g] - segStart[PP_MAXGEN * (size_t)r + g];
+    rootTot[r] = t;
+}
+__global__ void kpp_offsets(const PPNode* __restrict__ nodes, uint32_t N, const uint32_t* __restrict__ ex, const uint32_t* __restrict__ segStart, const uint32_t* __restrict__ segEnd,
+                            const uint32_t* __restrict__ rootBase, uint32_t* __restrict__ off) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t r = nodes[j].root, g = nodes[j].gen;
+    uint32_t o = rootBase[r];
+    for (uint32_t q = 0; q < g; q++) o += segEnd[PP_MAXGEN * (size_t)r + q] - segStart[PP_MAXGEN * (size_t)r + q];
+    off[j] = o + ex[j] - segStart[PP_MAXGEN * (size_t)r + g];
+}
+// node words, ownership of the coefficient blocks, the pool records of the new leaves, and the float part's op list
+__global__ void kpp_finalise(const PPNode* __restrict__ nodes, uint32_t N, const uint32_t* __restrict__ off, const uint32_t* __restrict__ firstLeaf, uint32_t base, uint32_t G3,
+                             uint32_t* __restrict__ oc, uint32_t* __restrict__ recOf, PoolRec* __restrict__ pool, OpDev* __restrict__ ops) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const PPNode nd = nodes[j];
+    const bool isRoot = nd.parent == NONE32;
+    const uint32_t at = base + off[j];
+    const uint32_t pci = isRoot ? nd.pci : base + off[nd.parent];
+    const uint32_t W = isRoot ? nd.word : pci + (nd.path & 7u);
+    OpDev op{}; op.srcLevel = nd.srcLevel; op.srcSlot = nd.srcSlot; op.scratch = j;
+    if (nd.split) {
+        oc[W] = (at & INDEX_MASK) | MARK_BIT;
+        op.kind = 0; op.samplesMask = nd.samplesMask; op.recycle = (isRoot && !nd.ignore) ? 1u : 0u; op.childPool = nd.childPool;
+    } else {
+        const uint32_t ci = (firstLeaf[nd.root] == j) ? nd.oldCoeff : at;
+        oc[W] = (ci & INDEX_MASK) | LEAF_BIT;
+        op.kind = 1; op.coeffIndex = ci;
+        if (nd.srcLevel == NONE32) {           // a pool node: it stays reachable for later post-passes with its refreshed pointers
+            PoolRec r{}; r.path = nd.path; r.pci = pci; r.coord = nd.coord; r.depth = nd.depth;
+            for (int k = 0; k < 6; k++) { r.nIdx[k] = nd.nIdx[k]; r.nDepth[k] = nd.nDepth[k]; }
+            pool[nd.srcSlot] = r;
+            recOf[(ci - G3) >> 3] = REC_POOL | nd.srcSlot;
+        }
+    }
+    ops[j] = op;
+}
+
 // final walk: leaf histogram + min border value (computeMinBorderValue, OctreeSdf.cpp:155-230).  Level-synchronous: one lane
-// per node of the current frontier; inner nodes append their 8 children to the next frontier.
+// per node of the current frontier; inner nodes append their 8 children to the next frontier.  Mark bits left by the post-pass are
+// cleared on the way (OctreeSdfBreadthFirstNoDelay.h:1191-1217: the reference's last step is such a walk).
 __global__ void kc_walk_init(int G, uint32_t* __restrict__ at, uint32_t* __restrict__ co) {
     const uint32_t cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= (uint32_t)(G * G * G)) return;
     at[cell] = cell; co[cell] = (cell % G) | (((cell / G) % G) << 10) | ((cell / (G * G)) << 20);
 }
-__global__ void kc_walk_level(const uint32_t* __restrict__ oc, const uint32_t* __restrict__ at, const uint32_t* __restrict__ coIn, uint32_t n, uint32_t d,
+__global__ void kc_walk_level(uint32_t* __restrict__ oc, const uint32_t* __restrict__ at, const uint32_t* __restrict__ coIn, uint32_t n, uint32_t d,
                               uint32_t* __restrict__ nextAt, uint32_t* __restrict__ nextCo, uint32_t* __restrict__ nextCount,
                               unsigned long long* __restrict__ leavesPerDepth, uint32_t* __restrict__ minBorderKey) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = i < n;
     const uint32_t w = valid ? oc[at[i]] : 0u;
+    if (w & MARK_BIT) oc[at[i]] = w & ~MARK_BIT;
     const uint32_t co = valid ? coIn[i] : 0u;
     const bool leaf = valid && (w & LEAF_BIT);
     const unsigned long long leafMask = __ballot(leaf);
@@ -670,14 +895,26 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<uint32_t> stats; SDF_TRY(stats.reserve(2));
     { const uint32_t init[2] = {0u, 0xFFFFFFFFu}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 8, hipMemcpyHostToDevice, st)); }
 
-    // the node array grows on the device; the host keeps a mirror of its node words for the post-pass planner
+    // The post-pass's integer part runs on the device (kpp_*); SDFHIP_CONT_POSTPASS=host keeps the serial planner of rounds 1-3,
+    // which replays the reference's loop on a host mirror of the node words.
+    const bool devicePP = !(getenv("SDFHIP_CONT_POSTPASS") && !strcmp(getenv("SDFHIP_CONT_POSTPASS"), "host"));
+    // the node array grows on the device (host planner: with a host mirror of its node words)
     DevBuf<uint32_t> oc; size_t ocCap = 0; uint32_t ocSize = G3;
+    DevBuf<uint32_t> recOf, firstOcc; size_t recCap = 0;      // per coefficient block: its owner / the first candidate naming it (device post-pass)
     auto ensureOc = [&](size_t need) -> int {
         if (need <= ocCap) return SDFHIP_OK;
         size_t cap = ocCap ? ocCap : (size_t)1 << 22;
         while (cap < need) cap *= 2;
         DevBuf<uint32_t> bigger; SDF_TRY(bigger.reserve(cap));
         if (oc.p) SDF_HIP_CHECK(hipMemcpyAsync(bigger.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
+        if (devicePP) {
+            const size_t rc = (cap - G3) / 8 + 1;
+            DevBuf<uint32_t> r2, f2; SDF_TRY(r2.reserve(rc)); SDF_TRY(f2.reserve(rc));
+            if (recCap) SDF_HIP_CHECK(hipMemcpyAsync(r2.p, recOf.p, 4ull * recCap, hipMemcpyDeviceToDevice, st));
+            SDF_HIP_CHECK(hipMemsetAsync(f2.p, 0xFF, 4ull * rc, st));
+            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            recOf = std::move(r2); firstOcc = std::move(f2); recCap = rc;
+        }
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         oc = std::move(bigger); ocCap = cap;
         return SDFHIP_OK;
@@ -685,24 +922,39 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SDF_TRY(ensureOc(G3));
     SDF_HIP_CHECK(hipMemsetAsync(oc.p, 0, 4ull * G3, st));
     Planner pl; pl.startDepth = startDepth; pl.G = G; pl.NM = makeMaskTable();
-    SDF_REQUIRE(pl.hoc.grow(G3), "out of host memory");
-    for (uint32_t i = 0; i < G3; i++) pl.hoc[i] = 0u;
+    if (!devicePP) {
+        SDF_REQUIRE(pl.hoc.grow(G3), "out of host memory");
+        for (uint32_t i = 0; i < G3; i++) pl.hoc[i] = 0u;
+    }
     // pool of post-pass nodes on the device
-    DevBuf<float> pCenter, pHalf, pVv; size_t poolCap = 0;
+    DevBuf<float> pCenter, pHalf, pVv; DevBuf<PoolRec> pRec; size_t poolCap = 0; uint32_t poolCount = 0;
     auto ensurePool = [&](size_t need) -> int {
         if (need <= poolCap) return SDFHIP_OK;
         size_t cap = poolCap ? poolCap : 4096;
         while (cap < need) cap *= 2;
-        DevBuf<float> c2, h2, v2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
+        DevBuf<float> c2, h2, v2; DevBuf<PoolRec> r2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
+        if (devicePP) SDF_TRY(r2.reserve(cap));
         if (poolCap) {
             SDF_HIP_CHECK(hipMemcpyAsync(c2.p, pCenter.p, 12 * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(h2.p, pHalf.p, 4 * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(v2.p, pVv.p, 256 * poolCap, hipMemcpyDeviceToDevice, st));
+            if (devicePP) SDF_HIP_CHECK(hipMemcpyAsync(r2.p, pRec.p, sizeof(PoolRec) * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipStreamSynchronize(st));
         }
-        pCenter = std::move(c2); pHalf = std::move(h2); pVv = std::move(v2); poolCap = cap;
+        pCenter = std::move(c2); pHalf = std::move(h2); pVv = std::move(v2); pRec = std::move(r2); poolCap = cap;
         return SDFHIP_OK;
     };
+    DevBuf<PPNode> ppNodesBuf; size_t ppNodesCap = 0;
+    auto ensureNodes = [&](size_t have, size_t need) -> int {
+        if (need <= ppNodesCap) return SDFHIP_OK;
+        size_t cap = ppNodesCap ? ppNodesCap : 4096;
+        while (cap < need) cap *= 2;
+        DevBuf<PPNode> b2; SDF_TRY(b2.reserve(cap));
+        if (have) { SDF_HIP_CHECK(hipMemcpyAsync(b2.p, ppNodesBuf.p, sizeof(PPNode) * have, hipMemcpyDeviceToDevice, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); }
+        ppNodesBuf = std::move(b2); ppNodesCap = cap;
+        return SDFHIP_OK;
+    };
+    DevBuf<uint32_t> ppFlag, ppScan, ppSplitFlag, ppSplitScan, ppFirstLeaf, ppSize, ppEx, ppOff, ppSegStart, ppSegEnd, ppRootTot, ppRootBase;
 
     std::vector<std::unique_ptr<CLevelHost>> LV(maxDepth + 1);
     {   // root level
@@ -780,6 +1032,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         const uint32_t base = ocSize;
         SDF_TRY(ensureOc((size_t)ocSize + allocTotal));
         kc_iter2_write<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, cd, startDepth, base, oc.p, stats.p);
+        if (devicePP && cd >= startDepth) kc_register_leaves<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, base, G3, recOf.p);
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->inner.p, L->childSlot.p, n));
         uint32_t numInner = 0; SDF_TRY(lastPlus(st, L->childSlot.p, L->inner.p, n, numInner));
         kc_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childSlot.p);
@@ -802,11 +1055,12 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         if (numCand) {
             SDF_TRY(clist.reserve(numCand));
             kc_compact_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, cflag.p, cscan.p, 24 * n, clist.p);
-            SDF_HIP_CHECK(hipMemcpyAsync(toSubdivide.data(), clist.p, 4ull * numCand, hipMemcpyDeviceToHost, st));
+            if (!devicePP) SDF_HIP_CHECK(hipMemcpyAsync(toSubdivide.data(), clist.p, 4ull * numCand, hipMemcpyDeviceToHost, st));
         }
         SDF_HIP_CHECK(hipGetLastError());
         ocSize += allocTotal;
         SDF_HIP_CHECK(hipStreamSynchronize(st)); lap(tIter);
+        if (!devicePP) {
         // ---------------- mirrors for the planner: integer node state of this level + the words written so far
         L->hCoord.resize(n); L->hPci.resize(n); L->hNIdx.resize(6ull * n); L->hWord.resize(n); L->hPath.resize(n); L->hNDepth.resize(6ull * n); L->hTerminal.resize(n);
         SDF_HIP_CHECK(hipMemcpyAsync(L->hCoord.data(), L->coord.p, 4ull * n, hipMemcpyDeviceToHost, st));
@@ -830,6 +1084,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         if (cd >= startDepth) for (uint32_t i = 0; i < n; i++) if (L->hWord[i] != NONE32) pl.hoc[L->hWord[i]] = hWordVals[i];
         lap(tMirror);
+        }
         // The exact samples of the NEXT level depend only on its node centres, not on the post-pass below: enqueue them now so
         // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).
         if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0 && !LV[cd + 1]->sampled) {
@@ -839,6 +1094,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_TRY(sampleBatchBegin(st, md, B, SS, stackBytes, T->info.num_traversals));      // ended at the top of the next iteration
             N->sampled = true;
         }
+        if (!devicePP) {
         pl.leaves.reserveFor(n);                     // sized once for the level; the slots of the entries sixteen ahead are prefetched
         for (uint32_t i = 0; i < n; i++) {
             if (i + 16 < n) pl.leaves.prefetch(L->hWord[i + 16]);
@@ -846,9 +1102,62 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             if (leaf) pl.leaves.emplace(L->hWord[i], LeafRef{cd, i});
         }
         lap(tLeafMap);
+        }
         numRescheduled += numCand;
         if (numCand == 0) continue;
 
+        std::vector<size_t> gBegin; uint32_t na = 0;      // the pass's op list on the device (dops): generation g = [gBegin[g], gBegin[g + 1])
+        if (devicePP) {
+            // ---------------- post-pass, integer part on the device: roots -> generations (decide, expand) -> allocation scan -> words + ops
+            SDF_TRY(ppFlag.reserve(numCand)); SDF_TRY(ppScan.reserve(numCand));
+            kpp_first<<<gridFor(numCand, 256), 256, 0, st>>>(clist.p, numCand, oc.p, G3, firstOcc.p);
+            kpp_rootflag<<<gridFor(numCand, 256), 256, 0, st>>>(clist.p, numCand, oc.p, G3, firstOcc.p, ppFlag.p);
+            SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, ppFlag.p, ppScan.p, numCand));
+            uint32_t numRoots = 0; SDF_TRY(lastPlus(st, ppScan.p, ppFlag.p, numCand, numRoots));
+            if (numRoots == 0) { lap(tPlan); continue; }
+            ppRoots += numRoots;
+            LevelIntTable LI{};
+            for (uint32_t d = 0; d <= maxDepth && d < 12; d++) if (LV[d]) LI.lv[d] = LevelInt{LV[d]->path.p, LV[d]->pci.p, LV[d]->coord.p, LV[d]->nIdx.p, LV[d]->nDepth.p};
+            SDF_TRY(ensureNodes(0, std::max<size_t>(4096, 16ull * numRoots)));
+            kpp_roots<<<gridFor(numCand, 256), 256, 0, st>>>(clist.p, numCand, oc.p, G3, firstOcc.p, ppFlag.p, ppScan.p, recOf.p, LI, pRec.p, ppNodesBuf.p);
+            uint32_t count = numRoots, N = numRoots, passSplits = 0;
+            gBegin.push_back(0);
+            for (uint32_t g = 0;; g++) {
+                SDF_REQUIRE(g < PP_MAXGEN, "internal: post-pass search deeper than the octree");
+                SDF_TRY(ppSplitFlag.reserve(count)); SDF_TRY(ppSplitScan.reserve(count));
+                kpp_decide<<<gridFor(count, 128), 128, 0, st>>>(ppNodesBuf.p, (uint32_t)gBegin[g], count, cd, startDepth, G, pl.NM, oc.p, ppSplitFlag.p);
+                SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, ppSplitFlag.p, ppSplitScan.p, count));
+                uint32_t ns = 0; SDF_TRY(lastPlus(st, ppSplitScan.p, ppSplitFlag.p, count, ns));
+                gBegin.push_back(N);
+                if (ns == 0) break;
+                SDF_REQUIRE((uint64_t)N + 8ull * ns < (1ull << 31), "post-pass too large");
+                SDF_TRY(ensureNodes(N, (size_t)N + 8ull * ns));
+                kpp_expand<<<gridFor(8ull * count, 256), 256, 0, st>>>(ppNodesBuf.p, (uint32_t)gBegin[g], count, ppSplitFlag.p, ppSplitScan.p, N, poolCount + 8u * passSplits, startDepth, G);
+                passSplits += ns; count = 8u * ns; N += count;
+            }
+            ppNodes += N; ppSplits += passSplits;
+            SDF_TRY(ppFirstLeaf.reserve(numRoots)); SDF_TRY(ppSegStart.reserve((size_t)PP_MAXGEN * numRoots)); SDF_TRY(ppSegEnd.reserve((size_t)PP_MAXGEN * numRoots));
+            SDF_TRY(ppRootTot.reserve(numRoots)); SDF_TRY(ppRootBase.reserve(numRoots)); SDF_TRY(ppSize.reserve(N)); SDF_TRY(ppEx.reserve(N)); SDF_TRY(ppOff.reserve(N));
+            SDF_HIP_CHECK(hipMemsetAsync(ppFirstLeaf.p, 0xFF, 4ull * numRoots, st));
+            SDF_HIP_CHECK(hipMemsetAsync(ppSegStart.p, 0, 4ull * PP_MAXGEN * numRoots, st));
+            SDF_HIP_CHECK(hipMemsetAsync(ppSegEnd.p, 0, 4ull * PP_MAXGEN * numRoots, st));
+            kpp_firstleaf<<<gridFor(N, 256), 256, 0, st>>>(ppNodesBuf.p, N, ppFirstLeaf.p);
+            kpp_sizes<<<gridFor(N, 256), 256, 0, st>>>(ppNodesBuf.p, N, ppFirstLeaf.p, ppSize.p);
+            SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, ppSize.p, ppEx.p, N));
+            kpp_bounds<<<gridFor(N, 256), 256, 0, st>>>(ppNodesBuf.p, N, ppSize.p, ppEx.p, ppSegStart.p, ppSegEnd.p);
+            kpp_roottot<<<gridFor(numRoots, 256), 256, 0, st>>>(numRoots, ppSegStart.p, ppSegEnd.p, ppRootTot.p);
+            SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, ppRootTot.p, ppRootBase.p, numRoots));
+            uint32_t passAlloc = 0; SDF_TRY(lastPlus(st, ppRootBase.p, ppRootTot.p, numRoots, passAlloc));
+            kpp_offsets<<<gridFor(N, 256), 256, 0, st>>>(ppNodesBuf.p, N, ppEx.p, ppSegStart.p, ppSegEnd.p, ppRootBase.p, ppOff.p);
+            SDF_REQUIRE((uint64_t)ocSize + passAlloc < (uint64_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
+            SDF_TRY(ensureOc((size_t)ocSize + passAlloc));
+            SDF_TRY(ensurePool((size_t)poolCount + 8ull * passSplits));
+            SDF_TRY(dops.reserve(N)); SDF_TRY(scratch.reserve(216ull * N));
+            kpp_finalise<<<gridFor(N, 256), 256, 0, st>>>(ppNodesBuf.p, N, ppOff.p, ppFirstLeaf.p, ocSize, G3, oc.p, recOf.p, pRec.p, dops.p);
+            SDF_HIP_CHECK(hipGetLastError());
+            ocSize += passAlloc; poolCount += 8u * passSplits; na = N;
+            lap(tPlan);
+        } else {
         // ---------------- post-pass, integer part on the host
         const uint32_t sizeBefore = ocSize;
         pl.patches.clear();
@@ -1023,23 +1332,28 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_HIP_CHECK(hipStreamSynchronize(st));
         }
         SDF_TRY(ensurePool(pl.pool.size()));
+            // all generations' ops in one array (scratch slot = global index)
+            std::vector<OpDev> all;
+            for (size_t g = 0; g < gens.size(); g++) { gBegin.push_back(all.size()); for (const OpDev& op : gens[g]) { all.push_back(op); all.back().scratch = (uint32_t)(all.size() - 1); } }
+            gBegin.push_back(all.size());
+            na = (uint32_t)all.size();
+            if (na) {
+                SDF_TRY(dops.reserve(all.size())); SDF_TRY(scratch.reserve(216 * all.size()));
+                SDF_HIP_CHECK(hipMemcpyAsync(dops.p, all.data(), sizeof(OpDev) * all.size(), hipMemcpyHostToDevice, st));
+                SDF_HIP_CHECK(hipStreamSynchronize(st));      // `all` goes out of scope
+            }
+        }
         LevelTable LT{};
         for (uint32_t d = 0; d <= maxDepth && d < 12; d++) if (LV[d]) LT.lv[d] = LevelPtrs{LV[d]->center.p, LV[d]->vv.p, LV[d]->coeff.p, LV[d]->mid.p, LV[d]->half};
         PoolDev PD{pCenter.p, pHalf.p, pVv.p};
         {
-            // all generations' ops in one array (scratch slot = global index); geometry first, then ONE launch for every exact
-            // sample of the post-pass, then fit / mid-point / children values generation by generation — no host round trip between
-            std::vector<OpDev> all; std::vector<size_t> gBegin;
-            for (size_t g = 0; g < gens.size(); g++) { gBegin.push_back(all.size()); for (const OpDev& op : gens[g]) { all.push_back(op); all.back().scratch = (uint32_t)(all.size() - 1); } }
-            gBegin.push_back(all.size());
-            if (!all.empty()) {
-                SDF_TRY(dops.reserve(all.size())); SDF_TRY(scratch.reserve(216 * all.size()));
-                SDF_HIP_CHECK(hipMemcpyAsync(dops.p, all.data(), sizeof(OpDev) * all.size(), hipMemcpyHostToDevice, st));
+            // geometry first, then ONE launch for every exact sample of the post-pass, then fit / mid-point / children values
+            // generation by generation — no host round trip between
+            if (na) {
                 for (size_t g = 0; g + 1 < gBegin.size(); g++) {
                     const uint32_t no = (uint32_t)(gBegin[g + 1] - gBegin[g]);
                     if (no) kc_pp_geom<<<gridFor(8ull * no, 256), 256, 0, st>>>(dops.p + gBegin[g], no, LT, PD, pCenter.p, pHalf.p);
                 }
-                const uint32_t na = (uint32_t)all.size();
                 if (nearestExactOnly()) kc_pp_sample_all<<<gridFor(19ull * na, 128), 128, stackBytes, st>>>(md, dops.p, na, LT, PD, scratch.p);
                 else {
                     SDF_TRY(ppPos.reserve(57ull * na)); SDF_TRY(ppSlot.reserve(19ull * na)); SDF_TRY(ppTri.reserve(19ull * na)); SDF_TRY(ppCount.reserve(1));
@@ -1064,7 +1378,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     T->info.num_samples += 19ull * no;
                 }
                 SDF_HIP_CHECK(hipGetLastError());
-                SDF_HIP_CHECK(hipStreamSynchronize(st));      // `all` goes out of scope
+                if (!devicePP) SDF_HIP_CHECK(hipStreamSynchronize(st));
             }
         }
         lap(tOps);

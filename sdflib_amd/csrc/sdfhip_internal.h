@@ -391,4 +391,5 @@ namespace sdfhip { void startEarlyBvhPlan(sdfhip_mesh* mesh); }      // bvh.hip:
 
 
 int sdfhip_mesh_ensure_bvh(sdfhip_mesh* mesh);
+namespace sdfhip { bool bvhBuildOnDevice(); }      // bvh.hip: the tree is built by the device builder (default) rather than planned on the host
 namespace sdfhip { int packFrames(hipStream_t st, const float* td, uint32_t numTriangles, float* frames); }

@@ -12,6 +12,7 @@ Every rank ends with the full, identical array (queries are then embarrassingly 
 The partition / assembly logic is backend-agnostic torch code so that it is covered by world_size-2 gloo tests.
 """
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -150,11 +151,23 @@ def build_octree_sharded(mesh, box, depth, start_depth, max_error, rank, world, 
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The sphere BVH is planned on the host and wants all its cores: planned by every rank at the same time on one node it takes
-# several times longer than planned once.  Rank `src` plans, the two arrays (72 + 8 B per triangle) are broadcast, the others import.
+# The sphere BVH.  Built on the device (the default since round 3: 7 ms at 327 680 triangles, 16 ms at 1.31 M) every rank builds its
+# own — the builder reproduces the reference's tree bit for bit, so the ranks agree without talking, and a broadcast of the two
+# arrays (80 B per triangle: 105 MB at 1.31 M) would only add a serial step.  The HOST planner (SDFHIP_BVH_BUILD=host) wants all
+# the cores of the node: planned by every rank at the same time it takes several times longer than planned once, so there rank `src`
+# plans, the arrays are broadcast and the others import them.
+
+def bvh_built_on_device():
+    return os.environ.get("SDFHIP_BVH_BUILD") != "host"
+
 
 def share_bvh(mesh, rank, world, dev, group=None, src=0):
-    """Collective.  Returns the seconds this rank spent (planning on `src`, waiting + import elsewhere)."""
+    """Collective under SDFHIP_BVH_BUILD=host (plan on `src`, broadcast, import); a local device build otherwise.  Returns the seconds
+    this rank spent."""
+    if bvh_built_on_device():
+        t0 = time.perf_counter()
+        mesh.build_bvh()
+        return time.perf_counter() - t0
     t0 = time.perf_counter()
     n = max(len(mesh.indices) - 1, 1)
     cdev = _collective_device(dev, group)

@@ -15,8 +15,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, host_bvh=False):
     try:
+        if host_bvh:
+            os.environ["SDFHIP_BVH_BUILD"] = "host"      # before the library is loaded: rank 0 plans, the arrays are broadcast
         os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         sys.path.insert(0, ROOT)
@@ -29,7 +31,8 @@ def _worker(rank, world, port, q):
         v, f = bumpy_icosphere(4)
         box = box_with_margin(v)
         mesh = S.Mesh(v, f, ctx)
-        sdist.share_bvh(mesh, rank, world, dev)                      # planned by rank 0, broadcast, imported by the others
+        sdist.share_bvh(mesh, rank, world, dev)                      # built by every rank on the device; host planner: rank 0 plans, broadcast, import
+        assert sdist.bvh_built_on_device() == (not host_bvh)
         assert mesh.build_bvh() == 0.0
         ref_mesh = S.Mesh(v, f, ctx)                                 # plans its own
         probe = ((np.random.default_rng(5).random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
@@ -68,12 +71,12 @@ def _worker(rank, world, port, q):
         raise
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_builds_with_several_ranks_on_one_gpu(world):
+@pytest.mark.parametrize("world,host_bvh", [(2, False), (3, False), (2, True)])
+def test_sharded_builds_with_several_ranks_on_one_gpu(world, host_bvh):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 32500 + (os.getpid() % 2000) + world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 32500 + (os.getpid() % 2000) + world + (10 if host_bvh else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, host_bvh)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(world)]
@@ -94,7 +97,7 @@ def test_bench_two_ranks_on_one_gpu(launcher):
         env.pop(k, None)
     head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(33500 + os.getpid() % 2000)]
     cmd = (head if launcher == "torchrun" else [sys.executable]) + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--subdiv", "5", "--depth", "6", "--queries", "1000000",
-           "--no-cpu-baseline", "--no-build-1m"]
+           "--no-cpu-baseline", "--no-build-1m" if launcher == "torchrun" else "--no-extras"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -104,5 +107,12 @@ def test_bench_two_ranks_on_one_gpu(launcher):
     assert abs(d["value"] - 2 * d["per_gpu_mqueries_s"]) < 1e-6 * d["value"] + 0.02
     assert d["roofline"]["frac"] > 0 and d["build"]["exchange_s"] >= 0
     assert d["collectives"]["ranks_seen"] == 2 and d["collectives"]["rank_sum_ok"] and d["collectives"]["octree_bytes_all_gathered_per_rank"] > 0
-    c = d["extras"]["continuity_octree"]
-    assert c["ranks_sharing_traversals"] == 2 and c["exchange_bytes"] > 0 and c["words"] > 0
+    if launcher == "torchrun":
+        c = d["extras"]["continuity_octree"]
+        assert c["ranks_sharing_traversals"] == 2 and c["exchange_bytes"] > 0 and c["words"] > 0
+    else:       # the 1.31 M-triangle build at N = 2 with the split north_star asks for: serial / sharded / exchange
+        b = d["build_1m"]
+        assert b["n_gpus"] == 2 and b["triangles"] == 1310720 and b["words"] == 20058064
+        sp = b["split"]
+        assert sp["serial_s"] > 0 and sp["sharded_s"] > 0 and sp["exchange_s"] >= 0 and sp["exchange_bytes_per_rank"] == 4 * b["words"]
+        assert b["end_to_end_s"] >= sp["serial_s"] + sp["sharded_s"]
