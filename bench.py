@@ -123,7 +123,19 @@ class Profile:
         sq = self.sq_row(kernel, n_threads)
         if sq and sq.get("SQ_THREAD_CYCLES_VALU_avg_per_dispatch"):
             out["valu_lanes_active"] = round(float(sq["SQ_THREAD_CYCLES_VALU_avg_per_dispatch"]) / (64.0 * float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"])), 3)
+        out.update(self.valu_issue(kernel, n_threads))
         return out
+
+    def valu_issue(self, kernel, n_threads=0):
+        """Share of the chip's VALU issue slots the kernel filled: SQ_ACTIVE_INST_VALU counts quad-cycles of vector-ALU execution (a wave64
+        instruction occupies its 16-lane SIMD for four cycles), so busy = 4 x counter / (dispatch time x 2.4 GHz x 1024 SIMDs), with the
+        dispatch time of the SAME profile.  This — not the 157 TFLOP/s sheet figure, which needs packed FMAs — is the ceiling of the kernels
+        that must reproduce the reference's separate fp32 multiplies and adds (-ffp-contract=off): 39.3 T lane-operations/s."""
+        sq, st = self.sq_row(kernel, n_threads), self.stats_row(kernel, n_threads)
+        if not (sq and st and float(st["avg_ns"]) > 0):
+            return {}
+        busy = 4.0 * float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"]) / (float(st["avg_ns"]) * 1e-9 * GPU_CLOCK_HZ * GPU_SIMDS)
+        return {"valu_issue_frac": round(busy, 3), "valu_issue_basis": f"4 x SQ_ACTIVE_INST_VALU / (profiled dispatch {float(st['avg_ns']) / 1e6:.3f} ms x {GPU_CLOCK_HZ / 1e9:.1f} GHz x {GPU_SIMDS} SIMDs)"}
 
 
 def roofline_block(kernel, kernel_ms, algorithmic_bytes, compulsory_bytes, tr):
@@ -328,6 +340,7 @@ def main():
 NEAR_KERNEL = "sdfhip::k_near_quads<256>"
 KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip"]
 FP32_VECTOR_PEAK_TFLOPS = 157.3
+GPU_CLOCK_HZ, GPU_SIMDS = 2.4e9, 1024          # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 
 
 def build_roofline(info, build_s, nv, nt, prof):
@@ -367,6 +380,7 @@ def build_roofline(info, build_s, nv, nt, prof):
             r["l2_hit"] = round(hit / (hit + miss), 4) if hit + miss > 0 else None
         if st:
             r["profile_avg_dispatch_ms"] = round(float(st["avg_ns"]) / 1e6, 3)
+        r.update(prof.valu_issue(NEAR_KERNEL))
         r["profile"] = prof.prefix
     return r
 
@@ -600,15 +614,19 @@ def exact_query_roofline(ex, pts, ms, prof, sample=20000):
     # compulsory: the streams + every array of the structure once (nodes, packed sets, byte masks, the packed 80-B triangle frames)
     compulsory = 16 * n + nodes.nbytes + sets.nbytes + masks.nbytes + 80 * int(i.num_triangles if hasattr(i, "num_triangles") else 0)
     r = roofline_block(EXACT_KERNEL, ms, bytes_q * n, compulsory, prof.traffic("exact_query", EXACT_KERNEL, 0))
-    r["kernel_ms_note"] = "locate + radix sort by leaf + the sorted kernel, HIP events around the whole call; traffic is the sorted kernel's"
+    r["kernel_ms_note"] = "locate + radix sort by leaf + the sorted kernel (k_exact_lists since round 4: decoded leaf lists, pipelined tiles), HIP events around the whole call; traffic and VALU figures are the sorted kernel's"
+    st = prof.stats_row(EXACT_KERNEL, 0) if not prof.stale("exact_query") else None
+    if st:
+        r["sorted_kernel_ms_profiled"] = round(float(st["avg_ns"]) / 1e6, 3); r["locate_and_sort_ms"] = round(ms - float(st["avg_ns"]) / 1e6, 3)
+    r["bound_regime"] = "VALU issue (valu_issue_frac): the kernel reproduces the reference's separate fp32 multiplies and adds, no FMA contraction"
     r.update({"mean_k": round(mean_k, 1), "max_k_sampled": int(ks.max()), "bytes_per_query_8d": round(bytes_q, 1),
-              "pair_evaluations_per_s": round(mean_k * n / (ms * 1e-3) / 1e9, 1), "tflop_s": round(flops / 1e12, 2), "fp32_vector_frac": round(flops / 157.3e12, 4),
+              "pair_evaluations_per_s": round(mean_k * n / (ms * 1e-3) / 1e9, 1), "tflop_s": round(flops / 1e12, 2), "fp32_vector_frac": round(flops / 157.3e12, 4), "lane_ops_peak_no_fma_tops": round(GPU_CLOCK_HZ * GPU_SIMDS * 16 / 1e12, 1),
               "note": "8(d) bytes are per query (k x 148 B of TriangleData each); a leaf's triangles are staged once per tile for all its queries, so the traffic that moves is "
                       "far below that figure and `achieved` counts the moved bytes only; the kernel is bound by its k distance evaluations per query (tflop_s, valu_lanes_active), not by bytes"})
     return r
 
 
-EXACT_KERNEL = "sdfhip::k_exact_tiles<false>"
+EXACT_KERNEL = "sdfhip::k_exact_lists<false>"
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 
 

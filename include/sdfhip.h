@@ -295,6 +295,10 @@ int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
 int sdfhip_exact_download(sdfhip_exact* tree, uint32_t* nodes, uint8_t* node_has_tri_idx, uint32_t* sets, uint8_t* masks);
 /* the TriangleData array the tree queries against (ExactOctreeSdf::getTrianglesData, ExactOctreeSdf.h:132); 37 floats each */
 int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host);
+/* ExactOctreeSdf::getDistance x2 (src/sdf/ExactOctreeSdf.cpp:38-320), batched.  The first batch of 16 384 points or more makes the tree's query
+ * tables (once, 1.4 ms at C3): per node a query can end in, its set / mask offsets and the DECODED list of the triangles that survive the
+ * two mask levels (4 bytes per surviving entry — 0.23 GB at C3, beside 63 MB of nodes / sets / masks).  Trees whose lists would exceed
+ * SDFHIP_EXACT_LISTS_MB (default 4096) decode per batch instead (SDFHIP_EXACT_QUERY=decode forces that path).  Same results either way. */
 int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad /* nullable */,
                        uint32_t* out_triangle /* nullable */, int where);
 

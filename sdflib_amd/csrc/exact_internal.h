@@ -43,6 +43,9 @@ struct sdfhip_exact {
     // per node that a query can end in: {set index, first mask offset, second mask offset, entries of the set} — what the walk from the
     // start grid finds on its way (exact_query.hip, ensureLeafCtx): made once, on the first batched query, 16 bytes per node
     sdfhip::DevBuf<uint32_t> leafCtx; bool leafCtxReady = false; std::mutex leafCtxLock;
+    // the survivors of every such node's set, decoded once (exact_query.hip, ensureLeafLists): triangle ids in list order, and per node
+    // {offset, count}; listsState: 0 = not made yet, 1 = ready, 2 = not kept (larger than SDFHIP_EXACT_LISTS_MB: the decoding kernel answers)
+    sdfhip::DevBuf<uint32_t> leafLists, leafList; int listsState = 0; uint64_t listEntries = 0;
     sdfhip::DevBuf<uint32_t> nodes;        // 2 words per node
     sdfhip::DevBuf<uint8_t> hasTri;
     sdfhip::DevBuf<uint32_t> sets;

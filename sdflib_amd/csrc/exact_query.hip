@@ -9,6 +9,8 @@
 #include "exact_internal.h"
 #include <hipcub/hipcub.hpp>
 #include <memory>
+#include <cstring>
+#include <cstdlib>
 
 namespace sdfhip {
 
@@ -118,6 +120,8 @@ static int ensureHostCopy(sdfhip_exact* T) {
 // distinct leaf in them the wave decodes the leaf's triangle list ONCE and all of the leaf's queries share the staged triangles.
 constexpr uint32_t QNONE = 0xFFFFFFFFu;
 
+// (A one-pass counting sort on the node id — rank = old value of a per-node counter, position = rank + scan — was built and measured in
+// round 4: 10 M returning atomics cost 0.33 ms and the scattered 4-byte writes 0.38 ms against 0.30 ms for the three radix passes; dropped.)
 __global__ void __launch_bounds__(256) k_exact_locate(ExactView v, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad,
                                                       uint32_t* __restrict__ tri, uint32_t* __restrict__ key, uint32_t* __restrict__ qidx) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -366,6 +370,212 @@ __global__ void __launch_bounds__(64) k_exact_tiles(ExactView v, const float* __
     }
 }
 
+// ---- decoded leaf lists + k_exact_lists (round 4) -------------------------------------------------------------------------------------
+// k_exact_tiles spends a quarter of its time decoding — the same packed set through the same two masks for every wave that meets the
+// leaf — and, measured per wave, most of the rest WAITING: a decode round and every 64-frame tile is a dependent memory round trip with
+// nothing issued behind it (VALU busy a third of a wave's lifetime).  So the survivors of every node a query can end in are decoded ONCE
+// per tree into one array of triangle ids (`leafLists`, node -> {offset, count} in `leafList`; made by the first batched query like
+// leafCtx; 4 B per surviving entry: 2.3 x 10^8 B at C3) and the query kernel becomes a flat software pipeline over the tiles of all
+// runs of a wave: while tile t is evaluated out of LDS the 80-byte frames of tile t + 1 are in flight to registers and the ids of tile
+// t + 2 behind them.  Same comparisons in the same list order as k_exact_tiles, i.e. the reference's `d < best` scan: same bits.
+// Trees whose lists would exceed SDFHIP_EXACT_LISTS_MB (default 4096) keep the decoding kernel.
+template <bool WRITE>
+__global__ void __launch_bounds__(64) k_exact_leaf_lists(ExactView v, const uint4* __restrict__ leafCtx, uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+                                                        uint32_t* __restrict__ lists) {
+    __shared__ uint32_t s_words[64 * EX_WORDS];
+    __shared__ uint32_t s_ids[EX_IDS];
+    const int lane = threadIdx.x;
+    const uint32_t node = blockIdx.x;
+    const uint4 ctx = leafCtx[node];
+    if (ctx.x == QNONE) { if (!WRITE && lane == 0) counts[node] = 0u; return; }
+    const uint32_t setIdx = ctx.x, m1i = ctx.y, m2i = ctx.z, cnt = ctx.w;
+    const bool m1 = m1i != QNONE, m2 = m2i != QNONE;
+    const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint64_t outBase = WRITE ? offsets[node] : 0ull;
+    uint32_t base = 0, r1 = 0, total = 0;
+    while (base < cnt) {
+        // one round of k_exact_tiles' decode: the same loads, ranks and unpacking
+        uint32_t nIds = 0;
+        const uint32_t left = cnt - base;
+        const uint32_t nch = (left + 63u) / 64u < (uint32_t)EX_BATCH ? (left + 63u) / 64u : (uint32_t)EX_BATCH;
+        const uint32_t endEntry = (base + 64u * nch < cnt) ? base + 64u * nch : cnt;
+        const uint32_t firstWord = (base * v.bits) >> 5;
+        const uint32_t nWords = ((endEntry * v.bits + 31u) >> 5) + 1u - firstWord;
+        const uint32_t r1start = r1;
+        uint32_t B1 = 0xFFu, B2 = 0xFFFFu;
+        if (m1) { const uint64_t at = (uint64_t)m1i + (base >> 3) + (uint32_t)lane; B1 = v.masks[at < v.maskBytes ? at : v.maskBytes]; }
+        if (m2) {
+            const uint64_t at = (uint64_t)m2i + (r1start >> 3) + (uint32_t)lane;
+            B2 = (uint32_t)v.masks[at < v.maskBytes ? at : v.maskBytes] | ((uint32_t)v.masks[at + 1 < v.maskBytes ? at + 1 : v.maskBytes] << 8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+        for (int j = 0; j < EX_WORDS; j++) {
+            const uint64_t at = (uint64_t)setIdx + 1u + firstWord + 64u * j + (uint32_t)lane;
+            if (64u * j < nWords) s_words[64 * j + lane] = v.sets[at <= v.setWords ? at : v.setWords];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (uint32_t c = 0; c < nch; c++) {
+            const uint32_t t = base + 64u * c + (uint32_t)lane;
+            const uint32_t b1 = (uint32_t)__shfl((int)B1, (int)(8u * c) + (lane >> 3));
+            const bool pass1 = t < cnt && (b1 & (0x80u >> (lane & 7))) != 0u;
+            const unsigned long long bal1 = __ballot(pass1);
+            const uint32_t rel = (r1start & 7u) + (r1 - r1start) + (uint32_t)__popcll(bal1 & ltMask);
+            r1 += (uint32_t)__popcll(bal1);
+            const uint32_t two = (uint32_t)__shfl((int)B2, (int)((rel >> 3) < 63u ? (rel >> 3) : 63u));
+            const uint32_t b2 = ((rel >> 3) == 64u) ? (two >> 8) : (two & 0xFFu);
+            const bool pass = pass1 && (m2 ? (b2 & (0x80u >> (rel & 7u))) != 0u : true);
+            const unsigned long long bal = __ballot(pass);
+            if (WRITE && pass) {
+                const uint32_t bIdx = t * v.bits - (firstWord << 5), w = bIdx >> 5, bit = bIdx & 31u;
+                const uint32_t w0 = s_words[w], w1 = s_words[w + 1];
+                s_ids[nIds + (uint32_t)__popcll(bal & ltMask)] = ((w0 << bit) >> (32u - v.bits)) | (uint32_t)((unsigned long long)w1 >> (64u - (bit + v.bits)));
+            }
+            nIds += (uint32_t)__popcll(bal);
+        }
+        base += 64u * nch;
+        if (WRITE) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (uint32_t k = (uint32_t)lane; k < nIds; k += 64u) lists[outBase + total + k] = s_ids[k];
+        }
+        total += nIds;
+    }
+    if (!WRITE && lane == 0) counts[node] = total;
+}
+__global__ void k_exact_list_table(const uint32_t* __restrict__ counts, const uint64_t* __restrict__ offsets, uint32_t n, uint2* __restrict__ leafList) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) leafList[i] = make_uint2((uint32_t)offsets[i], counts[i]);
+}
+__global__ void k_widen(const uint32_t* __restrict__ in, uint32_t n, uint64_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(64) k_exact_lists(ExactView v, const float* __restrict__ pts, uint64_t n, const uint32_t* __restrict__ skey, const uint32_t* __restrict__ sidx,
+                                                    const uint2* __restrict__ leafList, const uint32_t* __restrict__ lists, float* __restrict__ dist, float* __restrict__ grad,
+                                                    uint32_t* __restrict__ tri) {
+    __shared__ float4 s_tile[64 * 5];                                  // one tile: 64 packed frames of 80 bytes
+    const int lane = threadIdx.x;
+    const uint64_t e = (uint64_t)xcdLogicalBlock() * 64u + (uint64_t)lane;       // queries are sorted by leaf: a contiguous range of leaves per XCD
+    uint32_t myKey = v.numNodes, q = 0;
+    if (e < n) { myKey = skey[e]; q = sidx[e]; }
+    const bool active = myKey < v.numNodes;                             // sorted: the active lanes are a prefix of the wave
+    F3 p = F3{0.f, 0.f, 0.f};
+    uint32_t lOff = 0, lCnt = 0;
+    if (active) {
+        const uint2 c = leafList[myKey];
+        lOff = c.x; lCnt = c.y;
+        p = F3{pts[3 * (size_t)q], pts[3 * (size_t)q + 1], pts[3 * (size_t)q + 2]};
+    }
+    // runs: a leader per distinct leaf; tiles of all runs numbered through
+    const uint32_t prevKey = __shfl_up(myKey, 1);
+    const bool isLeader = active && (lane == 0 || prevKey != myKey);
+    const unsigned long long leaders = __ballot(isLeader), act = __ballot(active);
+    const int nActive = __popcll(act);
+    uint32_t rlen = 0;
+    if (isLeader) {
+        const unsigned long long after = (lane == 63) ? 0ull : (leaders >> (lane + 1));
+        const int next = after ? lane + 1 + (__ffsll((long long)after) - 1) : nActive;
+        rlen = (uint32_t)(next - lane);
+    }
+    const uint32_t nT = isLeader ? (lCnt + 63u) / 64u : 0u;
+    uint32_t tileBase = nT;                                              // inclusive scan over the lanes, made exclusive below
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(tileBase, d); if (lane >= d) tileBase += o; }
+    const uint32_t T = __shfl(tileBase, 63);
+    tileBase -= nT;
+    unsigned long long acc = EX_KEY_NONE;                // this lane's own query: (distance bits, position in its leaf's list) of the nearest so far
+    uint32_t accTri = 0;
+    // tile t -> its run (leader lane, list offset, entries, queries) and its first entry
+    struct TileRef { int L; uint32_t off, cnt, r, tb; };
+    auto tileOf = [&](uint32_t t) {
+        const unsigned long long m = __ballot(isLeader && t >= tileBase && t < tileBase + nT);
+        TileRef R; R.L = __ffsll((long long)m) - 1;
+        R.off = __shfl(lOff, R.L); R.cnt = __shfl(lCnt, R.L); R.r = __shfl(rlen, R.L); R.tb = (t - __shfl(tileBase, R.L)) * 64u;
+        return R;
+    };
+    auto loadId = [&](const TileRef& R) { return (R.tb + (uint32_t)lane < R.cnt) ? lists[(size_t)R.off + R.tb + (uint32_t)lane] : 0u; };
+    // the tile in flight: five registers of 16 bytes per lane (named, not an array: the compiler kept an array in scratch)
+    float4 fr0 = make_float4(0.f, 0.f, 0.f, 0.f), fr1 = fr0, fr2 = fr0, fr3 = fr0, fr4 = fr0;
+#define SDF_EX_GATHER(R, id)                                                                                     \
+    if ((R).tb + (uint32_t)lane < (R).cnt) {                                                                     \
+        const float4* src_ = reinterpret_cast<const float4*>(v.frames) + 5 * (size_t)(id);                       \
+        fr0 = src_[0]; fr1 = src_[1]; fr2 = src_[2]; fr3 = src_[3]; fr4 = src_[4];                                    \
+    }
+    TileRef cur{}, nxt{}, nx2{};
+    uint32_t idCur = 0, idNxt = 0, idNx2 = 0;
+    if (T > 0) { cur = tileOf(0); idCur = loadId(cur); SDF_EX_GATHER(cur, idCur) }
+    if (T > 1) { nxt = tileOf(1); idNxt = loadId(nxt); }
+    for (uint32_t t = 0; t < T; t++) {
+        const uint32_t nk = (cur.cnt - cur.tb < 64u) ? cur.cnt - cur.tb : 64u;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if ((uint32_t)lane < nk) {
+            float4* dst = s_tile + 5 * lane;
+            dst[0] = fr0; dst[1] = fr1; dst[2] = fr2; dst[3] = fr3; dst[4] = fr4;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // behind the evaluation: the frames of the next tile, the ids of the one after it
+        if (t + 1 < T) { SDF_EX_GATHER(nxt, idNxt) }
+        if (t + 2 < T) { nx2 = tileOf(t + 2); idNx2 = loadId(nx2); }
+        const int leader = cur.L;
+        const uint32_t r = cur.r;
+        const bool inRun = lane >= leader && lane < leader + (int)r;
+        const uint32_t nsub = (r + 20u) / 21u, part = (r + nsub - 1u) / nsub;
+        for (uint32_t sub = 0; sub < nsub; sub++) {
+            const uint32_t lo = sub * part, sz = (r - lo < part) ? r - lo : part;
+            const uint32_t G = 64u / sz, g = (uint32_t)lane / sz, i = (uint32_t)lane - g * sz;
+            const int owner = leader + (int)(lo + i);
+            const F3 po = F3{__shfl(p.x, owner & 63), __shfl(p.y, owner & 63), __shfl(p.z, owner & 63)};
+            unsigned long long best = EX_KEY_NONE;
+            if (g < G) {
+                for (uint32_t sIdx = g; sIdx < nk; sIdx += G) {
+                    const float4* fp = s_tile + 5 * sIdx;
+                    const float4 a = fp[0], bq = fp[1], c = fp[2], d4 = fp[3], e4 = fp[4];
+                    TriFrame fr;
+                    fr.origin = F3{a.x, a.y, a.z};
+                    fr.m[0] = a.w; fr.m[1] = bq.x; fr.m[2] = bq.y; fr.m[3] = bq.z; fr.m[4] = bq.w; fr.m[5] = c.x; fr.m[6] = c.y; fr.m[7] = c.z; fr.m[8] = c.w;
+                    fr.b = F2{d4.x, d4.y}; fr.c = F2{d4.z, d4.w}; fr.v2 = e4.x; fr.v3 = F2{e4.y, e4.z};
+                    const float d = sqDistPointTriangleSelect(po, fr);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (cur.tb + sIdx);
+                    best = key < best ? key : best;
+                }
+            }
+            // reduce over g (lanes i, i + sz, i + 2 sz, ...), result in lanes [0, sz); hand it to the queries' own lanes
+            for (uint32_t span = 1; span < G; span <<= 1) {
+                const int src = lane + (int)(span * sz);
+                const unsigned long long other = shflKey(best, src < 64 ? src : lane);
+                if (src < 64 && other < best) best = other;
+            }
+            const int from = lane - leader - (int)lo;              // lane of query (lo + from) holds it after the reduction
+            const bool mineValid = inRun && from >= 0 && from < (int)sz;
+            const unsigned long long mine = shflKey(best, mineValid ? from : lane);
+            const uint32_t cand = __shfl(idCur, (int)(((uint32_t)mine - cur.tb) & 63u));
+            if (mineValid && mine < acc) { acc = mine; accTri = cand; }
+        }
+        cur = nxt; idCur = idNxt; nxt = nx2; idNxt = idNx2;
+    }
+#undef SDF_EX_GATHER
+    if (active) {
+        const uint32_t bestTri = accTri;
+        if (GRAD) {
+            F3 gr;
+            dist[q] = signedDistPointTriangleGradLocal(p, v.td + (size_t)TD_FLOATS * bestTri, gr);
+            grad[3 * (size_t)q] = gr.x; grad[3 * (size_t)q + 1] = gr.y; grad[3 * (size_t)q + 2] = gr.z;
+        } else dist[q] = signedDistPointTriangle(p, v.td + (size_t)TD_FLOATS * bestTri);
+        if (tri) tri[q] = bestTri;
+    }
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -400,6 +610,37 @@ static int ensureLeafCtx(sdfhip_exact* T, const ExactView& v) {
         SDF_REQUIRE(depth < 64, "node array is not a tree");
     }
     T->leafCtxReady = true;
+    return SDFHIP_OK;
+}
+
+// The decoded lists (k_exact_leaf_lists): count, scan, write — once per tree, after leafCtx.
+static int ensureLeafLists(sdfhip_exact* T, const ExactView& v) {
+    std::lock_guard<std::mutex> own(T->leafCtxLock);
+    if (T->listsState != 0) return SDFHIP_OK;
+    hipStream_t st = T->ctx->stream;
+    const uint32_t nn = (uint32_t)T->info.num_nodes;
+    static const uint64_t capMB = [] { const char* e = getenv("SDFHIP_EXACT_LISTS_MB"); return e ? (uint64_t)strtoull(e, nullptr, 10) : 4096ull; }();
+    const uint4* lc = reinterpret_cast<const uint4*>(T->leafCtx.p);
+    DevBuf<uint32_t> counts; DevBuf<uint64_t> wide, offsets; DevBuf<unsigned char> tmp;
+    SDF_TRY(counts.reserve(nn)); SDF_TRY(wide.reserve(nn)); SDF_TRY(offsets.reserve(nn));
+    k_exact_leaf_lists<false><<<nn, 64, 0, st>>>(v, lc, counts.p, nullptr, nullptr);
+    k_widen<<<gridFor(nn, 256), 256, 0, st>>>(counts.p, nn, wide.p);
+    size_t tb = 0;
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, wide.p, offsets.p, (int)nn, st));
+    SDF_TRY(tmp.reserve(tb));
+    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, wide.p, offsets.p, (int)nn, st));
+    uint64_t lastOff = 0; uint32_t lastCnt = 0;
+    SDF_HIP_CHECK(hipMemcpyAsync(&lastOff, offsets.p + (nn - 1), 8, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(&lastCnt, counts.p + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    const uint64_t total = lastOff + lastCnt;
+    if (total >= (1ull << 32) || 4 * total > (capMB << 20)) { T->listsState = 2; return SDFHIP_OK; }
+    SDF_TRY(T->leafLists.reserve(total + 64)); SDF_TRY(T->leafList.reserve(2ull * nn));
+    k_exact_leaf_lists<true><<<nn, 64, 0, st>>>(v, lc, nullptr, offsets.p, T->leafLists.p);
+    k_exact_list_table<<<gridFor(nn, 256), 256, 0, st>>>(counts.p, offsets.p, nn, reinterpret_cast<uint2*>(T->leafList.p));
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));          // the temporaries die with this scope
+    T->listEntries = total; T->listsState = 1;
     return SDFHIP_OK;
 }
 
@@ -464,6 +705,7 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         sdfhip_exact_scratch& S = own.owns_lock() ? T->scratch : priv;
         DevBuf<uint32_t>&key = S.key, &keyS = S.keyS, &qi = S.qi, &qiS = S.qiS; DevBuf<unsigned char>& tmp = S.tmp;
         SDF_TRY(ensureLeafCtx(T, v));
+        SDF_TRY(ensureLeafLists(T, v));
         SDF_TRY(key.reserve(n)); SDF_TRY(keyS.reserve(n)); SDF_TRY(qi.reserve(n)); SDF_TRY(qiS.reserve(n));
         k_exact_locate<<<gridFor(n, 256), 256, 0, st>>>(v, p, n, d, g, t, key.p, qi.p);
         // keys are node ids, num_nodes for a query outside the grid (sorted last, skipped): only the bits such keys have are sorted on
@@ -474,7 +716,13 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         SDF_TRY(tmp.reserve(tb));
         SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, keyBits, st));
         const uint4* lc = reinterpret_cast<const uint4*>(T->leafCtx.p);
-        if (g) k_exact_tiles<true><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, lc, d, g, t);
+        static const bool decodeAlways = getenv("SDFHIP_EXACT_QUERY") && !strcmp(getenv("SDFHIP_EXACT_QUERY"), "decode");      // A/B: round 3's kernel
+        if (!decodeAlways && T->listsState == 1) {
+            const uint2* ll = reinterpret_cast<const uint2*>(T->leafList.p);
+            if (g) k_exact_lists<true><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, ll, T->leafLists.p, d, g, t);
+            else k_exact_lists<false><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, ll, T->leafLists.p, d, nullptr, t);
+        }
+        else if (g) k_exact_tiles<true><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, lc, d, g, t);
         else k_exact_tiles<false><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, lc, d, nullptr, t);
         SDF_HIP_CHECK(hipGetLastError());
         if (!own.owns_lock()) SDF_HIP_CHECK(hipStreamSynchronize(st));      // the private scratch dies with this scope

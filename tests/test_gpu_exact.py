@@ -1,5 +1,6 @@
 """GPU parity of the ExactOctreeSdf path (through the C ABI) vs the CPU oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -217,3 +218,37 @@ def test_exact_scalar_host_entry_equals_device_and_oracle(small, oracle):
         assert np.array_equal(bits(ds), bits(d0[k:k + m])) and np.array_equal(bits(ds), bits(dd[k:k + m]))
         ins = inside[k:k + m]
         assert np.array_equal(bits(gs[ins]), bits(g0[k:k + m][ins])) and np.array_equal(ts[ins], t0[k:k + m][ins])
+
+
+@pytest.mark.parametrize("env", [{}, {"SDFHIP_EXACT_QUERY": "decode"}, {"SDFHIP_EXACT_LISTS_MB": "0"}], ids=["lists", "decode-forced", "lists-over-the-cap"])
+def test_both_batched_query_kernels_answer_like_the_oracle(env):
+    """Round 4: the batched query reads the leaves' DECODED triangle lists (made once per tree) through a pipelined kernel; trees whose lists
+    would exceed SDFHIP_EXACT_LISTS_MB keep round 3's decoding kernel.  Both paths (the switches are read once per process, hence the child
+    processes) against the oracle: distances, gradients and triangle ids, incl. points outside the grid, empty leaves and long runs."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+import sdflib_amd as S
+from oracle import pyoracle as O
+from sdflib_amd.meshgen import bumpy_icosphere, torus_knot, box_with_margin, random_points_in_box
+b = lambda a: np.ascontiguousarray(a).view(np.uint32)
+for name, (v, f), (depth, start, mt) in (("sphere", bumpy_icosphere(4), (6, 2, 16)), ("knot", torus_knot(24, 8), (5, 1, 32)), ("sphere-coarse", bumpy_icosphere(3), (3, 1, 8))):
+    box = box_with_margin(v)
+    m = S.Mesh(v, f); e = S.ExactOctreeSdf(m, box, depth, start, mt)
+    oe = O.Exact(O.Mesh(v, f), box, depth, start, mt)
+    pts = random_points_in_box(box, 150001, seed=11); pts[::89] *= 2.5
+    pts[1000:3000] = pts[1000] + (pts[1000:3000] - pts[1000]) * 1e-3          # 2000 points in one leaf: runs longer than a wave
+    d0, g0, t0 = oe.query(pts, grad=True, tri=True)
+    box = np.asarray(box, dtype=np.float32)
+    inside = np.all((pts >= box[:3]) & (pts <= box[3:]), axis=1)          # gradient / id of a point outside the grid are not defined by the reference
+    for rep in range(2):          # the first call makes the tables
+        d, g, t = e.get_distance(pts, gradient=True, triangle=True)
+        assert np.array_equal(b(d), b(d0)) and np.array_equal(b(g[inside]), b(g0[inside])) and np.array_equal(t[inside], t0[inside]), name
+    assert np.array_equal(b(e.get_distance(pts)), b(d0)), name
+print("exact paths ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
+    assert r.returncode == 0 and "exact paths ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
