@@ -220,19 +220,17 @@ struct CullArgs {
 // VALU instruction), so a lane does not wait for its neighbours: as soon as its triangle is decided it takes the chunk's next
 // undecided entry (rank within the ballot of idle lanes), and every wave-loop iteration is one Frank-Wolfe step for the lanes
 // that hold a triangle.  Decisions land in a per-wave bit mask in LDS; the survivors are then written out in list order.
-// Round 4: a refill used to be three dependent gathers (list entry -> indices -> vertices) executed by the handful of lanes that had
-// just finished, in nearly every iteration of the loop — the wave waited for memory every step and a third of its VALU
-// instructions ran for a few lanes (0.64 lanes active).  The chunk is now STAGED through LDS in pieces of CULL_STAGE entries by all
-// 64 lanes (coalesced list reads, full-width gathers, eight round trips per chunk instead of one per step); a finished lane takes
-// its next triangle out of LDS.
-constexpr uint32_t CULL_STAGE = 128;
+// Measured in round 4 and NOT kept (profiles/r04_cull_experiments.txt): staging the chunk through LDS so that a refill costs no
+// dependent gathers, and holding refills back until 4 .. 24 lanes are idle - the kernel's time did not move (19.4 ms of a C3 build
+// either way).  What the per-launch trace shows instead: 10.2 of those 19.4 ms are the LAST level, 824 000 chunks of a hundred or
+// two entries each (one node per wave), i.e. two or three triangles per lane and then a tail in which the lanes whose Frank-Wolfe
+// runs are short wait for the long ones - the 0.64 lanes per VALU instruction.  The remedy is a wave that streams through several
+// nodes with two node contexts in LDS (idle lanes start the next node while the last triangles of the current one finish).
 __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
     __shared__ float s_region[4][64];
     __shared__ float s_min[4][8];
     __shared__ uint32_t s_corner[4][8];
     __shared__ uint32_t s_keep[4][CHUNK / 32];
-    __shared__ float s_tri[4][9][CULL_STAGE];          // the staged triangles' vertices relative to the node centre, component-major
-    __shared__ uint32_t s_tid[4][CULL_STAGE];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4u + (uint32_t)w;
     if (q >= a.numChunks) return;
@@ -247,7 +245,6 @@ __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
     const uint32_t begin = ck * CHUNK, end = (begin + CHUNK < len) ? begin + CHUNK : len;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t next = begin;                       // wave-uniform: first entry not handed out yet
-    uint32_t stageBase = begin, stageEnd = begin;      // entries [stageBase, stageEnd) are in LDS
     unsigned long long tests = 0;
     NearMinimizeState fw; int vId = 0; uint32_t myEntry = 0;
     bool busy = false, retired = false;
@@ -255,39 +252,20 @@ __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
         // idle lanes take the next entries of the chunk
         const unsigned long long idle = __ballot(!busy && !retired);
         if (idle != 0ull) {
-            if (next >= stageEnd && next < end) {          // (wave-uniform) everything staged is handed out: stage the next piece
-                stageBase = next; stageEnd = (next + CULL_STAGE < end) ? next + CULL_STAGE : end;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#pragma unroll
-                for (uint32_t j = 0; j < CULL_STAGE / 64u; j++) {
-                    const uint32_t e = 64u * j + (uint32_t)lane, k = stageBase + e;
-                    if (k < stageEnd) {
-                        const uint32_t t = a.plist[off + k];
-                        const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
-                        const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
-                        s_tid[w][e] = t;
-                        s_tri[w][0][e] = t0.x; s_tri[w][1][e] = t0.y; s_tri[w][2][e] = t0.z;
-                        s_tri[w][3][e] = t1.x; s_tri[w][4][e] = t1.y; s_tri[w][5][e] = t1.z;
-                        s_tri[w][6][e] = t2.x; s_tri[w][7][e] = t2.y; s_tri[w][8][e] = t2.z;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
             if (!busy && !retired) {
                 const uint32_t k = next + (uint32_t)__popcll(idle & ltMask);
-                if (k < stageEnd) {
-                    const uint32_t e = k - stageBase;
-                    const uint32_t t = s_tid[w][e];
-                    const F3 t0 = F3{s_tri[w][0][e], s_tri[w][1][e], s_tri[w][2][e]}, t1 = F3{s_tri[w][3][e], s_tri[w][4][e], s_tri[w][5][e]}, t2 = F3{s_tri[w][6][e], s_tri[w][7][e], s_tri[w][8][e]};
+                if (k < end) {
+                    const uint32_t t = a.plist[off + k];
+                    const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
+                    const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
                     const F3 pt = 0.3333333f * ((t0 + t1) + t2);
                     vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
                     myEntry = k - begin;
                     if (s_corner[w][vId] == t) atomicOr(&s_keep[w][myEntry >> 5], 1u << (myEntry & 31u));      // the corner's own nearest triangle is always kept
                     else { fw.start(t0, t1, t2); busy = true; }
-                } else if (k >= end) retired = true;          // (an entry beyond the staged piece: the lane waits for the next piece)
+                } else retired = true;
             }
-            const uint32_t room = stageEnd - next, want = (uint32_t)__popcll(idle);
-            next += (stageEnd < end && want > room) ? room : want;
+            next += (uint32_t)__popcll(idle);
             tests += (unsigned long long)__popcll(__ballot(busy) & idle);      // entries that entered the Frank-Wolfe test in this round
         }
         if (busy) {
