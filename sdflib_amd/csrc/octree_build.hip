@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(128) k_decide(DecideArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; q++) dst[q] = make_float4(c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]);
     }
-    atomicMax(a.valueRangeBits, __float_as_uint(absMax));
+    if (__float_as_uint(absMax) > *reinterpret_cast<volatile uint32_t*>(a.valueRangeBits)) atomicMax(a.valueRangeBits, __float_as_uint(absMax));      // (the maximum only grows: most leaves need no atomic)
     // border corners (computeMinBorderValue): a leaf corner lying on the box boundary contributes P(corner)
     const uint32_t co = a.coord[i];
     const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;

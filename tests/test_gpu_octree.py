@@ -776,7 +776,9 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
         c.set_bvh(sph, kids3)
 
 
-@pytest.mark.parametrize("subtree,build", [("1", "host"), ("512", "host"), ("8192", "host"), ("4096", "device"), ("512", "device"), ("8192", "device"), ("4096", "device-hostsums")])
+@pytest.mark.parametrize("subtree,build", [("1", "host"), ("4096", "device"), ("512", "device"),
+                                           pytest.param("512", "host", marks=pytest.mark.soak), pytest.param("8192", "host", marks=pytest.mark.soak),
+                                           pytest.param("8192", "device", marks=pytest.mark.soak), pytest.param("4096", "device-hostsums", marks=pytest.mark.soak)])
 def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build):
     """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
     k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
