@@ -921,6 +921,11 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
 // IntroSortLike::parallelPartition) — on as many workgroups as the range has chunks; parts that fit in LDS are finished by k_sort_parts
 // (devSortRounds), parts of at most 16 by k_sort_tiny.  What depends on an order besides — the fp64 centre sums in range order — runs on a
 // second stream behind each level's sort: three lanes per node add x, y and z (k_top_sums), the rest of the wave gathers.
+// Measured in round 4 and NOT kept (profiles/r04_bvh_persistent_rounds.txt): all rounds of a level in ONE persistent kernel — one workgroup per
+// CU striding over the chunks, the five phases separated by a device-wide barrier (monotone counter, release / acquire fences at agent
+// scope), prepare + emit on workgroup 0.  Identical trees, but 9 levels of the 1.31 M mesh took 19.4 ms instead of 9.2 ms: a barrier
+// across the eight XCDs costs ~25 us (every workgroup's release writes its L2 back, every acquire invalidates it), 624 of them per build,
+// while a launch of the five-kernel form costs ~7 us in a queue the host fills ahead.  The launches stay.
 struct GTask { uint32_t first, last, depth; };
 constexpr uint32_t kGsChunk = 2048;          // elements per workgroup in the round kernels (256 threads x 8)
 struct GsRound {
