@@ -1735,8 +1735,9 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     const uint32_t T = mesh->numTriangles;
     uint32_t S = bvhOffloadMax(); if (S == 0) S = 4096u;
     // a range leaves the rounds over global memory for k_sort_parts (LDS) at this length: a round costs ~50 us whatever its ranges, a workgroup's
-    // serial tail grows with the part (SDFHIP_BVH_PART, default 1024)
-    uint32_t partMax = 1024u; if (const char* e = getenv("SDFHIP_BVH_PART")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 32u) partMax = v; }
+    // serial tail grows with the part (SDFHIP_BVH_PART; default 4096 since round 4: 72 instead of 104 rounds at 327 680 triangles, 116 instead
+    // of 156 at 1.31 M - build_bvh 7.4 -> 6.8 ms and 16.0 -> 15.4 ms, profiles/r04_bvh_persistent_rounds.txt)
+    uint32_t partMax = 4096u; if (const char* e = getenv("SDFHIP_BVH_PART")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 32u) partMax = v; }
     if (partMax > S) partMax = S;
     const bool timing = getenv("SDFHIP_TIMING") != nullptr, debug = getenv("SDFHIP_BVH_DEBUG") != nullptr;
     const double t0 = nowSeconds();

@@ -776,7 +776,7 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
         c.set_bvh(sph, kids3)
 
 
-@pytest.mark.parametrize("subtree,build", [("1", "host"), ("4096", "device"), ("512", "device"),
+@pytest.mark.parametrize("subtree,build", [("1", "host"), ("4096", "device"), pytest.param("512", "device", marks=pytest.mark.soak),
                                            pytest.param("512", "host", marks=pytest.mark.soak), pytest.param("8192", "host", marks=pytest.mark.soak),
                                            pytest.param("8192", "device", marks=pytest.mark.soak), pytest.param("4096", "device-hostsums", marks=pytest.mark.soak)])
 def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build):
