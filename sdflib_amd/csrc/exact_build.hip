@@ -213,6 +213,7 @@ struct CullArgs {
     uint32_t* tmp;            // survivors of chunk q, compacted at tmp[q * CHUNK ...]
     uint32_t* chunkCount;     // survivors per chunk
     unsigned long long* cullTests;
+    uint32_t perWave;         // consecutive chunks a wave streams through
 };
 
 // THE hot kernel of the Exact build: one wave per chunk of a node's parent list.
@@ -224,69 +225,100 @@ struct CullArgs {
 // dependent gathers, and holding refills back until 4 .. 24 lanes are idle - the kernel's time did not move (19.4 ms of a C3 build
 // either way).  What the per-launch trace shows instead: 10.2 of those 19.4 ms are the LAST level, 824 000 chunks of a hundred or
 // two entries each (one node per wave), i.e. two or three triangles per lane and then a tail in which the lanes whose Frank-Wolfe
-// runs are short wait for the long ones - the 0.64 lanes per VALU instruction.  The remedy is a wave that streams through several
-// nodes with two node contexts in LDS (idle lanes start the next node while the last triangles of the current one finish).
+// runs are short wait for the long ones - the 0.64 lanes per VALU instruction.  The remedy, below: a wave streams through several
+// chunks with two chunk contexts in LDS (idle lanes start the next chunk while the last triangles of the current one finish):
+// k_cull 19.4 -> 15.0 ms per C3 build (the last level 10.3 -> 5.5 ms), build 41 -> 35.5 ms.
+// A wave STREAMS through `perWave` consecutive chunks with two chunk
+// contexts in LDS.  When the chunk handing out entries is exhausted, the lanes that fall idle start on the next chunk in the other
+// context while the last triangles of the old one finish; a context whose chunk has no running lane left writes its survivors out and
+// is free again.  The tail is paid once per wave instead of once per chunk; chunk bookkeeping (tmp, chunkCount) is unchanged.
 __global__ void __launch_bounds__(256) k_cull(CullArgs a) {
-    __shared__ float s_region[4][64];
-    __shared__ float s_min[4][8];
-    __shared__ uint32_t s_corner[4][8];
-    __shared__ uint32_t s_keep[4][CHUNK / 32];
+    __shared__ float s_region[4][2][64];
+    __shared__ float s_min[4][2][8];
+    __shared__ uint32_t s_corner[4][2][8];
+    __shared__ uint32_t s_keep[4][2][CHUNK / 32];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t q = blockIdx.x * 4u + (uint32_t)w;
-    if (q >= a.numChunks) return;
-    const uint32_t node = a.chunkNode[q];
-    const uint32_t ck = q - a.chunkBase[node];
-    s_region[w][lane] = a.region[64 * (size_t)node + lane];
-    if (lane < 8) { s_min[w][lane] = a.minDist[8 * (size_t)node + lane]; s_corner[w][lane] = a.cornerTri[8 * (size_t)node + lane]; }
-    if (lane < (int)(CHUNK / 32)) s_keep[w][lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const F3 ce = ldv(a.center, node);
-    const uint32_t off = a.pOff[node], len = a.pLen[node];
-    const uint32_t begin = ck * CHUNK, end = (begin + CHUNK < len) ? begin + CHUNK : len;
+    const uint32_t wave = blockIdx.x * 4u + (uint32_t)w;
+    const uint32_t qFirst = wave * a.perWave;
+    if (qFirst >= a.numChunks) return;
+    const uint32_t qLast = (qFirst + a.perWave < a.numChunks) ? qFirst + a.perWave : a.numChunks;      // one past
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t next = begin;                       // wave-uniform: first entry not handed out yet
+    // per context (wave-uniform): state 0 = empty, 1 = handing out entries, 2 = draining
+    int state[2] = {0, 0};
+    uint32_t cq[2] = {0, 0}, coff[2] = {0, 0}, cbegin[2] = {0, 0}, cend[2] = {0, 0}, cnext[2] = {0, 0};
+    F3 cce[2] = {F3{0.f, 0.f, 0.f}, F3{0.f, 0.f, 0.f}};
+    uint32_t qNext = qFirst;
     unsigned long long tests = 0;
-    NearMinimizeState fw; int vId = 0; uint32_t myEntry = 0;
-    bool busy = false, retired = false;
-    while (__ballot(!retired) != 0ull) {
-        // idle lanes take the next entries of the chunk
-        const unsigned long long idle = __ballot(!busy && !retired);
-        if (idle != 0ull) {
-            if (!busy && !retired) {
-                const uint32_t k = next + (uint32_t)__popcll(idle & ltMask);
-                if (k < end) {
-                    const uint32_t t = a.plist[off + k];
-                    const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
-                    const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
-                    const F3 pt = 0.3333333f * ((t0 + t1) + t2);
-                    vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
-                    myEntry = k - begin;
-                    if (s_corner[w][vId] == t) atomicOr(&s_keep[w][myEntry >> 5], 1u << (myEntry & 31u));      // the corner's own nearest triangle is always kept
-                    else { fw.start(t0, t1, t2); busy = true; }
-                } else retired = true;
-            }
-            next += (uint32_t)__popcll(idle);
-            tests += (unsigned long long)__popcll(__ballot(busy) & idle);      // entries that entered the Frank-Wolfe test in this round
+    NearMinimizeState fw; int vId = 0, slot = 0; uint32_t myEntry = 0;
+    bool busy = false;
+    for (;;) {
+        // a chunk for an empty context, if nobody is handing out entries
+        if (state[0] != 1 && state[1] != 1 && qNext < qLast && (state[0] == 0 || state[1] == 0)) {
+            const int s = state[0] == 0 ? 0 : 1;
+            const uint32_t q = qNext++;
+            const uint32_t node = a.chunkNode[q], ck = q - a.chunkBase[node];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            s_region[w][s][lane] = a.region[64 * (size_t)node + lane];
+            if (lane < 8) { s_min[w][s][lane] = a.minDist[8 * (size_t)node + lane]; s_corner[w][s][lane] = a.cornerTri[8 * (size_t)node + lane]; }
+            if (lane < (int)(CHUNK / 32)) s_keep[w][s][lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const uint32_t len = a.pLen[node];
+            cq[s] = q; cce[s] = ldv(a.center, node); coff[s] = a.pOff[node];
+            cbegin[s] = ck * CHUNK; cend[s] = (cbegin[s] + CHUNK < len) ? cbegin[s] + CHUNK : len; cnext[s] = cbegin[s];
+            state[s] = 1;
         }
+        const int feed = state[0] == 1 ? 0 : (state[1] == 1 ? 1 : -1);
+        // idle lanes take the next entries of the chunk that hands them out
+        if (feed >= 0) {
+            const unsigned long long idle = __ballot(!busy);
+            if (idle != 0ull) {
+                if (!busy) {
+                    const uint32_t k = cnext[feed] + (uint32_t)__popcll(idle & ltMask);
+                    if (k < cend[feed]) {
+                        const uint32_t t = a.plist[coff[feed] + k];
+                        const uint32_t i0 = a.m.idx[3 * t], i1 = a.m.idx[3 * t + 1], i2 = a.m.idx[3 * t + 2];
+                        const F3 ce = cce[feed];
+                        const F3 t0 = ldv(a.m.verts, i0) - ce, t1 = ldv(a.m.verts, i1) - ce, t2 = ldv(a.m.verts, i2) - ce;
+                        const F3 pt = 0.3333333f * ((t0 + t1) + t2);
+                        vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
+                        myEntry = k - cbegin[feed]; slot = feed;
+                        if (s_corner[w][feed][vId] == t) atomicOr(&s_keep[w][feed][myEntry >> 5], 1u << (myEntry & 31u));      // the corner's own nearest triangle is always kept
+                        else { fw.start(t0, t1, t2); busy = true; }
+                    }
+                }
+                cnext[feed] += (uint32_t)__popcll(idle);
+                tests += (unsigned long long)__popcll(__ballot(busy) & idle);      // entries that entered the Frank-Wolfe test in this round
+            }
+            if (cnext[feed] >= cend[feed]) state[feed] = 2;          // everything handed out: the chunk drains
+        }
+        const unsigned long long running = __ballot(busy);
+        // a draining chunk without a running lane: its survivors go out in list order, the context is free
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            if (state[s] == 2 && __ballot(busy && slot == s) == 0ull) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                uint32_t kept = 0;
+                for (uint32_t base = 0; cbegin[s] + base < cend[s]; base += 64) {
+                    const uint32_t e = base + (uint32_t)lane;
+                    const bool keep = (cbegin[s] + e < cend[s]) && ((s_keep[w][s][e >> 5] >> (e & 31u)) & 1u);
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) a.tmp[(size_t)cq[s] * CHUNK + kept + (uint32_t)__popcll(mask & ltMask)] = a.plist[coff[s] + cbegin[s] + e];
+                    kept += (uint32_t)__popcll(mask);
+                }
+                if (lane == 0) a.chunkCount[cq[s]] = kept;
+                state[s] = 0;
+            }
+        }
+        if (running == 0ull && state[0] == 0 && state[1] == 0 && qNext >= qLast) break;
         if (busy) {
             bool keep;
-            if (fw.step(a.half, &s_region[w][8 * vId], s_min[w][vId], keep)) {
-                if (keep) atomicOr(&s_keep[w][myEntry >> 5], 1u << (myEntry & 31u));
+            if (fw.step(a.half, &s_region[w][slot][8 * vId], s_min[w][slot][vId], keep)) {
+                if (keep) atomicOr(&s_keep[w][slot][myEntry >> 5], 1u << (myEntry & 31u));
                 busy = false;
             }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // survivors in list order
-    uint32_t kept = 0;
-    for (uint32_t base = 0; begin + base < end; base += 64) {
-        const uint32_t e = base + (uint32_t)lane;
-        const bool keep = (begin + e < end) && ((s_keep[w][e >> 5] >> (e & 31u)) & 1u);
-        const unsigned long long mask = __ballot(keep);
-        if (keep) a.tmp[(size_t)q * CHUNK + kept + (uint32_t)__popcll(mask & ltMask)] = a.plist[off + begin + e];
-        kept += (uint32_t)__popcll(mask);
-    }
-    if (lane == 0) { a.chunkCount[q] = kept; if (tests) atomicAdd(a.cullTests, tests); }
+    if (lane == 0 && tests) atomicAdd(a.cullTests, tests);
 }
 
 // packed lists: survivors of chunk q go to list[chunkScan[q] ...]; listOff[node] = chunkScan[first chunk of node]
@@ -775,7 +807,10 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             k_chunk_fill<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkNode.p);
             CullArgs ca{md, L->center.p, L->half, L->cornerTri.p, region.p, minDist.p, prevList, L->pOff.p, L->pLen.p, chunkNode.p, chunkBase.p, numChunks,
                         tmp.p, chunkCount.p, cullTests.p};
-            k_cull<<<gridFor(numChunks, 4), 256, 0, st>>>(ca);
+            // chunks per wave: enough waves to fill the chip several times over, then as long a stream per wave as that leaves (SDFHIP_CULL_STREAM overrides)
+            { static const int forced = getenv("SDFHIP_CULL_STREAM") ? atoi(getenv("SDFHIP_CULL_STREAM")) : 0;
+              uint32_t pw = forced > 0 ? (uint32_t)forced : numChunks / 32768u; if (pw < 1u) pw = 1u; if (pw > 16u && forced <= 0) pw = 16u; ca.perWave = pw; }      // (divisors 4096 .. 65536 and caps 16 .. 64 measured: a plateau)
+            k_cull<<<gridFor(gridFor(numChunks, ca.perWave), 4), 256, 0, st>>>(ca);
             SDF_TRY(scan.exclusive(chunkCount.p, chunkScan.p, numChunks));
             SDF_TRY(lastPlus(st, chunkScan.p, chunkCount.p, numChunks, total));
             SDF_TRY(L->list.reserve(total));
