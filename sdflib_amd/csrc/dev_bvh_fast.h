@@ -103,6 +103,11 @@ SDF_DEV unsigned short halfRoundedDown(float f) {
     if ((float)h > f) bits = (bits == 0u) ? (unsigned short)0x8001u : ((bits & 0x8000u) ? (unsigned short)(bits + 1u) : (unsigned short)(bits - 1u));
     return bits;
 }
+SDF_DEV unsigned short halfTowardsZero(float f) {
+    typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+    const half2_t h = __builtin_amdgcn_cvt_pkrtz(f, 0.f);
+    return (unsigned short)(__builtin_bit_cast(uint32_t, h) & 0xFFFFu);
+}
 SDF_DEV float halfBitsToFloat(unsigned short bits) { return (float)__builtin_bit_cast(_Float16, bits); }
 
 // Lower bounds of the distance from p to the four children of a wide node (layout: dev_bvh.h) and their references.
@@ -411,7 +416,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                                                       uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, uint32_t* __restrict__ counters,
                                                       uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount, int drainQuads, uint32_t chunk,
                                                       bool seedFromNeighbour, uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, int pass,
-                                                      uint32_t* __restrict__ best, uint32_t lead) {
+                                                      uint32_t* __restrict__ best, uint32_t lead, uint32_t multiSeed) {
     __shared__ uint32_t s_ref[BLOCK / 64][QUAD_STACK][16];
     __shared__ unsigned short s_lb[BLOCK / 64][QUAD_STACK][16];
     __shared__ uint32_t s_tq[BLOCK / 64][QUAD_TQ][16];
@@ -459,12 +464,23 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                     r = rr; have = true; qpass = phase;
                     p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
                     U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; sp = 0; steps = 0; stExpand = stIter = stTri = 0;
+                    // Up to THREE seed triangles, one per lane (the quad evaluates them in one drain round, i.e. at the price of one): the
+                    // triangles the leaders on either side of a follower ended on (the follower lies between them on the Morton curve) and
+                    // the one this quad's previous query ended on.  The smallest of the three distances is the first bound.
                     uint32_t seed = 0xFFFFFFFFu;
-                    if (seedTri) seed = seedTri[r];
-                    else if (qpass == 2) seed = __builtin_nontemporal_load(best + (r & ~(lead - 1u)));
-                    if (!(seed < b.numTriangles) && seedFromNeighbour) seed = lastTri;
+                    if (seedTri) { if (c == 0u) seed = seedTri[r]; }
+                    else if (c == 2u) { if (seedFromNeighbour) seed = lastTri; }
+                    else if (qpass == 2 && c < multiSeed) {
+                        uint32_t rl = r & ~(lead - 1u);
+                        if (c == 1u) rl = ((rl & 127u) + lead < 128u) ? rl + lead : rl + lead + (world - 1u) * 128u;      // the next leader (the next of this rank's 128-query blocks)
+                        if (rl < numReps) seed = __builtin_nontemporal_load(best + rl);
+                    }
+                    const uint32_t nibS = quadBallot(seed < b.numTriangles, lane);
                     if (b.numTriangles == 1u) { if (c == 0u) tq[0][quad] = 0u; nq = 1; mode = 0; }
-                    else if (seed < b.numTriangles) { if (c == 0u) tq[0][quad] = seed; nq = 1; mode = 2; }       // one triangle evaluation gives the first bound
+                    else if (nibS != 0u) {                                                                       // one drain round gives the first bound
+                        if (seed < b.numTriangles) tq[__popc(nibS & ((1u << c) - 1u))][quad] = seed;
+                        nq = __popc(nibS); mode = 2;
+                    }
                     else { mode = 1; seedRef = 0; }                                                              // a greedy descent does
                 }
             }
@@ -490,8 +506,11 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
         __builtin_amdgcn_wave_barrier();
         if (ref >= 0) {
             const float4* nd = b.wide + 8 * (size_t)ref;
-            const float4 h = nd[0], q = nd[1 + c];
-            const uint32_t cr = reinterpret_cast<const uint32_t*>(nd + 5)[c];
+            float4 h = nd[0], q = nd[1 + c];
+            uint32_t cr = reinterpret_cast<const uint32_t*>(nd + 5)[c];
+            // ONE memory round trip per expansion: left alone, the compiler fetches the radius word first, branches on childBound's
+            // "no such child" early-out and only then asks for the header and the rest of the record (two dependent latencies per pop)
+            asm volatile("" : "+v"(h.x), "+v"(h.y), "+v"(h.z), "+v"(h.w), "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w), "+v"(cr));
             const float lb = childBound(h, q, p);
             stExpand++;
             if (mode == 1) {
@@ -510,7 +529,9 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                 const float k1 = quadPermF<0x39>(key), k2 = quadPermF<0x4E>(key), k3 = quadPermF<0x93>(key);
                 const uint32_t c1 = (c + 1u) & 3u, c2 = (c + 2u) & 3u, c3 = (c + 3u) & 3u;
                 const int farther = ((k1 > key || (k1 == key && c1 > c)) ? 1 : 0) + ((k2 > key || (k2 == key && c2 > c)) ? 1 : 0) + ((k3 > key || (k3 == key && c3 > c)) ? 1 : 0);
-                if (isNode) { stk[sp + farther][quad] = cr; lbs[sp + farther][quad] = halfRoundedDown(lb); }
+                // the bound as a half rounded TOWARDS ZERO (one instruction): down for a positive bound; a negative one (the point is inside the
+                // child's volume) becomes a value <= 0, which like the exact one never exceeds U at the pop
+                if (isNode) { stk[sp + farther][quad] = cr; lbs[sp + farther][quad] = halfTowardsZero(lb); }
                 sp += __popc(nibN);
             }
         }
@@ -684,14 +705,16 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
 struct SimFrame { uint32_t node, b, e, info; };      // info = lo | hi << 8 | side << 16 (the child of `node` to enter: tested at pop time)
 
 template <int BLOCK>
-SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint32_t* __restrict__ ids, uint32_t* __restrict__ rk, uint32_t* __restrict__ frames) {
-    // sort the tied candidates by rank (position in the tree's leaf order): subsets of a subtree are then contiguous
+SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint32_t* __restrict__ ids, uint32_t* __restrict__ rk, uint32_t* __restrict__ frames, double* __restrict__ d2s) {
+    // sort the tied candidates by rank (position in the tree's leaf order): subsets of a subtree are then contiguous.  d2s (optional):
+    // their fp64 squared distances as the caller evaluated them, carried along so that a leaf costs no third evaluation
     for (int i = 0; i < n2; i++) rk[i * BLOCK] = bvh.triRank[ids[i * BLOCK]];
     for (int i = 1; i < n2; i++) {
         const uint32_t kr = rk[i * BLOCK], ki = ids[i * BLOCK];
+        const double kd = d2s ? d2s[i * BLOCK] : 0.0;
         int j = i - 1;
-        while (j >= 0 && rk[j * BLOCK] > kr) { rk[(j + 1) * BLOCK] = rk[j * BLOCK]; ids[(j + 1) * BLOCK] = ids[j * BLOCK]; j--; }
-        rk[(j + 1) * BLOCK] = kr; ids[(j + 1) * BLOCK] = ki;
+        while (j >= 0 && rk[j * BLOCK] > kr) { rk[(j + 1) * BLOCK] = rk[j * BLOCK]; ids[(j + 1) * BLOCK] = ids[j * BLOCK]; if (d2s) d2s[(j + 1) * BLOCK] = d2s[j * BLOCK]; j--; }
+        rk[(j + 1) * BLOCK] = kr; ids[(j + 1) * BLOCK] = ki; if (d2s) d2s[(j + 1) * BLOCK] = kd;
     }
     double best = sqrt(dmin2) * (1.0 + 1e-9);
     int bestTri = -1;
@@ -714,7 +737,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
         }
         if (e - b == 1u) {                                           // a leaf: exactly one candidate left, this triangle
             const uint32_t t = ids[lo * BLOCK];
-            const double d2 = triangleSq(bvh, t, p);
+            const double d2 = d2s ? d2s[lo * BLOCK] : triangleSq(bvh, t, p);
             if (d2 < best * best) { best = sqrt(d2); bestTri = (int)t; adopted = true; }
             pending = false;
             continue;
@@ -751,6 +774,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
                                                         const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
                                                         uint32_t* __restrict__ fbCount, uint32_t rank, uint32_t world) {
     __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK], s_frames[4 * (NEAR_MAX_TIES - 1) * BLOCK];
+    __shared__ double s_d2[NEAR_MAX_TIES * BLOCK];
     const uint64_t r64 = ((uint64_t)blockIdx.x * world + rank) * BLOCK + threadIdx.x;
     if (r64 >= numReps) return;
     const uint32_t r = (uint32_t)r64;
@@ -769,28 +793,35 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
             if (candLo[(size_t)i * numReps + r] <= u2) { live++; liveId = cand[(size_t)i * numReps + r]; liveLo = candLo[(size_t)i * numReps + r]; }
         if (live == 1u && liveLo > 0.f) res = liveId;
         else if (live >= 1u) {
+            // every live candidate is evaluated ONCE: the values stay in LDS (NEAR_MAX_TIES slots: more live candidates than that are
+            // rare and re-evaluated below) for the tie test and for the leaves of the replay
+            uint32_t* ids = s_ids + threadIdx.x; double* d2s = s_d2 + threadIdx.x;
+            const bool cached = live <= (uint32_t)NEAR_MAX_TIES;
+            uint32_t k = 0;
             for (uint32_t i = 0; i < nc; i++) {
                 if (!(candLo[(size_t)i * numReps + r] <= u2)) continue;
                 const uint32_t id = cand[(size_t)i * numReps + r];
                 const double d2 = triangleSq(b, id, p);
+                if (cached) { ids[k * BLOCK] = id; d2s[k * BLOCK] = d2; k++; }
                 if (d2 < dmin2) { dmin2 = d2; argmin = id; }
             }
             if (dmin2 >= 1e-200) {
                 const double thr = dmin2 * (1.0 + 4e-12);
-                // (the fp32 lower bound recorded with a candidate rules most of them out of the tied set without a second fp64 evaluation)
-                uint32_t maybe = 0;
-                for (uint32_t i = 0; i < nc; i++) maybe += ((double)candLo[(size_t)i * numReps + r] <= thr) ? 1u : 0u;
-                if (maybe == 1u) res = argmin;           // nobody else can be within the tie threshold
-                else {
-                    uint32_t* ids = s_ids + threadIdx.x;
-                    int n2 = 0;
+                int n2 = 0;
+                if (cached) {
+                    // (a tie's lower bound cannot exceed u2, the upper bound of the minimum: every tie is among the live candidates)
+                    for (uint32_t j = 0; j < k; j++) {
+                        const double d2 = d2s[j * BLOCK];
+                        if (d2 <= thr) { ids[n2 * BLOCK] = ids[j * BLOCK]; d2s[n2 * BLOCK] = d2; n2++; }
+                    }
+                } else {
                     for (uint32_t i = 0; i < nc; i++) {
                         const uint32_t id = cand[(size_t)i * numReps + r];
                         if ((double)candLo[(size_t)i * numReps + r] <= thr && triangleSq(b, id, p) <= thr) { if (n2 < NEAR_MAX_TIES) ids[n2 * BLOCK] = id; n2++; }
                     }
-                    if (n2 == 1) res = ids[0];
-                    else if (n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x);
                 }
+                if (n2 == 1) res = cached ? ids[0] : argmin;
+                else if (n2 >= 2 && n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x, cached ? d2s : nullptr);
             }
         }
     }
@@ -885,11 +916,12 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     if (quads) {
         static const uint32_t qPerCU = getenv("SDFHIP_NEAR_QBLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QBLOCKS_PER_CU")) : 6u;       // all resident (70 VGPRs: 7 waves per SIMD); measured 6 < 8 < 12: blocks that start late only add a tail
         static const uint32_t qchunk = (getenv("SDFHIP_NEAR_QCHUNK") && atoi(getenv("SDFHIP_NEAR_QCHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QCHUNK")) : 16u;      // queries a wave (16 quads) takes per atomic: measured 16 < 32 < 64
+        static const uint32_t multiSeed = getenv("SDFHIP_NEAR_MULTISEED") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_MULTISEED")) : 2u;       // leaders a follower is seeded from (1: the one before it; 2: the one after it as well)
         uint32_t qgrid = 256u * qPerCU;
         const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
         if (qgrid > needBlocks) qgrid = needBlocks;
         k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead);
+                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead, multiSeed);
     } else {
 #define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
         S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)
