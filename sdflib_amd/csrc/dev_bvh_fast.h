@@ -836,7 +836,10 @@ __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* 
     extern __shared__ uint32_t s_fb_stack[];
     const uint32_t count = *fbCount;
     if (blockIdx.x == 0 && threadIdx.x == 0 && first == 0u) atomicAdd(fbCount + 1, count);       // running total of a build (fbCount[0] restarts with every batch)
-    for (uint32_t i = first + blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+    // consecutive entries go to DIFFERENT workgroups (entry i = thread i / gridDim of block i % gridDim): the handful of points that get
+    // here (a tube's axis: 20 per torus-knot build) each walk thousands of nodes in fp64, and as neighbouring lanes of one wave their
+    // divergent walks ran one after the other (2.9 ms per batch); alone in a wave each takes its own time only (1.6 ms)
+    for (uint32_t i = first + threadIdx.x * gridDim.x + blockIdx.x; i < count; i += gridDim.x * BLOCK) {
         const uint32_t r = fbList[i];
         // The traversal starts from the candidate search's bound (fp32 upper bound of the squared distance incl. its error margin, i.e.
         // strictly above the minimum) instead of from infinity: the same answer (dev_bvh.h) without the visits that precede the first
