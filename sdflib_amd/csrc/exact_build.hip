@@ -129,22 +129,12 @@ __global__ void k_brute_finish(uint32_t n, int pointsPerNode, const uint32_t* __
 // profile: 4.9 GB x2 of FETCH per launch).  Thread = (point m, slice s): the tile's triangles s, s + 13, ... ; partial minima
 // are merged by (distance, list position), i.e. the first minimum in list order like the sequential scan.
 constexpr int BN_SLICES = 13;                     // 19 points x 13 slices = 247 of 256 threads
-__global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const float* __restrict__ center, float half, uint32_t n, const uint32_t* __restrict__ list,
-                                                            const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
-                                                            const uint32_t* __restrict__ skip, uint32_t* __restrict__ outTri) {
-    __shared__ float4 s_fr[64 * 5];
-    __shared__ float s_d[19 * BN_SLICES]; __shared__ uint32_t s_p[19 * BN_SLICES];
-    const uint32_t node = blockIdx.x;
-    if (node >= n) return;
-    if (skip && skip[node]) return;                                   // whole block
-    const int tid = threadIdx.x;
-    const int mi = tid / BN_SLICES, sl = tid - BN_SLICES * mi;
-    const bool worker = mi < 19;
-    const F3 p = ldv(center, node) + (worker ? midRel(mi) : F3{0.f, 0.f, 0.f}) * half;
-    const uint32_t off = listOff[node], len = listLen[node];
-    float best = INFINITY; uint32_t bestPos = NONE;
-    for (uint32_t base = 0; base < len; base += 64) {
-        const uint32_t cnt = (len - base < 64u) ? len - base : 64u;
+constexpr uint32_t BN_PIECE = 4096;               // entries of a LONG list one workgroup takes (k_brute_mids_long)
+// thread (point, slice) over the list entries [k0, k1) of a node: tiles of 64 frames through s_fr
+SDF_DEV void midsRange(const ExMesh& m, F3 p, bool worker, int sl, int tid, const uint32_t* __restrict__ list, uint32_t off, uint32_t k0, uint32_t k1,
+                       float4* s_fr, float& best, uint32_t& bestPos) {
+    for (uint32_t base = k0; base < k1; base += 64) {
+        const uint32_t cnt = (k1 - base < 64u) ? k1 - base : 64u;
         __syncthreads();                                              // previous tile fully consumed
         for (uint32_t e = (uint32_t)tid; e < 5u * cnt; e += 256u) {    // 5 x 16 B per triangle, coalesced within a frame
             const uint32_t k = e / 5u, c = e - 5u * k;
@@ -163,6 +153,24 @@ __global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const floa
             }
         }
     }
+}
+// longLen: nodes whose list is longer are left to k_brute_mids_long
+__global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const float* __restrict__ center, float half, uint32_t n, const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen,
+                                                            const uint32_t* __restrict__ skip, uint32_t* __restrict__ outTri, uint32_t longLen) {
+    __shared__ float4 s_fr[64 * 5];
+    __shared__ float s_d[19 * BN_SLICES]; __shared__ uint32_t s_p[19 * BN_SLICES];
+    const uint32_t node = blockIdx.x;
+    if (node >= n) return;
+    if (skip && skip[node]) return;                                   // whole block
+    const int tid = threadIdx.x;
+    const int mi = tid / BN_SLICES, sl = tid - BN_SLICES * mi;
+    const bool worker = mi < 19;
+    const F3 p = ldv(center, node) + (worker ? midRel(mi) : F3{0.f, 0.f, 0.f}) * half;
+    const uint32_t off = listOff[node], len = listLen[node];
+    if (len > longLen) return;                                        // whole block
+    float best = INFINITY; uint32_t bestPos = NONE;
+    midsRange(m, p, worker, sl, tid, list, off, 0u, len, s_fr, best, bestPos);
     if (worker) { s_d[tid] = best; s_p[tid] = bestPos; }
     __syncthreads();
     if (worker && sl == 0) {
@@ -172,6 +180,59 @@ __global__ void __launch_bounds__(256) k_brute_nearest_mids(ExMesh m, const floa
         }
         outTri[(size_t)node * 19 + mi] = (bestPos == NONE) ? (len ? list[off] : 0u) : list[off + bestPos];
     }
+}
+// The few nodes with LONG lists (near the centre of a round shape a node's list is most of the mesh: 300 000 entries x 19 points in
+// ONE workgroup was the whole duration of a level's launch): listed here, cut into pieces of BN_PIECE entries, a workgroup per piece
+// (k_brute_mids_long: persistent over the (node, piece) items, the pieces' minima meet in a 64-bit atomic minimum on
+// (distance bits << 32 | list position), the first minimum in list order as the sequential scan finds it), ids by k_brute_long_finish.
+__global__ void k_long_nodes(uint32_t n, const uint32_t* __restrict__ listLen, const uint32_t* __restrict__ skip, uint32_t longLen, uint2* __restrict__ items,
+                             uint32_t* __restrict__ itemCount, unsigned long long* __restrict__ keys) {
+    const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= n || (skip && skip[node]) || listLen[node] <= longLen) return;
+    const uint32_t np = (listLen[node] + BN_PIECE - 1u) / BN_PIECE;
+    const uint32_t base = atomicAdd(itemCount, np);
+    for (uint32_t q = 0; q < np; q++) items[base + q] = make_uint2(node, q);
+    for (int q = 0; q < 19; q++) keys[19 * (size_t)node + q] = ~0ull;
+}
+__global__ void __launch_bounds__(256) k_brute_mids_long(ExMesh m, const float* __restrict__ center, float half, const uint32_t* __restrict__ list,
+                                                         const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen, const uint2* __restrict__ items,
+                                                         const uint32_t* __restrict__ itemCount, unsigned long long* __restrict__ keys) {
+    __shared__ float4 s_fr[64 * 5];
+    __shared__ float s_d[19 * BN_SLICES]; __shared__ uint32_t s_p[19 * BN_SLICES];
+    const int tid = threadIdx.x;
+    const int mi = tid / BN_SLICES, sl = tid - BN_SLICES * mi;
+    const bool worker = mi < 19;
+    const uint32_t count = *itemCount;
+    for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+        const uint2 it = items[w];
+        const uint32_t node = it.x;
+        const uint32_t off = listOff[node], len = listLen[node];
+        const uint32_t k0 = it.y * BN_PIECE;
+        const uint32_t k1 = (k0 + BN_PIECE < len) ? k0 + BN_PIECE : len;
+        const F3 p = ldv(center, node) + (worker ? midRel(mi) : F3{0.f, 0.f, 0.f}) * half;
+        float best = INFINITY; uint32_t bestPos = NONE;
+        midsRange(m, p, worker, sl, tid, list, off, k0, k1, s_fr, best, bestPos);
+        __syncthreads();                                              // (s_d / s_p of the previous item are consumed)
+        if (worker) { s_d[tid] = best; s_p[tid] = bestPos; }
+        __syncthreads();
+        if (worker && sl == 0) {
+            for (int q = 1; q < BN_SLICES; q++) {
+                const float od = s_d[tid + q]; const uint32_t op = s_p[tid + q];
+                if (od < best || (od == best && op < bestPos)) { best = od; bestPos = op; }
+            }
+            if (bestPos != NONE) atomicMin(keys + 19 * (size_t)node + mi, ((unsigned long long)__float_as_uint(best) << 32) | bestPos);
+        }
+    }
+}
+__global__ void k_brute_long_finish(uint32_t n, const uint32_t* __restrict__ list, const uint32_t* __restrict__ listOff, const uint32_t* __restrict__ listLen, const uint32_t* __restrict__ skip,
+                                    uint32_t longLen, const unsigned long long* __restrict__ keys, uint32_t* __restrict__ outTri) {
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t node = item / 19u;
+    if (node >= n || (skip && skip[node])) return;
+    const uint32_t len = listLen[node];
+    if (len <= longLen) return;
+    const uint32_t pos = (uint32_t)keys[item], off = listOff[node];
+    outTri[item] = (pos == NONE) ? list[off] : list[off + pos];
 }
 
 // 8x8 corner-sphere radii of a node: lane l = 8*i + c  ->  dist(corner c, nearest triangle of corner i) - min_c
@@ -793,7 +854,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         }
         const uint32_t n = L->n;
         // ---- cull the parent lists into this level's lists
-        DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp;
+        DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp, longCount; DevBuf<uint2> longItems; DevBuf<unsigned long long> longKeys;
         SDF_TRY(region.reserve(64ull * n)); SDF_TRY(minDist.reserve(8ull * n)); SDF_TRY(nChunks.reserve(n)); SDF_TRY(chunkBase.reserve(n));
         k_node_regions<<<gridFor(64ull * n, 256), 256, 0, st>>>(md, L->center.p, L->half, n, L->cornerTri.p, region.p, minDist.p);
         k_chunk_counts<<<gridFor(n, 256), 256, 0, st>>>(n, L->pLen.p, nChunks.p);
@@ -831,16 +892,17 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             SDF_TRY(L->midTri.reserve(19ull * n));
             // few nodes with long lists near the root: a block per (node, point) keeps the chip busy; many nodes with short lists below:
             // a block per node shares the staged frames among the 19 points
-            if (n >= 4096) k_brute_nearest_mids<<<n, 256, 0, st>>>(md, L->center.p, L->half, n, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p);
-            else {
-                const uint32_t items = 19 * n;
-                const uint64_t avgLen = L->listTotal / (n ? n : 1u);
-                uint32_t slices = (uint32_t)(avgLen / (64u * 8u)); if (slices < 1u) slices = 1u; if (slices > 128u) slices = 128u;
-                DevBuf<unsigned long long> keys;
-                SDF_TRY(keys.reserve(items));
-                SDF_HIP_CHECK(hipMemsetAsync(keys.p, 0xFF, 8ull * items, st));
-                k_brute_nearest_sliced<64><<<items * slices, 64, 0, st>>>(md, L->center.p, L->half, n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, slices, keys.p);
-                k_brute_finish<<<gridFor(items, 256), 256, 0, st>>>(n, 19, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, keys.p, L->midTri.p);
+            {
+                // many nodes with short lists: a block per node shares the staged frames among the 19 points (k_brute_nearest_mids); the nodes
+                // with long lists (all of them near the root) are cut into pieces of BN_PIECE entries (k_brute_mids_long)
+                static const uint32_t longLen = getenv("SDFHIP_BRUTE_LONG") ? (uint32_t)atoi(getenv("SDFHIP_BRUTE_LONG")) : BN_PIECE;
+                const size_t maxItems = (size_t)L->listTotal / BN_PIECE + n + 1;
+                SDF_TRY(longItems.reserve(maxItems)); SDF_TRY(longCount.reserve(1)); SDF_TRY(longKeys.reserve(19ull * n));
+                SDF_HIP_CHECK(hipMemsetAsync(longCount.p, 0, 4, st));
+                k_long_nodes<<<gridFor(n, 256), 256, 0, st>>>(n, L->listLen.p, L->flag.p, longLen, longItems.p, longCount.p, longKeys.p);
+                k_brute_nearest_mids<<<n, 256, 0, st>>>(md, L->center.p, L->half, n, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, L->midTri.p, longLen);
+                k_brute_mids_long<<<2048, 256, 0, st>>>(md, L->center.p, L->half, L->list.p, L->listOff.p, L->listLen.p, longItems.p, longCount.p, longKeys.p);
+                k_brute_long_finish<<<gridFor(19ull * n, 256), 256, 0, st>>>(n, L->list.p, L->listOff.p, L->listLen.p, L->flag.p, longLen, longKeys.p, L->midTri.p);
             }
             std::unique_ptr<ExLevel> N(new ExLevel());
             N->depth = d + 1; N->n = 8u * L->numInner; N->half = 0.5f * L->half;
