@@ -498,28 +498,50 @@ SDF_DEV void childFinal(const MergeArgs& a, uint32_t child, const uint32_t*& l, 
     if (a.cflag[child]) { l = a.clist + a.clistOff[child]; len = a.clistLen[child]; }
     else { l = a.culist + a.clistOff[child]; len = a.cuLen[child]; }
 }
-// phase 1: union = elements of the node's filtered list present in any child's final list (order kept)
+// Is v among the 64 ascending entries of win (LDS; the entries behind a list's end are 0xFFFFFFFF)?  Six fixed steps.
+SDF_DEV bool windowContains(const uint32_t* win, uint32_t v) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (uint32_t step = 32; step >= 1; step >>= 1) pos += (win[pos + step - 1u] < v) ? step : 0u;
+    return win[pos] == v;
+}
+// A child's final list is a SUBSET of its parent's filtered list (k_cull filters the parent's list) and both ascend: the values of 64
+// consecutive parent entries can only be found among the NEXT 64 entries of the child's list behind a cursor that moves forward.  A chunk
+// therefore costs one round trip — the parent's 64 values and the eight 64-entry windows, all coalesced — and its look-ups are six-step
+// searches in LDS (before: galloping window searches and bisections in global memory, ~10 dependent fetches per element).
+// phase 1: union = elements of the node's filtered list present in any child's final list (order kept); one wave per node
 __global__ void __launch_bounds__(256) k_merge_union(MergeArgs a) {
+    __shared__ uint32_t s_win[4][8][64];
     const uint32_t node = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (node >= a.n || !a.inner[node]) return;
     const uint32_t off = a.listOff[node], len = a.listLen[node], cb = a.childBase[node];
+    const uint32_t* cl[8]; uint32_t clen[8], cur[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) { childFinal(a, cb + (uint32_t)c, cl[c], clen[c]); cur[c] = 0; }
     uint32_t kept = 0;
-    // Both lists ascend, so the part of a child's list that can hold the 64 values of a chunk is a window that only moves forward:
-    // lanes 0..7 keep the window of child `lane` (a galloping search from where it was), and an element is then looked up in windows of
-    // a few dozen entries instead of in whole lists of thousands (dependent loads per element: ~38 -> ~10)
-    const uint32_t* wl = nullptr; uint32_t wlen = 0, wLo = 0, wHi = 0;
-    if (lane < 8) childFinal(a, cb + (uint32_t)lane, wl, wlen);
     for (uint32_t base = 0; base < len; base += 64) {
         const uint32_t k = base + lane;
-        const uint32_t vmin = a.list[off + base], vmax = a.list[off + ((base + 63u < len) ? base + 63u : len - 1u)];
-        if (lane < 8) { wLo = lowerBoundFrom(wl, wlen, wLo, vmin); wHi = (vmax == 0xFFFFFFFFu) ? wlen : lowerBoundFrom(wl, wlen, wLo, vmax + 1u); }
-        bool keep = false; uint32_t v = 0;
-        if (k < len) v = a.list[off + k];
-        for (uint32_t c = 0; c < 8; c++) {
-            const uint32_t lo = __shfl(wLo, (int)c), hi = __shfl(wHi, (int)c);
-            if (k < len && !keep && hi > lo) { const uint32_t* l; uint32_t ll; childFinal(a, cb + c, l, ll); keep = sortedContains(l + lo, hi - lo, v); }
+        const uint32_t v = (k < len) ? a.list[off + k] : 0xFFFFFFFFu;
+        uint32_t w[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) w[c] = (cur[c] + (uint32_t)lane < clen[c]) ? cl[c][cur[c] + (uint32_t)lane] : 0xFFFFFFFFu;
+        const uint32_t vmax = (uint32_t)__shfl((int)v, (int)((len - base < 64u ? len - base : 64u) - 1u));
+#pragma unroll
+        for (int c = 0; c < 8; c++) s_win[wv][c][lane] = w[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bool keep = false;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            uint32_t cnt = (uint32_t)__popcll(__ballot(cur[c] + (uint32_t)lane < clen[c] && w[c] <= vmax));
+            if (k < len && !keep && cnt) keep = windowContains(s_win[wv][c], v);
+            if (cnt == 64u && cur[c] + 64u < clen[c] && cl[c][cur[c] + 64u] <= vmax) {       // (not a subset after all: the general search)
+                if (k < len && !keep) keep = sortedContains(cl[c] + cur[c] + 64u, clen[c] - cur[c] - 64u, v);
+                cnt = ((vmax == 0xFFFFFFFFu) ? clen[c] : lowerBoundFrom(cl[c], clen[c], cur[c] + 64u, vmax + 1u)) - cur[c];
+            }
+            cur[c] += cnt;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long mask = __ballot(keep);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (keep) a.ulist[off + kept + before] = v;
@@ -531,18 +553,33 @@ __global__ void k_mask_sizes(uint32_t n, const uint32_t* __restrict__ inner, con
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) maskBytes[i] = inner[i] ? 8u * ((uLen[i] + 7u) / 8u) : 0u;
 }
-// phase 2: per-child MSB-first byte masks over the union list; one wave per (node, child)
+// phase 2: per-child MSB-first byte masks over the union list; one wave per (node, child), the child's list streamed like in phase 1
+// (it is a subset of the union list)
 __global__ void __launch_bounds__(256) k_merge_masks(MergeArgs a) {
+    __shared__ uint32_t s_win[4][64];
     const uint32_t item = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t node = item >> 3, c = item & 7u;
     if (node >= a.n || !a.inner[node]) return;
     const uint32_t off = a.listOff[node], ul = a.uLen[node], nb = (ul + 7u) / 8u;
     const uint32_t* l; uint32_t ll; childFinal(a, a.childBase[node] + c, l, ll);
     uint8_t* dst = a.masks + a.maskOff[node] + (size_t)c * nb;
+    uint32_t cur = 0;
     for (uint32_t base = 0; base < ul; base += 64) {
         const uint32_t k = base + lane;
-        const bool in = (k < ul) && sortedContains(l, ll, a.ulist[off + k]);
+        const uint32_t v = (k < ul) ? a.ulist[off + k] : 0xFFFFFFFFu;
+        const uint32_t w = (cur + (uint32_t)lane < ll) ? l[cur + (uint32_t)lane] : 0xFFFFFFFFu;
+        const uint32_t vmax = (uint32_t)__shfl((int)v, (int)((ul - base < 64u ? ul - base : 64u) - 1u));
+        s_win[wv][lane] = w;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t cnt = (uint32_t)__popcll(__ballot(cur + (uint32_t)lane < ll && w <= vmax));
+        bool in = (k < ul) && cnt && windowContains(s_win[wv], v);
+        if (cnt == 64u && cur + 64u < ll && l[cur + 64u] <= vmax) {       // (not a subset after all: the general search)
+            if (k < ul && !in) in = sortedContains(l + cur + 64u, ll - cur - 64u, v);
+            cnt = ((vmax == 0xFFFFFFFFu) ? ll : lowerBoundFrom(l, ll, cur + 64u, vmax + 1u)) - cur;
+        }
+        cur += cnt;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const unsigned long long m = __ballot(in);
         if (lane < 8) {
             const uint32_t byteIdx = (base >> 3) + (uint32_t)lane;
