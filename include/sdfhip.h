@@ -83,6 +83,11 @@ typedef struct sdfhip_octree sdfhip_octree;
 typedef struct sdfhip_exact sdfhip_exact;
 
 const char* sdfhip_last_error(void);
+/* Which order of the reference's interpolateValue this library computes in (everything else is identical): 0 = the literal order of a
+ * SDFLIB_USE_ENOKI=OFF build (include/SdfLib/InterpolationMethods.h:432-439; libsdfhip.so), 1 = the four-wide dot products of a
+ * SDFLIB_USE_ENOKI=ON build, the reference's CMake default (:383-430; libsdfhip_enoki.so).  A compile-time option of the reference
+ * (CMakeLists.txt:24, 96-100), a link-time choice here: both libraries export the same ABI. */
+int sdfhip_interpolation_flavour(void);
 const char* sdfhip_version(void);
 /* sizeof(sdfhip_octree_info), sizeof(sdfhip_octree_params), sizeof(sdfhip_exact_info): lets a binding verify its struct mirrors */
 void sdfhip_abi_sizes(uint64_t out[3]);

@@ -2,7 +2,7 @@
 //
 // Restates TriCubicInterpolation and the subdivision rules (reference file:line):
 //   calculateCoefficients    include/SdfLib/InterpolationMethods.h:292-378
-//   interpolateValue         include/SdfLib/InterpolationMethods.h:432-439   (scalar, ENOKI off flavour)
+//   interpolateValue         include/SdfLib/InterpolationMethods.h:432-439   (scalar, ENOKI off flavour; -DORC_ENOKI_ORDER: :383-430)
 //   interpolateGradient      include/SdfLib/InterpolationMethods.h:442-455
 //   interpolateVertexValues  include/SdfLib/InterpolationMethods.h:457-497
 //   trapezoid / Simpson / by-distance rules   include/SdfLib/OctreeSdfUtils.h:60-85, 213-238, 87-138
@@ -83,13 +83,46 @@ static inline float powTerm(float t, float x, int i, float y, int j, float z, in
     return t;
 }
 
-static inline float tricubicValue(const float c[64], V3 f) {
+static inline float tricubicValueLiteral(const float c[64], V3 f) {
     float acc = 0.0f;
     for (int n = 0; n < 64; n++) {
         const int i = n & 3, j = (n >> 2) & 3, k = n >> 4;
         acc = acc + powTerm(c[n], f.x, i, f.y, j, f.z, k);
     }
     return acc;
+}
+// interpolateValue of the SDFLIB_USE_ENOKI=ON flavour (include/SdfLib/InterpolationMethods.h:383-430; the reference's CMake default,
+// CMakeLists.txt:24): four 4-wide power vectors x1 = (1, x, x x, (x x) x), x2 = y x1, x3 = y x2, x4 = y x3, every z-slab adds
+// dot(x1, c[16k..]) + dot(x2, c[16k+4..]) + dot(x3, c[16k+8..]) + dot(x4, c[16k+12..]) (left to right) to the sum and then multiplies
+// the four vectors by z.  enoki::dot of two Array<float, 4> = (a0 b0 + a1 b1) + (a2 b2 + a3 b3), every product rounded: that is
+// DPPS's documented order (Enoki's SSE4.2 path, _mm_dp_ps) and equally the order of Enoki's generic hsum(a * b) (low half + high half).
+// Enoki itself is NOT under /root/reference (fetched by libs/CMakeLists.txt:99-131): this order is restated from those semantics and
+// is "parity unpinned" like everything else that needs the absent third-party headers.
+static inline float tricubicValueEnoki(const float c[64], V3 f) {
+    float x[4][4];
+    x[0][0] = 1.0f; x[0][1] = f.x; x[0][2] = f.x * f.x; x[0][3] = f.x * f.x * f.x;
+    for (int j = 1; j < 4; j++) for (int i = 0; i < 4; i++) x[j][i] = f.y * x[j - 1][i];
+    float sum = 0.0f;
+    for (int k = 0; k < 4; k++) {
+        if (k > 0) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) x[j][i] = f.z * x[j][i];
+        float d[4];
+        for (int j = 0; j < 4; j++) {
+            const float* v = c + 16 * k + 4 * j;
+            d[j] = (x[j][0] * v[0] + x[j][1] * v[1]) + (x[j][2] * v[2] + x[j][3] * v[3]);
+        }
+        const float slab = d[0] + d[1] + d[2] + d[3];
+        sum = (k == 0) ? slab : sum + slab;
+    }
+    return sum;
+}
+// the flavour every direct caller of interpolateValue sees (rules, getDistance, minimum border value, the CONTINUITY builder's own
+// error estimate); interpolateVertexValues spells its value out literally in both flavours (InterpolationMethods.h:459-464)
+static inline float tricubicValue(const float c[64], V3 f) {
+#ifdef ORC_ENOKI_ORDER
+    return tricubicValueEnoki(c, f);
+#else
+    return tricubicValueLiteral(c, f);
+#endif
 }
 
 // Generic derivative sum: ex/ey/ez in {0,1} select which variables are differentiated once.
@@ -110,7 +143,7 @@ static inline V3 tricubicGradient(const float c[64], V3 f) {
 }
 
 static inline void tricubicVertexValues(const float c[64], V3 f, float nodeSize, float out[8]) {
-    out[0] = tricubicValue(c, f);
+    out[0] = tricubicValueLiteral(c, f);
     out[1] = tricubicDeriv(c, f, 1, 0, 0) / nodeSize;
     out[2] = tricubicDeriv(c, f, 0, 1, 0) / nodeSize;
     out[3] = tricubicDeriv(c, f, 0, 0, 1) / nodeSize;

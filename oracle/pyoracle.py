@@ -25,9 +25,11 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libsdf_oracle.so")
+        # SDFLIB_USE_ENOKI=1 (the name of the reference's CMake option): the oracle with interpolateValue in the Enoki flavour's order
+        enoki = os.environ.get("SDFLIB_USE_ENOKI", "0") not in ("", "0", "OFF", "off")
+        so = os.path.join(_HERE, "libsdf_oracle_enoki.so" if enoki else "libsdf_oracle.so")
         if not os.path.exists(so):
-            build()
+            build(force=True)
         L = C.CDLL(so)
         vp, u32, u64, f32, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_float, C.c_int32
         sig = {
@@ -42,6 +44,7 @@ def lib():
             "orc_point_values": (None, [vp, vp, vp, u64, vp]),
             "orc_fit_matrix": (None, [vp]), "orc_tricubic_fit": (None, [vp, f32, vp]),
             "orc_tricubic_value": (f32, [vp, vp]), "orc_tricubic_gradient": (None, [vp, vp, vp]),
+            "orc_tricubic_value_literal": (f32, [vp, vp]), "orc_tricubic_value_enoki": (f32, [vp, vp]), "orc_interpolation_flavour": (C.c_int, []),
             "orc_tricubic_vertex_values": (None, [vp, vp, f32, vp]), "orc_rule_value": (f32, [C.c_int, vp, vp, f32]),
             "orc_stencil": (None, [vp, vp, vp]), "orc_is_near_minimize": (C.c_int, [f32, vp, vp, f32, vp]),
             "orc_octree_build": (vp, [vp, vp, u32, u32, C.c_int, f32, f32, C.c_int, C.c_int]),

@@ -110,6 +110,15 @@ void orc_point_values(orc_mesh* m, const float* pts, const uint32_t* tris, uint6
 void orc_fit_matrix(int32_t* out) { const FitMatrix& f = fitMatrix(); for (int r = 0; r < 64; r++) for (int c = 0; c < 64; c++) out[64 * r + c] = f.m[r][c]; }
 void orc_tricubic_fit(const float* in, float ns, float* out) { tricubicFit(reinterpret_cast<const float(*)[8]>(in), ns, out); }
 float orc_tricubic_value(const float* c, const float f[3]) { return tricubicValue(c, ld3(f)); }
+float orc_tricubic_value_literal(const float* c, const float f[3]) { return tricubicValueLiteral(c, ld3(f)); }
+float orc_tricubic_value_enoki(const float* c, const float f[3]) { return tricubicValueEnoki(c, ld3(f)); }
+int orc_interpolation_flavour(void) {
+#ifdef ORC_ENOKI_ORDER
+    return 1;
+#else
+    return 0;
+#endif
+}
 void orc_tricubic_gradient(const float* c, const float f[3], float o[3]) { V3 g = tricubicGradient(c, ld3(f)); o[0] = g.x; o[1] = g.y; o[2] = g.z; }
 void orc_tricubic_vertex_values(const float* c, const float f[3], float ns, float o[8]) { tricubicVertexValues(c, ld3(f), ns, o); }
 float orc_rule_value(int rule, const float* c, const float* mid, float p1) { return ruleValue(rule, c, reinterpret_cast<const float(*)[8]>(mid), p1); }

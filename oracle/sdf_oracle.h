@@ -33,7 +33,10 @@ void orc_point_values(orc_mesh*, const float* pts, const uint32_t* tris, uint64_
 
 void orc_fit_matrix(int32_t* out_64x64);
 void orc_tricubic_fit(const float* in_8x8, float node_size, float* out64);
-float orc_tricubic_value(const float* c64, const float frac[3]);
+float orc_tricubic_value(const float* c64, const float frac[3]);            /* the library's flavour (see orc_interpolation_flavour) */
+float orc_tricubic_value_literal(const float* c64, const float frac[3]);    /* InterpolationMethods.h:432-439 */
+float orc_tricubic_value_enoki(const float* c64, const float frac[3]);      /* InterpolationMethods.h:383-430 */
+int orc_interpolation_flavour(void);                                        /* 0: SDFLIB_USE_ENOKI=OFF order (libsdf_oracle.so), 1: =ON order (libsdf_oracle_enoki.so) */
 void orc_tricubic_gradient(const float* c64, const float frac[3], float out[3]);
 void orc_tricubic_vertex_values(const float* c64, const float frac[3], float node_size, float out8[8]);
 float orc_rule_value(int rule, const float* c64, const float* mid_19x8, float param1);

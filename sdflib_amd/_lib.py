@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+# SDFLIB_USE_ENOKI=1 (the name of the reference's CMake option, read once at import): the library whose interpolateValue follows the
+# order of the reference's Enoki flavour (libsdfhip_enoki.so); everything else, the ABI included, is the same
+USE_ENOKI = os.environ.get("SDFLIB_USE_ENOKI", "0") not in ("", "0", "OFF", "off")
+LIB_PATH = os.path.join(_HERE, "libsdfhip_enoki.so" if USE_ENOKI else "libsdfhip.so")
 _LIB = None
 
 
@@ -58,6 +61,7 @@ class Exchange(C.Structure):
 _vp, _u32, _u64, _i32, _f32, _int = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float, C.c_int
 SIGNATURES = {
     "sdfhip_last_error": (C.c_char_p, []),
+    "sdfhip_interpolation_flavour": (_int, []),
     "sdfhip_version": (C.c_char_p, []),
     "sdfhip_ctx_create": (_int, [_int, _vp, _int, C.POINTER(_vp)]),
     "sdfhip_ctx_destroy": (_int, [_vp]),

@@ -215,6 +215,13 @@ using namespace sdfhip;
 extern "C" {
 
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
+int sdfhip_interpolation_flavour(void) {
+#ifdef SDFHIP_ENOKI_ORDER
+    return 1;
+#else
+    return 0;
+#endif
+}
 const char* sdfhip_version(void) { return "sdfhip 0.1 (gfx950)"; }
 void sdfhip_abi_sizes(uint64_t out[3]) { out[0] = sizeof(sdfhip_octree_info); out[1] = sizeof(sdfhip_octree_params); out[2] = sizeof(sdfhip_exact_info); }
 

@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                                                       uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, uint32_t* __restrict__ counters,
                                                       uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount, int drainQuads, uint32_t chunk,
                                                       bool seedFromNeighbour, uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, int pass,
-                                                      uint32_t* __restrict__ best, uint32_t lead, uint32_t multiSeed) {
+                                                      uint32_t* __restrict__ best, uint32_t lead, uint32_t multiSeed, uint32_t refillMin) {
     __shared__ uint32_t s_ref[BLOCK / 64][QUAD_STACK][16];
     __shared__ unsigned short s_lb[BLOCK / 64][QUAD_STACK][16];
     __shared__ uint32_t s_tq[BLOCK / 64][QUAD_TQ][16];
@@ -438,7 +438,10 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
     bool have = false, done = false, overflow = false;
     for (;;) {
         // ---- refill: quads without a query draw from the wave's chunk (one atomic per chunk)
+        // (the refill is a stretch of ~150 instructions and a memory round trip that the WHOLE wave executes for the quads that draw:
+        // it waits until refillMin quads are idle — or nobody has work left)
         uint64_t idle = __ballot(c == 0u && !have && !done);
+        if (idle != 0ull && (uint32_t)__popcll(idle) < refillMin && __ballot(have) != 0ull) idle = 0ull;
         while (idle != 0ull) {
             if (chunkNext >= chunkEnd) {
                 if (tried >= 8u && phase == 1) {
@@ -920,11 +923,12 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
         static const uint32_t qPerCU = getenv("SDFHIP_NEAR_QBLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QBLOCKS_PER_CU")) : 6u;       // all resident (70 VGPRs: 7 waves per SIMD); measured 6 < 8 < 12: blocks that start late only add a tail
         static const uint32_t qchunk = (getenv("SDFHIP_NEAR_QCHUNK") && atoi(getenv("SDFHIP_NEAR_QCHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QCHUNK")) : 16u;      // queries a wave (16 quads) takes per atomic: measured 16 < 32 < 64
         static const uint32_t multiSeed = getenv("SDFHIP_NEAR_MULTISEED") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_MULTISEED")) : 2u;       // leaders a follower is seeded from (1: the one before it; 2: the one after it as well)
+        static const uint32_t refillMin = getenv("SDFHIP_NEAR_REFILL") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_REFILL")) : 1u;       // idle quads a refill waits for
         uint32_t qgrid = 256u * qPerCU;
         const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
         if (qgrid > needBlocks) qgrid = needBlocks;
         k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead, multiSeed);
+                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead, multiSeed, refillMin);
     } else {
 #define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
         S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)

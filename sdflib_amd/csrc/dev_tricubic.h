@@ -2,7 +2,7 @@
 //
 // Reference behaviour reproduced (include/SdfLib/InterpolationMethods.h):
 //   calculateCoefficients :292-378   64 coefficients = constant 64x64 integer matrix x 64 scaled Hermite values
-//   interpolateValue      :432-439   sum of c[i+4j+16k] x^i y^j z^k, literal left-to-right products and sums
+//   interpolateValue      :432-439   sum of c[i+4j+16k] x^i y^j z^k, literal left-to-right products and sums (-DSDFHIP_ENOKI_ORDER: :383-430)
 //   interpolateGradient   :442-455   three derivative sums (normalised by the caller)
 //   interpolateVertexValues :457-497 value + 7 derivatives divided by nodeSize powers
 // and the subdivision rules of include/SdfLib/OctreeSdfUtils.h:60-85, 87-138, 213-238.
@@ -71,7 +71,7 @@ SDF_DEV void tricubicFit(float (&s)[64], float nodeSize, float (&out)[64]) {
 
 // ---- literal-order evaluation ("EXACT") -------------------------------------------------------------------
 template <typename CF>   // CF: callable n -> coefficient
-SDF_HD float tricubicValueExact(CF c, F3 f) {
+SDF_HD float tricubicValueLiteral(CF c, F3 f) {
     float acc = 0.0f;
 #pragma unroll
     for (int n = 0; n < 64; n++) {
@@ -86,6 +86,51 @@ SDF_HD float tricubicValueExact(CF c, F3 f) {
         acc = acc + t;
     }
     return acc;
+}
+
+// interpolateValue of the reference's SDFLIB_USE_ENOKI=ON flavour (InterpolationMethods.h:383-430, the CMake default): power vectors
+// x1 = (1, x, x x, (x x) x), x2 = y x1, x3 = y x2, x4 = y x3; every z-slab adds dot(x1, c[16k..]) + dot(x2, ..) + dot(x3, ..) + dot(x4, ..)
+// and the vectors are then multiplied by z; enoki::dot of two 4-vectors = (a0 b0 + a1 b1) + (a2 b2 + a3 b3) (DPPS's order, and that of
+// Enoki's generic hsum(a * b)).  Enoki's headers are not in the image: restated from those semantics, unpinned.
+template <typename CF>
+SDF_HD float tricubicValueEnoki(CF c, F3 f) {
+    float x[4][4];
+    x[0][0] = 1.0f; x[0][1] = f.x; x[0][2] = f.x * f.x; x[0][3] = f.x * f.x * f.x;
+#pragma unroll
+    for (int j = 1; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[j][i] = f.y * x[j - 1][i];
+    float sum = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[j][i] = f.z * x[j][i];
+        }
+        float d[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = 16 * k + 4 * j;
+            d[j] = (x[j][0] * c(b) + x[j][1] * c(b + 1)) + (x[j][2] * c(b + 2) + x[j][3] * c(b + 3));
+        }
+        const float slab = d[0] + d[1] + d[2] + d[3];
+        sum = (k == 0) ? slab : sum + slab;
+    }
+    return sum;
+}
+// What the reference's interpolateValue computes in the flavour this library is built for: libsdfhip.so = SDFLIB_USE_ENOKI OFF (the
+// literal order), libsdfhip_enoki.so (-DSDFHIP_ENOKI_ORDER) = ON.  Callers: the subdivision rules, getDistance, the minimum border value,
+// the CONTINUITY builder's own estimate.  interpolateVertexValues spells its value out literally in BOTH flavours (:459-464) and calls
+// tricubicValueLiteral.
+template <typename CF>
+SDF_HD float tricubicValueExact(CF c, F3 f) {
+#ifdef SDFHIP_ENOKI_ORDER
+    return tricubicValueEnoki(c, f);
+#else
+    return tricubicValueLiteral(c, f);
+#endif
 }
 
 template <int EX, int EY, int EZ, typename CF>

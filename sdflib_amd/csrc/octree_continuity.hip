@@ -97,7 +97,7 @@ SDF_HD void neighboursInGrid(uint32_t o, int gx, int gy, int gz, int G, uint32_t
 // interpolateVertexValues (InterpolationMethods.h:457-497)
 template <typename CF>
 SDF_DEV void vertexValuesExact(CF c, F3 f, float nodeSize, float* __restrict__ out8) {
-    out8[0] = tricubicValueExact(c, f);
+    out8[0] = tricubicValueLiteral(c, f);       // (interpolateVertexValues: literal in both flavours)
     out8[1] = tricubicDerivExact<1, 0, 0>(c, f) / nodeSize;
     out8[2] = tricubicDerivExact<0, 1, 0>(c, f) / nodeSize;
     out8[3] = tricubicDerivExact<0, 0, 1>(c, f) / nodeSize;

@@ -660,6 +660,18 @@ __global__ void __launch_bounds__(256) k_lattice_columns_exact(const float* __re
     const float fx = tx - floorf(tx), fy = ty - floorf(ty);
     const float4* src = reinterpret_cast<const float4*>(coef + 64ull * leaf);
     const size_t plane = (size_t)nx * ny, at0 = ((size_t)z0 * ny + y) * nx + x;
+#ifdef SDFHIP_ENOKI_ORDER
+    {   // the Enoki flavour's value multiplies its power vectors by z BEFORE the coefficients: nothing of a term but the vectors is shared along z
+        float cf[64];
+#pragma unroll
+        for (int n = 0; n < 16; n++) { const float4 q = src[n]; cf[4 * n] = q.x; cf[4 * n + 1] = q.y; cf[4 * n + 2] = q.z; cf[4 * n + 3] = q.w; }
+        size_t at = at0;
+        for (uint32_t z = z0; z < z1; z++, at += plane) {
+            const float tz = Fz[z] * scale, fz = tz - floorf(tz);
+            dist[at] = tricubicValueEnoki([&](int n) { return cf[n]; }, F3{fx, fy, fz});
+        }
+    }
+#else
     {
         float P[64];
         columnPrefixes<0, 0, 0>(src, fx, fy, P);
@@ -669,6 +681,7 @@ __global__ void __launch_bounds__(256) k_lattice_columns_exact(const float* __re
             dist[at] = columnPoint<0, 0, 0>(P, fz);
         }
     }
+#endif
     if (GRAD) {
         float PX[64], PY[64], PZ[64];
         columnPrefixes<1, 0, 0>(src, fx, fy, PX); columnPrefixes<0, 1, 0>(src, fx, fy, PY); columnPrefixes<0, 0, 1>(src, fx, fy, PZ);

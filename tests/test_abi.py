@@ -34,6 +34,21 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     assert sorted(SIGNATURES) == declared
 
 
+def test_enoki_flavour_library_exports_the_same_abi(built_lib):
+    """libsdfhip_enoki.so (interpolateValue in the order of the reference's SDFLIB_USE_ENOKI=ON flavour): same symbols, other flavour id.
+    Loading a second copy of the engine is harmless without a device call; the flavour query needs none."""
+    import ctypes as C
+    import sdflib_amd
+    path = os.path.join(os.path.dirname(sdflib_amd.LIB_PATH), "libsdfhip_enoki.so")
+    assert os.path.exists(path), "libsdfhip_enoki.so has not been built (make -C sdflib_amd/csrc)"
+    L = C.CDLL(path)
+    for name in _declared_symbols():
+        assert hasattr(L, name), f"{name} not exported by libsdfhip_enoki.so"
+    L.sdfhip_interpolation_flavour.restype = C.c_int
+    assert L.sdfhip_interpolation_flavour() == 1 and built_lib.sdfhip_interpolation_flavour() == 0
+    assert b"gfx950" in open(path, "rb").read()
+
+
 def test_code_object_targets_gfx950(built_lib):
     import sdflib_amd
     blob = open(sdflib_amd.LIB_PATH, "rb").read()
