@@ -164,6 +164,11 @@ int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_
 /* test hook, host only: mismatches between the BVH planner's threaded restatement of std::sort and std::sort itself on n keys */
 int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads);
 int sdfhip_test_heap_sort_matches_std(const double* keys, uint64_t n);     /* the restated libstdc++ heap sort vs std::make_heap + std::sort_heap */
+/* test hooks: the restated glibc acosf of the mesh preparation (dev_math.h::acosfGlibc) against the running libm on the bit patterns
+ * first_bits + i * stride, i < count (values outside [-1, 1] skipped) - its host compilation (no device needed; 0, 1, 2^32 = every float),
+ * and its device compilation.  Both return / store the number of differing results. */
+uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads);
+int sdfhip_test_acosf_device(sdfhip_ctx* ctx, uint32_t first_bits, uint32_t stride, uint32_t count, uint64_t* out_mismatches);
 /* the BVH planner alone, host memory in and out (no device needed): 8 doubles + 2 ints per inner node, max(num_triangles - 1, 1) nodes.
  * Replaces the tree half of tmd::TriangleMeshDistance::construct (TriangleMeshDistance.h:421-490); CPU tests compare it with the oracle's. */
 int sdfhip_test_plan_bvh(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, double* out_spheres, int32_t* out_children, double* seconds);

@@ -81,6 +81,8 @@ SIGNATURES = {
     "sdfhip_mesh_bvh_import": (_int, [_vp, _vp, _vp, _int]),
     "sdfhip_mesh_nearest": (_int, [_vp, _vp, _u64, _vp, _int]),
     "sdfhip_abi_sizes": (None, [_vp]),
+    "sdfhip_test_acosf_mismatches": (_u64, [_u32, _u32, _u64, _int]),
+    "sdfhip_test_acosf_device": (_int, [_vp, _u32, _u32, _u32, _vp]),
     "sdfhip_test_sort_matches_std": (_int, [_vp, _u64, _int]),
     "sdfhip_test_heap_sort_matches_std": (_int, [_vp, _u64]),
     "sdfhip_test_plan_bvh": (_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp]),

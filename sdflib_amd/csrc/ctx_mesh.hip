@@ -92,12 +92,13 @@ __global__ void k_edge_pair(const uint64_t* __restrict__ key, const uint32_t* __
     }
 }
 
-// cosine of the corner angle of half-edge he = 3 t + k (corner k of triangle t), clamped: the argument of the reference's acos
-// (TriangleUtils.cpp:85-86).  The arc cosine itself is taken on the HOST, by the platform's libm — the very function the
-// reference calls: libm's acosf is not correctly rounded, so no device implementation can promise its bits (ocml's differs in
-// the last ulp for some arguments), and one ulp in a vertex pseudonormal flips the sign of a sample that lies in the plane
-// spanned by it.  12 B per triangle each way; the host works while the device sorts the half-edges.
-__global__ void k_corner_cos(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numHalfEdges, float* __restrict__ cs) {
+// corner angle of half-edge he = 3 t + k (corner k of triangle t): the arc cosine of the clamped cosine (TriangleUtils.cpp:85-86).
+// The reference takes it with glm::acos, i.e. the platform's acosf, which is not correctly rounded — and one ulp in a vertex
+// pseudonormal flips the sign of a sample that lies in the plane spanned by it.  Rounds 1-3 therefore sent the cosines to the HOST's
+// libm and back (24 B per triangle over PCIe and a few ms of host threads); since round 4 the device runs glibc's algorithm itself
+// (dev_math.h::acosfGlibc, equal to the running libm on every float of [-1, 1]: sdfhip_test_acosf_mismatches).  angle = false
+// (SDFHIP_ACOS=host) writes the cosine and leaves the arc cosine to the host as before.
+__global__ void k_corner_cos(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numHalfEdges, float* __restrict__ cs, bool angle) {
     const uint32_t he = blockIdx.x * blockDim.x + threadIdx.x;
     if (he >= numHalfEdges) return;
     const uint32_t t = he / 3, k = he - 3 * t;
@@ -105,7 +106,12 @@ __global__ void k_corner_cos(const float* __restrict__ verts, const uint32_t* __
     const F3 pa = F3{verts[3 * a], verts[3 * a + 1], verts[3 * a + 2]};
     const F3 pb = F3{verts[3 * b], verts[3 * b + 1], verts[3 * b + 2]};
     const F3 pc = F3{verts[3 * c], verts[3 * c + 1], verts[3 * c + 2]};
-    cs[he] = gclamp(dot(normalize(pb - pa), normalize(pc - pa)), -1.0f, 1.0f);
+    const float cosine = gclamp(dot(normalize(pb - pa), normalize(pc - pa)), -1.0f, 1.0f);
+    cs[he] = angle ? acosfGlibc(cosine) : cosine;
+}
+__global__ void k_test_acosf(uint32_t firstBits, uint32_t stride, uint32_t count, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = acosfGlibc(__uint_as_float(firstBits + i * stride));
 }
 
 __global__ void k_vertex_normal_sum(const uint32_t* __restrict__ vkey, const uint32_t* __restrict__ val, uint32_t n,
@@ -215,6 +221,47 @@ using namespace sdfhip;
 extern "C" {
 
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
+// test hooks: acosfGlibc against the running libm.  Host compilation on the bit patterns first, first + stride, ... (count of them; the
+// values outside [-1, 1] are skipped), on `threads` host threads; and the DEVICE compilation on the same patterns.
+uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads) {
+    if (threads < 1) threads = 1;
+    std::vector<uint64_t> bad((size_t)threads, 0);
+    auto work = [&](int q) {
+        for (uint64_t i = (uint64_t)q; i < count; i += (uint64_t)threads) {
+            const uint32_t b = first_bits + (uint32_t)(i * stride);
+            float x; memcpy(&x, &b, 4);
+            if (!(std::fabs(x) <= 1.0f)) continue;
+            const float a = ::acosf(x), m = acosfGlibc(x);
+            if (memcmp(&a, &m, 4)) bad[(size_t)q]++;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int q = 1; q < threads; q++) th.emplace_back(work, q);
+    work(0);
+    for (std::thread& t : th) t.join();
+    uint64_t total = 0; for (uint64_t v : bad) total += v;
+    return total;
+}
+int sdfhip_test_acosf_device(sdfhip_ctx* ctx, uint32_t first_bits, uint32_t stride, uint32_t count, uint64_t* out_mismatches) {
+    SDF_REQUIRE(ctx && out_mismatches, "null argument");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    DevBuf<float> d; SDF_TRY(d.reserve(count ? count : 1));
+    k_test_acosf<<<gridFor(count, 256), 256, 0, st>>>(first_bits, stride, count, d.p);
+    std::vector<float> h(count);
+    SDF_HIP_CHECK(hipMemcpyAsync(h.data(), d.p, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    uint64_t bad = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t b = first_bits + i * stride;
+        float x; memcpy(&x, &b, 4);
+        if (!(std::fabs(x) <= 1.0f)) continue;
+        const float a = ::acosf(x);
+        if (memcmp(&a, &h[i], 4)) bad++;
+    }
+    *out_mismatches = bad;
+    return SDFHIP_OK;
+}
 int sdfhip_interpolation_flavour(void) {
 #ifdef SDFHIP_ENOKI_ORDER
     return 1;
@@ -346,10 +393,14 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
     DevBuf<float> cornerAngle;
     if ((rc = cornerAngle.reserve(nhe))) return fail(rc);
-    k_corner_cos<<<gridFor(nhe, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nhe, cornerAngle.p);
-    std::vector<float> hAngle(nhe);
-    SDF_HIP_CHECK(hipMemcpyAsync(hAngle.data(), cornerAngle.p, sizeof(float) * nhe, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    static const bool hostAcos = getenv("SDFHIP_ACOS") && !strcmp(getenv("SDFHIP_ACOS"), "host");
+    k_corner_cos<<<gridFor(nhe, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nhe, cornerAngle.p, !hostAcos);
+    std::vector<float> hAngle;
+    if (hostAcos) {
+        hAngle.resize(nhe);
+        SDF_HIP_CHECK(hipMemcpyAsync(hAngle.data(), cornerAngle.p, sizeof(float) * nhe, hipMemcpyDeviceToHost, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
     if ((rc = packFrames(st, m->dTri.p, nt, m->dFrames.p))) return fail(rc);
 
     DevBuf<uint64_t> eKey, eKeyS; DevBuf<uint32_t> vKey, vKeyS, val, valS, valS2, counter; DevBuf<float> vnormal; DevBuf<unsigned char> tmp;
@@ -368,7 +419,7 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p, bbox6 ? openKey.p : nullptr, bbox6 ? openHe.p : nullptr);
     SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
     SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
-    {   // the arc cosines, on host threads, while the device sorts (see k_corner_cos)
+    if (hostAcos) {   // the arc cosines on host threads while the device sorts (see k_corner_cos)
         unsigned parts = (unsigned)(nhe / 65536u); const unsigned hc = std::thread::hardware_concurrency();
         if (parts > (hc ? hc : 1u)) parts = hc ? hc : 1u;
         if (parts > 64u) parts = 64u;
@@ -379,8 +430,8 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
         for (unsigned q = 1; q < parts; q++) th.emplace_back(work, (uint64_t)nhe * q / parts, (uint64_t)nhe * (q + 1) / parts);
         work(0, (uint64_t)nhe / parts);
         for (std::thread& t : th) t.join();
+        SDF_HIP_CHECK(hipMemcpyAsync(cornerAngle.p, hAngle.data(), sizeof(float) * nhe, hipMemcpyHostToDevice, st));
     }
-    SDF_HIP_CHECK(hipMemcpyAsync(cornerAngle.p, hAngle.data(), sizeof(float) * nhe, hipMemcpyHostToDevice, st));
     k_vertex_normal_sum<<<gridFor(nhe, 256), 256, 0, st>>>(vKeyS.p, valS2.p, nhe, cornerAngle.p, m->dTri.p, vnormal.p);
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipMemcpyAsync(&m->unmatchedEdges, counter.p, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

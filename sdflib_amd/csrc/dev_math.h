@@ -45,6 +45,48 @@ SDF_HD float length(F3 v) { return sqrtf(dot(v, v)); }
 SDF_HD float gmin(float a, float b) { return (b < a) ? b : a; }
 SDF_HD float gmax(float a, float b) { return (a < b) ? b : a; }
 SDF_HD float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
+
+// acosf as glibc computes it (sysdeps/ieee754/flt-32/e_acosf.c, the fdlibm float routine: a rational approximation on |x| < 0.5, the
+// half-angle identities with a split square root beyond), operation for operation in fp32 with IEEE sqrt and division — so that the
+// corner angles of the vertex pseudonormals (TriangleUtils.cpp:85-86 calls glm::acos = the platform's acosf) are the ones the reference
+// gets on such a platform WITHOUT a round trip to the host.  libm's acosf is not correctly rounded, so this is an identity of
+// algorithms, not of specifications: sdfhip_test_acosf_mismatches (tests/test_abi.py) compares the host compilation of this very
+// function with the running libm on EVERY float of [-1, 1] (2 130 706 434 values: none differs on glibc 2.35), the GPU tests compare
+// the device compilation with libm; `SDFHIP_ACOS=host` restores the host's libm (for a platform whose libm is another algorithm).
+SDF_HD float acosfGlibc(float x) {
+    const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;
+    const float qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f, qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const int hx = (int)__builtin_bit_cast(unsigned, x), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000) return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000) return (x - x) / (x - x);
+    if (ix < 0x3f000000) {                      // |x| < 0.5
+        if (ix <= 0x23000000) return pio2_hi + pio2_lo;
+        const float z = x * x;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float r = p / q;
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) {                               // x < -0.5
+        const float z = (one + x) * 0.5f;
+        const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+        const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+        const float s = sqrtf(z);
+        const float r = p / q;
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (one - x) * 0.5f;           // x > 0.5
+    const float s = sqrtf(z);
+    const float df = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = one + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    const float r = p / q;
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
 SDF_HD float gsign(float x) { return (float)(0.0f < x) - (float)(x < 0.0f); }
 SDF_HD float gfract(float x) { return x - floorf(x); }
 

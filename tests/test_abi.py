@@ -34,6 +34,14 @@ def test_every_declared_symbol_is_exported_and_bound(built_lib):
     assert sorted(SIGNATURES) == declared
 
 
+def test_restated_acosf_equals_the_running_libm_on_every_float(built_lib):
+    """The mesh preparation takes the corner angles of the vertex pseudonormals on the device with glibc's acosf algorithm restated
+    (dev_math.h::acosfGlibc) instead of sending the cosines to the host's libm.  libm's acosf is not correctly rounded, so the claim is
+    checked exhaustively: the host compilation of that function against ::acosf on all 2 130 706 434 floats of [-1, 1]."""
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    assert built_lib.sdfhip_test_acosf_mismatches(0, 1, 1 << 32, threads) == 0
+
+
 def test_enoki_flavour_library_exports_the_same_abi(built_lib):
     """libsdfhip_enoki.so (interpolateValue in the order of the reference's SDFLIB_USE_ENOKI=ON flavour): same symbols, other flavour id.
     Loading a second copy of the engine is harmless without a device call; the flavour query needs none."""

@@ -70,19 +70,20 @@ b = lambda a: np.ascontiguousarray(a).view(np.uint32)
 v, f = bumpy_icosphere(4); box = box_with_margin(v)
 m = S.Mesh(v, f); om = O.Mesh(v, f)
 pts = random_points_in_box(box, 200001, seed=5); pts[::97] *= 2.0
+ins = np.ones(len(pts), bool); ins[::97] = False          # (the gradient of a point outside the grid is not defined by the reference)
 for alg, cont in ((S.ALG_NO_CONTINUITY, False), (S.ALG_CONTINUITY, True)):
     for rule in (O.RULE_TRAPEZOIDAL, O.RULE_SIMPSONS):
-        t = S.OctreeSdf(m, box, 6, 2, 1e-3, init_algorithm=alg, termination_rule=rule)
+        t = S.OctreeSdf(m, box, 6, 2, 1e-3, init_algorithm=alg, termination_rule=rule, num_threads=2)          # (2 threads = the reference's subtree layout, the oracle's default)
         o = O.Octree(om, box, 6, 2, 1e-3, rule=rule, continuity=cont)
         assert np.array_equal(t.get_octree_data(), o.data()), (alg, rule)
         assert b(np.float32(t.info.min_border_value)) == b(np.float32(o.min_border))
         d0, g0 = o.query(pts, grad=True)
         d, g = t.get_distance(pts, gradient=True)
-        assert np.array_equal(b(d), b(d0)) and np.array_equal(b(g), b(g0)), (alg, rule)
+        assert np.array_equal(b(d), b(d0)) and np.array_equal(b(g[ins]), b(g0[ins])), (alg, rule)
         assert np.array_equal(b(t.get_distance(pts)), b(d0))
         assert np.array_equal(b(t.get_distance(pts[:9])), b(d0[:9]))          # the host path of small batches
 # the leaf-driven lattice against the point kernel
-t = S.OctreeSdf(m, box, 6, 2, 1e-3)
+t = S.OctreeSdf(m, box, 6, 2, 1e-3, num_threads=2)
 bb = t.get_grid_bounding_box(); n = 96
 org = bb[:3] + 0.37 * (bb[3:] - bb[:3]) / n; step = (bb[3:] - bb[:3]) / n * 0.99
 dg, gg = t.get_distance_grid(org, step, (n, n, n), gradient=True)

@@ -28,6 +28,18 @@ def test_triangle_data_matches_oracle(small):
     assert np.array_equal(bits(a), bits(b))
 
 
+def test_device_acosf_equals_libm(gpu_ctx):
+    """dev_math.h::acosfGlibc as the DEVICE compiles it (IEEE sqrt and division) against the host's libm: every 64th float and the
+    neighbourhoods of the routine's branch points (+-0.5, +-1, 2^-57); tests/test_abi.py checks the host compilation on every float."""
+    import ctypes as C
+    from sdflib_amd._lib import lib, check
+    bad = C.c_uint64(0)
+    for first, stride, count in ((0, 64, 1 << 26), (0x3f000000 - (1 << 20), 1, 1 << 21), (0xbf000000 - (1 << 20), 1, 1 << 21),
+                                 (0x3f800000 - (1 << 21), 1, (1 << 21) + 16), (0xbf800000 - (1 << 21), 1, (1 << 21) + 16), (0x23000000 - 4096, 1, 8192), (0xa3000000 - 4096, 1, 8192)):
+        check(lib().sdfhip_test_acosf_device(gpu_ctx.h, first, stride, count, C.byref(bad)))
+        assert bad.value == 0, (hex(first), stride, count, bad.value)
+
+
 def test_nearest_triangle_ids_bit_exact(small, oracle):
     rng = np.random.default_rng(7)
     pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)
