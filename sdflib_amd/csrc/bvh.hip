@@ -937,7 +937,7 @@ struct GsRound {
 SDF_DEV uint32_t gsTaskCount(const GsRound& R) { const uint32_t n = *R.nTasksPtr; return n < R.maxTasks ? n : R.maxTasks; }
 
 // one workgroup: pivots (median of three to the front), chunk layout of the round; zeroes the next round's counter
-__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) {
+SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) {
     __shared__ uint32_t s_part[16]; __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nT = gsTaskCount(R);
@@ -969,6 +969,7 @@ __global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __rest
     }
     if (tid == 0) R.chunkBase[nT] = s_carry;
 }
+__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) { gsPrepare(R, nextCount, flags); }
 // which range and which of its chunks a workgroup of the round kernels works on
 struct GsChunk { uint32_t task; int f, m; uint32_t k; float pk; };
 SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c, uint32_t* s_task) {
@@ -1044,10 +1045,8 @@ __global__ void __launch_bounds__(256) k_gs_swap(GsRound R) {
     if (threadIdx.x == 0 && D) atomicAdd(&R.swapped[c.task], D);
 }
 // the cut of every range and what becomes of its two parts
-__global__ void __launch_bounds__(256) k_gs_emit(GsRound R, GTask* __restrict__ next, uint32_t* __restrict__ nextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
-                                                 GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= gsTaskCount(R)) return;
+SDF_DEV void gsEmitOne(const GsRound& R, uint32_t t, GTask* __restrict__ next, uint32_t* __restrict__ nextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
+                       GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
     const GTask task = R.tasks[t];
     const int f = (int)task.first + 1, m = (int)task.last - f;
     const uint32_t nl = R.totL[t], nr = R.totR[t], ms = R.swapped[t];
@@ -1063,6 +1062,18 @@ __global__ void __launch_bounds__(256) k_gs_emit(GsRound R, GTask* __restrict__ 
         else if (len > 16u) { const uint32_t at = atomicAdd(partCount, 1u); if (at < maxParts) parts[at] = out; else atomicOr(flags, 1u); }
         else if (len > 1u) { const uint32_t at = atomicAdd(tinyCount, 1u); if (at < maxTiny) tiny[at] = out; else atomicOr(flags, 1u); }
     }
+}
+// ONE workgroup ends a round and begins the next: the cuts of the round's ranges (their parts go to the next round's list, to the LDS
+// sorts or to the tiny sorts), then — the list complete — the next round's pivots and chunk layout (gsPrepare).  One launch per round
+// less than as two kernels; a range's pivot is still taken exactly once (the level's first round is prepared by k_gs_prepare).
+__global__ void __launch_bounds__(1024) k_gs_emit_prepare(GsRound R, GsRound Rnext, uint32_t* __restrict__ afterNextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
+                                                          GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
+    const uint32_t nT = gsTaskCount(R);
+    for (uint32_t t = threadIdx.x; t < nT; t += 1024u)
+        gsEmitOne(R, t, const_cast<GTask*>(Rnext.tasks), const_cast<uint32_t*>(Rnext.nTasksPtr), parts, partCount, maxParts, tiny, tinyCount, maxTiny, ldsMax, flags);
+    __threadfence_block();           // (the list and its count are read by this workgroup only)
+    __syncthreads();
+    gsPrepare(Rnext, afterNextCount, flags);
 }
 // a part that fits in LDS: the rest of its introsort in one workgroup
 __global__ void __launch_bounds__(256) k_sort_parts(KeyTri* __restrict__ K, const GTask* __restrict__ parts, uint32_t ldsMax, uint32_t* __restrict__ flags) {
@@ -1839,23 +1850,30 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         SDF_HIP_CHECK(hipMemcpyAsync(ctr.p, hostCtr, 16, hipMemcpyHostToDevice, st));
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         uint32_t pending = count;
+        // The host learns a round's outcome only by waiting for it: rounds are queued in groups, sized for the most ranges they can have (a
+        // range leaves at most two); a round without ranges costs four empty launches.  The first group of a level is as long as its longest
+        // node needs with halving cuts (+ 1: ranges of at most partMax keys leave the rounds), the groups behind it take two rounds each
+        // (rounds 1-4: always four at a time, 156 rounds for the 9 levels of the 1.31 M mesh, of which the levels needed about 60).
+        uint32_t longest = 0; for (const TopNode& nd : nodes) longest = std::max(longest, nd.e - nd.b);
+        int groupRounds = 1; for (uint32_t m = longest; m > partMax; m >>= 1) groupRounds++;
+        static const int forcedGroup = getenv("SDFHIP_BVH_ROUNDS_PER_SYNC") ? atoi(getenv("SDFHIP_BVH_ROUNDS_PER_SYNC")) : 0;
+        auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p}; };
+        k_gs_prepare<<<1, 1024, 0, st>>>(roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
         while (pending > 0) {
-            // the host learns a round's outcome only by waiting for it: kRoundsPerSync rounds are queued at a time, sized for the most ranges they
-            // can have (a range leaves at most two); a round without ranges costs five empty launches
-            constexpr int kRoundsPerSync = 4;
             uint32_t bound = pending;
-            for (int q = 0; q < kRoundsPerSync; q++) {
-                GsRound R{K.p, Ll.p, Rl.p, tasks.p + (size_t)curBuf * maxTasks, ctr.p + curBuf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p};
+            const int nowRounds = forcedGroup > 0 ? forcedGroup : groupRounds;
+            for (int q = 0; q < nowRounds; q++) {
+                const GsRound R = roundOf(curBuf), Rn = roundOf(curBuf ^ 1);
                 const unsigned chunkGrid = (unsigned)(T / kGsChunk + bound + 1u);
-                k_gs_prepare<<<1, 1024, 0, st>>>(R, ctr.p + (curBuf ^ 1), ctr.p + 4);
                 k_gs_count<<<chunkGrid, 256, 0, st>>>(R);
                 k_gs_fill<<<chunkGrid, 256, 0, st>>>(R);
                 k_gs_swap<<<chunkGrid, 256, 0, st>>>(R);
-                k_gs_emit<<<gridFor(bound, 256), 256, 0, st>>>(R, tasks.p + (size_t)(curBuf ^ 1) * maxTasks, ctr.p + (curBuf ^ 1), parts.p, ctr.p + 2, maxParts, tiny.p, ctr.p + 3, maxTiny, partMax, ctr.p + 4);
+                k_gs_emit_prepare<<<1, 1024, 0, st>>>(R, Rn, ctr.p + curBuf, parts.p, ctr.p + 2, maxParts, tiny.p, ctr.p + 3, maxTiny, partMax, ctr.p + 4);
                 curBuf ^= 1;
                 rounds++;
                 bound = (bound > maxTasks / 2u) ? maxTasks : 2u * bound;
             }
+            groupRounds = 2;
             SDF_HIP_CHECK(hipMemcpyAsync(hostCtr, ctr.p, 20, hipMemcpyDeviceToHost, st));
             SDF_HIP_CHECK(hipStreamSynchronize(st));
             if (hostCtr[4]) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: gave up at level %zu (flags %u: 1 = a work list overflowed, 2 = a long range out of introsort's depth)\n", l, hostCtr[4]); return SDFHIP_E_UNSUPPORTED; }
