@@ -33,15 +33,17 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB
 def source_hashes():
     """sha256 of every source file the kernels are compiled from (the GPU box has no .git, so a commit id cannot be read there)."""
     import glob, hashlib
-    files = sorted(glob.glob(os.path.join(ROOT, "sdflib_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sdflib_amd", "csrc", "*.h"))) + [os.path.join(ROOT, "include", "sdfhip.h")]
+    files = sorted(glob.glob(os.path.join(ROOT, "sdflib_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sdflib_amd", "csrc", "*.h"))) + [os.path.join(ROOT, "include", "sdfhip.h"),
+                                                                                                                                               os.path.join(ROOT, "sdflib_amd", "csrc", "Makefile")]      # (the compiler flags)
     return {os.path.relpath(p, ROOT): hashlib.sha256(open(p, "rb").read()).hexdigest()[:16] for p in files}
 
 
 # the files a kernel's code comes from: a counter profile is accepted for a kernel only if none of them changed since it was recorded
 KERNEL_SOURCES = {          # (sdfhip_internal.h holds host-side plumbing — allocation, error handling — and no kernel code: not listed)
-    "octree_query": ["sdflib_amd/csrc/octree_query.hip", "sdflib_amd/csrc/octree_internal.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/blocks.hip"],
-    "exact_query": ["sdflib_amd/csrc/exact_query.hip", "sdflib_amd/csrc/exact_internal.h", "sdflib_amd/csrc/dev_math.h"],
-    "fit_mfma": ["sdflib_amd/csrc/dev_fit_mfma.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_build.hip"],
+    "octree_query": ["sdflib_amd/csrc/octree_query.hip", "sdflib_amd/csrc/octree_lattice.hip", "sdflib_amd/csrc/octree_internal.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h",
+                     "sdflib_amd/csrc/blocks.hip", "sdflib_amd/csrc/Makefile"],
+    "exact_query": ["sdflib_amd/csrc/exact_query.hip", "sdflib_amd/csrc/exact_internal.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/Makefile"],
+    "fit_mfma": ["sdflib_amd/csrc/dev_fit_mfma.h", "sdflib_amd/csrc/dev_tricubic.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_build.hip", "sdflib_amd/csrc/Makefile"],
 }
 
 
@@ -338,7 +340,7 @@ def main():
 
 
 NEAR_KERNEL = "sdfhip::k_near_quads<256>"
-KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip"]
+KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip", "sdflib_amd/csrc/Makefile"]
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 GPU_CLOCK_HZ, GPU_SIMDS = 2.4e9, 1024          # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 

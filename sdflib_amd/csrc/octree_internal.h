@@ -28,6 +28,12 @@ struct BuildLevel {
     bool presampled = false;        // created and sampled up front (levels down to the start depth exist a priori)
 };
 
+// leaf-driven lattice evaluation (plan: octree_query.hip; column kernels: octree_lattice.hip)
+constexpr int kLatMaxLevels = 14;           // 3 x 13 bits of local cell coordinates in a sort key
+struct LatCols { uint32_t mx[kLatMaxLevels], my[kLatMaxLevels]; int levels; uint32_t G; };
+int latticeColumnsLaunch(hipStream_t st, bool exact, const float* coef, const float* F, const uint16_t* ranges, const uint4* desc, const uint32_t* sortedLeaf, uint32_t waves,
+                         const LatCols& C, uint32_t nx, uint32_t ny, float* d, float* g);
+
 }  // namespace sdfhip
 
 struct sdfhip_octree {
