@@ -1874,8 +1874,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
                 bound = (bound > maxTasks / 2u) ? maxTasks : 2u * bound;
             }
             groupRounds = 2;
-            SDF_HIP_CHECK(hipMemcpyAsync(hostCtr, ctr.p, 20, hipMemcpyDeviceToHost, st));
-            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            SDF_TRY(readBackWords(st, ctr.p, nullptr, 5, hostCtr));
             if (hostCtr[4]) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: gave up at level %zu (flags %u: 1 = a work list overflowed, 2 = a long range out of introsort's depth)\n", l, hostCtr[4]); return SDFHIP_E_UNSUPPORTED; }
             pending = hostCtr[curBuf];
         }

@@ -216,11 +216,65 @@ static void weldSeams(const float* verts, const float* bbox6, const std::vector<
 
 }  // namespace sdfhip
 
+namespace sdfhip {
+__global__ void k_mailbox(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int count, volatile uint32_t* mb, uint32_t seq) {
+    for (int i = 0; i < count; i++) mb[2 + i] = a[i] + (b ? b[i] : 0u);
+    __threadfence_system();
+    mb[0] = seq;
+}
+namespace {
+struct Mailbox {
+    uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; int device = -1;      // (256 pinned bytes per thread and device, kept to the end of the process)
+};
+}
+int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int count, uint32_t* out) {
+    SDF_REQUIRE(count >= 1 && count <= 8, "internal: readBackWords takes 1 to 8 words");
+    static const bool plain = getenv("SDFHIP_READBACK") && !strcmp(getenv("SDFHIP_READBACK"), "copy");      // the copies of rounds 1-4
+    thread_local Mailbox boxes[16];
+    int device = 0;
+    SDF_HIP_CHECK(hipGetDevice(&device));
+    if (!plain && device >= 0 && device < 16) {
+        Mailbox& M = boxes[device];
+        if (!M.host) {
+            void* h = nullptr;
+            if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&M.dev), h, 0) == hipSuccess) {
+                M.host = static_cast<uint32_t*>(h); M.host[0] = 0; M.device = device;
+            } else { (void)hipGetLastError(); if (h) (void)hipHostFree(h); }
+        }
+        if (M.host) {
+            const uint32_t seq = ++M.seq ? M.seq : ++M.seq;          // never 0
+            k_mailbox<<<1, 1, 0, st>>>(a, b, count, M.dev, seq);
+            SDF_HIP_CHECK(hipGetLastError());
+            volatile uint32_t* mb = M.host;
+            const double t0 = nowSeconds();
+            uint32_t spins = 0;
+            while (__atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) {
+                __builtin_ia32_pause();
+                if ((++spins & 0x3FFFu) == 0u && nowSeconds() - t0 > 0.05) {          // something long, or something wrong: let the runtime say which
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q != hipSuccess && q != hipErrorNotReady) { setError("HIP error while waiting for a read-back: %s", hipGetErrorString(q)); return SDFHIP_E_HIP; }
+                    if (q == hipSuccess && __atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) { SDF_HIP_CHECK(hipStreamSynchronize(st)); }
+                }
+            }
+            for (int i = 0; i < count; i++) out[i] = mb[2 + i];
+            return SDFHIP_OK;
+        }
+    }
+    uint32_t ha[8], hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SDF_HIP_CHECK(hipMemcpyAsync(ha, a, 4 * (size_t)count, hipMemcpyDeviceToHost, st));
+    if (b) SDF_HIP_CHECK(hipMemcpyAsync(hb, b, 4 * (size_t)count, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    for (int i = 0; i < count; i++) out[i] = ha[i] + hb[i];
+    return SDFHIP_OK;
+}
+}  // namespace sdfhip
+
 using namespace sdfhip;
 
 extern "C" {
 
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
+
 // test hooks: acosfGlibc against the running libm.  Host compilation on the bit patterns first, first + stride, ... (count of them; the
 // values outside [-1, 1] are skipped), on `threads` host threads; and the DEVICE compilation on the same patterns.
 uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads) {

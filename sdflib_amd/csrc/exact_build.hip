@@ -715,12 +715,7 @@ struct ScanHelper {
 static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
     total = 0;
     if (n == 0) return SDFHIP_OK;
-    uint32_t a = 0, b = 0;
-    SDF_HIP_CHECK(hipMemcpyAsync(&a, scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(&b, val + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    total = a + b;
-    return SDFHIP_OK;
+    return readBackWords(st, scan + (n - 1), val + (n - 1), 1, &total);
 }
 
 }  // namespace sdfhip

@@ -602,8 +602,7 @@ static int ensureLeafCtx(sdfhip_exact* T, const ExactView& v) {
         k_exact_ctx_level<<<gridFor(nIn, 256), 256, 0, st>>>(v, reinterpret_cast<const CtxItem*>(fa.p), nIn, depth, reinterpret_cast<CtxItem*>(fb.p), cnt.p, T->leafCtx.p, (uint32_t)nn);
         SDF_HIP_CHECK(hipGetLastError());
         uint32_t nOut = 0;
-        SDF_HIP_CHECK(hipMemcpyAsync(&nOut, cnt.p, 4, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_TRY(readBackWords(st, cnt.p, nullptr, 1, &nOut));
         SDF_REQUIRE(nOut <= nn, "node array is not a tree");
         std::swap(fa, fb);
         nIn = nOut;

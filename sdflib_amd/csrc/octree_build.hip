@@ -419,11 +419,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
                 SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, L->inner.p, L->childBase.p, (int)L->n, st));
                 if (need > scanTmpBytes) { SDF_TRY(scanTmp.reserve(need)); scanTmpBytes = need; }
                 SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.p, need, L->inner.p, L->childBase.p, (int)L->n, st));
-                uint32_t lastScan = 0, lastInner = 0;
-                SDF_HIP_CHECK(hipMemcpyAsync(&lastScan, L->childBase.p + (L->n - 1), 4, hipMemcpyDeviceToHost, st));
-                SDF_HIP_CHECK(hipMemcpyAsync(&lastInner, L->inner.p + (L->n - 1), 4, hipMemcpyDeviceToHost, st));
-                SDF_HIP_CHECK(hipStreamSynchronize(st));
-                L->numInner = lastScan + lastInner;
+                SDF_TRY(readBackWords(st, L->childBase.p + (L->n - 1), L->inner.p + (L->n - 1), 1, &L->numInner));
                 k_scale8<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->childBase.p);
             } else { SDF_HIP_CHECK(hipStreamSynchronize(st)); L->numInner = 0; }
             tDecide += nowSeconds() - t0;

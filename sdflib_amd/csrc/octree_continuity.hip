@@ -860,12 +860,7 @@ static int scanExclusive(hipStream_t st, DevBuf<unsigned char>& tmp, size_t& tmp
 static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
     total = 0;
     if (n == 0) return SDFHIP_OK;
-    uint32_t a = 0, b = 0;
-    SDF_HIP_CHECK(hipMemcpyAsync(&a, scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(&b, val + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    total = a + b;
-    return SDFHIP_OK;
+    return readBackWords(st, scan + (n - 1), val + (n - 1), 1, &total);
 }
 
 int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, sdfhip_octree** out) {
@@ -1364,8 +1359,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     SDF_HIP_CHECK(hipMemsetAsync(ppCount.p, 0, 4, st));
                     kc_pp_list<<<gridFor(19ull * na, 128), 128, 0, st>>>(dops.p, na, LT, PD, ppPos.p, ppSlot.p, ppCount.p);
                     uint32_t ns = 0;
-                    SDF_HIP_CHECK(hipMemcpyAsync(&ns, ppCount.p, 4, hipMemcpyDeviceToHost, st));
-                    SDF_HIP_CHECK(hipStreamSynchronize(st));
+                    SDF_TRY(readBackWords(st, ppCount.p, nullptr, 1, &ns));
                     if (ns) {
                         int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
                         SDF_TRY(nearestTwoPhase(st, md.bvh, ppPos.p, ns, ppTri.p, ctx->nearScratch, depth + 2, 0u, 1u));
@@ -1413,8 +1407,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_TRY(fa[cur ^ 1].reserve(cap)); SDF_TRY(fc[cur ^ 1].reserve(cap));
             SDF_HIP_CHECK(hipMemsetAsync(cnt.p, 0, 4, st));
             kc_walk_level<<<gridFor(n, 256), 256, 0, st>>>(oc.p, fa[cur].p, fc[cur].p, n, d, fa[cur ^ 1].p, fc[cur ^ 1].p, cnt.p, lpd.p, stats.p + 1);
-            SDF_HIP_CHECK(hipMemcpyAsync(&n, cnt.p, 4, hipMemcpyDeviceToHost, st));
-            SDF_HIP_CHECK(hipStreamSynchronize(st));
+            SDF_TRY(readBackWords(st, cnt.p, nullptr, 1, &n));
             cur ^= 1;
         }
     }

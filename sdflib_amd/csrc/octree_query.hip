@@ -248,8 +248,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
         SDF_TRY(next->src.reserve(8ull * cur->count));
         SDF_HIP_CHECK(hipMemsetAsync(counters.p, 0, 4, st));
         k_ql_level<<<gridFor(cur->count, 256), 256, 0, st>>>(T->data.p, numWords, levels.empty() ? nullptr : cur->src.p, cur->count, cur->rank.p, next->src.p, counters.p);
-        SDF_HIP_CHECK(hipMemcpyAsync(h, counters.p, 12, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        SDF_TRY(readBackWords(st, counters.p, nullptr, 3, h));
         SDF_REQUIRE(h[2] == 0, "node array is not a valid octree (index out of range)");
         levelNodes.push_back(cur->count); levelLeafBase.push_back(h[1]);
         levels.push_back(std::move(cur));

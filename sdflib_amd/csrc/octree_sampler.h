@@ -158,11 +158,8 @@ static int sampleBatchBegin(hipStream_t st, const MeshDev& md, const SampleBatch
     SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 39, st));
     k_sample_mark<<<gridFor(total, 256), 256, 0, st>>>(B, S.keyS.p, S.valS.p, S.isRep.p);
     SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, b2, S.isRep.p, S.scan.p, (int)total, st));
-    uint32_t lastScan = 0, lastFlag = 0;
-    SDF_HIP_CHECK(hipMemcpyAsync(&lastScan, S.scan.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipMemcpyAsync(&lastFlag, S.isRep.p + (total - 1), 4, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    const uint32_t numReps = lastScan + lastFlag;
+    uint32_t numReps = 0;
+    SDF_TRY(readBackWords(st, S.scan.p + (total - 1), S.isRep.p + (total - 1), 1, &numReps));
     SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repPos.reserve(3 * (size_t)numReps));
     k_sample_rep_list<<<gridFor(total, 256), 256, 0, st>>>(B, S.isRep.p, S.scan.p, S.valS.p, total, S.repSample.p, S.repPos.p);
     const uint32_t blocks = gridFor(numReps, 128);

@@ -300,6 +300,12 @@ struct DevBuf {
 
 static inline unsigned gridFor(uint64_t work, unsigned block) { return (unsigned)((work + block - 1) / block); }
 
+// A few words from the device for the host, behind whatever is queued on `st`: a one-thread kernel stores them and then a sequence
+// number into host-mapped pinned memory (one mailbox per host thread and device), the host spins on the sequence number.  Measured on the
+// box (tools/sync_probe): 10 us behind a small kernel against 23 us for hipMemcpyAsync into a pageable word + hipStreamSynchronize — and
+// the builders read a count back several times per level (ctx_mesh.hip).  count <= 8; b (optional): out[i] = a[i] + b[i].
+int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int count, uint32_t* out);
+
 // Point queries are answered in chunks of at most this many points (grid dimensions and the sort's element count are 32-bit;
 // host arrays are staged chunk by chunk).  SDFHIP_QUERY_CHUNK overrides it (tests run the chunk loop on small inputs).
 static inline uint64_t queryChunk(bool hostBuffers) {
