@@ -1058,7 +1058,9 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         SDF_HIP_CHECK(hipGetLastError());
         ocSize += allocTotal;
-        SDF_HIP_CHECK(hipStreamSynchronize(st)); lap(tIter);
+        static const bool timingSync = getenv("SDFHIP_TIMING") != nullptr;
+        if (!devicePP || timingSync) SDF_HIP_CHECK(hipStreamSynchronize(st));          // (the host planner reads the candidate list; otherwise only the phase times want it)
+        lap(tIter);
         if (!devicePP) {
         // ---------------- mirrors for the planner: integer node state of this level + the words written so far
         L->hCoord.resize(n); L->hPci.resize(n); L->hNIdx.resize(6ull * n); L->hWord.resize(n); L->hPath.resize(n); L->hNDepth.resize(6ull * n); L->hTerminal.resize(n);
