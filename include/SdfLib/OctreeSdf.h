@@ -1,7 +1,8 @@
 // sdflib::OctreeSdf — API-compatible with the reference class (include/SdfLib/OctreeSdf.h:20-300) for the hot path:
 // constructors, getDistance (scalar and batched), getters, OctreeNode layout.  Construction and batched queries run on
 // the MI355X through the libsdfhip C ABI; the scalar getDistance(vec3) reads the host copy of the node array that
-// getOctreeData() exposes (same array the reference's viewers upload), evaluated in the reference's literal order.
+// getOctreeData() exposes (same array the reference's viewers upload), evaluated in the order of the linked library's flavour
+// (libsdfhip.so: the reference's literal order; libsdfhip_enoki.so: its SDFLIB_USE_ENOKI=ON order).
 #ifndef SDFLIB_OCTREE_SDF_H
 #define SDFLIB_OCTREE_SDF_H
 #include <array>
@@ -212,8 +213,24 @@ private:
             const float inv = 1.0f / std::sqrt(gr[0] * gr[0] + gr[1] * gr[1] + gr[2] * gr[2]);
             g = glm::vec3(gr[0] * inv, gr[1] * inv, gr[2] * inv);
         }
+        // the value in the order of the library this program is linked with (the reference's compile-time choice SDFLIB_USE_ENOKI):
+        static const bool enokiOrder = sdfhip_interpolation_flavour() == 1;
+        if (enokiOrder) {          // InterpolationMethods.h:383-430: 4-wide power vectors, enoki::dot = (a0 b0 + a1 b1) + (a2 b2 + a3 b3)
+            float x[4][4];
+            x[0][0] = 1.0f; x[0][1] = f[0]; x[0][2] = f[0] * f[0]; x[0][3] = f[0] * f[0] * f[0];
+            for (int j = 1; j < 4; j++) for (int i = 0; i < 4; i++) x[j][i] = f[1] * x[j - 1][i];
+            float sum = 0.0f;
+            for (int k = 0; k < 4; k++) {
+                if (k > 0) for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) x[j][i] = f[2] * x[j][i];
+                float d[4];
+                for (int j = 0; j < 4; j++) { const float* v = c + 16 * k + 4 * j; d[j] = (x[j][0] * v[0] + x[j][1] * v[1]) + (x[j][2] * v[2] + x[j][3] * v[3]); }
+                const float slab = d[0] + d[1] + d[2] + d[3];
+                sum = (k == 0) ? slab : sum + slab;
+            }
+            return sum;
+        }
         float acc = 0.0f;
-        for (int n = 0; n < 64; n++) acc = acc + term(c[n], n & 3, (n >> 2) & 3, n >> 4);
+        for (int n = 0; n < 64; n++) acc = acc + term(c[n], n & 3, (n >> 2) & 3, n >> 4);          // :432-439, the literal order
         return acc;
     }
 

@@ -91,8 +91,23 @@ k, j, i = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
 P = (org[None, :].astype(np.float32) + np.stack([i, j, k], -1).reshape(-1, 3).astype(np.float32) * step[None, :].astype(np.float32)).astype(np.float32)
 dp, gp = t.get_distance(P, gradient=True)
 assert np.array_equal(b(dg.reshape(-1)), b(dp)) and np.array_equal(b(gg.reshape(-1, 3)), b(gp))
+# the reference-compatible C++ classes linked against libsdfhip_enoki.so (INTEGRATION.md: the flavour is a link-time choice)
+import os, subprocess, tempfile
+root = %r
+exe = "/tmp/sdflib_amd_test_cpp_api_enoki"; libdir = os.path.join(root, "sdflib_amd")
+subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "test_cpp_api.cpp"),
+                       "-L", libdir, "-lsdfhip_enoki", "-Wl,-rpath," + libdir, "-o", exe])
+v2, f2 = bumpy_icosphere(2); box2 = box_with_margin(v2); pts2 = random_points_in_box(box2, 5000, seed=17); pts2[:50] *= 3.0
+with tempfile.TemporaryDirectory() as td:
+    q = lambda n: os.path.join(td, n)
+    v2.tofile(q("v.bin")); f2.tofile(q("f.bin")); pts2.tofile(q("p.bin"))
+    env = dict(os.environ); env.pop("SDFLIB_DEVICES", None)
+    r = subprocess.run([exe, q("v.bin"), q("f.bin"), q("p.bin"), q("d.bin"), q("e.bin"), q("oct.bin"), q("exact.bin")], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "scalar-vs-batched mismatches 0" in r.stdout, r.stdout + r.stderr
+    oc2 = O.Octree(O.Mesh(v2, f2), box2, 5, 2, 1e-3, vertex_cache=False, layout=O.LAYOUT_SUBTREES)
+    assert np.array_equal(b(np.fromfile(q("d.bin"), dtype=np.float32)), b(oc2.query(pts2)))
 print("enoki flavour ok")
-''' % ROOT
+''' % (ROOT, ROOT)
 
 
 @pytest.mark.gpu
