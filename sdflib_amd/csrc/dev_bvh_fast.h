@@ -33,6 +33,9 @@
 namespace sdfhip {
 namespace {
 
+#ifndef RESOLVE_WAVES
+#define RESOLVE_WAVES 3
+#endif
 constexpr int NEAR_K = 16;
 constexpr int NEAR_MAX_TIES = 9;
 constexpr uint32_t NEAR_OVERFLOW = 0xFFu;
@@ -707,7 +710,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
 // node over the sorted range [b, e): left child = inner node + 1 over [b, mid), right child = inner node + (mid - b) over [mid, e)
 struct SimFrame { uint32_t node, b, e, info; };      // info = lo | hi << 8 | side << 16 (the child of `node` to enter: tested at pop time)
 
-template <int BLOCK>
+template <int BLOCK, int FS>
 SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint32_t* __restrict__ ids, uint32_t* __restrict__ rk, uint32_t* __restrict__ frames, double* __restrict__ d2s) {
     // sort the tied candidates by rank (position in the tree's leaf order): subsets of a subtree are then contiguous.  d2s (optional):
     // their fp64 squared distances as the caller evaluated them, carried along so that a leaf costs no third evaluation
@@ -729,7 +732,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
         if (!pending) {
             if (fsp == 0) break;
             fsp--;
-            const uint32_t pn = frames[(4 * fsp) * BLOCK], pb = frames[(4 * fsp + 1) * BLOCK], pe = frames[(4 * fsp + 2) * BLOCK], info = frames[(4 * fsp + 3) * BLOCK];
+            const uint32_t pn = frames[(4 * fsp) * FS], pb = frames[(4 * fsp + 1) * FS], pe = frames[(4 * fsp + 2) * FS], info = frames[(4 * fsp + 3) * FS];
             const int side = (int)((info >> 16) & 1u);
             // the deferred (farther) child: its test sees the distance found in the nearer subtree, as in the reference
             if (adopted && !sphereCloser(sphereTerms(bvh.sph + 4 * (size_t)pn, side, p), best)) continue;
@@ -761,8 +764,8 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
         const double dL = sphereDistExact(sphereTerms(nd, 0, p)), dR = sphereDistExact(sphereTerms(nd, 1, p));
         const bool leftFirst = dL < dR;
         const int second = leftFirst ? 1 : 0;
-        frames[(4 * fsp) * BLOCK] = node; frames[(4 * fsp + 1) * BLOCK] = b; frames[(4 * fsp + 2) * BLOCK] = e;
-        frames[(4 * fsp + 3) * BLOCK] = (second ? ((uint32_t)s | ((uint32_t)hi << 8)) : ((uint32_t)lo | ((uint32_t)s << 8))) | ((uint32_t)second << 16);
+        frames[(4 * fsp) * FS] = node; frames[(4 * fsp + 1) * FS] = b; frames[(4 * fsp + 2) * FS] = e;
+        frames[(4 * fsp + 3) * FS] = (second ? ((uint32_t)s | ((uint32_t)hi << 8)) : ((uint32_t)lo | ((uint32_t)s << 8))) | ((uint32_t)second << 16);
         fsp++;
         if (adopted && !((leftFirst ? dL : dR) < best)) { pending = false; continue; }
         const uint32_t nn = leftFirst ? node + 1u : node + (mid - b);
@@ -773,10 +776,13 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
 }
 
 template <int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
+__global__ void __launch_bounds__(BLOCK, RESOLVE_WAVES) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
                                                         const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
                                                         uint32_t* __restrict__ fbCount, uint32_t rank, uint32_t world) {
-    __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK], s_frames[4 * (NEAR_MAX_TIES - 1) * BLOCK];
+    // (the replay's frames — a few pushes and pops per query — live in private memory: as 16 KB of LDS per workgroup they were what
+    // capped the kernel at two waves per SIMD, and its time is dependent fetches, 1.7 resident waves per SIMD measured)
+    __shared__ uint32_t s_ids[NEAR_MAX_TIES * BLOCK], s_rk[NEAR_MAX_TIES * BLOCK];
+    uint32_t frames[4 * (NEAR_MAX_TIES - 1)];
     __shared__ double s_d2[NEAR_MAX_TIES * BLOCK];
     const uint64_t r64 = ((uint64_t)blockIdx.x * world + rank) * BLOCK + threadIdx.x;
     if (r64 >= numReps) return;
@@ -824,7 +830,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_resolve(BvhDev b, const float* _
                     }
                 }
                 if (n2 == 1) res = cached ? ids[0] : argmin;
-                else if (n2 >= 2 && n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, s_frames + threadIdx.x, cached ? d2s : nullptr);
+                else if (n2 >= 2 && n2 <= NEAR_MAX_TIES) res = resolveTies<BLOCK, 1>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, frames, cached ? d2s : nullptr);
             }
         }
     }
