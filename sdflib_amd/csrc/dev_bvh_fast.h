@@ -34,10 +34,15 @@ namespace sdfhip {
 namespace {
 
 #ifndef RESOLVE_WAVES
-#define RESOLVE_WAVES 3
+#define RESOLVE_WAVES 5
 #endif
 constexpr int NEAR_K = 16;
-constexpr int NEAR_MAX_TIES = 9;
+// (8 tie slots and a five-wave register budget: 16 KB of LDS per workgroup and 81 registers = five waves per SIMD — measured against
+// 9 / 3: k_near_resolve 1.85 -> 1.42 ms per C2 build, tools/gpu_resolve_occ_ab.sh; a ninth tie goes to the exact traversal like a tenth)
+#ifndef RESOLVE_MAX_TIES
+#define RESOLVE_MAX_TIES 8
+#endif
+constexpr int NEAR_MAX_TIES = RESOLVE_MAX_TIES;
 constexpr uint32_t NEAR_OVERFLOW = 0xFFu;
 constexpr uint32_t NEAR_UNRESOLVED = 0xFFFFFFFFu;
 
