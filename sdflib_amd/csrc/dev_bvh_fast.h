@@ -595,6 +595,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
         if (have && sp == 0 && nq == 0 && mode == 0) {
             if (c == 0u) {
                 candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); candU2[r] = U2;
+                if (overflow) longList[atomicAdd(longCount, 1u)] = r;          // more candidates than the list holds: k_near_long collects up to 1024 and reduces them to the exact ties
                 if (qpass == 1) best[r] = lastTri;
                 if (perQuery) { perQuery[4 * (size_t)r + 1] = stExpand; perQuery[4 * (size_t)r + 2] = stIter; perQuery[4 * (size_t)r + 3] = stTri; }
             }
@@ -620,7 +621,8 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
 // LDS with their lower bounds and filtered against the FINAL bound before they are written out.
 constexpr int NEAR_LONG_STACK = 6144, NEAR_LONG_CAND = 1024;
 __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ longList,
-                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, float* __restrict__ candLo, uint8_t* __restrict__ candCount, float* __restrict__ candU2) {
+                                                  const uint32_t* __restrict__ longCount, uint32_t* __restrict__ cand, float* __restrict__ candLo, uint8_t* __restrict__ candCount, float* __restrict__ candU2,
+                                                  uint32_t* __restrict__ why) {
     __shared__ uint2 s_stack[NEAR_LONG_STACK];
     __shared__ uint2 s_cand[NEAR_LONG_CAND];
     const uint32_t lane = threadIdx.x;
@@ -666,7 +668,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
                         __syncthreads();
                     }
                     nc = keep;
-                    if (nc + (uint32_t)__popcll(cm) > (uint32_t)NEAR_LONG_CAND) overflow = true;
+                    if (nc + (uint32_t)__popcll(cm) > (uint32_t)NEAR_LONG_CAND) { overflow = true; if (lane == 0) atomicAdd(why + 1, 1u); }
                 }
                 if (!overflow) {
                     if (isCand) s_cand[nc + (uint32_t)__popcll(cm & below)] = make_uint2((uint32_t)~ref, __float_as_uint(lo));
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
                 const bool keep = !(l[c] > U);
                 const uint64_t km = __ballot(keep);
                 const uint32_t n = (uint32_t)__popcll(km);
-                if (size + n > (uint32_t)NEAR_LONG_STACK) { overflow = true; break; }
+                if (size + n > (uint32_t)NEAR_LONG_STACK) { overflow = true; if (lane == 0) atomicAdd(why + 2, 1u); break; }
                 if (keep) s_stack[size + (uint32_t)__popcll(km & below)] = make_uint2(cr[c], __float_as_uint(l[c]));
                 size += n;
             }
@@ -705,9 +707,44 @@ __global__ void __launch_bounds__(64) k_near_long(BvhDev b, const float* __restr
                 if (k && at < (uint32_t)NEAR_K) { cand[(size_t)at * numReps + r] = c.x; candLo[(size_t)at * numReps + r] = __uint_as_float(c.y); }
                 out += (uint32_t)__popcll(km);
             }
-            if (out > (uint32_t)NEAR_K) overflow = true;
+            if (out > (uint32_t)NEAR_K) {
+                // More live candidates than the list holds (a point on a tube's axis: hundreds of triangles within the fp32 slack of the
+                // minimum).  Left as an overflow, the query went to the exact traversal on ONE lane (1.6 ms each; twenty of them were 4 of a
+                // torus-knot build's 20 ms).  Here the wave evaluates the fp64 distance of every live candidate (the traversal stack's LDS
+                // is free by now), takes the minimum and hands k_near_resolve the candidates within its tie threshold only — the set it
+                // would have reduced the full list to.
+                double* s_d2 = reinterpret_cast<double*>(s_stack);
+                const D3 pd = D3{(double)p.x, (double)p.y, (double)p.z};
+                double dmin2 = BVH_NO_BOUND;
+                __syncthreads();
+                for (uint32_t base = 0; base < nc; base += 64u) {
+                    const bool in = base + lane < nc;
+                    const uint2 c = in ? s_cand[base + lane] : make_uint2(0u, 0u);
+                    double d2 = BVH_NO_BOUND;
+                    if (in && __uint_as_float(c.y) <= U2) d2 = triangleSq(b, c.x, pd);
+                    if (in) s_d2[base + lane] = d2;
+                    dmin2 = d2 < dmin2 ? d2 : dmin2;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) { const double other = __shfl_xor(dmin2, o); dmin2 = other < dmin2 ? other : dmin2; }
+                __syncthreads();
+                out = 0;
+                if (dmin2 >= 1e-200 && dmin2 < BVH_NO_BOUND) {
+                    const double thr = dmin2 * (1.0 + 4e-12);
+                    for (uint32_t base = 0; base < nc; base += 64u) {
+                        const bool in = base + lane < nc;
+                        const uint2 c = in ? s_cand[base + lane] : make_uint2(0u, 0u);
+                        const bool k = in && s_d2[base + lane] <= thr;
+                        const uint64_t km = __ballot(k);
+                        const uint32_t at = out + (uint32_t)__popcll(km & below);
+                        if (k && at < (uint32_t)NEAR_K) { cand[(size_t)at * numReps + r] = c.x; candLo[(size_t)at * numReps + r] = __uint_as_float(c.y); }
+                        out += (uint32_t)__popcll(km);
+                    }
+                    if (out > (uint32_t)NEAR_K || out == 0u) { overflow = true; if (lane == 0) atomicAdd(why + 3, 1u); }
+                } else { overflow = true; if (lane == 0) atomicAdd(why + 4, 1u); }          // (a zero distance is the exact traversal's in any case)
+            }
         }
-        if (lane == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : out); candU2[r] = U2; }
+        if (lane == 0) { candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : out); candU2[r] = U2; atomicAdd(why, 1u); }
     }
 }
 
@@ -957,7 +994,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
         fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration; %u queries handed to k_near_long\n",
                 h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1), nLong);
     }
-    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p);
+    k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, S.fbCount.p + 24);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out, S.candU2.p);
     SDF_HIP_CHECK(hipGetLastError());
@@ -974,6 +1011,12 @@ static int nearTotals(hipStream_t st, NearScratch& S, NearTotals& out) {
     SDF_HIP_CHECK(hipMemcpyAsync(h, S.fbCount.p, sizeof(h), hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     out.fallbacks = h[1];
+    if (getenv("SDFHIP_TIMING")) {
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyAsync(w, S.fbCount.p + 24, 32, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
+            fprintf(stderr, "[sdfhip] nearest search: %u queries through k_near_long (of them left to the exact traversal: %u with more than %d candidates, %u stack overflows, %u with more than %d exact ties, %u at zero distance); %u answered by the exact traversal\n",
+                    w[0], w[1], NEAR_LONG_CAND, w[2], w[3], NEAR_K, w[4], h[1]);
+    }
     out.expansions = (uint64_t)h[20] | ((uint64_t)h[21] << 32); out.triangleTests = (uint64_t)h[22] | ((uint64_t)h[23] << 32);
     for (int i = 0; i < S.evUsed; i++) {
         float a = 0.f, b = 0.f;
