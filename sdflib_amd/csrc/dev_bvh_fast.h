@@ -817,6 +817,64 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
     return bestTri < 0 ? NEAR_UNRESOLVED : (uint32_t)bestTri;
 }
 
+// one query through phase 2; s_ids / s_rk / s_d2: TIES x BLOCK entries of LDS each
+template <int BLOCK, int TIES>
+SDF_DEV uint32_t resolveOne(const BvhDev& b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
+                            const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t r, uint32_t* s_ids, uint32_t* s_rk, double* s_d2) {
+    uint32_t frames[4 * (TIES - 1)];          // (the replay's frames - a few pushes and pops per query - live in private memory: as 16 KB of LDS per
+                                              // workgroup they were what capped the kernel at two waves per SIMD, and its time is dependent fetches)
+    const F3 pf = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
+    const D3 p = D3{(double)pf.x, (double)pf.y, (double)pf.z};
+    const uint32_t nc = candCount[r];
+    uint32_t res = NEAR_UNRESOLVED;
+    if (nc != NEAR_OVERFLOW && nc > 0u) {
+        // Only LIVE candidates — lower bound not above the search's final upper bound u2 — can be the minimum or tied with it (the
+        // minimum's own bounds enclose its distance, and a tie lies within 4e-12 of it): the others were recorded while the bound was
+        // still loose (6 candidates per query on average, 2-3 of them live) and cost no fp64 evaluation.  One live candidate with a
+        // positive lower bound IS the answer, unevaluated.
+        const float u2 = candU2[r];
+        double dmin2 = BVH_NO_BOUND; uint32_t argmin = NEAR_UNRESOLVED, live = 0, liveId = 0; float liveLo = 0.f;
+        for (uint32_t i = 0; i < nc; i++)
+            if (candLo[(size_t)i * numReps + r] <= u2) { live++; liveId = cand[(size_t)i * numReps + r]; liveLo = candLo[(size_t)i * numReps + r]; }
+        if (live == 1u && liveLo > 0.f) res = liveId;
+        else if (live >= 1u) {
+            // every live candidate is evaluated ONCE: the values stay in LDS (TIES slots: more live candidates than that are
+            // rare and re-evaluated below) for the tie test and for the leaves of the replay
+            uint32_t* ids = s_ids + threadIdx.x; double* d2s = s_d2 + threadIdx.x;
+            const bool cached = live <= (uint32_t)TIES;
+            uint32_t k = 0;
+            for (uint32_t i = 0; i < nc; i++) {
+                if (!(candLo[(size_t)i * numReps + r] <= u2)) continue;
+                const uint32_t id = cand[(size_t)i * numReps + r];
+                const double d2 = triangleSq(b, id, p);
+                if (cached) { ids[k * BLOCK] = id; d2s[k * BLOCK] = d2; k++; }
+                if (d2 < dmin2) { dmin2 = d2; argmin = id; }
+            }
+            if (dmin2 >= 1e-200) {
+                const double thr = dmin2 * (1.0 + 4e-12);
+                int n2 = 0;
+                if (cached) {
+                    // (a tie's lower bound cannot exceed u2, the upper bound of the minimum: every tie is among the live candidates)
+                    for (uint32_t j = 0; j < k; j++) {
+                        const double d2 = d2s[j * BLOCK];
+                        if (d2 <= thr) { ids[n2 * BLOCK] = ids[j * BLOCK]; d2s[n2 * BLOCK] = d2; n2++; }
+                    }
+                } else {
+                    for (uint32_t i = 0; i < nc; i++) {
+                        const uint32_t id = cand[(size_t)i * numReps + r];
+                        if ((double)candLo[(size_t)i * numReps + r] <= thr && triangleSq(b, id, p) <= thr) { if (n2 < TIES) ids[n2 * BLOCK] = id; n2++; }
+                    }
+                }
+                if (n2 == 1) res = cached ? ids[0] : argmin;
+                else if (n2 >= 2 && n2 <= TIES) res = resolveTies<BLOCK, 1>(b, p, dmin2, n2, ids, s_rk + threadIdx.x, frames, cached ? d2s : nullptr);
+            }
+        }
+    }
+    return res;
+}
+
+// (the body of resolveOne<BLOCK, NEAR_MAX_TIES>, spelled out: as a call it compiled to 96 registers with the frames in registers — selects per
+// access — instead of 81 with the frames in scratch, and took 1.86 instead of 1.42 ms per C2 build)
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK, RESOLVE_WAVES) k_near_resolve(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
                                                         const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
@@ -880,6 +938,23 @@ __global__ void __launch_bounds__(BLOCK, RESOLVE_WAVES) k_near_resolve(BvhDev b,
     if (res == NEAR_UNRESOLVED) fbList[atomicAdd(fbCount, 1u)] = r;
 }
 
+// The queries phase 2 left over, once more with room for every candidate the list can hold (NEAR_K ties: a vertex of valence 9 - 16
+// under a sample point, the rings of a tube around its axis): few queries, so the 32 KB of LDS per workgroup this takes do not matter.
+// An entry it decides is struck from the list (0xFFFFFFFF: k_near_fallback skips it) and counted in *late.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_near_resolve_many(BvhDev b, const float* __restrict__ pos, uint32_t numReps, const uint32_t* __restrict__ cand, const float* __restrict__ candLo,
+                                                             const uint8_t* __restrict__ candCount, const float* __restrict__ candU2, uint32_t* __restrict__ out, uint32_t* __restrict__ fbList,
+                                                             const uint32_t* __restrict__ fbCount, uint32_t* __restrict__ late) {
+    __shared__ uint32_t s_ids[NEAR_K * BLOCK], s_rk[NEAR_K * BLOCK];
+    __shared__ double s_d2[NEAR_K * BLOCK];
+    const uint32_t count = *fbCount;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += gridDim.x * BLOCK) {
+        const uint32_t r = fbList[i];
+        const uint32_t res = resolveOne<BLOCK, NEAR_K>(b, pos, numReps, cand, candLo, candCount, candU2, r, s_ids, s_rk, s_d2);
+        if (res != NEAR_UNRESOLVED) { out[r] = res; fbList[i] = 0xFFFFFFFFu; atomicAdd(late, 1u); }
+    }
+}
+
 // ---- phase 3 ---------------------------------------------------------------------------------------------------------
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* __restrict__ pos, const uint32_t* __restrict__ fbList, uint32_t* __restrict__ fbCount,
@@ -892,6 +967,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_fallback(BvhDev b, const float* 
     // divergent walks ran one after the other (2.9 ms per batch); alone in a wave each takes its own time only (1.6 ms)
     for (uint32_t i = first + threadIdx.x * gridDim.x + blockIdx.x; i < count; i += gridDim.x * BLOCK) {
         const uint32_t r = fbList[i];
+        if (r == 0xFFFFFFFFu) continue;          // decided by k_near_resolve_many after all
         // The traversal starts from the candidate search's bound (fp32 upper bound of the squared distance incl. its error margin, i.e.
         // strictly above the minimum) instead of from infinity: the same answer (dev_bvh.h) without the visits that precede the first
         // good triangle — the points that end up here sit among thousands of almost equidistant triangles (a tube's axis), and unbounded
@@ -996,6 +1072,7 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     }
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, S.fbCount.p + 24);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
+    k_near_resolve_many<128><<<64, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, S.fbCount.p + 30);
     k_near_fallback<128><<<256, 128, (size_t)stackDepth * 128 * sizeof(uint32_t), st>>>(bvh, pos, S.fbList.p, S.fbCount.p, 0u, out, S.candU2.p);
     SDF_HIP_CHECK(hipGetLastError());
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[2], st));
@@ -1007,15 +1084,15 @@ struct NearTotals { uint64_t fallbacks = 0, expansions = 0, triangleTests = 0; d
 static int nearTotals(hipStream_t st, NearScratch& S, NearTotals& out) {
     out = NearTotals();
     if (!S.counterReady) return SDFHIP_OK;
-    uint32_t h[24];
+    uint32_t h[32];
     SDF_HIP_CHECK(hipMemcpyAsync(h, S.fbCount.p, sizeof(h), hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
-    out.fallbacks = h[1];
+    out.fallbacks = h[1] - (h[1] >= h[30] ? h[30] : 0u);          // ([30]: struck from the lists by k_near_resolve_many)
     if (getenv("SDFHIP_TIMING")) {
         uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyAsync(w, S.fbCount.p + 24, 32, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess)
-            fprintf(stderr, "[sdfhip] nearest search: %u queries through k_near_long (of them left to the exact traversal: %u with more than %d candidates, %u stack overflows, %u with more than %d exact ties, %u at zero distance); %u answered by the exact traversal\n",
-                    w[0], w[1], NEAR_LONG_CAND, w[2], w[3], NEAR_K, w[4], h[1]);
+            fprintf(stderr, "[sdfhip] nearest search: %u queries through k_near_long (of them left to the exact traversal: %u with more than %d candidates, %u stack overflows, %u with more than %d exact ties, %u at zero distance); %u left over by k_near_resolve, %u of them decided by k_near_resolve_many, the others by the exact traversal\n",
+                    w[0], w[1], NEAR_LONG_CAND, w[2], w[3], NEAR_K, w[4], h[1], h[30]);
     }
     out.expansions = (uint64_t)h[20] | ((uint64_t)h[21] << 32); out.triangleTests = (uint64_t)h[22] | ((uint64_t)h[23] << 32);
     for (int i = 0; i < S.evUsed; i++) {
