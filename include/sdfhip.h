@@ -169,11 +169,18 @@ int sdfhip_test_heap_sort_matches_std(const double* keys, uint64_t n);     /* th
  * and its device compilation.  Both return / store the number of differing results. */
 uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads);
 int sdfhip_test_acosf_device(sdfhip_ctx* ctx, uint32_t first_bits, uint32_t stride, uint32_t count, uint64_t* out_mismatches);
+/* Which acosf the corner angles use is decided by the first mesh of a process (a self-check of the restatement against the running libm:
+ * on a host whose libm is another function the arc cosines are taken there, as the reference does).  Test hook: 1 forces the host's,
+ * 0 the device's, -1 makes the next mesh decide again. */
+void sdfhip_test_set_host_acos(int mode);
 /* the BVH planner alone, host memory in and out (no device needed): 8 doubles + 2 ints per inner node, max(num_triangles - 1, 1) nodes.
  * Replaces the tree half of tmd::TriangleMeshDistance::construct (TriangleMeshDistance.h:421-490); CPU tests compare it with the oracle's. */
 int sdfhip_test_plan_bvh(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, double* out_spheres, int32_t* out_children, double* seconds);
 /* development probe: per query [triangle id, inner nodes entered, deferred children popped, triangles evaluated] */
 int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4);
+/* the same counters for a second run in which every query starts from the bound of its own answer: the fewest visits ANY visiting order
+ * needs with this tree and these bounds (tools/gpu_near_hist.py) */
+int sdfhip_mesh_nearest_stats_preseeded(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4);
 /* Hermite sample [d, gx, gy, gz, 0,0,0,0] at each point for a given triangle id
  * (TriCubicInterpolation::calculatePointValues, InterpolationMethods.h:273-290) */
 int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t* tri_ids, uint64_t n, float* out8, int where);
@@ -308,7 +315,7 @@ int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host);
 /* ExactOctreeSdf::getDistance x2 (src/sdf/ExactOctreeSdf.cpp:38-320), batched.  The first batch of 16 384 points or more makes the tree's query
  * tables (once, 1.4 ms at C3): per node a query can end in, its set / mask offsets and the DECODED list of the triangles that survive the
  * two mask levels (4 bytes per surviving entry — 0.23 GB at C3, beside 63 MB of nodes / sets / masks).  Trees whose lists would exceed
- * SDFHIP_EXACT_LISTS_MB (default 4096) decode per batch instead (SDFHIP_EXACT_QUERY=decode forces that path).  Same results either way. */
+ * SDFHIP_EXACT_LISTS_MB (default 4096) (or half of the device's free memory, or whose allocation fails) decode per batch instead.  Same results either way. */
 int sdfhip_exact_query(sdfhip_exact* tree, const float* xyz, uint64_t n, float* out_dist, float* out_grad /* nullable */,
                        uint32_t* out_triangle /* nullable */, int where);
 

@@ -83,10 +83,12 @@ SIGNATURES = {
     "sdfhip_abi_sizes": (None, [_vp]),
     "sdfhip_test_acosf_mismatches": (_u64, [_u32, _u32, _u64, _int]),
     "sdfhip_test_acosf_device": (_int, [_vp, _u32, _u32, _u32, _vp]),
+    "sdfhip_test_set_host_acos": (None, [_int]),
     "sdfhip_test_sort_matches_std": (_int, [_vp, _u64, _int]),
     "sdfhip_test_heap_sort_matches_std": (_int, [_vp, _u64]),
     "sdfhip_test_plan_bvh": (_int, [_vp, _u32, _vp, _u32, _vp, _vp, _vp]),
     "sdfhip_mesh_nearest_stats": (_int, [_vp, _vp, _u64, _vp]),
+    "sdfhip_mesh_nearest_stats_preseeded": (_int, [_vp, _vp, _u64, _vp]),
     "sdfhip_mesh_point_values": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
     "sdfhip_octree_build": (_int, [_vp, _vp, C.POINTER(OctreeParams), C.POINTER(_vp)]),
     "sdfhip_octree_build_shard": (_int, [_vp, _vp, C.POINTER(OctreeParams), C.POINTER(_vp)]),

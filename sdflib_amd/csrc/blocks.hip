@@ -27,19 +27,9 @@ __global__ void k_is_near(const float* __restrict__ half, const float* __restric
 }
 
 // Counter calibration for the query kernel's access pattern (MI355X_MICROARCH.md: FETCH_SIZE is calibrated for coalesced 16-B/lane
-// streaming reads only): one lane per 256-byte block, 16 x dwordx4 like k_octree_query's coefficient load, blocks chosen by the
-// caller (a permutation -> every block exactly once -> the bytes that must cross the fabric are known exactly).
-__global__ void __launch_bounds__(256) k_gather_blocks(const uint32_t* __restrict__ data, const uint32_t* __restrict__ block, uint64_t n, float* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4* src = reinterpret_cast<const float4*>(data + 64ull * block[i]);
-    float acc = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) { const float4 v = src[q]; acc += (v.x + v.y) + (v.z + v.w); }
-    out[i] = acc;
-}
-
-// The same gather with the blocks fetched COOPERATIVELY: sixteen lanes read one lane's 256-byte block as one contiguous segment (an
+// streaming reads only): one 256-byte block per lane, fetched like k_octree_query_coop fetches its coefficients; the blocks are chosen by
+// the caller (a permutation -> every block exactly once -> the bytes that must cross the fabric are known exactly).
+// The blocks are fetched COOPERATIVELY: sixteen lanes read one lane's 256-byte block as one contiguous segment (an
 // instruction touches 8 cache lines instead of 64), the rows go through LDS to their owners, 16 source lanes at a time.
 constexpr int COOP_ROW = 68;                 // floats per LDS row: 64 + 4 of padding (b128 accesses of consecutive rows fall on different banks)
 __global__ void __launch_bounds__(256) k_gather_blocks_coop(const uint32_t* __restrict__ data, const uint32_t* __restrict__ block, uint64_t n, float* __restrict__ out) {
@@ -79,8 +69,7 @@ int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const u
     SDF_REQUIRE(ctx && dev_data && dev_block_ids && dev_out, "NULL argument");
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
-    if (getenv("SDFHIP_QUERY_LANE_LOADS")) k_gather_blocks<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);       // the pattern of k_octree_query
-    else k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);                                      // the pattern of k_octree_query_coop (default)
+    k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);          // the load pattern of k_octree_query_coop
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
     SDF_API_END

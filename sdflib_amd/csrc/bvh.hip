@@ -104,7 +104,6 @@ private:
             if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) { const int cap = (int)(2 * quota / period) - 1; if (cap >= 1 && cap < workers) workers = cap; }
             fclose(f);
         }
-        if (getenv("SDFHIP_BVH_POOL_THREADS")) workers = std::max(0, atoi(getenv("SDFHIP_BVH_POOL_THREADS")));
         for (int i = 0; i < workers; i++) std::thread([this] { worker(); }).detach();
         pthread_atfork(nullptr, nullptr, [] { g_plannerPoolForked.store(true); });
     }
@@ -434,7 +433,6 @@ struct HostBvhBuilder {
             if (n <= 16) IntroSortLike::insertionSort(tmp, tmp + n);          // what introsort does with a range this short
             else {
                 IntroSortLike sorter; sorter.maxThreads = sortThreads; sorter.scratchL = scratchL + begin; sorter.scratchR = scratchR + begin;
-                if (const char* e = getenv("SDFHIP_BVH_LIST_PARTITION")) sorter.minListPartition = (size_t)atol(e);
                 sorter.sort(tmp, tmp + n);
             }
             for (int i = 0; i < n; i++) order[begin + i] = tmp[i].tri;
@@ -1624,11 +1622,11 @@ extern "C" {
 // The planner's arrays — 8 doubles + 2 ints per node of output, 72 bytes per triangle of scratch: 200 MB at 1.31 M triangles — are 2 MB-aligned
 // blocks with a huge-page hint, touched up front by a few threads (first touch of a fresh mapping by all the planner's workers at once was
 // measured to stall single nodes for tens of milliseconds).  Allocating and faulting them in is a fifth of a plan's wall time, so blocks
-// given back are kept (up to SDFHIP_PLANNER_CACHE_MB, default 512) and handed to the next plan as they are.
+// given back are kept (up to 512 MB) and handed to the next plan as they are.
 struct PlannerBlocks {
     std::mutex m; std::vector<std::pair<void*, size_t>> idle, live; size_t idleBytes = 0;
     static PlannerBlocks& get() { static PlannerBlocks* p = new PlannerBlocks(); return *p; }
-    static size_t cap() { static const size_t v = (size_t)(getenv("SDFHIP_PLANNER_CACHE_MB") ? strtoull(getenv("SDFHIP_PLANNER_CACHE_MB"), nullptr, 10) : 512ull) << 20; return v; }
+    static size_t cap() { return (size_t)512 << 20; }
     void* take(size_t rounded) {
         std::lock_guard<std::mutex> g(m);
         size_t best = (size_t)-1;
@@ -1655,8 +1653,7 @@ static void* plannerAlloc(size_t bytes) {
     if (void* cached = PlannerBlocks::get().take(rounded)) return cached;
     void* p = nullptr;
     if (posix_memalign(&p, 2u << 20, rounded) != 0) throw std::bad_alloc();
-    static const bool noThp = getenv("SDFHIP_BVH_NO_THP") != nullptr;
-    if (!noThp) madvise(p, rounded, MADV_HUGEPAGE);
+    madvise(p, rounded, MADV_HUGEPAGE);
     int parts = (int)std::min<size_t>(16, rounded >> 21); if (parts < 1) parts = 1;
     PlannerPool::get().run(parts, [&](int c) {
         char* q = (char*)p;
@@ -1750,7 +1747,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     // of 156 at 1.31 M - build_bvh 7.4 -> 6.8 ms and 16.0 -> 15.4 ms, profiles/r04_bvh_persistent_rounds.txt)
     uint32_t partMax = 4096u; if (const char* e = getenv("SDFHIP_BVH_PART")) { const uint32_t v = (uint32_t)atoi(e); if (v >= 32u) partMax = v; }
     if (partMax > S) partMax = S;
-    const bool timing = getenv("SDFHIP_TIMING") != nullptr, debug = getenv("SDFHIP_BVH_DEBUG") != nullptr;
+    const bool timing = getenv("SDFHIP_TIMING") != nullptr;
     const double t0 = nowSeconds();
     const float4* triV = reinterpret_cast<const float4*>(mesh->dTriVerts.p);
     // the levels sorted in global memory: while some node is longer than S
@@ -1802,7 +1799,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     std::vector<EventHolder> sorted(nTop);
     // two side streams of the context: level 1 alone on the second (its two chains are as long as all deeper levels' together)
     struct Side { hipStream_t s; } side{nullptr}, side1{nullptr};
-    const bool useSide = [] { const char* e = getenv("SDFHIP_BVH_SIDE"); return !(e && e[0] == '0'); }();      // SDFHIP_BVH_SIDE=0: everything on the context's stream
+    const bool useSide = true;
     if (nTop && useSide) {
         for (hipStream_t& s : mesh->ctx->bvhSide) if (!s) SDF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         side.s = mesh->ctx->bvhSide[0]; side1.s = mesh->ctx->bvhSide[1];
@@ -1815,13 +1812,13 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     // 15.9 ms; above 100 000: 14.5 ms, but + 0.2 ms at 327 680 triangles, where there is no wait to remove.  A worker thread does everything for such a level on side1, so that the thread driving the rounds never waits for a pageable
     // copy: gather of the level's coordinates in range order on the device, download, one adding thread per node (the planner's loop), centres
     // back up, radii and records as for the other levels.  Declared BEFORE the guard below: the worker is joined, then the side streams are
-    // waited for, then the jobs' buffers go.  SDFHIP_BVH_HOST_SUMS=0: off.
+    // waited for, then the jobs' buffers go.
     const uint32_t kHostSumMin = [] { const char* e = getenv("SDFHIP_BVH_HOST_SUM_MIN"); const long v = e ? atol(e) : 0; return v >= 1000 ? (uint32_t)v : 200000u; }();
     struct HostSumJob { size_t level = 0; DevBuf<float> dG; std::unique_ptr<float, FreeDeleter> hG; hipEvent_t sortedBefore = nullptr; std::vector<double> centres; };
     struct HostSumQueue { std::mutex m; std::condition_variable cv; std::vector<std::unique_ptr<HostSumJob>> jobs; bool closed = false; } hostQueue;
     // whatever happens below, nothing of this call may still run on the side streams when its buffers are released
     struct SideGuard { hipStream_t a, b; ~SideGuard() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } sideGuard{useSide ? side.s : nullptr, useSide ? side1.s : nullptr};
-    const bool hostSumsOn = useSide && [] { const char* e = getenv("SDFHIP_BVH_HOST_SUMS"); return !(e && e[0] == '0'); }();
+    const bool hostSumsOn = useSide;
     struct HostSumWorker {
         std::thread th; int rc = SDFHIP_OK; double busy = 0; HostSumQueue* q = nullptr;
         void finish() { if (q) { { std::lock_guard<std::mutex> g(q->m); q->closed = true; } q->cv.notify_all(); } if (th.joinable()) th.join(); }
@@ -1831,7 +1828,6 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     // ctr: [0], [1] = pending ranges of this / the next round (alternating), [2] = parts for k_sort_parts, [3] = for k_sort_tiny, [4] = flags
     uint32_t hostCtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
-    std::vector<KeyTri> dbgPre, dbgPost;
     for (size_t l = 0; l < nTop; l++) {
         const std::vector<TopNode>& nodes = levels[l];
         const uint32_t count = (uint32_t)nodes.size();
@@ -1839,7 +1835,6 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         k_top_aabb<<<gridFor(T, 1024), 256, 0, st>>>(K.p, triV, dN, count, T, box.p + 6 * levelAt[l]);
         k_top_dims<<<gridFor(count, 256), 256, 0, st>>>(box.p + 6 * levelAt[l], count, dims.p + levelAt[l]);
         k_top_keys<<<gridFor(T, 256), 256, 0, st>>>(K.p, triV, dN, count, T, dims.p + levelAt[l]);
-        if (debug) { dbgPre.resize(T); SDF_HIP_CHECK(hipMemcpyAsync(dbgPre.data(), K.p, sizeof(KeyTri) * T, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); }
         // the level's nodes are the first round's ranges
         std::vector<GTask> first(count);
         for (uint32_t j = 0; j < count; j++) { const uint32_t len = nodes[j].e - nodes[j].b; int lg = 0; for (uint32_t m = len; m > 1; m >>= 1) lg++; first[j] = GTask{nodes[j].b, nodes[j].e, (uint32_t)(2 * lg)}; }
@@ -1856,12 +1851,11 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         // (rounds 1-4: always four at a time, 156 rounds for the 9 levels of the 1.31 M mesh, of which the levels needed about 60).
         uint32_t longest = 0; for (const TopNode& nd : nodes) longest = std::max(longest, nd.e - nd.b);
         int groupRounds = 1; for (uint32_t m = longest; m > partMax; m >>= 1) groupRounds++;
-        static const int forcedGroup = getenv("SDFHIP_BVH_ROUNDS_PER_SYNC") ? atoi(getenv("SDFHIP_BVH_ROUNDS_PER_SYNC")) : 0;
         auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p}; };
         k_gs_prepare<<<1, 1024, 0, st>>>(roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
         while (pending > 0) {
             uint32_t bound = pending;
-            const int nowRounds = forcedGroup > 0 ? forcedGroup : groupRounds;
+            const int nowRounds = groupRounds;
             for (int q = 0; q < nowRounds; q++) {
                 const GsRound R = roundOf(curBuf), Rn = roundOf(curBuf ^ 1);
                 const unsigned chunkGrid = (unsigned)(T / kGsChunk + bound + 1u);
@@ -1884,19 +1878,6 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snap);
         k_top_write<<<gridFor(count, 256), 256, 0, st>>>(dN, count, nullptr, nullptr, 0, mesh->dBvhSph.p, mesh->dBvhKids.p);
         SDF_HIP_CHECK(hipGetLastError());
-        if (debug) {
-            dbgPost.resize(T);
-            SDF_HIP_CHECK(hipMemcpyAsync(dbgPost.data(), K.p, sizeof(KeyTri) * T, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
-            size_t bad = 0;
-            for (uint32_t j = 0; j < count && bad < 5; j++) {
-                IntroSortLike sorter; sorter.sort(dbgPre.data() + nodes[j].b, dbgPre.data() + nodes[j].e);
-                for (uint32_t i = nodes[j].b; i < nodes[j].e; i++) if (dbgPre[i].tri != dbgPost[i].tri || memcmp(&dbgPre[i].key, &dbgPost[i].key, 4) != 0) {
-                    fprintf(stderr, "[sdfhip] bvh debug: level %zu node %u [%u, %u): element %u is triangle %d (key %.9g) on the device, %d (%.9g) by std::sort\n", l, j, nodes[j].b, nodes[j].e, i, dbgPost[i].tri, dbgPost[i].key, dbgPre[i].tri, dbgPre[i].key);
-                    bad++; break;
-                }
-            }
-            fprintf(stderr, "[sdfhip] bvh debug: level %zu (%u nodes) %s, %u parts, %u tiny parts\n", l, count, bad ? "DIFFERS" : "sorted like std::sort", hostCtr[2], hostCtr[3]);
-        }
         // behind this level's sort, on the side stream: centres (sums in this order), radii and sphere records of the NEXT level's nodes
         if (l + 1 < nTop) {
             hipStream_t ss = (l == 0) ? side1.s : side.s;
@@ -2178,7 +2159,7 @@ int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
     SDF_API_END
 }
 
-int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) {
+static int nearestStats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4, bool preseed) {
     SDF_API_BEGIN
     SDF_REQUIRE(mesh && xyz && out4, "NULL argument");
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
@@ -2189,14 +2170,14 @@ int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, u
     if (nearestExactOnly()) k_nearest_stats<<<gridFor(n, 128), 128, 0, st>>>(meshBvh(mesh), dp.p, n, dout.p);
     else {
         // the two-phase search's own counters: [id, wide-node expansions, wave iterations alive, triangle evaluations]; with
-        // SDFHIP_NEAR_PRESEED=1 of a second run seeded with the first run's answers (the fewest visits any visiting order can need)
+        // preseed of a second run seeded with the first run's answers (the fewest visits any visiting order can need)
         std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
         SDF_REQUIRE(n < (1ull << 22), "stats: at most 4 M points");
         int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++;
         DevBuf<uint32_t> ids; SDF_TRY(ids.reserve(n));
         SDF_HIP_CHECK(hipMemsetAsync(dout.p, 0, sizeof(uint32_t) * 4 * n, st));
         SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), dp.p, (uint32_t)n, ids.p, mesh->ctx->nearScratch, depth + 2, 0u, 1u, dout.p, nullptr));
-        if (getenv("SDFHIP_NEAR_PRESEED")) {
+        if (preseed) {
             SDF_HIP_CHECK(hipMemsetAsync(dout.p, 0, sizeof(uint32_t) * 4 * n, st));
             DevBuf<uint32_t> ids2; SDF_TRY(ids2.reserve(n));
             SDF_TRY(nearestTwoPhase(st, meshBvh(mesh), dp.p, (uint32_t)n, ids2.p, mesh->ctx->nearScratch, depth + 2, 0u, 1u, dout.p, ids.p));
@@ -2210,6 +2191,9 @@ int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, u
     return SDFHIP_OK;
     SDF_API_END
 }
+
+int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) { return nearestStats(mesh, xyz, n, out4, false); }
+int sdfhip_mesh_nearest_stats_preseeded(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4) { return nearestStats(mesh, xyz, n, out4, true); }
 
 int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t* tri_ids, uint64_t n, float* out8, int where) {
     SDF_API_BEGIN

@@ -12,10 +12,11 @@
 // otherwise single-owner edges keep the default (0,0,1).  They are counted in mesh->unmatchedEdges either way.
 #include "sdfhip_internal.h"
 #include <memory>
+#include <atomic>
 #include <thread>
 #include <cmath>
 #include "dev_math.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 #include <string.h>
 #include <map>
 #include <algorithm>
@@ -97,7 +98,7 @@ __global__ void k_edge_pair(const uint64_t* __restrict__ key, const uint32_t* __
 // pseudonormal flips the sign of a sample that lies in the plane spanned by it.  Rounds 1-3 therefore sent the cosines to the HOST's
 // libm and back (24 B per triangle over PCIe and a few ms of host threads); since round 4 the device runs glibc's algorithm itself
 // (dev_math.h::acosfGlibc, equal to the running libm on every float of [-1, 1]: sdfhip_test_acosf_mismatches).  angle = false
-// (SDFHIP_ACOS=host) writes the cosine and leaves the arc cosine to the host as before.
+// (a host whose libm is NOT that function: hostAcosNeeded below) writes the cosine and leaves the arc cosine to the host as before.
 __global__ void k_corner_cos(const float* __restrict__ verts, const uint32_t* __restrict__ idx, uint32_t numHalfEdges, float* __restrict__ cs, bool angle) {
     const uint32_t he = blockIdx.x * blockDim.x + threadIdx.x;
     if (he >= numHalfEdges) return;
@@ -223,43 +224,52 @@ __global__ void k_mailbox(const uint32_t* __restrict__ a, const uint32_t* __rest
     mb[0] = seq;
 }
 namespace {
-struct Mailbox {
-    uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; int device = -1;      // (256 pinned bytes per thread and device, kept to the end of the process)
+// Pinned, mapped mailboxes: a POOL per device that calls borrow from (as many boxes come to exist as calls have ever overlapped: the
+// build threads of multi.hip and the callers' query threads come and go, and a box per thread was lost with its thread).
+struct Mailbox { uint32_t* host = nullptr; uint32_t* dev = nullptr; uint32_t seq = 0; };
+struct MailboxPool {
+    std::mutex lock; std::vector<Mailbox> idle[16];
+    bool take(int device, Mailbox& M) {
+        {
+            std::lock_guard<std::mutex> g(lock);
+            if (!idle[device].empty()) { M = idle[device].back(); idle[device].pop_back(); return true; }
+        }
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&M.dev), h, 0) == hipSuccess) {
+            M.host = static_cast<uint32_t*>(h); M.host[0] = 0; M.seq = 0; return true;
+        }
+        (void)hipGetLastError(); if (h) (void)hipHostFree(h);
+        return false;
+    }
+    void give(int device, const Mailbox& M) { std::lock_guard<std::mutex> g(lock); idle[device].push_back(M); }
 };
+MailboxPool& mailboxes() { static MailboxPool* p = new MailboxPool; return *p; }       // (never destroyed: no HIP call at process exit)
 }
 int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int count, uint32_t* out) {
     SDF_REQUIRE(count >= 1 && count <= 8, "internal: readBackWords takes 1 to 8 words");
-    static const bool plain = getenv("SDFHIP_READBACK") && !strcmp(getenv("SDFHIP_READBACK"), "copy");      // the copies of rounds 1-4
-    thread_local Mailbox boxes[16];
     int device = 0;
     SDF_HIP_CHECK(hipGetDevice(&device));
-    if (!plain && device >= 0 && device < 16) {
-        Mailbox& M = boxes[device];
-        if (!M.host) {
-            void* h = nullptr;
-            if (hipHostMalloc(&h, 256, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess && hipHostGetDevicePointer(reinterpret_cast<void**>(&M.dev), h, 0) == hipSuccess) {
-                M.host = static_cast<uint32_t*>(h); M.host[0] = 0; M.device = device;
-            } else { (void)hipGetLastError(); if (h) (void)hipHostFree(h); }
-        }
-        if (M.host) {
-            const uint32_t seq = ++M.seq ? M.seq : ++M.seq;          // never 0
-            k_mailbox<<<1, 1, 0, st>>>(a, b, count, M.dev, seq);
-            SDF_HIP_CHECK(hipGetLastError());
-            volatile uint32_t* mb = M.host;
-            const double t0 = nowSeconds();
-            uint32_t spins = 0;
-            while (__atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) {
-                __builtin_ia32_pause();
-                if ((++spins & 0x3FFFu) == 0u && nowSeconds() - t0 > 0.05) {          // something long, or something wrong: let the runtime say which
-                    const hipError_t q = hipStreamQuery(st);
-                    if (q != hipSuccess && q != hipErrorNotReady) { setError("HIP error while waiting for a read-back: %s", hipGetErrorString(q)); return SDFHIP_E_HIP; }
-                    if (q == hipSuccess && __atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) { SDF_HIP_CHECK(hipStreamSynchronize(st)); }
-                }
+    Mailbox M;
+    if (device >= 0 && device < 16 && mailboxes().take(device, M)) {
+        struct Return { int device; Mailbox& M; ~Return() { mailboxes().give(device, M); } } giveBack{device, M};
+        const uint32_t seq = ++M.seq ? M.seq : ++M.seq;          // never 0
+        k_mailbox<<<1, 1, 0, st>>>(a, b, count, M.dev, seq);
+        SDF_HIP_CHECK(hipGetLastError());
+        volatile uint32_t* mb = M.host;
+        const double t0 = nowSeconds();
+        uint32_t spins = 0;
+        while (__atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0x3FFFu) == 0u && nowSeconds() - t0 > 0.05) {          // something long, or something wrong: let the runtime say which
+                const hipError_t q = hipStreamQuery(st);
+                if (q != hipSuccess && q != hipErrorNotReady) { setError("HIP error while waiting for a read-back: %s", hipGetErrorString(q)); return SDFHIP_E_HIP; }
+                if (q == hipSuccess && __atomic_load_n(&M.host[0], __ATOMIC_ACQUIRE) != seq) { SDF_HIP_CHECK(hipStreamSynchronize(st)); }
             }
-            for (int i = 0; i < count; i++) out[i] = mb[2 + i];
-            return SDFHIP_OK;
         }
+        for (int i = 0; i < count; i++) out[i] = mb[2 + i];
+        return SDFHIP_OK;
     }
+    // (no pinned memory to be had: two pageable copies)
     uint32_t ha[8], hb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     SDF_HIP_CHECK(hipMemcpyAsync(ha, a, 4 * (size_t)count, hipMemcpyDeviceToHost, st));
     if (b) SDF_HIP_CHECK(hipMemcpyAsync(hb, b, 4 * (size_t)count, hipMemcpyDeviceToHost, st));
@@ -269,12 +279,39 @@ int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int coun
 }
 }  // namespace sdfhip
 
+namespace sdfhip {
+// The corner angles' arc cosines run on the device as glibc 2.35's algorithm restated (dev_math.h::acosfGlibc).  The reference calls the
+// RUNNING libm, and one ulp in a pseudonormal can flip the sign of a sample: on a host whose acosf is another function (a newer glibc with
+// the correctly rounded CORE-MATH routine, musl ...) the restatement would silently differ from what the reference computes there.  So
+// the first mesh of a process compares the two on 80 000 bit patterns — a stride through [-1, 1] plus the neighbourhoods of the
+// algorithm's branch points (0, 2^-26, 0.5, 1) — and on any mismatch the arc cosines are taken on the host by the running libm, as in
+// rounds 1-3 (logged once).  -1: not decided yet; the test hook sdfhip_test_set_host_acos forces either path.
+static std::atomic<int> g_hostAcos{-1};
+static bool hostAcosNeeded() {
+    int v = g_hostAcos.load(std::memory_order_acquire);
+    if (v >= 0) return v != 0;
+    uint64_t bad = 0;
+    auto probe = [&](uint32_t bits) { float x; memcpy(&x, &bits, 4); if (!(std::fabs(x) <= 1.0f)) return; const float a = ::acosf(x), m = acosfGlibc(x); if (memcmp(&a, &m, 4)) bad++; };
+    for (uint32_t i = 0; i < 32768u; i++) { probe(i * 32537u); probe(0x80000000u | (i * 32537u)); }       // 0 .. 0x3F80xxxx: every exponent of [0, 1], both signs
+    const uint32_t centres[4] = {0x00000000u, 0x32800000u /* 2^-26 */, 0x3F000000u /* 0.5 */, 0x3F800000u /* 1 */};
+    for (uint32_t c : centres)
+        for (uint32_t k = 0; k < 2048u; k++) { probe(c + k); probe((c - k) & 0x7FFFFFFFu); probe(0x80000000u | (c + k)); probe(0x80000000u | ((c - k) & 0x7FFFFFFFu)); }
+    v = bad ? 1 : 0;
+    int expected = -1;
+    if (g_hostAcos.compare_exchange_strong(expected, v) && bad)
+        fprintf(stderr, "[sdfhip] the running libm's acosf differs from the device's restatement of glibc's (%llu of 81 920 probes): arc cosines are taken on the host\n", (unsigned long long)bad);
+    return g_hostAcos.load(std::memory_order_acquire) != 0;
+}
+}  // namespace sdfhip
+
 using namespace sdfhip;
 
 extern "C" {
 
 const char* sdfhip_last_error(void) { return g_lastError.c_str(); }
 
+// test hook: 1 forces the host's acosf for the corner angles, 0 the device's, -1 lets the next mesh decide by the self-check again
+void sdfhip_test_set_host_acos(int mode) { g_hostAcos.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_release); }
 // test hooks: acosfGlibc against the running libm.  Host compilation on the bit patterns first, first + stride, ... (count of them; the
 // values outside [-1, 1] are skipped), on `threads` host threads; and the DEVICE compilation on the same patterns.
 uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads) {
@@ -447,7 +484,7 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
     DevBuf<float> cornerAngle;
     if ((rc = cornerAngle.reserve(nhe))) return fail(rc);
-    static const bool hostAcos = getenv("SDFHIP_ACOS") && !strcmp(getenv("SDFHIP_ACOS"), "host");
+    const bool hostAcos = hostAcosNeeded();
     k_corner_cos<<<gridFor(nhe, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nhe, cornerAngle.p, !hostAcos);
     std::vector<float> hAngle;
     if (hostAcos) {
@@ -463,15 +500,15 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
         (rc = vnormal.reserve(3ull * nv))) return fail(rc);
     k_halfedge_keys<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, eKey.p, vKey.p, val.p);
     size_t tb1 = 0, tb2 = 0;
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb1, eKey.p, eKeyS.p, val.p, valS.p, (int)nhe, 0, 64, st));
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
+    SDF_HIP_CHECK(devSortPairs(nullptr, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, (unsigned)64, st));
+    SDF_HIP_CHECK(devSortPairs(nullptr, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, (unsigned)32, st));
     if ((rc = tmp.reserve(tb1 > tb2 ? tb1 : tb2))) return fail(rc);
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (int)nhe, 0, 64, st));
+    SDF_HIP_CHECK(devSortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, (unsigned)64, st));
     SDF_HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), st));
     DevBuf<uint64_t> openKey; DevBuf<uint32_t> openHe;
     if (bbox6 && ((rc = openKey.reserve(nhe)) || (rc = openHe.reserve(nhe)))) return fail(rc);
     k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p, bbox6 ? openKey.p : nullptr, bbox6 ? openHe.p : nullptr);
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (int)nhe, 0, 32, st));
+    SDF_HIP_CHECK(devSortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, (unsigned)32, st));
     SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
     if (hostAcos) {   // the arc cosines on host threads while the device sorts (see k_corner_cos)
         unsigned parts = (unsigned)(nhe / 65536u); const unsigned hc = std::thread::hardware_concurrency();

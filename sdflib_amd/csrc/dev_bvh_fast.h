@@ -6,7 +6,7 @@
 // every visit (Eberly's point/triangle routine above all) executed by a wave in which few lanes need it at any moment.
 // Here the work is split so that almost all of it is free of the order and of fp64:
 //
-//  1. k_near_candidates — per lane, any order, fp32 only: a branch-and-bound over the same tree (fp32 spheres, 48-byte triangle
+//  1. k_near_quads — four lanes per query, any order, fp32 only: a branch-and-bound over the same tree (fp32 spheres, 48-byte triangle
 //     records) with CONSERVATIVE tests: U2 is an upper bound of the true minimum squared distance (fp32 value + its error bound),
 //     a child is skipped only if its sphere's lower bound (fp32 value - its error bound) exceeds U, a triangle is recorded as a
 //     candidate iff its fp32 distance minus its error bound does not exceed U2.  Every triangle whose exact distance is within
@@ -148,265 +148,6 @@ SDF_DEV void wideBounds(ND nd, F3 p, float l[4], uint32_t cr[4]) {
     for (int c = 0; c < 4; c++) l[c] = childBound(h, nd[1 + c], p);
 }
 
-// ---- phase 1 ---------------------------------------------------------------------------------------------------------
-// Every iteration of a lane is ONE pop: a stack entry (child reference + the lower bound of its sphere, kept as a half rounded
-// DOWN) is dropped if the bound has been overtaken, expanded if it is an inner node (both children tested, the survivors pushed,
-// the nearer one on top), or — a triangle — put into the lane's queue of pending evaluations.  The queues are drained by the whole
-// wave at once (when some lane's queue is full, or nobody has nodes left): the fp32 point/triangle routine is the longest stretch
-// of code of the search, and run per visit it would execute for the two or three lanes that happen to sit at a leaf.
-
-constexpr int NEAR_QUEUE = 4;              // pending triangle evaluations per lane
-constexpr int NEAR_DRAIN_LANES = 40;        // a drain round is worth its instructions once this many lanes have one pending
-constexpr int NEAR_CHUNK = 32;              // runs a wave takes per atomic
-constexpr int NEAR_RUN = 1;                 // consecutive queries a lane works through (each seeded by the one before; > 1 was measured to starve the launch: a batch has ~8 queries per resident lane)
-constexpr int NEAR_TWO_PASS_MIN = 32768;    // batches of this many queries and more run as leaders + followers
-
-// PERSISTENT waves: a lane that has finished its query takes the next one (one atomic per wave and refill), so a wave stays full
-// until the work runs out instead of idling behind its longest traversal (half the lanes of a wave, measured).  The queries are
-// dealt in Morton order; XCD x serves the x-th contiguous eighth of them (its L2 then holds the BVH of one region of space) and
-// moves on to the other eighths when its own is exhausted.
-// cand: [NEAR_K][numReps] ids; candCount[r] = number of ids written or NEAR_OVERFLOW.  counters: 8 u32, zero before the launch.
-// LDS: references u32 [stackDepth][BLOCK], queue u32 [NEAR_QUEUE][BLOCK], bounds u16 [stackDepth][BLOCK].
-template <int BLOCK, bool PACKED, bool COOP>
-__global__ void __launch_bounds__(BLOCK) k_near_candidates(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
-                                                           uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, int stackDepth, uint32_t* __restrict__ counters,
-                                                           uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
-                                                           unsigned long long* __restrict__ stats, int drainLanes, uint32_t chunk, bool seedFromNeighbour,
-                                                           uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, uint32_t run, int pass, uint32_t* __restrict__ best, uint32_t stageOff, uint32_t lead, bool directTri) {
-    extern __shared__ uint32_t s_near_stack[];
-    uint32_t stIter = 0, stPop = 0, stPruned = 0, stExpand = 0, stTri = 0, stSeed = 0, stDrain = 0;
-    unsigned long long accExpand = 0, accTri = 0;
-    uint32_t* stkRef = s_near_stack + threadIdx.x;
-    uint32_t* queue = s_near_stack + (size_t)stackDepth * BLOCK + threadIdx.x;
-    unsigned short* stkLb = reinterpret_cast<unsigned short*>(s_near_stack + (size_t)(stackDepth + NEAR_QUEUE) * BLOCK) + threadIdx.x;      // (not PACKED only)
-    // PACKED (trees of at most 2^21 triangles): one word per stack entry — the reference in 22 bits (two's complement), the bound as the
-    // top 10 bits of a non-negative half rounded down (5 bits of mantissa: a bound within 3 % above U is expanded instead of dropped) —
-    // 128 instead of 192 bytes of LDS per lane for 32 entries: 8 instead of 6 workgroups per CU
-    // COOP: the node / triangle records of a wave's lanes are fetched COOPERATIVELY — eight lanes read the 16-byte pieces of one lane's
-    // 128-byte node (four lanes those of a 48-byte triangle record) as one contiguous request, and the pieces reach their owner through
-    // a staging area in LDS (32 nodes of 7 x 16 B, or 64 triangle records of 3 x 16 B, per wave).  A lane-private fetch is six (three)
-    // dwordx4 instructions that each touch 64 different cache lines, and the texture addresser works through them a lane at a time:
-    // VMEM instructions x 64 lanes / 256 CUs came to the kernel's whole duration in the counters (tools/pmc_near.sh).
-    float4* stage = reinterpret_cast<float4*>(s_near_stack + stageOff) + (threadIdx.x >> 6) * (32 * 7);
-    auto stPush = [&](int at, uint32_t ref, float lb) {
-        if (PACKED) stkRef[at * BLOCK] = (ref & 0x3FFFFFu) | ((uint32_t)(halfRoundedDown(fmaxf(lb, 0.f)) >> 5) << 22);
-        else { stkRef[at * BLOCK] = ref; stkLb[at * BLOCK] = halfRoundedDown(lb); }
-    };
-    // this rank's queries: the 128-query blocks blk with blk % world == rank, numbered consecutively
-    const uint32_t allBlocks = (numReps + 127u) / 128u;
-    const uint32_t mine = allBlocks > rank ? (allBlocks - rank + world - 1u) / world : 0u;
-    // pass 0: every query in one sweep.  pass 1: two PHASES in one launch — first the LEADERS (every eighth query of the Morton order),
-    // then, as soon as no leader is left to hand out, the others, each seeded with the triangle its leader ended on (best[], 0xFFFFFFFF
-    // until the leader has finished: the lane's previous triangle seeds the query then) — the leader is at most seven positions back in
-    // the order, i.e. one or two lattice steps away.  (As two launches the leaders' launch ran one query per lane: 36 % of the time for
-    // an eighth of the queries.)  The followers are dealt from the start of the order, whose leaders were the first to be taken.
-    const uint32_t all = mine * 128u;
-    int phase = pass;                            // wave-uniform
-    uint32_t total = phase == 0 ? all : all / lead;
-    uint32_t per = (((total + 127u) / 128u + 7u) / 8u) * 128u;             // queries per XCD range
-    int qpass = 0;                               // the phase this lane's run belongs to
-    const uint32_t lane = __lane_id();
-    uint32_t xcd = blockIdx.x & 7u; uint32_t tried = 0;
-    uint32_t chunkNext = 0, chunkEnd = 0;        // wave-uniform
-    uint32_t runNext = 0, runEnd = 0;            // this lane's run of consecutive queries
-    uint32_t r = 0; F3 p = F3{0.f, 0.f, 0.f};
-    float U = 3.0e38f, U2 = 3.0e38f;            // upper bounds of the minimum distance / squared distance
-    uint32_t nc = 0; bool overflow = false;
-    int sp = 0, nq = 0;
-    uint32_t steps = 0;
-    int mode = 0, seedRef = 0;        // 1: greedy first descent (nearest child only, nothing pushed) to get a bound; 2: waiting for its triangle
-    bool have = false, done = false;
-    uint32_t lastTri = 0xFFFFFFFFu;   // the triangle that gave this lane's previous query its final bound: the next query (a Morton neighbour) is seeded with it
-    static_assert(NEAR_QUEUE >= 1, "the seed uses a queue slot");
-    for (;;) {
-        // ---- refill: the wave owns a chunk [chunkNext, chunkEnd) of its XCD's range — ONE atomic per chunk (an atomic per refill was
-        // measured to serialise the whole launch on eight addresses) — and hands it out in RUNS of `run` consecutive queries per lane:
-        // a lane works through its run in order, so the triangle that bounded its previous query belongs to the Morton NEIGHBOUR of
-        // the next one and seeds it almost exactly (with single queries dealt lane by lane the lane's previous query lay 20-60
-        // positions back: measured 96 expansions + 27 triangle tests per query against 67 + 11 with a perfect seed).
-        uint64_t idle = __ballot(!have && !done);
-        while (idle != 0ull) {
-            const bool needRun = !have && !done && runNext >= runEnd;
-            const uint64_t need = __ballot(needRun);
-            if (need != 0ull) {
-                if (chunkNext >= chunkEnd) {
-                    if (tried >= 8u && phase == 1) {      // the leaders are all taken: on to the followers
-                        phase = 2; tried = 0; xcd = blockIdx.x & 7u;
-                        total = all - all / lead; per = (((total + 127u) / 128u + 7u) / 8u) * 128u;
-                        continue;
-                    }
-                    if (tried >= 8u) { if (needRun) done = true; idle = __ballot(!have && !done); continue; }
-                    const uint32_t lo = xcd * per, hi = (lo + per < total) ? lo + per : total;
-                    uint32_t base = 0;
-                    if (lane == 0u) base = atomicAdd(counters + xcd + (phase == 2 ? 10u : 0u), chunk);
-                    base = __shfl(base, 0) + lo;
-                    if (base >= hi) { tried++; xcd = (xcd + 1u) & 7u; continue; }       // this range is exhausted: the next XCD's, or stop after all eight
-                    chunkNext = base; chunkEnd = (base + chunk < hi) ? base + chunk : hi;
-                }
-                const uint32_t availRuns = (chunkEnd - chunkNext + run - 1u) / run;
-                const uint32_t slot = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
-                if (needRun && slot < availRuns) { runNext = chunkNext + slot * run; runEnd = (runNext + run < chunkEnd) ? runNext + run : chunkEnd; qpass = phase; }
-                const uint32_t want = (uint32_t)__popcll(need);
-                const uint32_t given = want < availRuns ? want : availRuns;
-                chunkNext = (chunkNext + given * run < chunkEnd) ? chunkNext + given * run : chunkEnd;
-            }
-            if (!have && !done && runNext < runEnd) {
-                const uint32_t j = runNext++;
-                const uint32_t q = qpass == 0 ? j : (qpass == 1 ? lead * j : j + j / (lead - 1u) + 1u);
-                const uint32_t rr = ((q >> 7) * world + rank) * 128u + (q & 127u);
-                if (rr < numReps) {
-                    r = rr; have = true;
-                    p = F3{pos[3 * (size_t)r], pos[3 * (size_t)r + 1], pos[3 * (size_t)r + 2]};
-                    U = 3.0e38f; U2 = 3.0e38f; nc = 0; overflow = false; nq = 0; steps = 0;
-                    // With no bound yet the first descent would push every sibling it passes (three per level): it is made
-                    // greedily first, pushing nothing; the search proper then starts at the root with the bound of that one triangle.
-                    if (b.numTriangles == 1u) { queue[0] = 0u; nq = 1; sp = 0; mode = 0; }
-                    else if (seedTri) { queue[0] = seedTri[r]; nq = 1; sp = 0; mode = 2; }                                        // dev probe: the search seeded with its own answer
-                    else if (qpass == 2 && __builtin_nontemporal_load(best + (r & ~(lead - 1u))) < b.numTriangles) { queue[0] = __builtin_nontemporal_load(best + (r & ~(lead - 1u))); nq = 1; sp = 0; mode = 2; }
-                    else if (seedFromNeighbour && lastTri != 0xFFFFFFFFu) { queue[0] = lastTri; nq = 1; sp = 0; mode = 2; }      // one triangle evaluation instead of a ten-step descent
-                    else { sp = 1; mode = 1; seedRef = 0; }
-                }
-            }
-            idle = __ballot(!have && !done);          // lanes that drew a query beyond numReps (the padded tail) or no run yet draw again
-        }
-        if (__ballot(have) == 0ull) break;
-        if (have) stIter++;
-        if (stats) { const uint64_t aliveNow = __ballot(have); if (lane == 0u) { atomicAdd(stats + 10, 1ull); atomicAdd(stats + 11, (unsigned long long)__popcll(aliveNow)); } }
-        // ---- one pop per walking lane: a 4-wide node (one 64-byte line) or a triangle
-        if (have && mode == 2 && nq == 0) { mode = 0; stPush(0, 0u, PACKED ? 0.f : -65504.f); sp = 1; }      // seeded: the root
-        const bool walking = have && sp > 0 && mode != 2;
-        int expandRef = -1;          // the node this lane expands in this iteration
-        if (walking && nq < NEAR_QUEUE) {
-            int ref; float lbound;
-            if (mode == 1) { ref = seedRef; lbound = -3.0e38f; stSeed++; }
-            else if (PACKED) { sp--; steps++; const uint32_t e = stkRef[sp * BLOCK]; ref = (int)(e << 10) >> 10; lbound = halfBitsToFloat((unsigned short)((e >> 22) << 5)); stPop++; }
-            else { sp--; steps++; ref = (int)stkRef[sp * BLOCK]; lbound = halfBitsToFloat(stkLb[sp * BLOCK]); stPop++; }
-            if (lbound > U) stPruned++;
-            if (!(lbound > U)) {
-                if (ref >= 0 && sp + 4 > stackDepth) steps = 0xFFFFFFF0u;        // the (short) stack would overflow: a job for k_near_long
-                else if (ref >= 0) expandRef = ref;
-                else { queue[nq * BLOCK] = (uint32_t)~ref; nq++; }
-            }
-        }
-        float4 nd[6];
-        if (COOP) {
-            const uint64_t act = __ballot(expandRef >= 0);
-            if (act != 0ull) {
-                // all loads first (one memory round trip), then the two halves of the wave through the staging area
-                float4 v[8];
-#pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) {
-                    const int rsrc = __shfl(expandRef, 8 * s8 + (int)(lane >> 3));
-                    v[s8] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (((act >> (8 * s8)) & 0xFFull) != 0ull && rsrc >= 0 && (lane & 7u) < 6u) v[s8] = b.wide[8 * (size_t)rsrc + (lane & 7u)];
-                }
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    if (((act >> (32 * half)) & 0xFFFFFFFFull) == 0ull) continue;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; s4++)
-                        if ((lane & 7u) < 6u) stage[(8 * s4 + (int)(lane >> 3)) * 7 + (int)(lane & 7u)] = v[4 * half + s4];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if ((int)(lane >> 5) == half && expandRef >= 0) {
-#pragma unroll
-                        for (int k = 0; k < 6; k++) nd[k] = stage[(int)(lane & 31u) * 7 + k];
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-            }
-        }
-        if (expandRef >= 0) {
-            float l[4]; uint32_t cr[4];
-            if (COOP) wideBounds(&nd[0], p, l, cr);
-            else wideBounds(b.wide + 8 * (size_t)expandRef, p, l, cr);
-            stExpand++;
-            // sort the four by bound (ascending), push the survivors farthest first: the nearest is popped next
-#define SDF_CE(i, j) { const bool sw_ = l[j] < l[i]; const float tl = sw_ ? l[j] : l[i], th = sw_ ? l[i] : l[j]; const uint32_t rl = sw_ ? cr[j] : cr[i], rh = sw_ ? cr[i] : cr[j]; l[i] = tl; l[j] = th; cr[i] = rl; cr[j] = rh; }
-            SDF_CE(0, 1) SDF_CE(2, 3) SDF_CE(0, 2) SDF_CE(1, 3) SDF_CE(1, 2)
-#undef SDF_CE
-            if (mode == 1) {
-                seedRef = (int)cr[0];
-                if (seedRef < 0) { queue[nq * BLOCK] = (uint32_t)~seedRef; nq++; mode = 2; }
-            } else {
-#pragma unroll
-                for (int c = 3; c >= 0; c--)
-                    if (!(l[c] > U)) {
-                        // a surviving TRIANGLE goes straight to the queue while there is room (an iteration saved: popping it would only move it there)
-                        if (directTri && (int)cr[c] < 0 && nq < NEAR_QUEUE) { queue[nq * BLOCK] = ~cr[c]; nq++; }
-                        else { stPush(sp, cr[c], l[c]); sp++; }
-                    }
-            }
-        }
-        // ---- one drain round when enough lanes have a triangle pending, a lane is stuck on a full queue, or nobody walks any more
-        const uint64_t pend = __ballot(have && nq > 0);
-        if (pend != 0ull && (__popcll(pend) >= drainLanes || __ballot(have && nq >= NEAR_QUEUE) != 0ull || __ballot(have && sp > 0 && mode != 2) == 0ull)) {
-            if (have) stDrain++;
-            const bool draining = have && nq > 0;
-            uint32_t t = 0xFFFFFFFFu;
-            if (draining) { nq--; stTri++; t = queue[nq * BLOCK]; }
-            float4 tq[3];
-            if (COOP) {
-                const uint64_t dact = __ballot(draining);
-                float4* tstage = stage;          // 64 records of 3 x 16 bytes: the node staging area's 3584 bytes hold them
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) {
-                    const uint32_t tsrc = (uint32_t)__shfl((int)t, 16 * s4 + (int)(lane >> 2));
-                    if (((dact >> (16 * s4)) & 0xFFFFull) != 0ull && tsrc != 0xFFFFFFFFu && (lane & 3u) < 3u)
-                        tstage[(16 * s4 + (int)(lane >> 2)) * 3 + (int)(lane & 3u)] = b.triV[3 * (size_t)tsrc + (lane & 3u)];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (draining) { tq[0] = tstage[(int)lane * 3]; tq[1] = tstage[(int)lane * 3 + 1]; tq[2] = tstage[(int)lane * 3 + 2]; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            if (draining) {
-                const TriBounds tb = COOP ? triBounds32(tq[0], tq[1], tq[2], p) : triBounds32(b, t, p);
-                if (tb.lo <= U2) {
-                    if (tb.hi < U2) { U2 = tb.hi; U = __builtin_amdgcn_sqrtf(U2) * 1.000001f + 1e-37f; lastTri = t; }
-                    if (mode != 2) {                        // (the seed triangle only lends its bound: the search meets it again)
-                        if (nc == (uint32_t)NEAR_K) {       // rare: drop the entries the bound has overtaken since they were recorded
-                            if (stats) atomicAdd(stats + 9, 1ull);
-                            // (against the STORED lower bounds: re-evaluating sixteen triangles here, in one lane while the other 63 wait, was
-                            // measured to happen for every third query and to cost the wave as much as everything else it does).  The sixteen
-                            // bounds are fetched by independent loads (one memory latency, not sixteen); entries move only behind the first gap.
-                            uint32_t keepMask = 0;
-#pragma unroll
-                            for (uint32_t i = 0; i < (uint32_t)NEAR_K; i++) keepMask |= (candLo[(size_t)i * numReps + r] <= U2) ? (1u << i) : 0u;
-                            uint32_t keep = (uint32_t)__builtin_ctz(~keepMask);             // the leading run of kept entries stays where it is
-                            for (uint32_t i = keep + 1u; i < (uint32_t)NEAR_K; i++)
-                                if ((keepMask >> i) & 1u) {
-                                    cand[(size_t)keep * numReps + r] = cand[(size_t)i * numReps + r];
-                                    candLo[(size_t)keep * numReps + r] = candLo[(size_t)i * numReps + r];
-                                    keep++;
-                                }
-                            nc = keep;
-                        }
-                        if (nc < (uint32_t)NEAR_K) { cand[(size_t)nc * numReps + r] = t; candLo[(size_t)nc * numReps + r] = tb.lo; nc++; } else overflow = true;
-                    }
-                }
-            }
-        }
-        // ---- finished queries; a query that turns out to be long (a point with thousands of almost equidistant triangles) is
-        // handed to k_near_long, where a whole wave works on it: left to one lane, its dependent chain of pops alone outlasts the
-        // rest of the launch (measured: the longest of 1.5 M traversals took as long as all the others together)
-        if (have && sp == 0 && nq == 0 && mode == 0) {
-            candCount[r] = (uint8_t)(overflow ? NEAR_OVERFLOW : nc); candU2[r] = U2; have = false;
-            if (qpass == 1) best[r] = lastTri;
-            if (perQuery) { perQuery[4 * (size_t)r + 1] = stExpand; perQuery[4 * (size_t)r + 2] = stIter; perQuery[4 * (size_t)r + 3] = stTri; }
-            if (stats) {
-                atomicAdd(stats + 0, 1ull); atomicAdd(stats + 1, (unsigned long long)stIter); atomicAdd(stats + 2, (unsigned long long)stPop); atomicAdd(stats + 3, (unsigned long long)stPruned);
-                atomicAdd(stats + 4, (unsigned long long)stExpand); atomicAdd(stats + 5, (unsigned long long)stTri); atomicAdd(stats + 6, (unsigned long long)stSeed); atomicAdd(stats + 7, (unsigned long long)stDrain);
-                atomicAdd(stats + 8, (unsigned long long)nc);
-            }
-            accExpand += stExpand; accTri += stTri;
-            stIter = stPop = stPruned = stExpand = stTri = stSeed = stDrain = 0;
-        }
-        if (have && steps > maxSteps) { longList[atomicAdd(longCount, 1u)] = r; candCount[r] = (uint8_t)NEAR_OVERFLOW; have = false; if (qpass == 1) best[r] = lastTri; accExpand += stExpand; accTri += stTri; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { accExpand += __shfl_xor(accExpand, o); accTri += __shfl_xor(accTri, o); }
-    if (lane == 0u) { atomicAdd(reinterpret_cast<unsigned long long*>(counters + 18), accExpand); atomicAdd(reinterpret_cast<unsigned long long*>(counters + 20), accTri); }
-}
-
 // ---- phase 1, QUAD form -------------------------------------------------------------------------------------------------
 // Four lanes per query: lane c of a quad tests child c of the popped wide node (one 16-byte record each: a quad reads the node's
 // 64 bytes of child records as one contiguous request), the survivors are ranked inside the quad (three DPP rotations) and pushed on
@@ -433,7 +174,7 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
     const uint32_t allBlocks = (numReps + 127u) / 128u;
     const uint32_t mine = allBlocks > rank ? (allBlocks - rank + world - 1u) / world : 0u;
     const uint32_t all = mine * 128u;
-    int phase = pass;                            // wave-uniform (k_near_candidates: leaders, then followers)
+    int phase = pass;                            // wave-uniform: 0 = one sweep; 1 = the leaders (every lead-th query), then 2 = the followers
     uint32_t total = phase == 0 ? all : all / lead;
     uint32_t per = (((total + 127u) / 128u + 7u) / 8u) * 128u;
     uint32_t xcd = blockIdx.x & 7u, tried = 0, chunkNext = 0, chunkEnd = 0;
@@ -570,6 +311,9 @@ __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __r
                     const uint32_t nibR = quadBallot(rec, lane);
                     const uint32_t k = (uint32_t)__popc(nibR);
                     if (nc + k > (uint32_t)NEAR_K) {    // rare: drop the entries the bound has overtaken since they were recorded (lane 0 of the quad)
+                        // (lane 0 reads entries the quad's other lanes stored in earlier drain rounds, through __restrict__ pointers: the stores are
+                        // made visible and the loads kept behind them explicitly)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         uint32_t keep = nc;
                         if (c == 0u) {
                             uint32_t keepMask = 0;
@@ -987,7 +731,18 @@ typedef sdfhip_near_scratch NearScratch;
 struct NearPlainAlloc { AllocState saved; NearPlainAlloc() { saved = tlsAlloc(); tlsAlloc().active = false; } ~NearPlainAlloc() { tlsAlloc() = saved; } };
 static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
 
-// Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  stackDepth = BVH depth + 2.
+// Launch constants of the candidate search, each the winner of a measured sweep (profiles/r04g_near_seeds_roundtrip_ab.txt):
+constexpr uint32_t NEAR_TWO_PASS_MIN = 32768;   // batches of this many queries and more run as leaders + followers
+constexpr uint32_t NEAR_LEAD = 8;               // every 8th query of the Morton order is a leader (4: 9.2 ms, 16: 9.0 ms against 8.8 per C2 build); a power of two <= 128
+constexpr uint32_t NEAR_QBLOCKS_PER_CU = 6;     // resident workgroups of 256 per CU (7: 9.06 ms, 8: 9.44 ms: more waves only add L2 misses)
+constexpr uint32_t NEAR_QCHUNK = 16;            // queries a wave (16 quads) takes per atomic (32, 64: slower)
+constexpr uint32_t NEAR_MULTISEED = 2;          // leaders a follower is seeded from: the one before it and the one after it
+constexpr uint32_t NEAR_REFILL_MIN = 1;         // idle quads a refill waits for (2 - 4: 8.71 / 8.82 / 8.93 ms, within noise of 1)
+constexpr int NEAR_DRAIN_QUAD_LANES = 40;       // lanes with a triangle to test that make a drain round worth its instructions (32: 8.85, 48: 9.0 ms)
+constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query)
+
+// Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  seedTri (dev probe, sdfhip_mesh_nearest_stats): the
+// search of query r starts from the bound of triangle seedTri[r].
 static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, uint32_t n, uint32_t* out, NearScratch& S, int stackDepth, uint32_t rank, uint32_t world,
                            uint32_t* perQuery = nullptr, const uint32_t* seedTri = nullptr) {
     if (n == 0) return SDFHIP_OK;
@@ -1006,70 +761,18 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
         while (S.evMade < 3 * (S.evUsed + 1)) { SDF_HIP_CHECK(hipEventCreate(&S.ev[S.evMade])); S.evMade++; }
         S.evUsed++;
     }
-    // a 4-wide level leaves at most three entries behind, i.e. 3 * levels + 1 in the worst case; the stacks are kept SHORTER than that
-    // (LDS per lane decides how many waves a CU holds) and a query that would overflow its stack goes to k_near_long with the long ones
-    const int worst = 3 * (stackDepth / 2 + 1) + 2;
-    // measured: 32 entries for trees up to 2^20 triangles (C2, torus knot: 34 is 5 % slower, fewer waves per CU), 34 above (1.31 M triangles:
-    // one more 4-wide level, and with 32 entries 2.3 % of a level's queries overflowed into the low-occupancy long kernel: 0.039 -> 0.032 s)
-    static const int capEnv = getenv("SDFHIP_NEAR_STACK") ? atoi(getenv("SDFHIP_NEAR_STACK")) : 0;
-    const int cap = capEnv ? capEnv : (bvh.numTriangles > (1u << 20) ? 34 : 32);
-    const int sd = worst < cap ? worst : cap;
-    static const bool packedEnv = !(getenv("SDFHIP_NEAR_PACKED") && getenv("SDFHIP_NEAR_PACKED")[0] == '0');
-    const bool packed = packedEnv && bvh.numTriangles <= (1u << 21);
-    static const uint32_t lead = (getenv("SDFHIP_NEAR_LEAD") && atoi(getenv("SDFHIP_NEAR_LEAD")) >= 2) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LEAD")) : 8u;          // a power of two <= 128
-    static const bool directTri = !(getenv("SDFHIP_NEAR_DIRECT") && getenv("SDFHIP_NEAR_DIRECT")[0] == '0');
-    static const bool coop = !(getenv("SDFHIP_NEAR_COOP") && getenv("SDFHIP_NEAR_COOP")[0] == '0');
-    const size_t ldsBase = (size_t)(sd + NEAR_QUEUE) * 128 * 4 + (packed ? 0 : (size_t)sd * 128 * 2);
-    const size_t lds = ldsBase + (coop ? 2 * 32 * 7 * 16 : 0);           // + a staging area per wave
-    static const uint32_t perCU = getenv("SDFHIP_NEAR_BLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_BLOCKS_PER_CU")) : 12u;
-    uint32_t grid = 256u * perCU;
-    if (grid > mine) grid = mine;
-    static const uint32_t maxSteps = getenv("SDFHIP_NEAR_LONG") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_LONG")) : 1536u;
-    static const bool wantStats = getenv("SDFHIP_NEAR_STATS") != nullptr;
-    static const uint32_t run = (getenv("SDFHIP_NEAR_RUN") && atoi(getenv("SDFHIP_NEAR_RUN")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_RUN")) : (uint32_t)NEAR_RUN;
-    static const uint32_t chunkRuns = (getenv("SDFHIP_NEAR_CHUNK") && atoi(getenv("SDFHIP_NEAR_CHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_CHUNK")) : (uint32_t)NEAR_CHUNK;
-    const uint32_t chunk = chunkRuns * run;         // queries a wave takes per atomic: whole runs
-    static const int drainLanes = getenv("SDFHIP_NEAR_DRAIN") ? atoi(getenv("SDFHIP_NEAR_DRAIN")) : NEAR_DRAIN_LANES;
-    DevBuf<unsigned long long> stats;
-    if (wantStats) { SDF_TRY(stats.reserve(16)); SDF_HIP_CHECK(hipMemsetAsync(stats.p, 0, 128, st)); }
-    static const bool seedNeighbour = !(getenv("SDFHIP_NEAR_SEED") && !strcmp(getenv("SDFHIP_NEAR_SEED"), "descent"));       // A/B switch: the greedy descent of round 2
     // Leaders first (batches of NEAR_TWO_PASS_MIN queries and more): every eighth query of the Morton order, then the rest, each seeded
-    // with the triangle its leader ended on.  A search seeded with its own answer needs 67 expansions + 11 triangle tests on the C2
-    // mesh's level-7 samples (tools/gpu_near_hist.py), seeded by the lane's previous query (20-60 positions back) 96 + 27; the leader is
-    // at most seven positions back.  
-    static const uint32_t twoPassMin = getenv("SDFHIP_NEAR_TWO_PASS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_TWO_PASS")) : (uint32_t)NEAR_TWO_PASS_MIN;
-    const bool twoPass = !seedTri && twoPassMin != 0u && n >= twoPassMin;
+    // with the triangles the leaders on either side of it ended on.  A search seeded with its own answer needs 67 expansions + 11 triangle
+    // tests on the C2 mesh's level-7 samples (tools/gpu_near_hist.py), seeded by the quad's previous query alone 77 + 21.
+    const bool twoPass = !seedTri && n >= NEAR_TWO_PASS_MIN;
     if (twoPass) { SDF_TRY(S.best.reserve(n)); SDF_HIP_CHECK(hipMemsetAsync(S.best.p, 0xFF, sizeof(uint32_t) * (size_t)n, st)); }
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[0], st));
-    static const bool quads = !(getenv("SDFHIP_NEAR_KERNEL") && !strcmp(getenv("SDFHIP_NEAR_KERNEL"), "lanes"));
-    static const int drainQuads = getenv("SDFHIP_NEAR_DRAINQ") ? atoi(getenv("SDFHIP_NEAR_DRAINQ")) : 40;          // lanes with a triangle to test that make a drain round worth its instructions
-    if (quads) {
-        static const uint32_t qPerCU = getenv("SDFHIP_NEAR_QBLOCKS_PER_CU") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QBLOCKS_PER_CU")) : 6u;       // all resident (70 VGPRs: 7 waves per SIMD); measured 6 < 8 < 12: blocks that start late only add a tail
-        static const uint32_t qchunk = (getenv("SDFHIP_NEAR_QCHUNK") && atoi(getenv("SDFHIP_NEAR_QCHUNK")) > 0) ? (uint32_t)atoi(getenv("SDFHIP_NEAR_QCHUNK")) : 16u;      // queries a wave (16 quads) takes per atomic: measured 16 < 32 < 64
-        static const uint32_t multiSeed = getenv("SDFHIP_NEAR_MULTISEED") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_MULTISEED")) : 2u;       // leaders a follower is seeded from (1: the one before it; 2: the one after it as well)
-        static const uint32_t refillMin = getenv("SDFHIP_NEAR_REFILL") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_REFILL")) : 1u;       // idle quads a refill waits for
-        uint32_t qgrid = 256u * qPerCU;
-        const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
-        if (qgrid > needBlocks) qgrid = needBlocks;
-        k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, maxSteps, S.longList.p, S.fbCount.p + 10,
-                                                        drainQuads, qchunk, seedNeighbour, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, lead, multiSeed, refillMin);
-    } else {
-#define SDF_NEAR_LAUNCH(P, C) k_near_candidates<128, P, C><<<xcdGrid(grid), 128, lds, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, sd, S.fbCount.p + 2, maxSteps, S.longList.p, \
-        S.fbCount.p + 10, wantStats ? stats.p : nullptr, drainLanes, chunk, seedNeighbour, perQuery, seedTri, run, twoPass ? 1 : 0, S.best.p, (uint32_t)(ldsBase / 4), lead, directTri)
-    if (packed) { if (coop) SDF_NEAR_LAUNCH(true, true); else SDF_NEAR_LAUNCH(true, false); }
-    else { if (coop) SDF_NEAR_LAUNCH(false, true); else SDF_NEAR_LAUNCH(false, false); }
-#undef SDF_NEAR_LAUNCH
-    }
+    uint32_t qgrid = 256u * NEAR_QBLOCKS_PER_CU;          // all resident (72 VGPRs: 7 waves per SIMD)
+    const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
+    if (qgrid > needBlocks) qgrid = needBlocks;
+    k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, NEAR_MAX_STEPS, S.longList.p, S.fbCount.p + 10,
+                                                    NEAR_DRAIN_QUAD_LANES, NEAR_QCHUNK, true, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, NEAR_LEAD, NEAR_MULTISEED, NEAR_REFILL_MIN);
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[1], st));
-    if (wantStats) {
-        unsigned long long h[12];
-        SDF_HIP_CHECK(hipMemcpyAsync(h, stats.p, sizeof(h), hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
-        uint32_t nLong = 0;
-        SDF_HIP_CHECK(hipMemcpyAsync(&nLong, S.fbCount.p + 10, 4, hipMemcpyDeviceToHost, st)); SDF_HIP_CHECK(hipStreamSynchronize(st));
-        const double q = (double)(h[0] ? h[0] : 1);
-        fprintf(stderr, "[sdfhip] near stats: %llu queries; per query: wave iterations while alive %.1f, pops %.1f (pruned %.1f), expansions %.1f, triangles %.1f, seed steps %.1f, drain rounds %.1f, candidates %.2f; list compactions %.3f per query; %.1f of 64 lanes alive per wave iteration; %u queries handed to k_near_long\n",
-                h[0], h[1] / q, h[2] / q, h[3] / q, h[4] / q, h[5] / q, h[6] / q, h[7] / q, h[8] / q, h[9] / q, (double)h[11] / (double)(h[10] ? h[10] : 1), nLong);
-    }
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, S.fbCount.p + 24);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
     k_near_resolve_many<128><<<64, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, S.fbCount.p + 30);

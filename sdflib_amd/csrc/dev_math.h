@@ -52,7 +52,7 @@ SDF_HD float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi);
 // gets on such a platform WITHOUT a round trip to the host.  libm's acosf is not correctly rounded, so this is an identity of
 // algorithms, not of specifications: sdfhip_test_acosf_mismatches (tests/test_abi.py) compares the host compilation of this very
 // function with the running libm on EVERY float of [-1, 1] (2 130 706 434 values: none differs on glibc 2.35), the GPU tests compare
-// the device compilation with libm; `SDFHIP_ACOS=host` restores the host's libm (for a platform whose libm is another algorithm).
+// the device compilation with libm; on a platform whose libm is another algorithm the first mesh's self-check (ctx_mesh.hip, hostAcosNeeded) sends the arc cosines to the host's libm instead.
 SDF_HD float acosfGlibc(float x) {
     const float one = 1.0f, pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
     const float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f, pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f;

@@ -11,7 +11,7 @@
 //   k_cull          : the hot kernel. Work item = 1024-entry chunk of a node's PARENT list; one wave per chunk, lanes
 //                     stride the chunk, gather 3 indices + 3 vertices per triangle, run the Frank-Wolfe test, and
 //                     compact the survivors IN ORDER with __ballot + mbcnt prefix (lists stay ascending by id)
-//   hipcub scan + k_compact : chunk counts -> packed per-node lists
+//   prefix sum + k_compact : chunk counts -> packed per-node lists
 //   k_brute_nearest / k_brute_nearest_mids : first-minimum nearest triangle of a node's sample points over the node's list
 //                     (block per (node, corner) at the root; block per node with LDS-staged frames for the 19 mid-points)
 //   k_merge_*       : the "second visit" of the last two levels: sorted union of the children's lists + per-child
@@ -21,7 +21,7 @@
 // Compile with -ffp-contract=off.
 #include "exact_internal.h"
 #include "dev_gjk.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -705,9 +705,9 @@ struct ScanHelper {
     int exclusive(const uint32_t* in, uint32_t* out, uint32_t n) {
         if (n == 0) return SDFHIP_OK;
         size_t need = 0;
-        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, st));
+        SDF_HIP_CHECK(devExclusiveSum(nullptr, need, in, out, (size_t)n, st));
         if (need > bytes) { SDF_TRY(tmp.reserve(need)); bytes = need; }
-        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, in, out, (int)n, st));
+        SDF_HIP_CHECK(devExclusiveSum(tmp.p, need, in, out, (size_t)n, st));
         return SDFHIP_OK;
     }
 };
@@ -900,9 +900,8 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             k_chunk_fill<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkNode.p);
             CullArgs ca{md, L->center.p, L->half, L->cornerTri.p, region.p, minDist.p, prevList, L->pOff.p, L->pLen.p, chunkNode.p, chunkBase.p, numChunks,
                         tmp.p, chunkCount.p, cullTests.p};
-            // chunks per wave: enough waves to fill the chip several times over, then as long a stream per wave as that leaves (SDFHIP_CULL_STREAM overrides)
-            { static const int forced = getenv("SDFHIP_CULL_STREAM") ? atoi(getenv("SDFHIP_CULL_STREAM")) : 0;
-              uint32_t pw = forced > 0 ? (uint32_t)forced : numChunks / 32768u; if (pw < 1u) pw = 1u; if (pw > 16u && forced <= 0) pw = 16u; ca.perWave = pw; }      // (divisors 4096 .. 65536 and caps 16 .. 64 measured: a plateau)
+            // chunks per wave: enough waves to fill the chip several times over, then as long a stream per wave as that leaves
+            { uint32_t pw = numChunks / 32768u; if (pw < 1u) pw = 1u; if (pw > 16u) pw = 16u; ca.perWave = pw; }      // (divisors 4096 .. 65536 and caps 16 .. 64 measured: a plateau, profiles/r04_cull_experiments.txt)
             k_cull<<<gridFor(gridFor(numChunks, ca.perWave), 4), 256, 0, st>>>(ca);
             SDF_TRY(scan.exclusive(chunkCount.p, chunkScan.p, numChunks));
             SDF_TRY(lastPlus(st, chunkScan.p, chunkCount.p, numChunks, total));
@@ -927,7 +926,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             {
                 // many nodes with short lists: a block per node shares the staged frames among the 19 points (k_brute_nearest_mids); the nodes
                 // with long lists (all of them near the root) are cut into pieces of BN_PIECE entries (k_brute_mids_long)
-                static const uint32_t longLen = getenv("SDFHIP_BRUTE_LONG") ? (uint32_t)atoi(getenv("SDFHIP_BRUTE_LONG")) : BN_PIECE;
+                const uint32_t longLen = BN_PIECE;
                 const size_t maxItems = (size_t)L->listTotal / BN_PIECE + n + 1;
                 SDF_TRY(longItems.reserve(maxItems)); SDF_TRY(longCount.reserve(1)); SDF_TRY(longKeys.reserve(19ull * n));
                 SDF_HIP_CHECK(hipMemsetAsync(longCount.p, 0, 4, st));

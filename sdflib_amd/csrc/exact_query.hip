@@ -7,7 +7,7 @@
 // streams the set through the mask chain with two running rank counters instead, so it needs no scratch at all.
 // Compile with -ffp-contract=off.
 #include "exact_internal.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 #include <memory>
 #include <cstring>
 #include <cstdlib>
@@ -612,11 +612,10 @@ static int ensureLeafCtx(sdfhip_exact* T, const ExactView& v) {
     return SDFHIP_OK;
 }
 
-// The decoded lists (k_exact_leaf_lists): count, scan, write — once per tree, after leafCtx.
-static int ensureLeafLists(sdfhip_exact* T, const ExactView& v) {
-    std::lock_guard<std::mutex> own(T->leafCtxLock);
-    if (T->listsState != 0) return SDFHIP_OK;
-    hipStream_t st = T->ctx->stream;
+// The decoded lists (k_exact_leaf_lists): count, scan, write — once per tree, after leafCtx.  The lists are an ACCELERATION: when they
+// do not fit (more than SDFHIP_EXACT_LISTS_MB, default 4096, or more than half of what the device has free) or an allocation for them
+// fails (a co-tenanted or nearly full device), the tree answers through the decoding kernel as it did before they existed.
+static int makeLeafLists(sdfhip_exact* T, const ExactView& v, hipStream_t st) {
     const uint32_t nn = (uint32_t)T->info.num_nodes;
     static const uint64_t capMB = [] { const char* e = getenv("SDFHIP_EXACT_LISTS_MB"); return e ? (uint64_t)strtoull(e, nullptr, 10) : 4096ull; }();
     const uint4* lc = reinterpret_cast<const uint4*>(T->leafCtx.p);
@@ -625,21 +624,35 @@ static int ensureLeafLists(sdfhip_exact* T, const ExactView& v) {
     k_exact_leaf_lists<false><<<nn, 64, 0, st>>>(v, lc, counts.p, nullptr, nullptr);
     k_widen<<<gridFor(nn, 256), 256, 0, st>>>(counts.p, nn, wide.p);
     size_t tb = 0;
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, wide.p, offsets.p, (int)nn, st));
+    SDF_HIP_CHECK(devExclusiveSum(nullptr, tb, wide.p, offsets.p, (size_t)nn, st));
     SDF_TRY(tmp.reserve(tb));
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, wide.p, offsets.p, (int)nn, st));
+    SDF_HIP_CHECK(devExclusiveSum(tmp.p, tb, wide.p, offsets.p, (size_t)nn, st));
     uint64_t lastOff = 0; uint32_t lastCnt = 0;
     SDF_HIP_CHECK(hipMemcpyAsync(&lastOff, offsets.p + (nn - 1), 8, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipMemcpyAsync(&lastCnt, counts.p + (nn - 1), 4, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const uint64_t total = lastOff + lastCnt;
-    if (total >= (1ull << 32) || 4 * total > (capMB << 20)) { T->listsState = 2; return SDFHIP_OK; }
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) { (void)hipGetLastError(); freeB = ~(size_t)0; }
+    if (total >= (1ull << 32) || 4 * total > (capMB << 20) || 4 * total > freeB / 2) { T->listsState = 2; return SDFHIP_OK; }
     SDF_TRY(T->leafLists.reserve(total + 64)); SDF_TRY(T->leafList.reserve(2ull * nn));
     k_exact_leaf_lists<true><<<nn, 64, 0, st>>>(v, lc, nullptr, offsets.p, T->leafLists.p);
     k_exact_list_table<<<gridFor(nn, 256), 256, 0, st>>>(counts.p, offsets.p, nn, reinterpret_cast<uint2*>(T->leafList.p));
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));          // the temporaries die with this scope
     T->listEntries = total; T->listsState = 1;
+    return SDFHIP_OK;
+}
+static int ensureLeafLists(sdfhip_exact* T, const ExactView& v) {
+    std::lock_guard<std::mutex> own(T->leafCtxLock);
+    if (T->listsState != 0) return SDFHIP_OK;
+    if (makeLeafLists(T, v, T->ctx->stream) != SDFHIP_OK) {
+        // no room for the lists: what was reserved goes back, the decoding kernel answers (and the failed allocation is not the caller's error)
+        (void)hipGetLastError();
+        T->leafLists.release(); T->leafList.release();
+        T->listEntries = 0; T->listsState = 2;
+        SDF_HIP_CHECK(hipStreamSynchronize(T->ctx->stream));
+    }
     return SDFHIP_OK;
 }
 
@@ -711,12 +724,11 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
         // (21 instead of 32 at a million nodes: three radix passes instead of four)
         int keyBits = 1; while (keyBits < 32 && (1ull << keyBits) <= T->info.num_nodes) keyBits++;
         size_t tb = 0;
-        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, keyBits, st));
+        SDF_HIP_CHECK(devSortPairs(nullptr, tb, key.p, keyS.p, qi.p, qiS.p, (size_t)n, 0, (unsigned)keyBits, st));
         SDF_TRY(tmp.reserve(tb));
-        SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (int)n, 0, keyBits, st));
+        SDF_HIP_CHECK(devSortPairs(tmp.p, tb, key.p, keyS.p, qi.p, qiS.p, (size_t)n, 0, (unsigned)keyBits, st));
         const uint4* lc = reinterpret_cast<const uint4*>(T->leafCtx.p);
-        static const bool decodeAlways = getenv("SDFHIP_EXACT_QUERY") && !strcmp(getenv("SDFHIP_EXACT_QUERY"), "decode");      // A/B: round 3's kernel
-        if (!decodeAlways && T->listsState == 1) {
+        if (T->listsState == 1) {
             const uint2* ll = reinterpret_cast<const uint2*>(T->leafList.p);
             if (g) k_exact_lists<true><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, ll, T->leafLists.p, d, g, t);
             else k_exact_lists<false><<<xcdGrid(gridFor(n, 64)), 64, 0, st>>>(v, p, n, keyS.p, qiS.p, ll, T->leafLists.p, d, nullptr, t);

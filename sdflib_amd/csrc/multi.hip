@@ -133,7 +133,7 @@ struct ThreadBarrier {                     // all `n` threads, or none: a rank t
         const uint64_t ph = phase;
         if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); return true; }
         cv.wait(g, [&] { return phase != ph || failed; });
-        return !failed;
+        return phase != ph;          // decided per PHASE: a barrier that completed lets every waiter through, also one that wakes after a later failure (its peers are already in the collective)
     }
     void fail() { std::lock_guard<std::mutex> g(m); failed = true; cv.notify_all(); }
 };

@@ -10,7 +10,7 @@
 //   sampleBatch (octree_sampler.h)     : exact samples of whole levels: dedup by lattice point, fp64 BVH nearest triangle per
 //                                        unique point (dev_bvh.h), fp32 Hermite datum per sample
 //   k_decide          : one lane per node: 64x64 fit (reference summation order), 19-point error rule, leaf/inner
-//   hipcub ExclusiveSum + k_scatter_children : child slots; the 27-point stencil is handed down to the 8 children
+//   prefix sum + k_scatter_children : child slots; the 27-point stencil is handed down to the 8 children
 // and afterwards the breadth-first arrays are relabelled into the reference's array layout:
 //   k_alloc (bottom-up) : words needed by every subtree ; k_emit (top-down) : pre-order offsets, children 7..0,
 // which is exactly the order in which the reference's DFS stack appends blocks (OctreeSdfDepthFirst.h:213-336).
@@ -21,7 +21,7 @@
 #include "dev_tricubic.h"
 #include "dev_fit_mfma.h"
 #include "octree_sampler.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 #include <cmath>
 #include <cstring>
 
@@ -416,9 +416,9 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
             } else k_decide<false><<<gridFor(L->n, 128), 128, 0, st>>>(a);
             if (d < maxDepth) {
                 size_t need = 0;
-                SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, L->inner.p, L->childBase.p, (int)L->n, st));
+                SDF_HIP_CHECK(devExclusiveSum(nullptr, need, L->inner.p, L->childBase.p, (size_t)L->n, st));
                 if (need > scanTmpBytes) { SDF_TRY(scanTmp.reserve(need)); scanTmpBytes = need; }
-                SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp.p, need, L->inner.p, L->childBase.p, (int)L->n, st));
+                SDF_HIP_CHECK(devExclusiveSum(scanTmp.p, need, L->inner.p, L->childBase.p, (size_t)L->n, st));
                 SDF_TRY(readBackWords(st, L->childBase.p + (L->n - 1), L->inner.p + (L->n - 1), 1, &L->numInner));
                 k_scale8<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->childBase.p);
             } else { SDF_HIP_CHECK(hipStreamSynchronize(st)); L->numInner = 0; }

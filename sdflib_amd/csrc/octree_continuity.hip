@@ -6,16 +6,15 @@
 // disabled ("canonical" mode).  The reference runs, per depth: Iter 1 (parallel over nodes), Iter 2 (serial over nodes),
 // and a serial post-pass that re-subdivides coarse leaves next to finer neighbours.
 //
-// MI355X split — plan on the host, compute on the device:
-//   * everything that touches a float runs in HIP kernels: exact samples (fp64 BVH), 8-slot 64x64 fits, termination
-//     rule, the "can the coarse neighbour's polynomial stand in for this sample" tests, Hermite interpolation of the
-//     replaced samples, the hand-down of the 27-point stencil to children;
+// MI355X form — everything runs in HIP kernels; the host only sizes buffers from a handful of counts it reads back:
+//   * exact samples (two-phase nearest search), 8-slot 64x64 fits, termination rule, the "can the coarse neighbour's polynomial
+//     stand in for this sample" tests, Hermite interpolation of the replaced samples, the hand-down of the 27-point stencil to children;
 //   * Iter 2 is NOT serial here: within one level the leaf flags it reads are final after Iter 1, so neighbour masks are
 //     order independent and the only serial thing, the allocation order, is an exclusive scan in node order;
-//   * the post-pass is split: its control flow depends only on INTEGER state (leaf / mark bits, child indices, neighbour
-//     words), never on float values, so the host replays it on a mirror of the node words and emits a list of float-free
-//     "ops" (subdivide with sample mask / finalise leaf at slot) grouped by local BFS generation; the device then executes
-//     every generation of all scheduled leaves at once.
+//   * the post-pass's control flow depends only on INTEGER state (leaf / mark bits, child indices, neighbour words), never on
+//     float values: kpp_* replay it on the device (roots -> generations of decide / expand -> allocation scan -> words), emitting
+//     float-free "ops" (subdivide with sample mask / finalise leaf at slot) grouped by local BFS generation; kc_pp_* then execute
+//     every generation of all scheduled leaves at once.  (Rounds 1-3 replayed it on the host over a mirror of the node words.)
 // The reference's quirks are kept where they shape the output: child paths are truncated to 8 bits (its node constructor
 // takes a uint8_t), re-created leaves are registered under parentChildrenIndex + childId even at the start depth, mark
 // bits are cleared at the end.  mValueRange (never initialised in the reference) starts at 0.
@@ -24,11 +23,9 @@
 #include "dev_bvh.h"
 #include "dev_tricubic.h"
 #include "octree_sampler.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 #include <cmath>
 #include <cstring>
-#include <unordered_map>
-#include <sys/mman.h>
 #include <algorithm>
 #include <cstdlib>
 
@@ -303,15 +300,6 @@ __global__ void kc_compact_cand(const uint32_t* __restrict__ cand, const uint32_
     if (i < n && flag[i]) out[scan[i]] = cand[i];
 }
 __global__ void kc_mul8(uint32_t n, uint32_t* __restrict__ v) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] *= 8u; }
-// the planner's mirror needs the WORDS of a level's nodes (8 topology words per 64-word payload block: 2 % of the array)
-__global__ void kc_gather_words(const uint32_t* __restrict__ idx, uint32_t n, const uint32_t* __restrict__ oc, uint32_t* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (idx[i] != NONE32) ? oc[idx[i]] : 0u;
-}
-__global__ void kc_patch(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, uint32_t n, uint32_t* __restrict__ oc) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) oc[idx[i]] = val[i];
-}
 
 // ---- post-pass ops (float part) ------------------------------------------------------------------------------------------
 // A node of the post-pass lives either in a level (src = depth << 26 | slot is NOT used; see refs below) or in the pool.
@@ -752,8 +740,6 @@ struct CLevelHost {
     bool sampled = false;      // the 19 exact mid-point samples were already enqueued (overlapped with the previous level's post-pass)
     uint32_t depth = 0, n = 0; float half = 0.f;
     DevBuf<float> center, vv, coeff, mid; DevBuf<uint32_t> coord, pci, nIdx, word, cand, allocSize, allocOff, inner, childSlot; DevBuf<uint8_t> path, nDepth, terminal;
-    // host mirrors of the integer state (the post-pass planner reads them)
-    std::vector<uint32_t> hCoord, hPci, hNIdx, hWord; std::vector<uint8_t> hPath, hNDepth, hTerminal;
     int alloc(uint32_t count) {
         n = count;
         SDF_TRY(center.reserve(3ull * n)); SDF_TRY(vv.reserve(64ull * n)); SDF_TRY(coeff.reserve(64ull * n)); SDF_TRY(mid.reserve(152ull * n));
@@ -765,86 +751,6 @@ struct CLevelHost {
     CLevelDev dev() { return CLevelDev{n, half, center.p, coord.p, path.p, pci.p, nIdx.p, nDepth.p, word.p, vv.p, coeff.p, mid.p, terminal.p, cand.p, allocSize.p, allocOff.p, inner.p, childSlot.p}; }
 };
 
-// integer state of a node the post-pass can visit (level node or pool node)
-struct PNode { uint32_t path, pci, nIdx[6]; uint8_t nDepth[6]; uint32_t coord, depth; bool ignore; uint32_t srcLevel, srcSlot; };
-struct LeafRef { uint32_t level, slot; };        // level == NONE32 -> pool slot
-
-// word -> node table of the post-pass (insert-if-absent + lookup): open addressing, power-of-two capacity, load <= 1/2
-struct LeafMap {
-    std::vector<uint32_t> keys; std::vector<LeafRef> vals; size_t count = 0, mask = 0;
-    LeafMap() { rehash(1u << 16); }
-    static size_t mix(uint32_t k) { uint64_t x = (uint64_t)k * 0x9E3779B97F4A7C15ull; return (size_t)(x >> 20); }
-    void rehash(size_t cap) {
-        std::vector<uint32_t> ok; std::vector<LeafRef> ov; ok.swap(keys); ov.swap(vals);
-        keys.assign(cap, NONE32); vals.resize(cap); mask = cap - 1; count = 0;
-        for (size_t i = 0; i < ok.size(); i++) if (ok[i] != NONE32) emplace(ok[i], ov[i]);
-    }
-    void emplace(uint32_t k, LeafRef v) {
-        if (2 * (count + 1) > keys.size()) rehash(keys.size() * 2);
-        size_t i = mix(k) & mask;
-        while (keys[i] != NONE32) { if (keys[i] == k) return; i = (i + 1) & mask; }
-        keys[i] = k; vals[i] = v; count++;
-    }
-    void reserveFor(size_t more) { size_t cap = keys.size(); while (2 * (count + more + 1) > cap) cap *= 2; if (cap != keys.size()) rehash(cap); }
-    void prefetch(uint32_t k) const { const size_t i = mix(k) & mask; __builtin_prefetch(&keys[i]); __builtin_prefetch(&vals[i]); }
-    const LeafRef* find(uint32_t k) const {
-        size_t i = mix(k) & mask;
-        while (keys[i] != NONE32) { if (keys[i] == k) return &vals[i]; i = (i + 1) & mask; }
-        return nullptr;
-    }
-};
-
-// Host mirror of the node array.  The planner touches 8 words of every 2 KB it appends (a child block, then eight reserved 256-byte
-// leaf payloads), i.e. EVERY page of the appended range once: with 4 KB pages that was a page fault per two subdivisions, a third of
-// the planner's time.  The mirror is therefore one reservation of address space for the largest possible array (30-bit index = 4 GB,
-// MAP_NORESERVE: untouched pages cost nothing), 2 MB aligned with a huge-page hint, so growing is free and a fault brings in 2 MB.
-struct HostWords {
-    uint32_t* p = nullptr; size_t n = 0; void* base = nullptr; size_t mapped = 0; size_t heapCap = 0;
-    HostWords() = default;
-    HostWords(const HostWords&) = delete;
-    HostWords& operator=(const HostWords&) = delete;
-    ~HostWords() { if (base) munmap(base, mapped); else std::free(p); }
-    size_t size() const { return n; }
-    uint32_t* data() { return p; }
-    uint32_t& operator[](size_t i) { return p[i]; }
-    const uint32_t& operator[](size_t i) const { return p[i]; }
-    bool grow(size_t newSize) {                   // contents of the new part are unspecified
-        if (newSize > (size_t)INDEX_MASK + 1u) return false;
-        if (!p) {
-            const size_t want = ((size_t)INDEX_MASK + 1u) * sizeof(uint32_t) + (2u << 20);
-            void* q = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
-            if (q != MAP_FAILED) {
-                base = q; mapped = want;
-                p = (uint32_t*)(((uintptr_t)q + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1));
-                if (!getenv("SDFHIP_NO_THP")) madvise(p, (size_t)(INDEX_MASK + 1ull) * sizeof(uint32_t), MADV_HUGEPAGE);
-            }
-        }
-        if (!base && newSize > heapCap) {          // the reservation was refused (strict overcommit): an ordinary growing block
-            size_t c = heapCap ? heapCap : (size_t)1 << 22;
-            while (c < newSize) c *= 2;
-            uint32_t* q = (uint32_t*)std::realloc(p, c * sizeof(uint32_t));
-            if (!q) return false;
-            p = q; heapCap = c;
-        }
-        n = newSize;
-        return true;
-    }
-};
-
-struct Planner {
-    HostWords hoc;                                // host mirror of the node words (payload regions are don't-care)
-    std::vector<uint32_t> newBlocks;              // child blocks (8 words) appended by the current post-pass
-    LeafMap leaves;                               // octree word -> node (first registration wins, like std::map::insert)
-    std::vector<PNode> pool;                      // nodes created by the post-pass
-    std::vector<std::pair<uint32_t, uint32_t>> patches;   // (index, value) for words that existed before this post-pass
-    std::vector<uint32_t> marked;
-    uint32_t startDepth = 0; int G = 1; MaskTable NM;
-    bool isLeaf(uint32_t at) const { return (hoc[at] & LEAF_BIT) != 0; }
-    bool isMarked(uint32_t at) const { return (hoc[at] & MARK_BIT) != 0; }
-    uint32_t childrenIndex(uint32_t at) const { return hoc[at] & INDEX_MASK; }
-    void setWord(uint32_t at, uint32_t v, uint32_t sizeBefore) { hoc[at] = v; if (at < sizeBefore) patches.push_back(std::make_pair(at, v)); }
-};
-
 static uint32_t outwardSign(uint32_t n, uint32_t c) {
     return ((((n & c) >> 2) & 1u) << ((n & 1u) | ((n & 2u) >> 1))) + ((((n & c) >> 1) & 1u) << (n & 1u)) + (n & c & 1u);
 }
@@ -852,9 +758,9 @@ static uint32_t outwardSign(uint32_t n, uint32_t c) {
 static int scanExclusive(hipStream_t st, DevBuf<unsigned char>& tmp, size_t& tmpBytes, const uint32_t* in, uint32_t* out, uint32_t n) {
     if (n == 0) return SDFHIP_OK;
     size_t need = 0;
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, st));
+    SDF_HIP_CHECK(devExclusiveSum(nullptr, need, in, out, (size_t)n, st));
     if (need > tmpBytes) { SDF_TRY(tmp.reserve(need)); tmpBytes = need; }
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, in, out, (int)n, st));
+    SDF_HIP_CHECK(devExclusiveSum(tmp.p, need, in, out, (size_t)n, st));
     return SDFHIP_OK;
 }
 static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
@@ -894,10 +800,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<uint32_t> stats; SDF_TRY(stats.reserve(2));
     { const uint32_t init[2] = {0u, 0xFFFFFFFFu}; SDF_HIP_CHECK(hipMemcpyAsync(stats.p, init, 8, hipMemcpyHostToDevice, st)); }
 
-    // The post-pass's integer part runs on the device (kpp_*); SDFHIP_CONT_POSTPASS=host keeps the serial planner of rounds 1-3,
-    // which replays the reference's loop on a host mirror of the node words.
-    const bool devicePP = !(getenv("SDFHIP_CONT_POSTPASS") && !strcmp(getenv("SDFHIP_CONT_POSTPASS"), "host"));
-    // the node array grows on the device (host planner: with a host mirror of its node words)
+    // the node array grows on the device; the post-pass's integer part runs there too (kpp_*)
     DevBuf<uint32_t> oc; size_t ocCap = 0; uint32_t ocSize = G3;
     DevBuf<uint32_t> recOf, firstOcc; size_t recCap = 0;      // per coefficient block: its owner / the first candidate naming it (device post-pass)
     auto ensureOc = [&](size_t need) -> int {
@@ -906,7 +809,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         while (cap < need) cap *= 2;
         DevBuf<uint32_t> bigger; SDF_TRY(bigger.reserve(cap));
         if (oc.p) SDF_HIP_CHECK(hipMemcpyAsync(bigger.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
-        if (devicePP) {
+        {
             const size_t rc = (cap - G3) / 8 + 1;
             DevBuf<uint32_t> r2, f2; SDF_TRY(r2.reserve(rc)); SDF_TRY(f2.reserve(rc));
             if (recCap) SDF_HIP_CHECK(hipMemcpyAsync(r2.p, recOf.p, 4ull * recCap, hipMemcpyDeviceToDevice, st));
@@ -920,11 +823,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     };
     SDF_TRY(ensureOc(G3));
     SDF_HIP_CHECK(hipMemsetAsync(oc.p, 0, 4ull * G3, st));
-    Planner pl; pl.startDepth = startDepth; pl.G = G; pl.NM = makeMaskTable();
-    if (!devicePP) {
-        SDF_REQUIRE(pl.hoc.grow(G3), "out of host memory");
-        for (uint32_t i = 0; i < G3; i++) pl.hoc[i] = 0u;
-    }
+    const MaskTable NM = makeMaskTable();
     // pool of post-pass nodes on the device
     DevBuf<float> pCenter, pHalf, pVv; DevBuf<PoolRec> pRec; size_t poolCap = 0; uint32_t poolCount = 0;
     auto ensurePool = [&](size_t need) -> int {
@@ -932,12 +831,12 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         size_t cap = poolCap ? poolCap : 4096;
         while (cap < need) cap *= 2;
         DevBuf<float> c2, h2, v2; DevBuf<PoolRec> r2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
-        if (devicePP) SDF_TRY(r2.reserve(cap));
+        SDF_TRY(r2.reserve(cap));
         if (poolCap) {
             SDF_HIP_CHECK(hipMemcpyAsync(c2.p, pCenter.p, 12 * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(h2.p, pHalf.p, 4 * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipMemcpyAsync(v2.p, pVv.p, 256 * poolCap, hipMemcpyDeviceToDevice, st));
-            if (devicePP) SDF_HIP_CHECK(hipMemcpyAsync(r2.p, pRec.p, sizeof(PoolRec) * poolCap, hipMemcpyDeviceToDevice, st));
+            SDF_HIP_CHECK(hipMemcpyAsync(r2.p, pRec.p, sizeof(PoolRec) * poolCap, hipMemcpyDeviceToDevice, st));
             SDF_HIP_CHECK(hipStreamSynchronize(st));
         }
         pCenter = std::move(c2); pHalf = std::move(h2); pVv = std::move(v2); pRec = std::move(r2); poolCap = cap;
@@ -988,7 +887,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SS.near = &ctx->nearScratch; ctx->nearScratch.counterReady = false;      // (builds on one context are serialised by its buildLock)
     if (ctx->exchange.world >= 1 && ctx->exchange.acquire) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
     DevBuf<float> ppPos; DevBuf<uint32_t> ppSlot, ppTri, ppCount;      // post-pass samples through the two-phase search
-    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> dpi, dpv, cflag, cscan, clist, wordVals; std::vector<uint32_t> hWordVals;      // post-pass device buffers, grow-only
+    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> cflag, cscan, clist;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
         // write the same centres / coordinates again together with everything else — and take the root corners and all their
         // mid-point samples in ONE deduplicated batch instead of one latency-bound launch per level.
@@ -1008,7 +907,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         SDF_TRY(sampleBatch(st, md, B, SS, stackBytes, T->info.num_traversals));
     }
-    double tIter = 0, tMirror = 0, tLeafMap = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
+    double tIter = 0, tPlan = 0, tOps = 0; double tMark = nowSeconds();
     auto lap = [&](double& acc) { const double now = nowSeconds(); acc += now - tMark; tMark = now; };
     for (uint32_t cd = sod; cd <= maxDepth; cd++) {
         SDF_TRY(sampleBatchEnd(st, md, SS));       // the samples begun during the previous level's planning
@@ -1024,14 +923,14 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         kc_fit_rule<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, P->rule, sqThr, param1, oc.p);
         // ---------------- Iter 2
-        kc_iter2_masks<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, pl.NM, oc.p);
+        kc_iter2_masks<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, NM, oc.p);
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->allocSize.p, L->allocOff.p, n));
         uint32_t allocTotal = 0; SDF_TRY(lastPlus(st, L->allocOff.p, L->allocSize.p, n, allocTotal));
         SDF_REQUIRE((uint64_t)ocSize + allocTotal < (uint64_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
         const uint32_t base = ocSize;
         SDF_TRY(ensureOc((size_t)ocSize + allocTotal));
         kc_iter2_write<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, cd, startDepth, base, oc.p, stats.p);
-        if (devicePP && cd >= startDepth) kc_register_leaves<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, base, G3, recOf.p);
+        if (cd >= startDepth) kc_register_leaves<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, base, G3, recOf.p);
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->inner.p, L->childSlot.p, n));
         uint32_t numInner = 0; SDF_TRY(lastPlus(st, L->childSlot.p, L->inner.p, n, numInner));
         kc_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childSlot.p);
@@ -1050,42 +949,15 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         kc_flag_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, 24 * n, cflag.p);
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, cflag.p, cscan.p, 24 * n));
         SDF_TRY(lastPlus(st, cscan.p, cflag.p, 24 * n, numCand));
-        std::vector<uint32_t> toSubdivide(numCand);
         if (numCand) {
             SDF_TRY(clist.reserve(numCand));
             kc_compact_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, cflag.p, cscan.p, 24 * n, clist.p);
-            if (!devicePP) SDF_HIP_CHECK(hipMemcpyAsync(toSubdivide.data(), clist.p, 4ull * numCand, hipMemcpyDeviceToHost, st));
         }
         SDF_HIP_CHECK(hipGetLastError());
         ocSize += allocTotal;
         static const bool timingSync = getenv("SDFHIP_TIMING") != nullptr;
-        if (!devicePP || timingSync) SDF_HIP_CHECK(hipStreamSynchronize(st));          // (the host planner reads the candidate list; otherwise only the phase times want it)
+        if (timingSync) SDF_HIP_CHECK(hipStreamSynchronize(st));          // (only the phase times want it)
         lap(tIter);
-        if (!devicePP) {
-        // ---------------- mirrors for the planner: integer node state of this level + the words written so far
-        L->hCoord.resize(n); L->hPci.resize(n); L->hNIdx.resize(6ull * n); L->hWord.resize(n); L->hPath.resize(n); L->hNDepth.resize(6ull * n); L->hTerminal.resize(n);
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hCoord.data(), L->coord.p, 4ull * n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hPci.data(), L->pci.p, 4ull * n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hNIdx.data(), L->nIdx.p, 24ull * n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hWord.data(), L->word.p, 4ull * n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hPath.data(), L->path.p, n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hNDepth.data(), L->nDepth.p, 6ull * n, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(L->hTerminal.data(), L->terminal.p, n, hipMemcpyDeviceToHost, st));
-        SDF_REQUIRE(pl.hoc.grow(ocSize), "out of host memory");
-        // The planner reads node WORDS only (leaf / mark bits, child indices) and only of nodes down to this level; the words of
-        // this level's nodes — written by kc_iter2_write into blocks appended by the previous level, or into the grid — are all
-        // that has changed on the device since the last mirror (the post-pass's own words are the host's: it uploads them as
-        // patches).  Gather them instead of copying the array region, 98 % of which is coefficient payload.
-        if (cd >= startDepth) {
-            SDF_TRY(wordVals.reserve(n));
-            kc_gather_words<<<gridFor(n, 256), 256, 0, st>>>(L->word.p, n, oc.p, wordVals.p);
-            hWordVals.resize(n);
-            SDF_HIP_CHECK(hipMemcpyAsync(hWordVals.data(), wordVals.p, 4ull * n, hipMemcpyDeviceToHost, st));
-        }
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
-        if (cd >= startDepth) for (uint32_t i = 0; i < n; i++) if (L->hWord[i] != NONE32) pl.hoc[L->hWord[i]] = hWordVals[i];
-        lap(tMirror);
-        }
         // The exact samples of the NEXT level depend only on its node centres, not on the post-pass below: enqueue them now so
         // that the GPU traverses the BVH while the host plans (the post-pass device ops queue up behind them on the stream).
         if (cd + 1 < maxDepth && LV[cd + 1] && LV[cd + 1]->n > 0 && !LV[cd + 1]->sampled) {
@@ -1095,20 +967,11 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_TRY(sampleBatchBegin(st, md, B, SS, stackBytes, T->info.num_traversals));      // ended at the top of the next iteration
             N->sampled = true;
         }
-        if (!devicePP) {
-        pl.leaves.reserveFor(n);                     // sized once for the level; the slots of the entries sixteen ahead are prefetched
-        for (uint32_t i = 0; i < n; i++) {
-            if (i + 16 < n) pl.leaves.prefetch(L->hWord[i + 16]);
-            const bool leaf = (cd >= maxDepth) || L->hTerminal[i];
-            if (leaf) pl.leaves.emplace(L->hWord[i], LeafRef{cd, i});
-        }
-        lap(tLeafMap);
-        }
         numRescheduled += numCand;
         if (numCand == 0) continue;
 
         std::vector<size_t> gBegin; uint32_t na = 0;      // the pass's op list on the device (dops): generation g = [gBegin[g], gBegin[g + 1])
-        if (devicePP) {
+        {
             // ---------------- post-pass, integer part on the device: roots -> generations (decide, expand) -> allocation scan -> words + ops
             SDF_TRY(ppFlag.reserve(numCand)); SDF_TRY(ppScan.reserve(numCand));
             kpp_first<<<gridFor(numCand, 256), 256, 0, st>>>(clist.p, numCand, oc.p, G3, firstOcc.p);
@@ -1126,7 +989,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             for (uint32_t g = 0;; g++) {
                 SDF_REQUIRE(g < PP_MAXGEN, "internal: post-pass search deeper than the octree");
                 SDF_TRY(ppSplitFlag.reserve(count)); SDF_TRY(ppSplitScan.reserve(count));
-                kpp_decide<<<gridFor(count, 128), 128, 0, st>>>(ppNodesBuf.p, (uint32_t)gBegin[g], count, cd, startDepth, G, pl.NM, oc.p, ppSplitFlag.p);
+                kpp_decide<<<gridFor(count, 128), 128, 0, st>>>(ppNodesBuf.p, (uint32_t)gBegin[g], count, cd, startDepth, G, NM, oc.p, ppSplitFlag.p);
                 SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, ppSplitFlag.p, ppSplitScan.p, count));
                 uint32_t ns = 0; SDF_TRY(lastPlus(st, ppSplitScan.p, ppSplitFlag.p, count, ns));
                 gBegin.push_back(N);
@@ -1158,191 +1021,6 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             SDF_HIP_CHECK(hipGetLastError());
             ocSize += passAlloc; poolCount += 8u * passSplits; na = N;
             lap(tPlan);
-        } else {
-        // ---------------- post-pass, integer part on the host
-        const uint32_t sizeBefore = ocSize;
-        pl.patches.clear();
-        std::vector<std::vector<OpDev>> gens;
-        auto addOp = [&](uint32_t gen, const OpDev& op) { if (gens.size() <= gen) gens.resize(gen + 1); gens[gen].push_back(op); };
-        std::vector<PNode> cache; std::vector<uint32_t> genOf;      // work list of one scheduled leaf, reused
-        cache.reserve(4096); genOf.reserve(4096);
-        if (pl.pool.capacity() < pl.pool.size() + 5ull * numCand) pl.pool.reserve(2 * (pl.pool.size() + 5ull * numCand));      // (growth by doubling would copy the pool several times per level)
-        pl.leaves.reserveFor(5ull * numCand);                 // one rehash up front instead of several in the middle of the pass
-        for (uint32_t si = 0; si < numCand; si++) {
-            // the planner is bound by host cache misses (random reads of the leaf table, the level mirrors and the word mirror):
-            // run two prefetch stages ahead of the candidate being processed
-            if (si + 16 < numCand) pl.leaves.prefetch(toSubdivide[si + 16]);
-            if (si + 8 < numCand) {
-                const LeafRef* nx = pl.leaves.find(toSubdivide[si + 8]);
-                if (nx && nx->level != NONE32) {
-                    const CLevelHost* S = LV[nx->level].get(); const uint32_t q = nx->slot;
-                    __builtin_prefetch(&S->hPath[q]); __builtin_prefetch(&S->hPci[q]); __builtin_prefetch(&S->hCoord[q]);
-                    __builtin_prefetch(&S->hNIdx[6ull * q]); __builtin_prefetch(&S->hNIdx[6ull * q + 5]); __builtin_prefetch(&S->hNDepth[6ull * q]);
-                } else if (nx) __builtin_prefetch(&pl.pool[nx->slot]);
-            }
-            if (si + 4 < numCand) {       // third stage: the neighbour words of the candidate four ahead (its mirrors are cached by now)
-                const LeafRef* nx = pl.leaves.find(toSubdivide[si + 4]);
-                if (nx && nx->level != NONE32) {
-                    const CLevelHost* S = LV[nx->level].get(); const uint32_t q = nx->slot;
-                    for (int k = 0; k < 6; k++) { const uint32_t ix = S->hNIdx[6ull * q + k] & INDEX_MASK; if (ix < pl.hoc.size()) __builtin_prefetch(&pl.hoc[ix]); }
-                    if (S->hPci[q] != NONE32 && (size_t)S->hPci[q] + 8 <= pl.hoc.size()) __builtin_prefetch(&pl.hoc[S->hPci[q]]);
-                }
-            }
-            const LeafRef* it = pl.leaves.find(toSubdivide[si]);
-            if (!it) continue;
-            const LeafRef found = *it;             // the table may grow below
-            // materialise the integer state of the scheduled leaf
-            PNode root;
-            if (found.level != NONE32) {
-                CLevelHost* S = LV[found.level].get(); const uint32_t s = found.slot;
-                root.path = S->hPath[s]; root.pci = S->hPci[s]; root.coord = S->hCoord[s]; root.depth = found.level; root.ignore = false;
-                for (int k = 0; k < 6; k++) { root.nIdx[k] = S->hNIdx[6ull * s + k]; root.nDepth[k] = S->hNDepth[6ull * s + k]; }
-                root.srcLevel = found.level; root.srcSlot = s;
-            } else { root = pl.pool[found.slot]; }
-            uint32_t pword;
-            if (root.depth > startDepth) pword = root.pci + (root.path & 7u);
-            else pword = (root.coord >> 20) * G * G + ((root.coord >> 10) & 1023u) * G + (root.coord & 1023u);
-            if (!pl.isLeaf(pword)) continue;
-            ppRoots++;
-            bool recycled = false; const uint32_t oldCoeffIndex = pl.childrenIndex(pword);
-            bool first = true;
-            cache.clear(); genOf.clear();
-            cache.push_back(root); genOf.push_back(0);
-            size_t ci = 0;
-            while (ci < cache.size()) {
-                PNode node = cache[ci]; const uint32_t gen = genOf[ci]; ci++; ppNodes++;
-                const uint32_t depthN = node.depth, c = node.path & 7u;
-                const int gx = (int)(node.coord & 1023u), gy = (int)((node.coord >> 10) & 1023u), gz = (int)(node.coord >> 20);
-                uint32_t word = NONE32;
-                if (depthN > startDepth) word = node.pci + c; else if (depthN == startDepth) word = (uint32_t)(gz * G * G + gy * G + gx);
-                uint32_t samplesMask = 0, subdividedMask = 0;
-                if (depthN > startDepth) {
-                    for (uint32_t nb = 1; nb <= 6; nb++) {
-                        const uint32_t sign = outwardSign(nb, c);
-                        uint32_t& ix = node.nIdx[nb - 1];
-                        if (((ix >> 30) & 1u) != 0) continue;
-                        if ((!first || (ix >> 31)) && pl.isLeaf(ix & ~B31)) { ix = B31 | ix; samplesMask |= pl.NM.m[4 * (nb - 1) + sign]; }
-                        else {
-                            if (!first || (ix >> 31)) { ix = pl.childrenIndex(ix & ~B31); node.nDepth[nb - 1]++; }
-                            while (node.nDepth[nb - 1] < depthN && node.nDepth[nb - 1] < cd) {
-                                const uint32_t dd = depthN - node.nDepth[nb - 1];
-                                const uint32_t cid = (3 * dd < 32) ? ((node.path >> (3 * dd)) & 7u) : 0u;
-                                ix += (nb ^ cid);
-                                if (pl.isLeaf(ix & ~B31)) { ix = B31 | ix; samplesMask |= pl.NM.m[4 * (nb - 1) + sign]; break; }
-                                ix = pl.childrenIndex(ix & ~B31); node.nDepth[nb - 1]++;
-                            }
-                            if (cd >= depthN && !(ix >> 31)) {
-                                const uint32_t next = (ix & ~B31) + (nb ^ c);
-                                subdividedMask |= (pl.isLeaf(next) || pl.isMarked(next)) ? 0u : pl.NM.m[4 * (nb - 1) + sign];
-                            }
-                        }
-                    }
-                }
-                if (cd >= depthN) {
-                    if (depthN > startDepth) {
-                        const uint32_t nc = ~c, pci = node.pci; const uint32_t* N = node.nIdx;
-                        auto upd = [&](uint32_t nid, uint32_t dir, uint32_t sign) {
-                            const bool leafish = (nid >> 31) || (nid >> 30) || pl.isLeaf(nid + (dir ^ c)) || pl.isMarked(nid + (dir ^ c));
-                            subdividedMask |= leafish ? 0u : pl.NM.m[4 * (dir - 1) + sign];
-                        };
-                        upd(pci, 1u, nc & 1u); upd(pci, 2u, (nc >> 1) & 1u); upd(pci, 4u, (nc >> 2) & 1u);
-                        upd(pci, 3u, nc & 3u); upd(pci, 5u, ((nc >> 1) & 2u) + (nc & 1u)); upd(pci, 6u, (nc >> 1) & 3u);
-                        upd(N[0], 3u, 2u ^ (c & 3u)); upd(N[0], 5u, ((nc >> 1) & 2u) + (c & 1u));
-                        upd(N[1], 3u, 1u ^ (c & 3u)); upd(N[1], 6u, 2u ^ ((c >> 1) & 3u));
-                        upd(N[3], 5u, ((c >> 1) & 2u) + (nc & 1u)); upd(N[3], 6u, 1u ^ ((c >> 1) & 3u));
-                    } else if (depthN == startDepth) {
-                        forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) {
-                            const int x = gx + dx, y = gy + dy, z = gz + dz;
-                            if (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) {
-                                const uint32_t at = (uint32_t)(z * G * G + y * G + x);
-                                subdividedMask |= (pl.isLeaf(at) || pl.isMarked(at)) ? 0u : pl.NM.m[4 * (dir - 1) + sign];
-                            }
-                        });
-                    }
-                    samplesMask = ~subdividedMask;
-                }
-                OpDev op{}; op.srcLevel = node.srcLevel; op.srcSlot = node.srcSlot;
-                if (cd >= depthN && samplesMask != 0xFFFFFFFFu) {
-                    ppSplits++;
-                    op.kind = 0; op.samplesMask = samplesMask; op.recycle = (first && !node.ignore) ? 1u : 0u;
-                    const uint32_t childIndex = (uint32_t)pl.hoc.size();
-                    pl.setWord(word, (childIndex & INDEX_MASK) | MARK_BIT, sizeBefore);
-                    pl.marked.push_back(word);
-                    SDF_REQUIRE(pl.hoc.grow(pl.hoc.size() + 8), "out of host memory");
-                    for (uint32_t q8 = 0; q8 < 8; q8++) pl.hoc[childIndex + q8] = LEAF_BIT;
-                    pl.newBlocks.push_back(childIndex);
-                    op.childPool = (uint32_t)pl.pool.size();
-                    for (uint32_t ch = 0; ch < 8; ch++) {
-                        PNode k{};
-                        k.path = (uint8_t)((node.path << 3) | ch); k.pci = childIndex; k.depth = depthN + 1; k.ignore = false;
-                        k.coord = (2u * (uint32_t)gx + (ch & 1u)) | ((2u * (uint32_t)gy + ((ch >> 1) & 1u)) << 10) | ((2u * (uint32_t)gz + (ch >> 2)) << 20);
-                        if (depthN == startDepth) { neighboursInGrid(ch, gx, gy, gz, G, k.nIdx); for (int q = 0; q < 6; q++) k.nDepth[q] = (uint8_t)depthN; }
-                        else neighboursVector(ch, c, node.pci, depthN, node.nIdx, node.nDepth, k.nIdx, k.nDepth);
-                        k.srcLevel = NONE32; k.srcSlot = (uint32_t)pl.pool.size();
-                        pl.pool.push_back(k);
-                        cache.push_back(k); genOf.push_back(gen + 1);
-                        pl.leaves.prefetch(childIndex + ch);          // where the child registers itself when it is finalised (a table of tens of MB: a miss otherwise)
-                        for (int q = 0; q < 6; q++) { const uint32_t ix = k.nIdx[q] & INDEX_MASK; if (ix < pl.hoc.size()) __builtin_prefetch(&pl.hoc[ix]); }
-                    }
-                    addOp(gen, op);
-                } else {
-                    op.kind = 1;
-                    uint32_t at = (uint32_t)pl.hoc.size();
-                    if (recycled) { pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); SDF_REQUIRE(pl.hoc.grow(pl.hoc.size() + 64), "out of host memory"); }
-                    else { at = oldCoeffIndex; pl.setWord(word, (at & INDEX_MASK) | LEAF_BIT, sizeBefore); recycled = true; }
-                    op.coeffIndex = at;
-                    addOp(gen, op);
-                    // the finalised node stays reachable for later post-passes (first registration of a key wins)
-                    node.ignore = true;
-                    if (node.srcLevel == NONE32) pl.pool[node.srcSlot] = node;      // its refreshed neighbour words travel with it
-                    const uint32_t key = node.pci + c;
-                    if (node.srcLevel == NONE32) pl.leaves.emplace(key, LeafRef{NONE32, node.srcSlot});
-                    else {
-                        // a level leaf re-finalised in place: the reference pushes an `ignore` copy that is only reachable if its
-                        // key was free; that happens at the start depth, where the key wraps to pci + childId
-                        if (!pl.leaves.find(key)) {
-                            PNode copy = node; copy.srcLevel = node.srcLevel; copy.srcSlot = node.srcSlot;
-                            pl.pool.push_back(copy);
-                            pl.leaves.emplace(key, LeafRef{NONE32, (uint32_t)pl.pool.size() - 1});
-                        }
-                    }
-                }
-                first = false;
-            }
-        }
-        lap(tPlan);
-        SDF_REQUIRE(pl.hoc.size() < (size_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
-        // ---------------- upload the integer result, then run the float part generation by generation
-        SDF_TRY(ensureOc(pl.hoc.size()));
-        // only the appended child blocks carry information (their final words go up as patches); the appended 64-word leaf blocks
-        // are written by the device ops below
-        for (uint32_t b : pl.newBlocks) for (uint32_t q8 = 0; q8 < 8; q8++) pl.patches.push_back(std::make_pair(b + q8, pl.hoc[b + q8]));
-        pl.newBlocks.clear();
-        ocSize = (uint32_t)pl.hoc.size();
-        if (!pl.patches.empty()) {
-            // one patch per word, carrying its FINAL value (a word can be rewritten within a post-pass; the patch kernel is parallel)
-            std::vector<uint32_t> pi(pl.patches.size());
-            for (size_t k = 0; k < pl.patches.size(); k++) pi[k] = pl.patches[k].first;
-            std::sort(pi.begin(), pi.end()); pi.erase(std::unique(pi.begin(), pi.end()), pi.end());
-            std::vector<uint32_t> pv(pi.size());
-            for (size_t k = 0; k < pi.size(); k++) pv[k] = pl.hoc[pi[k]];
-            SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
-            SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
-            SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
-            kc_patch<<<gridFor(pi.size(), 256), 256, 0, st>>>(dpi.p, dpv.p, (uint32_t)pi.size(), oc.p);
-            SDF_HIP_CHECK(hipStreamSynchronize(st));
-        }
-        SDF_TRY(ensurePool(pl.pool.size()));
-            // all generations' ops in one array (scratch slot = global index)
-            std::vector<OpDev> all;
-            for (size_t g = 0; g < gens.size(); g++) { gBegin.push_back(all.size()); for (const OpDev& op : gens[g]) { all.push_back(op); all.back().scratch = (uint32_t)(all.size() - 1); } }
-            gBegin.push_back(all.size());
-            na = (uint32_t)all.size();
-            if (na) {
-                SDF_TRY(dops.reserve(all.size())); SDF_TRY(scratch.reserve(216 * all.size()));
-                SDF_HIP_CHECK(hipMemcpyAsync(dops.p, all.data(), sizeof(OpDev) * all.size(), hipMemcpyHostToDevice, st));
-                SDF_HIP_CHECK(hipStreamSynchronize(st));      // `all` goes out of scope
-            }
         }
         LevelTable LT{};
         for (uint32_t d = 0; d <= maxDepth && d < 12; d++) if (LV[d]) LT.lv[d] = LevelPtrs{LV[d]->center.p, LV[d]->vv.p, LV[d]->coeff.p, LV[d]->mid.p, LV[d]->half};
@@ -1378,24 +1056,13 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
                     T->info.num_samples += 19ull * no;
                 }
                 SDF_HIP_CHECK(hipGetLastError());
-                if (!devicePP) SDF_HIP_CHECK(hipStreamSynchronize(st));
             }
         }
         lap(tOps);
     }
     SDF_TRY(sampleBatchEnd(st, md, SS));
-    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, mirrors %.3f s, leaf map %.3f s, post-pass planner %.3f s, post-pass device ops %.3f s; post-pass: %llu scheduled, %llu still leaves, %llu nodes visited, %llu splits\n", tIter, tMirror, tLeafMap, tPlan, tOps,
+    if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, post-pass planning (device) %.3f s, post-pass ops %.3f s (host clock; phases overlap unless timing is on); post-pass: %llu scheduled, %llu still leaves, %llu nodes visited, %llu splits\n", tIter, tPlan, tOps,
                                             (unsigned long long)numRescheduled, (unsigned long long)ppRoots, (unsigned long long)ppNodes, (unsigned long long)ppSplits);
-    // clear the mark bits (OctreeSdfBreadthFirstNoDelay.h:1191-1217)
-    if (!pl.marked.empty()) {
-        std::vector<uint32_t> pi(pl.marked), pv(pl.marked.size());
-        for (size_t k = 0; k < pi.size(); k++) { pl.hoc[pi[k]] &= ~MARK_BIT; pv[k] = pl.hoc[pi[k]]; }
-        DevBuf<uint32_t> dpi, dpv; SDF_TRY(dpi.reserve(pi.size())); SDF_TRY(dpv.reserve(pv.size()));
-        SDF_HIP_CHECK(hipMemcpyAsync(dpi.p, pi.data(), 4 * pi.size(), hipMemcpyHostToDevice, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(dpv.p, pv.data(), 4 * pv.size(), hipMemcpyHostToDevice, st));
-        kc_patch<<<gridFor(pi.size(), 256), 256, 0, st>>>(dpi.p, dpv.p, (uint32_t)pi.size(), oc.p);
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
-    }
     // final statistics on the device
     DevBuf<unsigned long long> lpd; SDF_TRY(lpd.reserve(16));
     SDF_HIP_CHECK(hipMemsetAsync(lpd.p, 0, 128, st));

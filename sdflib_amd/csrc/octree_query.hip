@@ -13,7 +13,7 @@
 #include "dev_tricubic.h"
 #include <string.h>
 #include <cmath>
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 
 namespace sdfhip {
 
@@ -106,17 +106,7 @@ SDF_HD float queryOne(const QueryTree& t, F3 p, float* grad) {
     return evalLeaf<EVAL, GRAD>(c, f, grad);
 }
 
-template <int EVAL, bool GRAD>
-__global__ void __launch_bounds__(256) k_octree_query(QueryTree t, const float* __restrict__ pts, uint64_t n, float* __restrict__ dist, float* __restrict__ grad) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float g[3] = {0.f, 0.f, 0.f};
-    const float d = queryOne<EVAL, GRAD>(t, F3{pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]}, g);
-    dist[i] = d;
-    if (GRAD) { grad[3 * i] = g[0]; grad[3 * i + 1] = g[1]; grad[3 * i + 2] = g[2]; }
-}
-
-// The same query with the coefficient blocks fetched cooperatively (the default): a lane-private 256-byte block costs sixteen load
+// The batched query.  The coefficient blocks are fetched cooperatively: a lane-private 256-byte block (round 1) costs sixteen load
 // instructions that each touch 64 different cache lines (one per lane), and the texture path handles a line per cycle; here sixteen
 // lanes read one lane's block as ONE contiguous segment, so an instruction touches 8 lines, and the rows go through LDS to their
 // owners, sixteen queries at a time (4.3 KB of LDS per wave).  Measured, 10 M queries: C2 0.446 -> 0.331 ms, the HBM-resident
@@ -595,11 +585,11 @@ static int ensureLatticePlan(sdfhip_octree* T, const float origin[3], const floa
         k_lat_groups<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, count.p);
         k_lat_group_waves<<<gridFor(groups, 256), 256, 0, st>>>(count.p, (uint32_t)groups, C, wavesOf.p);
         size_t need = 0;
-        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, wavesOf.p, P.groupWaveBase.p, (int)groups, st));
+        SDF_HIP_CHECK(devExclusiveSum(nullptr, need, wavesOf.p, P.groupWaveBase.p, (size_t)groups, st));
         DevBuf<uint8_t> tmp;
         SDF_TRY(tmp.reserve(need + 16));
-        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, wavesOf.p, P.groupWaveBase.p, (int)groups, st));
-        SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(tmp.p, need, count.p, P.groupLeafBase.p, (int)groups, st));
+        SDF_HIP_CHECK(devExclusiveSum(tmp.p, need, wavesOf.p, P.groupWaveBase.p, (size_t)groups, st));
+        SDF_HIP_CHECK(devExclusiveSum(tmp.p, need, count.p, P.groupLeafBase.p, (size_t)groups, st));
         uint32_t lastBase = 0, lastWaves = 0;
         SDF_HIP_CHECK(hipMemcpyAsync(&lastBase, P.groupWaveBase.p + groups - 1, 4, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(&lastWaves, wavesOf.p + groups - 1, 4, hipMemcpyDeviceToHost, st));
@@ -610,10 +600,10 @@ static int ensureLatticePlan(sdfhip_octree* T, const float origin[3], const floa
             SDF_TRY(P.waveDesc.reserve(4ull * P.waves));
             k_lat_keys<<<gridFor(T->qLeaves, 256), 256, 0, st>>>(T->qLeafCell.p, (uint32_t)T->qLeaves, L, C, P.ranges.p, key.p, val.p);
             size_t sortNeed = 0;
-            SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (int)T->qLeaves, 0, 64, st));
+            SDF_HIP_CHECK(devSortPairs(nullptr, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (size_t)T->qLeaves, 0, (unsigned)64, st));
             DevBuf<uint8_t> sortTmp;
             SDF_TRY(sortTmp.reserve(sortNeed + 16));
-            SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(sortTmp.p, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (int)T->qLeaves, 0, 64, st));
+            SDF_HIP_CHECK(devSortPairs(sortTmp.p, sortNeed, key.p, keyS.p, val.p, P.sortedLeaf.p, (size_t)T->qLeaves, 0, (unsigned)64, st));
             k_lat_waves<<<gridFor(P.waves, 256), 256, 0, st>>>(P.groupWaveBase.p, P.groupLeafBase.p, count.p, (uint32_t)groups, (uint32_t)levels, P.waves,
                                                             reinterpret_cast<uint4*>(P.waveDesc.p));
             SDF_HIP_CHECK(hipGetLastError());
@@ -635,23 +625,12 @@ static QueryTree makeQueryTree(const sdfhip_octree* T) {
 
 template <typename... A>
 static void launchQuery(int eval_mode, bool grad, unsigned blocks, hipStream_t st, A... a) {
-    static const bool laneLoads = getenv("SDFHIP_QUERY_LANE_LOADS") != nullptr;        // A/B switch: every lane fetches its own block (k_octree_query)
-    if (!laneLoads) {
-        if (eval_mode == SDFHIP_EVAL_EXACT) {
-            if (grad) k_octree_query_coop<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(a...);
-            else k_octree_query_coop<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(a...);
-        } else {
-            if (grad) k_octree_query_coop<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(a...);
-            else k_octree_query_coop<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(a...);
-        }
-        return;
-    }
     if (eval_mode == SDFHIP_EVAL_EXACT) {
-        if (grad) k_octree_query<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(a...);
-        else k_octree_query<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(a...);
+        if (grad) k_octree_query_coop<SDFHIP_EVAL_EXACT, true><<<blocks, 256, 0, st>>>(a...);
+        else k_octree_query_coop<SDFHIP_EVAL_EXACT, false><<<blocks, 256, 0, st>>>(a...);
     } else {
-        if (grad) k_octree_query<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(a...);
-        else k_octree_query<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(a...);
+        if (grad) k_octree_query_coop<SDFHIP_EVAL_FAST, true><<<blocks, 256, 0, st>>>(a...);
+        else k_octree_query_coop<SDFHIP_EVAL_FAST, false><<<blocks, 256, 0, st>>>(a...);
     }
 }
 

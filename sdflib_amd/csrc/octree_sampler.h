@@ -3,7 +3,7 @@
 #pragma once
 #include "dev_bvh_fast.h"
 #include "dev_tricubic.h"
-#include <hipcub/hipcub.hpp>
+#include "dev_prims.h"
 
 namespace sdfhip {
 namespace {
@@ -151,13 +151,13 @@ static int sampleBatchBegin(hipStream_t st, const MeshDev& md, const SampleBatch
     SDF_TRY(S.isRep.reserve(total)); SDF_TRY(S.scan.reserve(total));
     k_sample_keys<<<gridFor(total, 256), 256, 0, st>>>(B, S.key.p, S.val.p);
     size_t b1 = 0, b2 = 0;
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 39, st));
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, S.isRep.p, S.scan.p, (int)total, st));
+    SDF_HIP_CHECK(devSortPairs(nullptr, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (size_t)total, 0, (unsigned)39, st));
+    SDF_HIP_CHECK(devExclusiveSum(nullptr, b2, S.isRep.p, S.scan.p, (size_t)total, st));
     const size_t need = b1 > b2 ? b1 : b2;
     if (need > S.tmpBytes) { SDF_TRY(S.tmp.reserve(need)); S.tmpBytes = need; }
-    SDF_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (int)total, 0, 39, st));
+    SDF_HIP_CHECK(devSortPairs(S.tmp.p, b1, S.key.p, S.keyS.p, S.val.p, S.valS.p, (size_t)total, 0, (unsigned)39, st));
     k_sample_mark<<<gridFor(total, 256), 256, 0, st>>>(B, S.keyS.p, S.valS.p, S.isRep.p);
-    SDF_HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(S.tmp.p, b2, S.isRep.p, S.scan.p, (int)total, st));
+    SDF_HIP_CHECK(devExclusiveSum(S.tmp.p, b2, S.isRep.p, S.scan.p, (size_t)total, st));
     uint32_t numReps = 0;
     SDF_TRY(readBackWords(st, S.scan.p + (total - 1), S.isRep.p + (total - 1), 1, &numReps));
     SDF_TRY(S.repSample.reserve(numReps)); SDF_TRY(S.repPos.reserve(3 * (size_t)numReps));

@@ -220,11 +220,11 @@ def test_exact_scalar_host_entry_equals_device_and_oracle(small, oracle):
         assert np.array_equal(bits(gs[ins]), bits(g0[k:k + m][ins])) and np.array_equal(ts[ins], t0[k:k + m][ins])
 
 
-@pytest.mark.parametrize("env", [{}, {"SDFHIP_EXACT_QUERY": "decode"}, {"SDFHIP_EXACT_LISTS_MB": "0"}], ids=["lists", "decode-forced", "lists-over-the-cap"])
+@pytest.mark.parametrize("env", [{}, {"SDFHIP_EXACT_LISTS_MB": "0"}], ids=["lists", "lists-over-the-cap"])
 def test_both_batched_query_kernels_answer_like_the_oracle(env):
     """Round 4: the batched query reads the leaves' DECODED triangle lists (made once per tree) through a pipelined kernel; trees whose lists
-    would exceed SDFHIP_EXACT_LISTS_MB keep round 3's decoding kernel.  Both paths (the switches are read once per process, hence the child
-    processes) against the oracle: distances, gradients and triangle ids, incl. points outside the grid, empty leaves and long runs."""
+    would exceed SDFHIP_EXACT_LISTS_MB (or half of the device's free memory, or whose allocation fails) keep round 3's decoding kernel.  Both
+    paths (the switch is read once per process, hence the child processes) against the oracle: distances, gradients and triangle ids, incl. points outside the grid, empty leaves and long runs."""
     import subprocess
     import sys
     from conftest import ROOT

@@ -40,6 +40,23 @@ def test_device_acosf_equals_libm(gpu_ctx):
         assert bad.value == 0, (hex(first), stride, count, bad.value)
 
 
+def test_host_acos_path_gives_the_same_triangle_data(gpu_ctx, oracle):
+    """The arc cosines of the corner angles on the host's libm (the path a process takes by itself when the self-check of the restated
+    glibc routine against the running libm fails) and on the device give the same TriangleData, bit for bit — and the oracle's."""
+    import sdflib_amd as S
+    from sdflib_amd._lib import lib
+    from sdflib_amd import meshgen
+    v, f = meshgen.bumpy_icosphere(3)
+    ref = oracle.Mesh(v, f).triangle_data()
+    try:
+        for mode in (1, 0, -1):
+            lib().sdfhip_test_set_host_acos(mode)
+            td = S.Mesh(v, f, gpu_ctx).triangle_data()
+            assert np.array_equal(bits(ref), bits(td)), mode
+    finally:
+        lib().sdfhip_test_set_host_acos(-1)
+
+
 def test_nearest_triangle_ids_bit_exact(small, oracle):
     rng = np.random.default_rng(7)
     pts = ((rng.random((20000, 3), dtype=np.float32) * 2 - 1) * 1.4).astype(np.float32)

@@ -2,7 +2,7 @@
 mid-point samples of octree levels from a built tree (Morton order, as the sampler feeds them), runs the two-phase search with
 per-query counters (sdfhip_mesh_nearest_stats) and prints, per level: expansions / triangle evaluations per query, their
 quantiles, the share of all expansions spent in each bucket of |distance| (in cells of that level), and the same with every
-query seeded with its own answer (SDFHIP_NEAR_PRESEED: the fewest visits ANY visiting order needs with this tree and these bounds).
+query seeded with its own answer (sdfhip_mesh_nearest_stats_preseeded: the fewest visits ANY visiting order needs with this tree and these bounds).
 Usage: python tools/gpu_near_hist.py [subdiv] [levels, e.g. 5,6,7,8]"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -42,11 +42,12 @@ def level_points(level):
     key, first = np.unique(key, return_index=True)
     lat = lat[first]
     return len(idx), np.ascontiguousarray((bb[:3] + lat.astype(np.float32) * np.float32(size / 2 ** (level + 1))).astype(np.float32))
-def run(pts):
+def run(pts, preseed=False):
     n = len(pts); out = np.zeros((n, 4), np.uint32)
+    fn = lib().sdfhip_mesh_nearest_stats_preseeded if preseed else lib().sdfhip_mesh_nearest_stats
     for a in range(0, n, 3_000_000):
         b = min(n, a + 3_000_000)
-        check(lib().sdfhip_mesh_nearest_stats(m.h, pts[a:b].ctypes.data_as(C.c_void_p), b - a, out[a:b].ctypes.data_as(C.c_void_p)))
+        check(fn(m.h, pts[a:b].ctypes.data_as(C.c_void_p), b - a, out[a:b].ctypes.data_as(C.c_void_p)))
     return out
 for level in levels:
     nodes, pts = level_points(level)
@@ -54,9 +55,7 @@ for level in levels:
     cell = size / 2 ** level
     print(f"== level {level}: {nodes} nodes, {len(pts)} unique mid-points, cell {cell:.5f}", flush=True)
     for mode in ("default", "preseed"):
-        if mode == "preseed": os.environ["SDFHIP_NEAR_PRESEED"] = "1"
-        else: os.environ.pop("SDFHIP_NEAR_PRESEED", None)
-        out = run(pts)
+        out = run(pts, preseed=(mode == "preseed"))
         ex, it, tr = out[:, 1].astype(np.int64), out[:, 2].astype(np.int64), out[:, 3].astype(np.int64)
         long = (it == 0).sum()
         q = np.percentile(ex, [10, 50, 90, 99, 99.9])
@@ -66,4 +65,3 @@ for level in levels:
             sel = (dist >= a * cell) & (dist < b * cell)
             if sel.any():
                 print(f"    |d| in [{a}, {b}) cells: {sel.mean()*100:5.1f} % of the points, {ex[sel].sum() / max(ex.sum(), 1) * 100:5.1f} % of the expansions, mean {ex[sel].mean():.0f} expansions {tr[sel].mean():.0f} triangles", flush=True)
-os.environ.pop("SDFHIP_NEAR_PRESEED", None)
