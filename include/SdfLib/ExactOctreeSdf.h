@@ -46,8 +46,10 @@ public:
         mBox = BoundingBox(glm::vec3(mInfo.box_min[0], mInfo.box_min[1], mInfo.box_min[2]), glm::vec3(mInfo.box_max[0], mInfo.box_max[1], mInfo.box_max[2]));
     }
     ~ExactOctreeSdf() override { release(); }
-    ExactOctreeSdf(const ExactOctreeSdf&) = delete;
-    ExactOctreeSdf& operator=(const ExactOctreeSdf&) = delete;
+    // Copies are deep, as the reference's implicitly generated ones are (include/SdfLib/ExactOctreeSdf.h:91-93 holds std::vectors): the four
+    // arrays are read back and a device tree of its own, owning its TriangleData, is made from them (default context, no replicas).
+    ExactOctreeSdf(const ExactOctreeSdf& o) : SdfFunction(o) { copyFrom(o); }
+    ExactOctreeSdf& operator=(const ExactOctreeSdf& o) { if (this != &o) { release(); copyFrom(o); } return *this; }
     ExactOctreeSdf(ExactOctreeSdf&& o) noexcept { *this = std::move(o); }
     ExactOctreeSdf& operator=(ExactOctreeSdf&& o) noexcept {
         if (this != &o) {
@@ -129,6 +131,17 @@ protected:
     }
 
 private:
+    void copyFrom(const ExactOctreeSdf& o) {
+        mInfo = o.mInfo; mBox = o.mBox; mTree = nullptr; mMesh = nullptr; mReplicas.clear(); mReplicaMeshes.clear();
+        if (!o.mTree) return;
+        std::vector<OctreeNode> nodes(mInfo.num_nodes); std::vector<uint8_t> has(mInfo.num_nodes), masks(mInfo.num_mask_bytes + 1); std::vector<uint32_t> sets(mInfo.num_set_words + 1);
+        detail::check(sdfhip_exact_download(o.mTree, reinterpret_cast<uint32_t*>(nodes.data()), has.data(), sets.data(), masks.data()));
+        const std::vector<TriangleUtils::TriangleData> td = o.getTrianglesData();
+        detail::check(sdfhip_exact_from_data(detail::defaultContext(), &mInfo, reinterpret_cast<const uint32_t*>(nodes.data()), sets.data(), masks.data(),
+                                             reinterpret_cast<const float*>(td.data()), &mTree));
+        if (mInfo.start_grid_cell_size > 0.f) detail::check(sdfhip_exact_set_start_grid_cell_size(mTree, mInfo.start_grid_cell_size));      // the build's, not the stored box's
+        detail::check(sdfhip_exact_get_info(mTree, &mInfo));
+    }
     void release() {
         if (mTree) sdfhip_exact_destroy(mTree);
         for (sdfhip_exact* t : mReplicas) if (t) sdfhip_exact_destroy(t);

@@ -54,8 +54,10 @@ public:
         build(mesh, box, depth, startDepth, rule, params, initAlgorithm, numThreads);
     }
     ~OctreeSdf() override { release(); }
-    OctreeSdf(const OctreeSdf&) = delete;
-    OctreeSdf& operator=(const OctreeSdf&) = delete;
+    // Copies are deep, as the reference's implicitly generated ones are (include/SdfLib/OctreeSdf.h:146-172 holds a std::vector): the host
+    // array is copied and a device tree of its own is made from it (on the default context; a copy has no multi-device replicas).
+    OctreeSdf(const OctreeSdf& o) : SdfFunction(o) { copyFrom(o); }
+    OctreeSdf& operator=(const OctreeSdf& o) { if (this != &o) { release(); copyFrom(o); } return *this; }
     OctreeSdf(OctreeSdf&& o) noexcept { *this = std::move(o); }
     OctreeSdf& operator=(OctreeSdf&& o) noexcept {
         if (this != &o) {
@@ -174,6 +176,16 @@ private:
         mStartGridCellSize = info.start_grid_cell_size;      // built: largest extent of the INPUT box / grid size (OctreeSdf.cpp:43-52), not the stored box's
         mOctreeData.resize(info.num_words);
         detail::check(sdfhip_octree_download(mTree, reinterpret_cast<uint32_t*>(mOctreeData.data()), SDFHIP_HOST));
+    }
+    void copyFrom(const OctreeSdf& o) {
+        mBox = o.mBox; mValueRange = o.mValueRange; mMinBorderValue = o.mMinBorderValue; mStartGridSize = o.mStartGridSize; mStartGridXY = o.mStartGridXY;
+        mStartGridCellSize = o.mStartGridCellSize; mMaxDepth = o.mMaxDepth; mOctreeData = o.mOctreeData;
+        mTree = nullptr; mReplicas.clear();
+        if (!o.mTree || mOctreeData.empty()) return;
+        const float box[6] = {mBox.min.x, mBox.min.y, mBox.min.z, mBox.max.x, mBox.max.y, mBox.max.z};
+        detail::check(sdfhip_octree_from_data(detail::defaultContext(), reinterpret_cast<const uint32_t*>(mOctreeData.data()), mOctreeData.size(), SDFHIP_HOST, box, box + 3,
+                                              mStartGridSize, mMaxDepth, mValueRange, mMinBorderValue, &mTree));
+        detail::check(sdfhip_octree_set_start_grid_cell_size(mTree, mStartGridCellSize));      // a built tree's cell size is the build's, not the stored box's (OctreeSdf.cpp:43-52)
     }
     void release() {
         if (mTree) sdfhip_octree_destroy(mTree);

@@ -305,6 +305,9 @@ int sdfhip_exact_emit_shard(sdfhip_exact* shard, uint64_t node_offset, uint64_t 
 /* Wrap assembled arrays for queries; TriangleData stays in `mesh` (which must outlive the tree).  has may be NULL (all 1). */
 int sdfhip_exact_from_parts(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_exact_info* info, const uint32_t* nodes, const uint8_t* node_has_tri_idx,
                             const uint32_t* sets, const uint8_t* masks, int where, sdfhip_exact** out);
+/* A copy of a BUILT tree made through sdfhip_exact_from_data answers like the original only with the build's cell size
+ * (info.start_grid_cell_size; see sdfhip_octree_set_start_grid_cell_size); before the first batched query. */
+int sdfhip_exact_set_start_grid_cell_size(sdfhip_exact* tree, float cell_size);
 int sdfhip_exact_destroy(sdfhip_exact* tree);
 int sdfhip_exact_get_info(sdfhip_exact* tree, sdfhip_exact_info* out);
 /* nodes: 2 u32 per node {childrenIndex, trianglesArrayIndex}; node_has_tri_idx: 1 where the reference writes

@@ -103,6 +103,7 @@ SIGNATURES = {
     "sdfhip_octree_query_grid": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp, _vp, _int, _int]),
     "sdfhip_exact_build": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _u32, C.POINTER(_vp)]),
     "sdfhip_exact_from_data": (_int, [_vp, C.POINTER(ExactInfo), _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
+    "sdfhip_exact_set_start_grid_cell_size": (_int, [_vp, _f32]),
     "sdfhip_exact_destroy": (_int, [_vp]),
     "sdfhip_exact_get_info": (_int, [_vp, C.POINTER(ExactInfo)]),
     "sdfhip_exact_download": (_int, [_vp, _vp, _vp, _vp, _vp]),

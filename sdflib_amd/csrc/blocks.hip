@@ -116,3 +116,7 @@ int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* rad
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsBlocks() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_fit_exact)); (void)hipGetLastError(); } }

@@ -2218,3 +2218,7 @@ int sdfhip_mesh_point_values(sdfhip_mesh* mesh, const float* xyz, const uint32_t
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsBvh() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_top_init)); (void)hipGetLastError(); } }

@@ -304,6 +304,8 @@ static bool hostAcosNeeded() {
 }
 }  // namespace sdfhip
 
+namespace sdfhip { void loadKernelsCtxMesh(); void loadKernelsBvh(); void loadKernelsOctreeBuild(); void loadKernelsOctreeContinuity(); void loadKernelsOctreeQuery(); void loadKernelsOctreeLattice();
+                   void loadKernelsBlocks(); void loadKernelsExactBuild(); void loadKernelsExactQuery(); void loadKernelsMulti(); }
 using namespace sdfhip;
 
 extern "C" {
@@ -380,6 +382,15 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
     if (stream_mode == SDFHIP_STREAM_BORROWED) { c->stream = (hipStream_t)stream; c->ownsStream = false; }
     else { SDF_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->ownsStream = true; }
     BigBlockCache::get().addRef(c->device, c->stream);
+    {   // every translation unit's code object onto this device now, once per device and process
+        static std::mutex m; static bool loaded[64] = {};
+        std::lock_guard<std::mutex> g(m);
+        if (device_id < 64 && !loaded[device_id]) {
+            loaded[device_id] = true;
+            loadKernelsCtxMesh(); loadKernelsBvh(); loadKernelsOctreeBuild(); loadKernelsOctreeContinuity(); loadKernelsOctreeQuery(); loadKernelsOctreeLattice();
+            loadKernelsBlocks(); loadKernelsExactBuild(); loadKernelsExactQuery(); loadKernelsMulti();
+        }
+    }
     *out = c;
     return SDFHIP_OK;
     SDF_API_END
@@ -575,3 +586,7 @@ int sdfhip_mesh_triangle_data(sdfhip_mesh* mesh, float* out_host) {
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsCtxMesh() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_triangle_frames)); (void)hipGetLastError(); } }

@@ -1113,3 +1113,7 @@ int sdfhip_exact_download(sdfhip_exact* T, uint32_t* nodes, uint8_t* has, uint32
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsExactBuild() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_mul8)); (void)hipGetLastError(); } }

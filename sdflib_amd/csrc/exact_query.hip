@@ -749,6 +749,16 @@ int sdfhip_exact_query(sdfhip_exact* T, const float* xyz, uint64_t n, float* out
     SDF_API_END
 }
 
+int sdfhip_exact_set_start_grid_cell_size(sdfhip_exact* tree, float cell_size) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(tree && cell_size > 0.f, "bad argument");
+    std::lock_guard<std::mutex> own(tree->leafCtxLock);
+    SDF_REQUIRE(!tree->leafCtxReady, "the cell size must be set before the first batched query");
+    tree->cellSize = cell_size; tree->info.start_grid_cell_size = cell_size;
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
 int sdfhip_exact_from_data(sdfhip_ctx* ctx, const sdfhip_exact_info* info, const uint32_t* nodes, const uint32_t* sets, const uint8_t* masks,
                            const float* triangle_data, sdfhip_exact** out) {
     SDF_API_BEGIN
@@ -820,3 +830,7 @@ int sdfhip_exact_triangle_data(sdfhip_exact* tree, float* out_host) {
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsExactQuery() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_widen)); (void)hipGetLastError(); } }

@@ -518,3 +518,7 @@ int sdfhip_multi_exact_build(sdfhip_multi* M, const float* xyz, uint32_t nv, con
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsMulti() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_add_u32)); (void)hipGetLastError(); } }

@@ -208,23 +208,33 @@ struct EmitArgs {
     const uint32_t* nextAlloc; uint32_t* nextPos; uint32_t* nextBlk;
     // destination: absolute index a < gridEnd lives in grid[a - gridBegin], otherwise in body[a - bodyOffset]
     uint32_t* grid; uint32_t gridBegin, gridEnd; uint32_t* body; uint64_t bodyOffset;
+    // LAYOUT mode (k_emit<true>): the level's slice of the query layout instead — the node's word (as the reference array would hold it) into
+    // qOrig, its layout word into qTopo (inner: index of its child block in the next level's slice; leaf: LEAF_BIT | block id), a leaf's
+    // coefficients into its 256-byte-aligned block of qCoef.  Leaves take their block ids in level order: id = leafBase + (i - inner nodes before i).
+    uint32_t* qTopo; uint32_t* qOrig; float* qCoef; uint32_t nextLevelBase, leafBase;
 };
 
 // top-down: write node words and leaf payloads at their reference positions; children are laid out 7..0
+template <bool LAYOUT>
 __global__ void __launch_bounds__(256) k_emit(EmitArgs a) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid >> 4, q = gid & 15u;     // 16 lanes per node: each copies one float4 of a leaf payload
     if (i >= a.n) return;
     const uint32_t pos = a.pos[i], blk = a.blk[i];
     const bool leaf = a.flag[i] != 0u;
+    const uint32_t cbase = a.childBase[i];           // 8 x (inner nodes before i); for an inner node: its first child in the next level
     if (q == 0) {
         const uint32_t word = (blk & INDEX_MASK) | (leaf ? LEAF_BIT : 0u);
-        if (pos < a.gridEnd) a.grid[pos - a.gridBegin] = word; else a.body[pos - a.bodyOffset] = word;
+        if (LAYOUT) { a.qOrig[i] = word; a.qTopo[i] = leaf ? (LEAF_BIT | (a.leafBase + i - (cbase >> 3))) : a.nextLevelBase + cbase; }
+        else if (pos < a.gridEnd) a.grid[pos - a.gridBegin] = word; else a.body[pos - a.bodyOffset] = word;
     }
     if (leaf) {
         const float4 v = reinterpret_cast<const float4*>(a.coeff)[16 * (size_t)i + q];
-        uint32_t* d = a.body + (blk - a.bodyOffset) + 4 * q;      // blocks always live in the body
-        d[0] = __float_as_uint(v.x); d[1] = __float_as_uint(v.y); d[2] = __float_as_uint(v.z); d[3] = __float_as_uint(v.w);
+        if (LAYOUT) reinterpret_cast<float4*>(a.qCoef)[16 * (size_t)(a.leafBase + i - (cbase >> 3)) + q] = v;
+        else {
+            uint32_t* d = a.body + (blk - a.bodyOffset) + 4 * q;      // blocks always live in the body
+            d[0] = __float_as_uint(v.x); d[1] = __float_as_uint(v.y); d[2] = __float_as_uint(v.z); d[3] = __float_as_uint(v.w);
+        }
     } else if (q < 8) {
         const uint32_t cb = a.childBase[i];
         uint32_t off = blk + 8u;
@@ -259,6 +269,68 @@ static uint32_t dfsRankOfCell(uint32_t x, uint32_t y, uint32_t z, uint32_t start
     }
     (void)sod;
     return rank;
+}
+
+// The finished levels written out top-down (the caller is inside an AllocScope on the context's stream): as the reference's array — grid
+// words of this shard's cells into dGrid, its subtree bodies (first word = absolute index body_offset) into dBody — or, layout = true
+// (complete builds only), as the tree's query layout (sdfhip_octree::qTopo / qOrig / qCoef; see EmitArgs).
+static int emitLevels(sdfhip_octree* T, uint64_t body_offset, uint32_t* dGrid, uint32_t* dBody, bool layout) {
+    hipStream_t st = T->ctx->stream;
+    const uint32_t sod = T->startOctreeDepth, startDepth = T->params.start_depth, maxDepth = T->params.depth;
+    const uint32_t G = 1u << startDepth, G3 = G * G * G;
+    const uint32_t cellBegin = T->info.cell_begin, cellEnd = T->info.cell_end, nCells = cellEnd - cellBegin;
+    BuildLevel* S = T->levels[startDepth - sod].get();
+    SDF_REQUIRE(S && S->n == nCells, "internal: start level missing");
+    // body offsets of the cells: prefix sums of the root subtree sizes in body order
+    std::vector<uint32_t> rootAlloc(nCells), rootBlk(nCells);
+    SDF_HIP_CHECK(hipMemcpyAsync(rootAlloc.data(), S->alloc.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    if (T->params.layout == SDFHIP_LAYOUT_SUBTREES) {
+        uint64_t off = body_offset;
+        for (uint32_t c = 0; c < nCells; c++) { rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
+    } else {
+        std::vector<uint32_t> cellOfRank(G3);
+        for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++)
+            cellOfRank[dfsRankOfCell(x, y, z, startDepth, sod)] = z * G * G + y * G + x;
+        uint64_t off = body_offset;
+        for (uint32_t r = 0; r < G3; r++) { const uint32_t c = cellOfRank[r]; rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
+    }
+    DevBuf<uint32_t> dRootBlk; SDF_TRY(dRootBlk.reserve(nCells));
+    SDF_HIP_CHECK(hipMemcpyAsync(dRootBlk.p, rootBlk.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
+    k_init_start_pos<<<gridFor(nCells, 256), 256, 0, st>>>(nCells, cellBegin, dRootBlk.p, S->pos.p, S->blk.p);
+    uint64_t totalNodes = 0, totalLeaves = 0;
+    if (layout) {
+        SDF_REQUIRE(nCells == G3, "internal: the query layout is emitted by complete builds only");
+        std::vector<uint32_t> levelNodes, levelLeafBase(1, 0u);
+        for (uint32_t d = startDepth; d <= maxDepth; d++) {
+            const BuildLevel* L = T->levels[d - sod].get();
+            if (!L || L->n == 0) break;
+            totalNodes += L->n; totalLeaves += L->numLeaves;
+            levelNodes.push_back(L->n); levelLeafBase.push_back((uint32_t)totalLeaves);
+        }
+        SDF_REQUIRE(totalNodes < (1ull << 30), "tree too large for the query layout");
+        SDF_TRY(T->qTopo.reserve(totalNodes)); SDF_TRY(T->qOrig.reserve(totalNodes)); SDF_TRY(T->qCoef.reserve(64ull * (totalLeaves ? totalLeaves : 1)));
+        T->qNodes = totalNodes; T->qLeaves = totalLeaves; T->qLevelNodes = levelNodes; T->qLevelLeafBase = levelLeafBase;
+    }
+    uint64_t levelBase = 0, leafBase = 0;
+    for (uint32_t d = startDepth; d <= maxDepth; d++) {
+        BuildLevel* L = T->levels[d - sod].get();
+        if (!L || L->n == 0) break;
+        BuildLevel* N = (d < maxDepth) ? T->levels[d + 1 - sod].get() : nullptr;
+        EmitArgs ea{L->n, L->flag.p, L->childBase.p, L->coeff.p, L->pos.p, L->blk.p,
+                    N ? N->alloc.p : nullptr, N ? N->pos.p : nullptr, N ? N->blk.p : nullptr,
+                    dGrid, cellBegin, G3, dBody, body_offset,
+                    layout ? T->qTopo.p + levelBase : nullptr, layout ? T->qOrig.p + levelBase : nullptr, layout ? T->qCoef.p : nullptr, (uint32_t)(levelBase + L->n), (uint32_t)leafBase};
+        // grid words exist only for the start level; deeper node words always live in bodies
+        if (d > startDepth) { ea.gridBegin = 0; ea.gridEnd = 0; }
+        if (layout) k_emit<true><<<gridFor(16ull * L->n, 256), 256, 0, st>>>(ea);
+        else k_emit<false><<<gridFor(16ull * L->n, 256), 256, 0, st>>>(ea);
+        levelBase += L->n; leafBase += L->numLeaves;
+    }
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    if (layout) T->qReady = true;
+    return SDFHIP_OK;
 }
 
 static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, bool shardOnly, sdfhip_octree** out) {
@@ -421,7 +493,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
                 SDF_HIP_CHECK(devExclusiveSum(scanTmp.p, need, L->inner.p, L->childBase.p, (size_t)L->n, st));
                 SDF_TRY(readBackWords(st, L->childBase.p + (L->n - 1), L->inner.p + (L->n - 1), 1, &L->numInner));
                 k_scale8<<<gridFor(L->n, 256), 256, 0, st>>>(L->n, L->childBase.p);
-            } else { SDF_HIP_CHECK(hipStreamSynchronize(st)); L->numInner = 0; }
+            } else { SDF_HIP_CHECK(hipMemsetAsync(L->childBase.p, 0, 4ull * L->n, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); L->numInner = 0; }      // (no inner node before any node: k_emit ranks the leaves by it)
             tDecide += nowSeconds() - t0;
             L->numLeaves = L->n - L->numInner;
         } else {
@@ -495,9 +567,10 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
     T->built = true;
 
     if (!shardOnly) {
-        SDF_TRY(T->data.reserve((size_t)G3 + bodyWords));
-        int rc = sdfhip_octree_emit_shard(T.get(), G3, T->data.p, T->data.p + G3, SDFHIP_DEVICE);
-        if (rc != SDFHIP_OK) return rc;
+        // A complete build is born with its QUERY layout (node words packed breadth-first + 256-byte-aligned coefficient blocks) and without
+        // a resident copy of the reference's array: the first query costs nothing extra (round 4: 7.2 ms of re-walking the array at C2, and
+        // both copies resident), and download / device_words / .bin rebuild the array from the layout bit for bit (k_ql_restore).
+        SDF_TRY(emitLevels(T.get(), G3, nullptr, nullptr, true));
         T->hasData = true;
         T->levels.clear();
     }
@@ -535,9 +608,9 @@ int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* d
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
-    const uint32_t sod = T->startOctreeDepth, startDepth = T->params.start_depth, maxDepth = T->params.depth;
+    const uint32_t startDepth = T->params.start_depth;
     const uint32_t G = 1u << startDepth, G3 = G * G * G;
-    const uint32_t cellBegin = T->info.cell_begin, cellEnd = T->info.cell_end, nCells = cellEnd - cellBegin;
+    const uint32_t nCells = T->info.cell_end - T->info.cell_begin;
     SDF_REQUIRE(body_offset >= G3 && body_offset + T->info.body_words <= (uint64_t)INDEX_MASK, "body_offset out of range");
     DevBuf<uint32_t> tmpGrid, tmpBody;
     uint32_t* dGrid = dst_grid; uint32_t* dBody = dst_body;
@@ -545,37 +618,7 @@ int sdfhip_octree_emit_shard(sdfhip_octree* T, uint64_t body_offset, uint32_t* d
         SDF_TRY(tmpGrid.reserve(nCells)); SDF_TRY(tmpBody.reserve(T->info.body_words));
         dGrid = tmpGrid.p; dBody = tmpBody.p;
     }
-    BuildLevel* S = T->levels[startDepth - sod].get();
-    SDF_REQUIRE(S && S->n == nCells, "internal: start level missing");
-    // body offsets of the cells: prefix sums of the root subtree sizes in body order
-    std::vector<uint32_t> rootAlloc(nCells), rootBlk(nCells);
-    SDF_HIP_CHECK(hipMemcpyAsync(rootAlloc.data(), S->alloc.p, 4ull * nCells, hipMemcpyDeviceToHost, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
-    if (T->params.layout == SDFHIP_LAYOUT_SUBTREES) {
-        uint64_t off = body_offset;
-        for (uint32_t c = 0; c < nCells; c++) { rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
-    } else {
-        std::vector<uint32_t> cellOfRank(G3);
-        for (uint32_t z = 0; z < G; z++) for (uint32_t y = 0; y < G; y++) for (uint32_t x = 0; x < G; x++)
-            cellOfRank[dfsRankOfCell(x, y, z, startDepth, sod)] = z * G * G + y * G + x;
-        uint64_t off = body_offset;
-        for (uint32_t r = 0; r < G3; r++) { const uint32_t c = cellOfRank[r]; rootBlk[c] = (uint32_t)off; off += rootAlloc[c]; }
-    }
-    DevBuf<uint32_t> dRootBlk; SDF_TRY(dRootBlk.reserve(nCells));
-    SDF_HIP_CHECK(hipMemcpyAsync(dRootBlk.p, rootBlk.data(), 4ull * nCells, hipMemcpyHostToDevice, st));
-    k_init_start_pos<<<gridFor(nCells, 256), 256, 0, st>>>(nCells, cellBegin, dRootBlk.p, S->pos.p, S->blk.p);
-    for (uint32_t d = startDepth; d <= maxDepth; d++) {
-        BuildLevel* L = T->levels[d - sod].get();
-        if (!L || L->n == 0) break;
-        BuildLevel* N = (d < maxDepth) ? T->levels[d + 1 - sod].get() : nullptr;
-        EmitArgs ea{L->n, L->flag.p, L->childBase.p, L->coeff.p, L->pos.p, L->blk.p,
-                    N ? N->alloc.p : nullptr, N ? N->pos.p : nullptr, N ? N->blk.p : nullptr,
-                    dGrid, cellBegin, G3, dBody, body_offset};
-        // grid words exist only for the start level; deeper node words always live in bodies
-        if (d > startDepth) { ea.gridBegin = 0; ea.gridEnd = 0; }
-        k_emit<<<gridFor(16ull * L->n, 256), 256, 0, st>>>(ea);
-    }
-    SDF_HIP_CHECK(hipGetLastError());
+    SDF_TRY(emitLevels(T, body_offset, dGrid, dBody, false));
     if (where == SDFHIP_HOST) {
         SDF_HIP_CHECK(hipMemcpyAsync(dst_grid, dGrid, 4ull * nCells, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(dst_body, dBody, 4ull * T->info.body_words, hipMemcpyDeviceToHost, st));
@@ -645,3 +688,7 @@ const uint32_t* sdfhip_octree_device_words(sdfhip_octree* tree) {
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsOctreeBuild() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_scale8)); (void)hipGetLastError(); } }

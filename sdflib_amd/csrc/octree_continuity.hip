@@ -1089,10 +1089,14 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     { const uint32_t k = hs[1]; const uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k; float f; memcpy(&f, &b, 4); T->info.min_border_value = (k == 0xFFFFFFFFu) ? INFINITY : f; }
     T->info.num_words = ocSize; T->info.cell_end = G3; T->info.body_words = ocSize - G3; T->info.body_offset = G3;
     T->info.post_pass_scheduled = numRescheduled;
-    // shrink to fit
-    SDF_TRY(T->data.reserve(ocSize));
-    SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
-    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    // The tree keeps its QUERY layout, made here from the working array (one sweep per level, the blocks come from this build's
+    // allocation scope), and no resident copy of the array: download / device_words / .bin rebuild it from the layout bit for bit.
+    SDF_TRY(octreeLayoutFromArray(T.get(), oc.p));
+    if (T->qNodes + 64ull * T->qLeaves != (uint64_t)ocSize) {          // words that belong to no node or coefficient block: such an array cannot be rebuilt from the layout and stays
+        SDF_TRY(T->data.reserve(ocSize));
+        SDF_HIP_CHECK(hipMemcpyAsync(T->data.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+    }
     T->hasData = true; T->built = true;
     SDF_TRY(sampleFallbacks(st, SS, T->info));
     T->info.seconds_total = nowSeconds() - tStart;
@@ -1101,3 +1105,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
 }
 
 }  // namespace sdfhip
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsOctreeContinuity() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&kc_mul8)); (void)hipGetLastError(); } }

@@ -44,7 +44,9 @@ struct sdfhip_octree {
     bool dataPinned = false;                // sdfhip_octree_device_words handed the array's address out: it is not released automatically any more
     bool hasData = false;                   // an assembled array EXISTS; it need not be resident: a compacted tree (sdfhip_octree_compact, or
                                             // automatically above SDFHIP_COMPACT_ABOVE_MB) keeps the query layout only and rebuilds it on demand
-    // Query-side layout, derived from `data` on the first query (octree_query.hip, ensureQueryLayout): the node words alone, packed
+    // Query-side layout — what the builders emit (round 5: a built tree is born with it and has NO resident array; the array is rebuilt
+    // from it when download / device_words / a .bin file asks), or what the first query derives from `data` for a tree that arrived as an
+    // array (octree_query.hip, ensureQueryLayout): the node words alone, packed
     // breadth-first (a few MB: the dependent loads of the walk stay in L2), and the leaves' coefficients as 256-byte-ALIGNED blocks
     // (a block is exactly two 128-byte lines; in `data` a block starts at any multiple of 4 bytes and straddles three).
     sdfhip::DevBuf<uint32_t> qTopo;         // [G^3 start cells][level 1 blocks]...: inner word = index of the 8-word child block, leaf word = LEAF_BIT | block id
@@ -81,4 +83,5 @@ namespace sdfhip {
 // octree_query.hip: the node array of a tree whose resident copy may have been released in favour of the query layout
 int octreeMaterialize(sdfhip_octree* tree);                                   // makes tree->data resident again
 int octreeDownload(sdfhip_octree* tree, uint32_t* out_words, int where);      // without keeping it resident
+int octreeLayoutFromArray(sdfhip_octree* tree, const uint32_t* data);         // the query layout of the tree whose reference array is `data` (device)
 }

@@ -203,3 +203,7 @@ int latticeColumnsLaunch(hipStream_t st, bool exact, const float* coef, const fl
 }
 
 }  // namespace sdfhip
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsOctreeLattice() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_lattice_columns<true>)); (void)hipGetLastError(); } }

@@ -212,9 +212,9 @@ __global__ void k_ql_fill(const uint32_t* __restrict__ data, const uint32_t* __r
     for (int q = 0; q < 16; q++) to[q] = make_float4(__uint_as_float(from[4 * q]), __uint_as_float(from[4 * q + 1]), __uint_as_float(from[4 * q + 2]), __uint_as_float(from[4 * q + 3]));
 }
 
-static int ensureQueryLayout(sdfhip_octree* T) {
-    std::lock_guard<std::mutex> own(T->qLock);
-    if (T->qReady) return SDFHIP_OK;
+// The layout of the tree whose reference array is `data` (device, info.num_words words; need not be T->data: the CONTINUITY builder
+// converts its working array and never makes a resident copy).  Caller holds T->qLock or owns T exclusively.
+int octreeLayoutFromArray(sdfhip_octree* T, const uint32_t* data) {
     sdfhip_ctx* ctx = T->ctx;
     hipStream_t st = ctx->stream;
     const uint64_t numWords = T->info.num_words;
@@ -237,7 +237,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
         std::unique_ptr<Level> next(new Level());
         SDF_TRY(next->src.reserve(8ull * cur->count));
         SDF_HIP_CHECK(hipMemsetAsync(counters.p, 0, 4, st));
-        k_ql_level<<<gridFor(cur->count, 256), 256, 0, st>>>(T->data.p, numWords, levels.empty() ? nullptr : cur->src.p, cur->count, cur->rank.p, next->src.p, counters.p);
+        k_ql_level<<<gridFor(cur->count, 256), 256, 0, st>>>(data, numWords, levels.empty() ? nullptr : cur->src.p, cur->count, cur->rank.p, next->src.p, counters.p);
         SDF_TRY(readBackWords(st, counters.p, nullptr, 3, h));
         SDF_REQUIRE(h[2] == 0, "node array is not a valid octree (index out of range)");
         levelNodes.push_back(cur->count); levelLeafBase.push_back(h[1]);
@@ -253,12 +253,25 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     uint64_t base = 0;
     for (size_t i = 0; i < levels.size(); i++) {
         Level& L = *levels[i];
-        k_ql_fill<<<gridFor(L.count, 256), 256, 0, st>>>(T->data.p, i == 0 ? nullptr : L.src.p, L.rank.p, L.count, T->qTopo.p + base, T->qOrig.p + base, (uint32_t)(base + L.count), T->qCoef.p);
+        k_ql_fill<<<gridFor(L.count, 256), 256, 0, st>>>(data, i == 0 ? nullptr : L.src.p, L.rank.p, L.count, T->qTopo.p + base, T->qOrig.p + base, (uint32_t)(base + L.count), T->qCoef.p);
         base += L.count;
     }
     SDF_HIP_CHECK(hipGetLastError());
     SDF_HIP_CHECK(hipStreamSynchronize(st));           // the level buffers are released below
     T->qNodes = total; T->qLeaves = leaves; T->qLevelNodes = levelNodes; T->qLevelLeafBase = levelLeafBase; T->qReady = true;
+    return SDFHIP_OK;
+}
+
+// Trees that arrive as arrays (sdfhip_octree_from_data: loaded files, reassembled shards, broadcasts) get their layout on the first query;
+// trees built here are born with it (octree_build.hip: emitQueryLayout; octree_continuity.hip) and never pass through this.
+static int ensureQueryLayout(sdfhip_octree* T) {
+    std::lock_guard<std::mutex> own(T->qLock);
+    if (T->qReady) return SDFHIP_OK;
+    SDF_REQUIRE(T->data.p, "tree has neither its node array nor a query layout");
+    SDF_TRY(octreeLayoutFromArray(T, T->data.p));
+    sdfhip_ctx* ctx = T->ctx;
+    hipStream_t st = ctx->stream;
+    const uint64_t numWords = T->info.num_words, total = T->qNodes, leaves = T->qLeaves;
     // The layout holds everything the array holds (node words + coefficient blocks), so a LARGE array need not stay on the device beside
     // it: above SDFHIP_COMPACT_ABOVE_MB (default 1024) it is released here and rebuilt on demand (octreeMaterialize).
     static const uint64_t compactAbove = (getenv("SDFHIP_COMPACT_ABOVE_MB") ? strtoull(getenv("SDFHIP_COMPACT_ABOVE_MB"), nullptr, 10) : 1024ull) << 20;
@@ -794,3 +807,7 @@ int sdfhip_octree_query_grid(sdfhip_octree* T, const float origin[3], const floa
 }
 
 }  // extern "C"
+
+// (sdfhip_ctx_create: the runtime loads a translation unit's code object on the first use of one of its kernels — milliseconds that would
+// otherwise land in the first build or the first query of a process)
+namespace sdfhip { void loadKernelsOctreeQuery() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&k_octree_query_coop<SDFHIP_EVAL_EXACT, false>)); (void)hipGetLastError(); } }

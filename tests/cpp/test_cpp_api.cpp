@@ -55,6 +55,30 @@ int main(int argc, char** argv) {
         std::printf("depth density levels %zu total %.9g\n", dens.size(), total * 1.0f);
         const auto td = ex.getTrianglesData();
         std::printf("triangles %zu normal0 %.9g %.9g %.9g\n", td.size(), td[0].getTriangleNormal().x, td[0].getTriangleNormal().y, td[0].getTriangleNormal().z);
+        // deep copies (the reference's classes are implicitly copyable: OctreeSdf.h:146-172, ExactOctreeSdf.h:91-93): a copy answers like the
+        // original, has its own device tree (it survives the original) and its own host array
+        size_t copyMism = 0;
+        {
+            std::unique_ptr<sdflib::OctreeSdf> oc2;
+            std::unique_ptr<sdflib::ExactOctreeSdf> ex2;
+            {
+                sdflib::OctreeSdf octCopy(oct);              // copy construction
+                sdflib::OctreeSdf octAssigned; octAssigned = octCopy;          // copy assignment
+                oc2.reset(new sdflib::OctreeSdf(octAssigned));
+                sdflib::ExactOctreeSdf exCopy(ex);
+                sdflib::ExactOctreeSdf exAssigned; exAssigned = exCopy;
+                ex2.reset(new sdflib::ExactOctreeSdf(exAssigned));
+            }      // the intermediate copies are gone here
+            std::vector<float> d3(n), e3(n); std::vector<glm::vec3> g3(n);
+            oc2->getDistances(pts, n, d3.data(), g3.data());
+            ex2->getDistances(pts, n, e3.data());
+            for (size_t i = 0; i < n; i++) if (d3[i] != d[i] || g3[i].x != g[i].x || g3[i].y != g[i].y || g3[i].z != g[i].z || e3[i] != de[i] || oc2->getDistance(pts[i]) != d[i]) copyMism++;
+            if (oc2->getOctreeData().size() != oct.getOctreeData().size() || oc2->getOctreeData().data() == oct.getOctreeData().data()) copyMism++;
+            oc2->getOctreeData()[0].childrenIndex ^= 1u;              // the copy's array is its own
+            if (oc2->getOctreeData()[0].childrenIndex == oct.getOctreeData()[0].childrenIndex) copyMism++;
+            if (ex2->getMaxTrianglesInLeafs() != ex.getMaxTrianglesInLeafs() || ex2->getOctreeData().size() != ex.getOctreeData().size()) copyMism++;
+        }
+        std::printf("copy-vs-original mismatches %zu\n", copyMism);
         sdflib::ExactOctreeSdf moved = std::move(ex);
         std::printf("moved exact scalar %.9g\n", moved.getDistance(pts[0]));
     }

@@ -46,6 +46,7 @@ def test_cpp_api_matches_oracle(tmp_path, oracle, devices):
     r = subprocess.run([EXE, p("v.bin"), p("f.bin"), p("p.bin"), p("d.bin"), p("e.bin"), p("oct.bin"), p("exact.bin")], capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "scalar-vs-batched mismatches 0" in r.stdout and "reloaded-vs-built mismatches 0" in r.stdout
+    assert "copy-vs-original mismatches 0" in r.stdout, r.stdout          # deep copy construction / assignment of both classes
     assert f"replicas {3 if devices else 1}" in r.stdout, r.stdout
     # a start grid of 4^3 unit cells: the leaf volumes add up to 8^-startDepth * 64 = 1 (OctreeSdf.cpp:270-276 weights from depth 0)
     total = float(r.stdout.split("depth density levels")[1].split("total")[1].split()[0])

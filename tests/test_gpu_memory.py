@@ -16,22 +16,34 @@ def test_compacted_tree_answers_and_downloads_the_same_bits(oracle, gpu_ctx):
     gm = S.Mesh(v, f, gpu_ctx)
     pts = random_points_in_box(box, 50000, seed=3)
     for alg in (S.ALG_NO_CONTINUITY, S.ALG_CONTINUITY):
+        # a BUILT tree is born with the query layout and without a resident copy of the reference's array (round 5): one copy on the device
         t = S.OctreeSdf(gm, box, 6, 2, 1e-3, init_algorithm=alg, num_threads=2)
-        words = t.get_octree_data()
+        array_bytes = 4 * int(t.info.num_words)
+        born = t.device_bytes()
+        assert born < 1.1 * array_bytes, (born, array_bytes)          # layout = array + 4 bytes per node + block alignment
         d0, g0 = t.get_distance(pts, gradient=True)
-        before = t.device_bytes()
-        t.compact()
-        after = t.device_bytes()
-        assert after < 0.62 * before, (before, after)                 # array gone; layout = array + 4 bytes per node + block alignment
-        assert np.array_equal(t.get_octree_data(), words)             # rebuilt from the layout, transiently
-        assert t.device_bytes() == after
-        d1, g1 = t.get_distance(pts, gradient=True)
+        assert t.device_bytes() == born                               # the first query made nothing
+        words = t.get_octree_data()                                   # rebuilt from the layout, transiently
+        assert t.device_bytes() == born
+        # the same tree arriving as an ARRAY (a loaded file, reassembled shards): the first query derives the layout, compact() drops the array
+        i = t.info
+        a = S.OctreeSdf.from_data(gpu_ctx, words, i.box_min, i.box_max, i.start_grid_size, i.max_depth, i.value_range, i.min_border_value, cell_size=i.start_grid_cell_size)
+        d1, g1 = a.get_distance(pts, gradient=True)
         assert np.array_equal(bits(d0), bits(d1)) and np.array_equal(bits(g0), bits(g1))
+        before = a.device_bytes()
+        a.compact()
+        after = a.device_bytes()
+        assert after < 0.62 * before, (before, after)                 # array gone
+        assert np.array_equal(a.get_octree_data(), words)             # rebuilt from the layout, transiently
+        assert a.device_bytes() == after
+        d2, g2 = a.get_distance(pts, gradient=True)
+        assert np.array_equal(bits(d0), bits(d2)) and np.array_equal(bits(g0), bits(g2))
         n = 24
         bb = t.get_grid_bounding_box(); step = np.full(3, (bb[3] - bb[0]) / n, np.float32); org = (bb[:3] + 0.5 * step).astype(np.float32)
         dl = t.get_distance_grid(org, step, (n, n, n), eval_mode=S.EVAL_FAST)
-        assert np.isfinite(dl).all()
-        t.close()
+        da = a.get_distance_grid(org, step, (n, n, n), eval_mode=S.EVAL_FAST)
+        assert np.isfinite(dl).all() and np.array_equal(bits(dl), bits(da))
+        t.close(); a.close()
     # an array with words that belong to no node keeps its array
     t = S.OctreeSdf(gm, box, 4, 1, 1e-3, num_threads=2)
     w = np.concatenate([t.get_octree_data(), np.arange(100, dtype=np.uint32)])
@@ -42,9 +54,9 @@ def test_compacted_tree_answers_and_downloads_the_same_bits(oracle, gpu_ctx):
     assert loose.device_bytes() == b0 and np.array_equal(loose.get_octree_data(), w)
 
 
-def test_large_array_is_compacted_by_its_first_query_and_the_caches_give_memory_back(oracle):
+def test_large_tree_holds_one_copy_and_the_caches_give_memory_back(oracle):
     """Depth-9 tree (1.6 GB node array, the largest transient blocks of any build in the suite), then a small build in the same
-    context: the first query leaves ONE copy of the tree on the device, the context's caches sit below their high-water mark after the
+    context: ONE copy of the tree is on the device from the start (the builders emit the query layout), the context's caches sit below their high-water mark after the
     build, and after closing the tree and trimming the device is back where it started."""
     import torch
     import sdflib_amd as S
@@ -60,8 +72,9 @@ def test_large_array_is_compacted_by_its_first_query_and_the_caches_give_memory_
     assert array_bytes > (1 << 30)
     assert ctx.cached_bytes() <= (1100 << 20), ctx.cached_bytes()         # blocks above the 512 MB mark were freed when the build returned; the nearest search's lists stay
     pts = random_points_in_box(box, 100000, seed=1)
+    assert t.device_bytes() < 1.1 * array_bytes, (t.device_bytes(), array_bytes)      # born with the layout only: no resident copy of the array
     d0 = t.get_distance(pts)
-    assert t.device_bytes() < 1.1 * array_bytes, (t.device_bytes(), array_bytes)      # layout only: the array was released
+    assert t.device_bytes() < 1.1 * array_bytes, (t.device_bytes(), array_bytes)
     words = t.get_octree_data()                                           # rebuilt from the layout
     assert len(words) == int(t.info.num_words)
     raw = oracle.octree_query_raw(words, t.get_grid_bounding_box(), t.info.start_grid_size, t.info.min_border_value, pts)
