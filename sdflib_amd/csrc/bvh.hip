@@ -1180,18 +1180,88 @@ __global__ void __launch_bounds__(256) k_top_keys(KeyTri* __restrict__ K, const 
     const float4 q0 = triV[3 * t];
     K[i].key = dim == 0 ? q0.x : (dim == 1 ? q0.y : q0.z);
 }
-// the nine coordinates of every triangle in the order of `order` (the first nine floats of its record): what a host thread sums for a long node
-__global__ void k_top_gather9(const uint32_t* __restrict__ order, const float* __restrict__ triV12, uint32_t n, float* __restrict__ out9) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9ull * n) return;
-    const uint32_t e = (uint32_t)(i / 9u), k = (uint32_t)(i % 9u);
-    out9[i] = triV12[12 * (size_t)order[e] + k];
-}
 __global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_t* __restrict__ snap) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) snap[i] = (uint32_t)K[i].tri; }
-// centre of a node = its vertices summed in range order, three chains (x, y, z) of 3 n additions each: one wave per node, all lanes gather 64
-// triangles and lay their coordinates out as doubles, lanes 0..2 add them in order (a workgroup per node: 256 triangles per step)
-__global__ void __launch_bounds__(256) k_top_sums(const uint32_t* __restrict__ order, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, double* __restrict__ centres) {
+// Centre of a node = its vertices summed in range order by the reference, three chains (x, y, z) of 3 n dependent fp64 additions each.
+// Round 5: the chains are reproduced IN PARALLEL and verified.  A chain is cut into chunks of kSumChunk triangles; (1) k_csum_local adds
+// every chunk up from zero, (2) k_csum_scan turns the chunk sums of a node into the value each chunk would START from, (3) k_csum_check
+// re-runs every chunk from that value with the reference's very additions and compares where it ends with where the next chunk starts,
+// bit for bit.  If every boundary of a node agrees, the chunks laid end to end ARE the sequential chain (by induction from the first chunk,
+// which starts from 0 like the reference) and the last chunk's end is the reference's sum — whether or not an addition rounded on the way.
+// The guesses of (1) + (2) are right whenever no addition of the chain rounds, which is the rule for fp32 coordinates summed in fp64
+// (3.9 M additions of the 1.31 M-triangle mesh's longest chain: none rounds); a node with a disagreeing boundary is flagged and summed by
+// the serial chain (k_top_sums, which then runs for flagged nodes only).  Rounds 3-4 ran the serial chain for every node (13 ms per
+// 655 360 triangles on a lane, bound by the latency of dependent additions) and sent the longest nodes' coordinates to HOST threads.
+constexpr uint32_t kSumChunk = 32;          // triangles per chunk: 96 additions per chain and lane
+struct CsumLevel { const uint32_t* order; const float4* triV; const TopNode* nodes; uint32_t count; const uint32_t* chunkBase; uint32_t totalChunks; double* csum; double* cin; uint32_t* status; double* centres; };
+SDF_DEV uint32_t csumNodeOf(const uint32_t* __restrict__ chunkBase, uint32_t count, uint32_t c) {
+    uint32_t lo = 0, hi = count - 1;
+    while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (chunkBase[mid] <= c) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+// the additions of one chunk, in the reference's order: per triangle its three vertices, per vertex x, y, z into their chains
+SDF_DEV void csumChunk(const CsumLevel& L, const TopNode& nd, uint32_t k, double& sx, double& sy, double& sz) {
+    const uint32_t b = nd.b + k * kSumChunk, e = (nd.e - b < kSumChunk) ? nd.e : b + kSumChunk;
+    for (uint32_t i = b; i < e; i++) {
+        const size_t t = (size_t)L.order[i];
+        const float4 q0 = L.triV[3 * t], q1 = L.triV[3 * t + 1]; const float q2 = reinterpret_cast<const float*>(L.triV)[12 * t + 8];
+        sx += (double)q0.x; sy += (double)q0.y; sz += (double)q0.z;
+        sx += (double)q0.w; sy += (double)q1.x; sz += (double)q1.y;
+        sx += (double)q1.z; sy += (double)q1.w; sz += (double)q2;
+    }
+}
+__global__ void __launch_bounds__(256) k_csum_local(CsumLevel L) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= L.totalChunks) return;
+    const uint32_t j = csumNodeOf(L.chunkBase, L.count, c);
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    csumChunk(L, L.nodes[j], c - L.chunkBase[j], sx, sy, sz);
+    L.csum[3 * (size_t)c] = sx; L.csum[3 * (size_t)c + 1] = sy; L.csum[3 * (size_t)c + 2] = sz;
+}
+// one workgroup per node: exclusive prefix sums of its chunk sums (thread t takes a contiguous share, thread 0 chains the 256 share totals)
+__global__ void __launch_bounds__(256) k_csum_scan(CsumLevel L) {
+    __shared__ double s_tot[256][3];
+    const uint32_t j = blockIdx.x, c0 = L.chunkBase[j], n = L.chunkBase[j + 1] - c0, t = threadIdx.x;
+    const uint32_t per = (n + 255u) / 256u, a = t * per < n ? t * per : n, z = a + per < n ? a + per : n;
+    double sx = 0.0, sy = 0.0, sz = 0.0;
+    for (uint32_t k = a; k < z; k++) { sx += L.csum[3 * (size_t)(c0 + k)]; sy += L.csum[3 * (size_t)(c0 + k) + 1]; sz += L.csum[3 * (size_t)(c0 + k) + 2]; }
+    s_tot[t][0] = sx; s_tot[t][1] = sy; s_tot[t][2] = sz;
+    __syncthreads();
+    if (t == 0) {
+        double px = 0.0, py = 0.0, pz = 0.0;
+        for (int i = 0; i < 256; i++) { const double x = s_tot[i][0], y = s_tot[i][1], w = s_tot[i][2]; s_tot[i][0] = px; s_tot[i][1] = py; s_tot[i][2] = pz; px += x; py += y; pz += w; }
+        L.status[j] = 0u;
+    }
+    __syncthreads();
+    sx = s_tot[t][0]; sy = s_tot[t][1]; sz = s_tot[t][2];
+    for (uint32_t k = a; k < z; k++) {
+        const size_t c = (size_t)(c0 + k);
+        L.cin[3 * c] = sx; L.cin[3 * c + 1] = sy; L.cin[3 * c + 2] = sz;
+        sx += L.csum[3 * c]; sy += L.csum[3 * c + 1]; sz += L.csum[3 * c + 2];
+    }
+}
+__global__ void __launch_bounds__(256) k_csum_check(CsumLevel L) {
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    if (c >= L.totalChunks) return;
+    const uint32_t j = csumNodeOf(L.chunkBase, L.count, c);
+    const TopNode nd = L.nodes[j];
+    double sx = L.cin[3 * (size_t)c], sy = L.cin[3 * (size_t)c + 1], sz = L.cin[3 * (size_t)c + 2];
+    csumChunk(L, nd, c - L.chunkBase[j], sx, sy, sz);
+    if (c + 1u < L.chunkBase[j + 1]) {
+        const bool same = __double_as_longlong(sx) == __double_as_longlong(L.cin[3 * (size_t)(c + 1)]) && __double_as_longlong(sy) == __double_as_longlong(L.cin[3 * (size_t)(c + 1) + 1]) &&
+                          __double_as_longlong(sz) == __double_as_longlong(L.cin[3 * (size_t)(c + 1) + 2]);
+        if (!same) atomicOr(&L.status[j], 1u);
+    } else {
+        const double cnt = (double)(3u * (nd.e - nd.b));
+        L.centres[3 * (size_t)j] = sx / cnt; L.centres[3 * (size_t)j + 1] = sy / cnt; L.centres[3 * (size_t)j + 2] = sz / cnt;
+    }
+}
+// The serial chain: one workgroup per node, all lanes gather 256 triangles and lay their coordinates out as doubles, lanes 0..2 add them in
+// order.  status != nullptr: only the nodes k_csum_check flagged (counted in *serialNodes).
+__global__ void __launch_bounds__(256) k_top_sums(const uint32_t* __restrict__ order, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, double* __restrict__ centres,
+                                                  const uint32_t* __restrict__ status, uint32_t* __restrict__ serialNodes) {
     __shared__ double s_v[256][9];
+    if (status && status[blockIdx.x] == 0u) return;
+    if (status && threadIdx.x == 0) atomicAdd(serialNodes, 1u);
     const TopNode nd = nodes[blockIdx.x];
     const int tid = threadIdx.x;
     const uint32_t nn = nd.e - nd.b;
@@ -1571,9 +1641,6 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     if (hybrid) SDF_TRY(finishOnDevice(mesh, *hybrid, st));
     if (onDevice) SDF_TRY(buildTreeOnDevice(mesh, st));
     {
-        float scale = 0.f;
-        for (float c : mesh->hVerts) scale = std::max(scale, std::fabs(c));
-        mesh->bvhCoordScale = scale;
         SDF_TRY(mesh->dBvhSph32.reserve(nSph));
         k_sph32<<<gridFor(nSph, 256), 256, 0, st>>>(mesh->dBvhSph.p, nSph, mesh->dBvhSph32.p);
     }
@@ -1772,6 +1839,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     const uint32_t maxChunks = T / kGsChunk + maxTasks + 1u;
     DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, totL, totR, swapped, cntL, cntR, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
     DevBuf<int> dims; DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
+    DevBuf<uint32_t> sumBase, sumStatus; DevBuf<double> csum, cin; std::vector<uint32_t> sumBaseH; std::vector<size_t> sumChunkAt;
     SDF_TRY(K.reserve(T)); SDF_TRY(snaps.reserve((size_t)T * (nTop ? nTop : 1))); SDF_TRY(ctr.reserve(8)); SDF_TRY(dFail.reserve(1));
     if (nTop) {
         SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(totL.reserve(maxTasks)); SDF_TRY(totR.reserve(maxTasks));
@@ -1780,6 +1848,20 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         std::vector<TopNode> flat; flat.reserve(tableNodes);
         for (size_t l = 0; l < nTop; l++) flat.insert(flat.end(), levels[l].begin(), levels[l].end());
         SDF_HIP_CHECK(hipMemcpyAsync(dNodes.p, flat.data(), sizeof(TopNode) * tableNodes, hipMemcpyHostToDevice, st));
+        // the chunks of the parallel centre sums (k_csum_*): per level the first chunk of every node (+ the end), numbered through the levels
+        sumBaseH.assign(tableNodes + nTop + 1, 0u); sumChunkAt.assign(nTop + 1, 0);
+        size_t chunksAll = 0;
+        for (size_t l = 0; l < nTop; l++) {
+            sumChunkAt[l] = chunksAll;
+            uint32_t run = 0;
+            for (size_t j = 0; j < levels[l].size(); j++) { sumBaseH[levelAt[l] + l + j] = run; run += (levels[l][j].e - levels[l][j].b + kSumChunk - 1u) / kSumChunk; }
+            sumBaseH[levelAt[l] + l + levels[l].size()] = run;
+            chunksAll += run;
+        }
+        sumChunkAt[nTop] = chunksAll;
+        SDF_TRY(sumBase.reserve(sumBaseH.size())); SDF_TRY(csum.reserve(3 * chunksAll + 3)); SDF_TRY(cin.reserve(3 * chunksAll + 3)); SDF_TRY(sumStatus.reserve(tableNodes + 1));
+        SDF_HIP_CHECK(hipMemcpyAsync(sumBase.p, sumBaseH.data(), 4 * sumBaseH.size(), hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipMemsetAsync(sumStatus.p + tableNodes, 0, 4, st));          // [tableNodes]: nodes summed by the serial chain
         SDF_HIP_CHECK(hipStreamSynchronize(st));        // (flat goes out of scope)
         k_top_init<<<gridFor(tableNodes, 256), 256, 0, st>>>(box.p, r2.p, (uint32_t)tableNodes);
     }
@@ -1804,27 +1886,8 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         for (hipStream_t& s : mesh->ctx->bvhSide) if (!s) SDF_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         side.s = mesh->ctx->bvhSide[0]; side1.s = mesh->ctx->bvhSide[1];
     } else { side.s = st; side1.s = st; }
-    // Centre sums of LONG nodes (more than kHostSumMin = 200 000 triangles, SDFHIP_BVH_HOST_SUM_MIN: levels 1 - 2 at 1.31 M triangles, none at
-    // 327 680) on host threads instead of k_top_sums: a chain of dependent fp64 additions is what bounds them — 13 ms per 655 360 triangles on a
-    // lane, 2.3 ms on a CPU core INCLUDING the gather and the 47 MB download (measured) — and the device's side stream runs the levels one after
-    // the other.  Measured at 1.31 M triangles (profiles/r03_bvh_host_sums_thresholds.txt): nodes above 400 000 on the host (level 1 only) 20.4 ms,
-    // exactly as without — it was the deeper levels queued behind each other that the build waited 5.3 ms for, not level 1 —; above 200 000:
-    // 15.9 ms; above 100 000: 14.5 ms, but + 0.2 ms at 327 680 triangles, where there is no wait to remove.  A worker thread does everything for such a level on side1, so that the thread driving the rounds never waits for a pageable
-    // copy: gather of the level's coordinates in range order on the device, download, one adding thread per node (the planner's loop), centres
-    // back up, radii and records as for the other levels.  Declared BEFORE the guard below: the worker is joined, then the side streams are
-    // waited for, then the jobs' buffers go.
-    const uint32_t kHostSumMin = [] { const char* e = getenv("SDFHIP_BVH_HOST_SUM_MIN"); const long v = e ? atol(e) : 0; return v >= 1000 ? (uint32_t)v : 200000u; }();
-    struct HostSumJob { size_t level = 0; DevBuf<float> dG; std::unique_ptr<float, FreeDeleter> hG; hipEvent_t sortedBefore = nullptr; std::vector<double> centres; };
-    struct HostSumQueue { std::mutex m; std::condition_variable cv; std::vector<std::unique_ptr<HostSumJob>> jobs; bool closed = false; } hostQueue;
     // whatever happens below, nothing of this call may still run on the side streams when its buffers are released
     struct SideGuard { hipStream_t a, b; ~SideGuard() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } sideGuard{useSide ? side.s : nullptr, useSide ? side1.s : nullptr};
-    const bool hostSumsOn = useSide;
-    struct HostSumWorker {
-        std::thread th; int rc = SDFHIP_OK; double busy = 0; HostSumQueue* q = nullptr;
-        void finish() { if (q) { { std::lock_guard<std::mutex> g(q->m); q->closed = true; } q->cv.notify_all(); } if (th.joinable()) th.join(); }
-        ~HostSumWorker() { finish(); }
-    } hostWorker;
-    hostWorker.q = &hostQueue;
     // ctr: [0], [1] = pending ranges of this / the next round (alternating), [2] = parts for k_sort_parts, [3] = for k_sort_tiny, [4] = flags
     uint32_t hostCtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t rounds = 0;
@@ -1887,56 +1950,15 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
                 SDF_HIP_CHECK(hipStreamWaitEvent(ss, sorted[l].e, 0));
             }
             const uint32_t nc = (uint32_t)levels[l + 1].size(); const size_t at = levelAt[l + 1];
-            uint32_t shortest = 0xFFFFFFFFu; for (const TopNode& nd : levels[l + 1]) shortest = std::min(shortest, nd.e - nd.b);
-            if (hostSumsOn && shortest > kHostSumMin && nc <= 16u) {
-                std::unique_ptr<HostSumJob> job(new HostSumJob());
-                job->level = l + 1; job->sortedBefore = sorted[l].e;
-                SDF_TRY(job->dG.reserve(9 * (size_t)T));
-                job->hG.reset((float*)plannerAlloc(36 * (size_t)T));
-                SDF_REQUIRE(job->hG != nullptr, "out of host memory");
-                { std::lock_guard<std::mutex> g(hostQueue.m); hostQueue.jobs.push_back(std::move(job)); }
-                hostQueue.cv.notify_all();
-                if (!hostWorker.th.joinable()) {
-                    const int device = mesh->ctx->device; hipStream_t s1 = side1.s;
-                    hostWorker.th = std::thread([&, device, s1]() {
-                        auto fail = [&](int rc) { if (hostWorker.rc == SDFHIP_OK) hostWorker.rc = rc; };
-                        if (hipSetDevice(device) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
-                        for (size_t next = 0;;) {
-                            HostSumJob* jp = nullptr;
-                            { std::unique_lock<std::mutex> g(hostQueue.m); hostQueue.cv.wait(g, [&] { return next < hostQueue.jobs.size() || hostQueue.closed; }); if (next < hostQueue.jobs.size()) jp = hostQueue.jobs[next++].get(); }
-                            if (!jp) return;                           // closed and nothing left
-                            const double tj = nowSeconds();
-                            HostSumJob& job = *jp;
-                            const std::vector<TopNode>& nodes = levels[job.level];
-                            const uint32_t nc2 = (uint32_t)nodes.size(); const size_t at2 = levelAt[job.level];
-                            const uint32_t* snapPrev = snaps.p + (size_t)T * (job.level - 1);      // the order this level's parent left = this level's range order
-                            if (hipStreamWaitEvent(s1, job.sortedBefore, 0) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
-                            k_top_gather9<<<gridFor(9ull * T, 256), 256, 0, s1>>>(snapPrev, reinterpret_cast<const float*>(triV), T, job.dG.p);
-                            if (hipMemcpyAsync(job.hG.get(), job.dG.p, 36 * (size_t)T, hipMemcpyDeviceToHost, s1) != hipSuccess || hipStreamSynchronize(s1) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
-                            job.centres.assign(3 * (size_t)nc2, 0.0);
-                            std::vector<std::thread> adders;
-                            for (uint32_t j = 0; j < nc2; j++) adders.emplace_back([&, j]() {
-                                const float* q = job.hG.get() + 9 * (size_t)nodes[j].b;
-                                const size_t nv = 3 * (size_t)(nodes[j].e - nodes[j].b);
-                                double sx = 0.0, sy = 0.0, sz = 0.0;
-                                for (size_t v = 0; v < nv; v++) { sx += (double)q[3 * v]; sy += (double)q[3 * v + 1]; sz += (double)q[3 * v + 2]; }
-                                const double cnt = (double)nv;
-                                job.centres[3 * (size_t)j] = sx / cnt; job.centres[3 * (size_t)j + 1] = sy / cnt; job.centres[3 * (size_t)j + 2] = sz / cnt;
-                            });
-                            for (std::thread& a : adders) a.join();
-                            if (hipMemcpyAsync(centres.p + 3 * at2, job.centres.data(), 24 * (size_t)nc2, hipMemcpyHostToDevice, s1) != hipSuccess) { fail(SDFHIP_E_HIP); return; }
-                            k_top_radius<<<gridFor(T, 1024), 256, 0, s1>>>(snapPrev, triV, dNodes.p + at2, nc2, T, centres.p + 3 * at2, r2.p + at2);
-                            k_top_write<<<gridFor(nc2, 256), 256, 0, s1>>>(dNodes.p + at2, nc2, centres.p + 3 * at2, r2.p + at2, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
-                            if (hipGetLastError() != hipSuccess) { fail(SDFHIP_E_HIP); return; }
-                            hostWorker.busy += nowSeconds() - tj;
-                        }
-                    });
-                }
-            } else {
-                k_top_sums<<<nc, 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, centres.p + 3 * at);
-                k_top_radius<<<gridFor(T, 1024), 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, T, centres.p + 3 * at, r2.p + at);
-                k_top_write<<<gridFor(nc, 256), 256, 0, ss>>>(dNodes.p + at, nc, centres.p + 3 * at, r2.p + at, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
-            }
+            // centres: in parallel and verified, the serial chain for the nodes whose verification failed (k_csum_*, k_top_sums)
+            const uint32_t chunks = (uint32_t)(sumChunkAt[l + 2 <= nTop ? l + 2 : nTop] - sumChunkAt[l + 1]);
+            const CsumLevel CL{snap, triV, dNodes.p + at, nc, sumBase.p + at + (l + 1), chunks, csum.p + 3 * sumChunkAt[l + 1], cin.p + 3 * sumChunkAt[l + 1], sumStatus.p + at, centres.p + 3 * at};
+            k_csum_local<<<gridFor(chunks, 256), 256, 0, ss>>>(CL);
+            k_csum_scan<<<nc, 256, 0, ss>>>(CL);
+            k_csum_check<<<gridFor(chunks, 256), 256, 0, ss>>>(CL);
+            k_top_sums<<<nc, 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, centres.p + 3 * at, sumStatus.p + at, sumStatus.p + tableNodes);
+            k_top_radius<<<gridFor(T, 1024), 256, 0, ss>>>(snap, triV, dNodes.p + at, nc, T, centres.p + 3 * at, r2.p + at);
+            k_top_write<<<gridFor(nc, 256), 256, 0, ss>>>(dNodes.p + at, nc, centres.p + 3 * at, r2.p + at, 1, mesh->dBvhSph.p, mesh->dBvhKids.p);
         }
     }
     const double tTop = nowSeconds();
@@ -1958,10 +1980,12 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     if (timing) SDF_HIP_CHECK(hipMemcpyAsync(clk, dClk.p, 32, hipMemcpyDeviceToHost, st));
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     const double tSub = nowSeconds();
-    hostWorker.finish();                             // (it enqueues on side1: joined before side1 is waited for)
-    if (hostWorker.rc != SDFHIP_OK) { setError("BVH build: the host centre sums failed"); return hostWorker.rc; }
     if (nTop && useSide) { SDF_HIP_CHECK(hipStreamSynchronize(side.s)); SDF_HIP_CHECK(hipStreamSynchronize(side1.s)); }
-    if (timing && !hostQueue.jobs.empty()) fprintf(stderr, "[sdfhip] bvh on the device: centre sums of %zu long level(s) on host threads, %.4f s from the level's sort being waited for to its records being queued\n", hostQueue.jobs.size(), hostWorker.busy);
+    if (timing && nTop) {
+        uint32_t serial = 0;
+        if (hipMemcpy(&serial, sumStatus.p + tableNodes, 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+        fprintf(stderr, "[sdfhip] bvh on the device: centre sums of %zu nodes in parallel (verified chunk by chunk), %u of them redone by the serial chain\n", tableNodes - levels[0].size(), serial);
+    }
     if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
                         nTop, rounds, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
     if (failed || hostCtr[4]) return SDFHIP_E_UNSUPPORTED;

@@ -476,11 +476,12 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
     for (uint64_t i = 0; i < 3ull * nt; i++) SDF_REQUIRE(indices[i] < nv, "triangle index out of range");
     // NaN / infinite coordinates make the reference's std::sort comparator inconsistent (undefined behaviour): rejected here
-    for (uint64_t i = 0; i < 3ull * nv; i++) SDF_REQUIRE(std::isfinite(xyz[i]), "non-finite vertex coordinate");
+    float coordScale = 0.f;          // max |coordinate|: bounds the fp32 rounding of the BVH's sphere centres (sdfhip_mesh::bvhCoordScale)
+    for (uint64_t i = 0; i < 3ull * nv; i++) { SDF_REQUIRE(std::isfinite(xyz[i]), "non-finite vertex coordinate"); coordScale = std::max(coordScale, std::fabs(xyz[i])); }
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     std::unique_ptr<sdfhip_mesh> owner(new sdfhip_mesh());      // released on success only: every early return below frees it
     sdfhip_mesh* m = owner.get();
-    m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;
+    m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt; m->bvhCoordScale = coordScale;
     m->hVerts.assign(xyz, xyz + 3ull * nv);
     m->hIdx.assign(indices, indices + 3ull * nt);
     if (flags & SDFHIP_MESH_PLAN_BVH_EARLY) sdfhip::startEarlyBvhPlan(m);      // the planner (host threads) runs under everything below

@@ -807,7 +807,7 @@ def test_imported_bvh_of_another_shape_is_refused(gpu_ctx):
 
 @pytest.mark.parametrize("subtree,build", [("1", "host"), ("4096", "device"), pytest.param("512", "device", marks=pytest.mark.soak),
                                            pytest.param("512", "host", marks=pytest.mark.soak), pytest.param("8192", "host", marks=pytest.mark.soak),
-                                           pytest.param("8192", "device", marks=pytest.mark.soak), pytest.param("4096", "device-hostsums", marks=pytest.mark.soak)])
+                                           pytest.param("8192", "device", marks=pytest.mark.soak)])
 def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build):
     """The tree as the DEVICE holds it after sdfhip_mesh_build_bvh — top planned on the host, every range of at most 4096 triangles built by
     k_bvh_subtrees (ordered fp64 centre sums, libstdc++'s introsort restated per lane) — walked together with the oracle's from the root:
@@ -817,17 +817,17 @@ def test_hybrid_bvh_plan_equals_the_oracles_tree(oracle, gpu_ctx, subtree, build
     # the switch is read once per process: the hybrid plans run in a child
     code = "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_octree as t; t._hybrid_cases_check()" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     # build == "device": the top of the tree is sorted on the device as well (SDFHIP_BVH_BUILD=device: introsort as rounds over global memory,
-    # centre sums three lanes per node) — no host plan at all unless a long range exhausts introsort's depth limit
-    # build == "device-hostsums": the device build with the centre sums of every level of at most 16 nodes of more than 1000 triangles on the
-    # host worker thread (SDFHIP_BVH_HOST_SUM_MIN=1000; the default, 200 000, reaches it only on the 1.31 M-triangle mesh)
+    # centre sums in parallel, verified chunk by chunk, the serial chain for the nodes whose verification fails: k_csum_*) — no host plan at
+    # all unless a long range exhausts introsort's depth limit
     env = dict(os.environ, SDFHIP_BVH_DEVICE_SUBTREES=subtree, SDFHIP_BVH_BUILD="device" if build.startswith("device") else build, SDFHIP_TIMING="1")
-    if build == "device-hostsums": env["SDFHIP_BVH_HOST_SUM_MIN"] = "1000"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "hybrid cases ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-    if build == "device-hostsums":
-        jobs = sum(int(l.split("centre sums of ")[1].split()[0]) for l in r.stderr.splitlines() if "long level(s) on host threads" in l)
-        assert jobs >= 20, f"only {jobs} levels were summed on the host: the variant no longer exercises the worker"
     if build.startswith("device"):
+        # both ways of summing a node's centre were exercised: verified in parallel (the rule) and redone by the serial chain (the case whose
+        # coordinates span seven decades: its additions round)
+        lines = [l for l in r.stderr.splitlines() if "centre sums of" in l and "in parallel" in l]
+        par = sum(int(l.split("centre sums of ")[1].split()[0]) for l in lines); ser = sum(int(l.split("), ")[1].split()[0]) for l in lines)
+        assert par >= 100 and 1 <= ser < par // 4, (par, ser)
         built = r.stderr.count("bvh: built on the device")
         assert built >= len(_hybrid_cases()) - 2, f"only {built} trees were built on the device:\n" + "\n".join(l for l in r.stderr.splitlines() if "gave up" in l)[-2000:]
 
@@ -849,6 +849,10 @@ def _hybrid_cases():
     for n in (4095, 4096, 4097, 8191, 8193, 12289):                           # around the threshold: the root handed over whole, or split just above it
         cases.append((v5, f5[:n]))
     cases.append(meshgen.torus_knot(nu=512, nv=80))
+    # coordinates over seven decades (a soup as far as geometry goes: the tree only sees vertices): fp64 sums of such fp32 values ROUND, the
+    # verification of the parallel centre sums fails for the long nodes and the serial chain redoes them
+    wide = (v * np.float32(10.0) ** rng.uniform(-4.0, 3.0, size=(len(v), 1)).astype(np.float32)).astype(np.float32)
+    cases.append((wide, f))
     cases.append(meshgen.bumpy_icosphere(7))
     cases.append(meshgen.bumpy_icosphere(8))                                  # 1.31 M triangles: ranges that exhaust introsort's depth limit (heap sort)
     return cases
