@@ -2040,6 +2040,18 @@ static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st
     return failed ? SDFHIP_E_UNSUPPORTED : SDFHIP_OK;
 }
 
+// the mesh's arrays on the host (the host planner's input): kept from the mesh's creation when the host planner is the builder, fetched
+// from the device when the device builder hands a tree over to it
+static int hostArrays(sdfhip_mesh* mesh) {
+    if (!mesh->hVerts.empty() && !mesh->hIdx.empty()) return SDFHIP_OK;
+    hipStream_t st = mesh->ctx->stream;
+    mesh->hVerts.resize(3ull * mesh->numVertices); mesh->hIdx.resize(3ull * mesh->numTriangles);
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->hVerts.data(), mesh->dVerts.p, 4 * mesh->hVerts.size(), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(mesh->hIdx.data(), mesh->dIdx.p, 4 * mesh->hIdx.size(), hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    return SDFHIP_OK;
+}
+
 extern "C" {
 
 int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
@@ -2062,10 +2074,11 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     PlannedBvh P;
     if (mesh->early.th.joinable()) mesh->early.th.join();        // a plan started under the mesh preparation (sdfhip_mesh_create_opt)
     if (mesh->early.plan) { P = std::move(*static_cast<PlannedBvh*>(mesh->early.plan)); delete static_cast<PlannedBvh*>(mesh->early.plan); mesh->early.plan = nullptr; }
-    else P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, offload);
+    else { SDF_TRY(hostArrays(mesh)); P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, offload); }
     double tPlanned = nowSeconds();
     int rc = installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST, false, P.tasks.empty() ? nullptr : &P);
     if (rc == SDFHIP_E_UNSUPPORTED && !P.tasks.empty()) {         // a device sort met introsort's depth limit: libstdc++'s heap sort decides that order
+        SDF_TRY(hostArrays(mesh));
         P = planBvhHost(mesh->hVerts.data(), mesh->hIdx.data(), mesh->numTriangles, 0);
         tPlanned = nowSeconds();
         rc = installBvh(mesh, P.sph.get(), P.kids.get(), SDFHIP_HOST);

@@ -134,3 +134,20 @@ def test_ctypes_struct_mirrors_have_the_c_sizes():
     out = (C.c_uint64 * 3)()
     lib().sdfhip_abi_sizes(out)
     assert [int(x) for x in out] == [C.sizeof(OctreeInfo), C.sizeof(OctreeParams), C.sizeof(ExactInfo)]
+
+
+def test_every_switch_of_the_library_is_listed_here_or_in_a_named_test():
+    """The census the header of this file states: a switch added to the library without a test fails here."""
+    import glob, re
+    found = set()
+    for path in glob.glob(os.path.join(ROOT, "sdflib_amd", "csrc", "*.h*")):
+        found |= set(re.findall(r'getenv\("(SDFHIP_[A-Z_0-9]+)"\)', open(path).read()))
+    from test_gpu_switches import _CASES
+    here = {k for env, _ in _CASES.values() for k in env}
+    elsewhere = {"SDFHIP_BVH_BUILD", "SDFHIP_BVH_DEVICE_SUBTREES", "SDFHIP_TIMING", "SDFHIP_BVH_SORT_THREADS", "SDFHIP_BVH_PAR_DEPTH", "SDFHIP_BVH_MIN_PARALLEL",
+                 "SDFHIP_BVH_PAR_PARTITION", "SDFHIP_MULTI_CUTS", "SDFHIP_EXACT_LISTS_MB", "SDFHIP_QUERY_CHUNK"}
+    assert found <= here | elsewhere, sorted(found - here - elsewhere)
+    assert len(found) <= 20, sorted(found)
+    tests_text = "".join(open(p).read() for p in glob.glob(os.path.join(ROOT, "tests", "*.py")))
+    for k in elsewhere & found:
+        assert k in tests_text, k

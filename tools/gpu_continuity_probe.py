@@ -1,7 +1,7 @@
 """CONTINUITY build of the C2 configuration with the phase times (SDFHIP_TIMING=1)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("SDFHIP_TIMING", "1")
+if not os.environ.get("PROBE_QUIET"): os.environ.setdefault("SDFHIP_TIMING", "1")
 import torch
 import sdflib_amd as S
 from sdflib_amd import meshgen

@@ -3,7 +3,7 @@
 # build's launches in start order, and the idle gaps between consecutive kernels aggregated by (kernel before -> kernel after).
 # Usage: tools/trace_gaps.sh [ENV=V ...]
 export TMPDIR=/tmp; REPO=$PWD; OUT=$REPO/gpurun_out/trace_gaps; mkdir -p $OUT; cd /tmp
-env SDFHIP_TIMING= "$@" timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/${PROBE_SCRIPT:-gpu_continuity_probe.py} > $OUT/t.log 2>&1
+env -u SDFHIP_TIMING PROBE_QUIET=1 "$@" timeout 300 rocprofv3 --kernel-trace -d $OUT/t -o p -- python $REPO/tools/${PROBE_SCRIPT:-gpu_continuity_probe.py} > $OUT/t.log 2>&1
 grep -E "^build|build_bvh" $OUT/t.log | tail -4
 python - <<PY
 import sqlite3,glob,collections
