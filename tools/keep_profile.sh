@@ -4,6 +4,7 @@
 TAG=$1
 SRC=gpurun_out/prof_$TAG
 for k in kernel_stats pmc pmc_sq; do cp $SRC/summary_$k.csv profiles/${TAG}_bench_$k.csv; done
+[ -f $SRC/summary_copies.txt ] && cp $SRC/summary_copies.txt profiles/${TAG}_bench_copies.txt
 python - <<PY
 import json, subprocess
 m = json.load(open("$SRC/summary_meta.json"))

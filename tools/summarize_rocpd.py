@@ -73,6 +73,30 @@ def main(src, prefix):
             if k.startswith("sdfhip") and any(c in v for c in SQ):
                 n = max(v[c][0] for c in SQ if c in v)
                 w.writerow([k, n] + [f"{v[c][1]:.6g}" if c in v else "" for c in SQ])
+    # Where the runtime's own copy / fill kernels come from (hipMemcpyAsync device-to-device and pageable host copies run as
+    # __amd_rocclr_copyBuffer, hipMemsetAsync as fillBufferAligned): by duration class and by the library kernel launched just before them.
+    with open(prefix + "_copies.txt", "w") as f:
+        seq = db.execute("select name, start, end, grid_x from kernels order by start").fetchall()
+        for what in ("__amd_rocclr_copyBuffer", "__amd_rocclr_fillBufferAligned"):
+            classes = {"< 10 us": [0, 0], "10 - 100 us": [0, 0], "0.1 - 1 ms": [0, 0], ">= 1 ms": [0, 0]}
+            before = {}
+            last = "(start)"
+            for name, st, en, grid in seq:
+                if what in name:
+                    d = en - st
+                    c = "< 10 us" if d < 10_000 else ("10 - 100 us" if d < 100_000 else ("0.1 - 1 ms" if d < 1_000_000 else ">= 1 ms"))
+                    classes[c][0] += 1; classes[c][1] += d
+                    e = before.setdefault(last, [0, 0]); e[0] += 1; e[1] += d
+                elif "rocclr" not in name:
+                    last = short(name)
+            n = sum(v[0] for v in classes.values()); t = sum(v[1] for v in classes.values())
+            f.write(f"{what}: {n} launches, {t / 1e6:.2f} ms ({100 * t / tot:.1f} % of the trace's kernel time)\n")
+            for c, (k, d) in classes.items():
+                f.write(f"    {c:12s} {k:6d} launches {d / 1e6:9.3f} ms\n")
+            f.write("  by the library kernel launched before them:\n")
+            for k, (c, d) in sorted(before.items(), key=lambda kv: -kv[1][1])[:14]:
+                f.write(f"    {d / 1e6:9.3f} ms in {c:5d}  after {k}\n")
+    print(open(prefix + "_copies.txt").read())
     print(open(prefix + "_kernel_stats.csv").read()[:3000])
     print(open(prefix + "_pmc.csv").read())
 
