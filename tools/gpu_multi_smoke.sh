@@ -35,6 +35,11 @@ cat "$OUT/multi_smoke_cpp.log"
 grep -q "transport rccl" "$OUT/multi_smoke_cpp.log" || { echo "FAIL: the RCCL transport was not used"; rc=1; }
 [ "$(grep -c 'mismatches 0 scalars_equal 1' "$OUT/multi_smoke_cpp.log")" -eq 3 ] || { echo "FAIL: arrays differ from the single-device build"; rc=1; }
 
+echo "== 1b. the same over staged device-to-device copies (SDFHIP_MULTI_TRANSPORT=copy between DISTINCT devices)"
+SDFHIP_MULTI_TRANSPORT=copy timeout 600 /tmp/sdflib_amd_multi_smoke /tmp/ms_v.bin /tmp/ms_f.bin /tmp/ms_box.bin "$DEVS" > "$OUT/multi_smoke_cpp_copy.log" 2>&1 || rc=1
+grep -q "transport copy" "$OUT/multi_smoke_cpp_copy.log" || { echo "FAIL: the copy transport was not used"; rc=1; }
+[ "$(grep -c 'mismatches 0 scalars_equal 1' "$OUT/multi_smoke_cpp_copy.log")" -eq 3 ] || { echo "FAIL (copy transport): arrays differ from the single-device build"; rc=1; }
+
 echo "== 2. bench.py --gpus $N (torch.distributed nccl, one process per GPU)"
 timeout 900 python bench.py --gpus "$N" --steps 3 --warmup 1 --subdiv 5 --depth 6 --queries 1000000 --no-cpu-baseline > "$OUT/multi_smoke_bench.json" 2> "$OUT/multi_smoke_bench.err" || rc=1
 python - "$OUT/multi_smoke_bench.json" "$N" <<'PY' || rc=1
