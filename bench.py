@@ -422,10 +422,14 @@ def end_to_end_build(ctx, v, f, box, depth, start_depth, dev):
     torch.cuda.synchronize(); t3 = time.perf_counter()
     t.get_distance(q, out=o); torch.cuda.synchronize(); t4 = time.perf_counter()
     t.get_distance(q, out=o); torch.cuda.synchronize(); t5 = time.perf_counter()
+    words = t.get_octree_data(); t6 = time.perf_counter()       # what the C++ class's constructor does for getOctreeData(): the reference's array rebuilt from the layout + downloaded
+    array_s, array_mb = t6 - t5, 4 * len(words) / 1e6
+    del words
     t.close()
     return {"end_to_end_s": round(tb - t0, 4), "mesh_prep_s": round(t1 - t0, 4), "bvh_s_after_mesh": round(t2 - t1, 4),
             "octree_s": round(tb - t2, 4), "query_layout_s": round(max((t4 - t3) - (t5 - t4), 0.0), 5),
             "time_to_first_query_s": round((tb - t0) + (t4 - t3), 4),
+            "array_download_s": round(array_s, 4), "array_download_note": f"the reference's node array ({array_mb:.0f} MB) rebuilt from the query layout and copied to a pageable host array (getOctreeData / saveToFile)",
             "time_to_first_query_note": "host arrays in -> the first batch of 65 536 distances back (mesh upload + TriangleData, BVH, octree build, first query incl. anything it makes once)"}
 
 

@@ -337,6 +337,7 @@ int octreeMaterialize(sdfhip_octree* T) {
 int octreeDownload(sdfhip_octree* T, uint32_t* out_words, int where) {
     hipStream_t st = T->ctx->stream;
     std::lock_guard<std::mutex> own(T->qLock);
+    AllocScope allocScope(st);       // the transient array comes from the context's block cache (what every built tree's download goes through)
     if (where == SDFHIP_DEVICE) { SDF_TRY(octreeWordsInto(T, out_words)); SDF_HIP_CHECK(hipStreamSynchronize(st)); return SDFHIP_OK; }
     DevBuf<uint32_t> tmp;                              // a compacted tree is rebuilt in a transient block: its footprint stays what it was
     const uint32_t* src = T->data.p;
