@@ -32,7 +32,15 @@ def worker(rank, world, port, seed0, cases, q):
             tree, _ = sdist.build_octree_sharded(mesh, box, depth, start, thr, rank, world, dev)
             single = S.OctreeSdf(mesh, box, depth, start, thr, num_threads=2)
             assert np.array_equal(tree.get_octree_data(), single.get_octree_data()), f"seed {s}: sharded OctreeSdf"
-            assert np.array_equal(bits(tree.get_distance(pts)), bits(single.get_distance(pts))), f"seed {s}: sharded OctreeSdf answers"
+            dt, ds = tree.get_distance(pts), single.get_distance(pts)
+            if not np.array_equal(bits(dt), bits(ds)):      # which side is wrong, and does it stay wrong
+                from oracle import pyoracle as O
+                i = single.info
+                ref = O.octree_query_raw(single.get_octree_data(), single.get_grid_bounding_box(), i.start_grid_size, i.min_border_value, pts)
+                dt2, ds2 = tree.get_distance(pts), single.get_distance(pts)
+                raise AssertionError(f"seed {s} rank {rank}: sharded OctreeSdf answers: reassembled tree differs from the oracle at {int((bits(dt) != bits(ref)).sum())} points "
+                                     f"(asked again: {int((bits(dt2) != bits(ref)).sum())}), single build at {int((bits(ds) != bits(ref)).sum())} (again: {int((bits(ds2) != bits(ref)).sum())}); "
+                                     f"cell sizes {tree.info.start_grid_cell_size!r} / {i.start_grid_cell_size!r}, first differing point {pts[np.nonzero(bits(dt) != bits(ds))[0][0]]}, box {box}")
             ct, _ = sdist.build_continuity_sharded(mesh, box, depth, start, thr, rank, world, dev)
             c1 = S.OctreeSdf(mesh, box, depth, start, thr, init_algorithm=S.ALG_CONTINUITY, num_threads=2)
             assert np.array_equal(ct.get_octree_data(), c1.get_octree_data()), f"seed {s}: CONTINUITY with shared traversals"
