@@ -561,7 +561,7 @@ def extras(tree, mesh, box, pts, out, dev, rank, world=1, prof=None):
     q = pts
     if world == 1:      # the same build again: without the first build's one-time costs (scratch blocks of the context, code objects)
         reb = []
-        for _ in range(2):      # (two: one rebuild in four was seen to take 0.2 s on the box - a device allocation, not the kernels; both are reported)
+        for _ in range(2):      # (two, both reported: on some boxes a multi-GB hipMalloc takes 0.2-0.3 s; since r05z2 the caches keep the build's scratch below their mark, 1/32 of the device, and a rebuild allocates nothing)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             ex2 = S.ExactOctreeSdf(mesh, box, 7, 3, 128)
             torch.cuda.synchronize(); reb.append(round(time.perf_counter() - t0, 4))

@@ -104,7 +104,7 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
 /* Device memory the context keeps for reuse (transient blocks of past builds in per-stream caches, the nearest search's candidate
- * lists, host-pointer staging buffers).  Kept automatically below a high-water mark (SDFHIP_CACHE_KEEP_MB, default 512, applied when a
+ * lists, host-pointer staging buffers).  Kept automatically below a high-water mark (SDFHIP_CACHE_KEEP_MB, default 1/32 of the device memory, applied when a
  * build returns); sdfhip_ctx_trim waits for the context's stream and frees what exceeds keep_bytes (0: everything). */
 int sdfhip_ctx_trim(sdfhip_ctx* ctx, uint64_t keep_bytes);
 int sdfhip_ctx_cached_bytes(sdfhip_ctx* ctx, uint64_t* out_bytes);

@@ -777,6 +777,9 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     hipStream_t st = ctx->stream;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const double tStart = nowSeconds();
+    static const bool timing = getenv("SDFHIP_TIMING") != nullptr;      // per-level wall times (every level ends in a stream synchronisation) and the allocator's share
+    const double alloc0 = g_allocSeconds(); const long allocCalls0 = g_allocCalls();
+    std::vector<double> levelSeconds;
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
     E->ctx = ctx; E->mesh = mesh;
     const float sx = box_max[0] - box_min[0], sy = box_max[1] - box_min[1], sz = box_max[2] - box_min[2];
@@ -850,9 +853,11 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     }
 
     const uint32_t* prevList = allList.p;
+    levelSeconds.push_back(nowSeconds() - tStart);
     for (uint32_t d = sod; d <= maxDepth; d++) {
         ExLevel* L = LV[d - sod].get();
         if (!L || L->n == 0) break;
+        const double tLevel = nowSeconds();
         if (d == startDepth && d > sod) {
             std::unique_ptr<ExLevel> R(new ExLevel());
             R->depth = d; R->n = G3; R->half = L->half;
@@ -948,6 +953,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         SDF_HIP_CHECK(hipStreamSynchronize(st));
         L->midTri.release(); L->center.release(); L->cornerTri.release();
         prevList = L->list.p;
+        levelSeconds.push_back(nowSeconds() - tLevel);
     }
 
     // ---- merge steps, deepest first: depth maxDepth-1 then maxDepth-2
@@ -1026,6 +1032,12 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     E->levels.clear();
     E->built = true;
     I.seconds_total = nowSeconds() - tStart;
+    if (timing) {
+        std::string per; char b[32];
+        for (size_t i = 0; i < levelSeconds.size(); i++) { snprintf(b, sizeof b, "%s%.1f", i ? " " : "", 1e3 * levelSeconds[i]); per += b; }
+        fprintf(stderr, "[sdfhip] exact build: %.1f ms (roots, then the levels from depth %u: %s ms); block cache / hipMalloc / hipFree inside: %ld calls, %.1f ms\n",
+                1e3 * I.seconds_total, sod, per.c_str(), g_allocCalls() - allocCalls0, 1e3 * (g_allocSeconds() - alloc0));
+    }
     *out = E.release();
     return SDFHIP_OK;
 }

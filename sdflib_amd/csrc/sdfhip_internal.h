@@ -77,7 +77,7 @@ struct AllocScope {
 // (a build asks for ~250 of them) are carved out of 64 MB slabs in power-of-two size classes, a released block waits in its class — a
 // context's first build costs a handful of hipMalloc calls, later ones none (250 runtime calls of ~14 us each before).
 // How long cached memory lives: (i) a HIGH-WATER MARK — when an API call that allocated through the cache returns (~AllocScope) and the
-// (device, stream) lists hold more than keepBytes() (SDFHIP_CACHE_KEEP_MB, default 512), the largest blocks, then idle slabs, are freed
+// (device, stream) lists hold more than keepBytes() (SDFHIP_CACHE_KEEP_MB, default 1/32 of the device's memory), the largest blocks, then idle slabs, are freed
 // until they do not: a process that built one huge tree does not sit on that build's peak scratch for ever; (ii) sdfhip_ctx_trim(ctx,
 // keep_bytes) on request; (iii) when the last context of a (device, stream) is destroyed (trimStream) — blocks released after that are
 // freed at once; (iv) when an allocation fails, everything cached on the device is freed and the request retried once (trimDevice).
@@ -90,7 +90,19 @@ struct BigBlockCache {
     std::vector<std::pair<Key, int>> refs;            // live contexts per (device, stream)
     static constexpr size_t kSlabBytes = 64u << 20;
     static BigBlockCache& get() { static BigBlockCache c; return c; }
-    static size_t keepBytes() { static const size_t v = (size_t)(getenv("SDFHIP_CACHE_KEEP_MB") ? strtoull(getenv("SDFHIP_CACHE_KEEP_MB"), nullptr, 10) : 512ull) << 20; return v; }
+    // Default mark: 1/32 of the device's memory (9 GB of an MI355X's 288 GB).  The transient blocks of the largest builds the tests and
+    // the bench run (ExactOctreeSdf depth 7: 5.7 GB of cull scratch; OctreeSdf depth 9: 1.6 GB) stay below it, so a rebuild asks the runtime
+    // for nothing: multi-GB hipMalloc calls are usually lazy (1-3 ms for 5.7 GB) but were seen to take 0.2-0.3 s each on some boxes
+    // (profiles/r05z_bench_n1.json's exact leg, the round-4 "one rebuild in four"); with 512 MB every large build paid them again.
+    static size_t keepBytes() {
+        static const size_t v = [] {
+            if (const char* e = getenv("SDFHIP_CACHE_KEEP_MB")) return (size_t)strtoull(e, nullptr, 10) << 20;
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || totalB == 0) { (void)hipGetLastError(); return (size_t)512 << 20; }
+            return totalB / 32;
+        }();
+        return v;
+    }
     Lists& listOf(Key k) { for (auto& e : lists) if (!(e.first < k) && !(k < e.first)) return e.second; lists.emplace_back(k, Lists()); return lists.back().second; }
     void addRef(int dev, hipStream_t st) { std::lock_guard<std::mutex> g(m); for (auto& r : refs) if (r.first.device == dev && r.first.stream == st) { r.second++; return; } refs.emplace_back(Key{dev, st}, 1); }
     int dropRef(int dev, hipStream_t st) {           // returns the contexts left on that stream
@@ -212,8 +224,11 @@ inline AllocScope::~AllocScope() {
     tlsAlloc() = prev;
     if (mine.active && !prev.active) {               // the outermost scope of an API call
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && BigBlockCache::get().cachedBytes(dev, mine.stream) > BigBlockCache::keepBytes())
+        if (hipGetDevice(&dev) == hipSuccess && BigBlockCache::get().cachedBytes(dev, mine.stream) > BigBlockCache::keepBytes()) {
+            const double t0 = nowSeconds(); const size_t before = BigBlockCache::get().cachedBytes(dev, mine.stream);
             BigBlockCache::get().trimTo(dev, mine.stream, BigBlockCache::keepBytes());
+            if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] block cache: %zu MB above the mark given back to the device in %.1f ms\n", (before - BigBlockCache::get().cachedBytes(dev, mine.stream)) >> 20, 1e3 * (nowSeconds() - t0));
+        }
     }
 }
 

@@ -112,7 +112,7 @@ def test_switch_changes_no_bit(name):
     assert r.returncode == 0 and "switch ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     if name == "cache-keep-0":
         # what stays cached when a build returns: with a mark of 0 MB only what the mark does not govern (the nearest search's lists), with
-        # the default mark (512 MB) the build's transient blocks as well
+        # the default mark (1/32 of the device) the build's transient blocks as well
         kept0 = int(r.stdout.split("CACHED")[1].split()[0])
         r2 = subprocess.run([sys.executable, "-c", _COMMON + body + "\nprint('switch ok')\n"], capture_output=True, text=True, env=dict(os.environ), timeout=600)
         assert r2.returncode == 0, r2.stderr[-2000:]
