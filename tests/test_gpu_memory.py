@@ -71,7 +71,7 @@ def test_large_tree_holds_one_copy_and_the_caches_give_memory_back(oracle):
     array_bytes = 4 * int(t.info.num_words)
     assert array_bytes > (1 << 30)
     mark = torch.cuda.mem_get_info(0)[1] // 32                            # the caches' default high-water mark: 1/32 of the device (SDFHIP_CACHE_KEEP_MB overrides)
-    assert ctx.cached_bytes() <= mark + (600 << 20), (ctx.cached_bytes(), mark)         # blocks above the mark were freed when the build returned; the nearest search's lists stay
+    assert ctx.cached_bytes() <= mark + (1 << 30), (ctx.cached_bytes(), mark)         # blocks above the mark were freed when the build returned; the nearest search's lists and slabs with a live block stay
     pts = random_points_in_box(box, 100000, seed=1)
     assert t.device_bytes() < 1.1 * array_bytes, (t.device_bytes(), array_bytes)      # born with the layout only: no resident copy of the array
     d0 = t.get_distance(pts)
