@@ -930,7 +930,7 @@ struct GsRound {
     KeyTri* K; uint32_t* Ll; uint32_t* Rl;                          // keys; index lists by position
     const GTask* tasks; const uint32_t* nTasksPtr; uint32_t maxTasks;
     float* pk; uint32_t* chunkBase; uint32_t* totL; uint32_t* totR; uint32_t* swapped;       // per range
-    uint32_t* cntL; uint32_t* cntR;                                  // per chunk
+    uint32_t* cntL; uint32_t* cntR; uint32_t* chunkTask;             // per chunk (chunkTask: the range a chunk belongs to, written with the round's layout)
 };
 SDF_DEV uint32_t gsTaskCount(const GsRound& R) { const uint32_t n = *R.nTasksPtr; return n < R.maxTasks ? n : R.maxTasks; }
 
@@ -960,7 +960,11 @@ SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint3
         __syncthreads();
         uint32_t before = 0;
         for (int w = 0; w < wave; w++) before += s_part[w];
-        if (t < nT) R.chunkBase[t] = s_carry + before + incl - nch;
+        if (t < nT) {
+            const uint32_t cb = s_carry + before + incl - nch;
+            R.chunkBase[t] = cb;
+            for (uint32_t k = 0; k < nch; k++) R.chunkTask[cb + k] = t;      // (the round kernels' workgroups read their range here: a binary search of chunkBase by
+        }                                                                    //  one thread was ten dependent loads at the head of every workgroup of three kernels per round)
         __syncthreads();
         if (tid == 1023) s_carry += before + incl;
         __syncthreads();
@@ -970,12 +974,10 @@ SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint3
 __global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) { gsPrepare(R, nextCount, flags); }
 // which range and which of its chunks a workgroup of the round kernels works on
 struct GsChunk { uint32_t task; int f, m; uint32_t k; float pk; };
-SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c, uint32_t* s_task) {
+SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c) {
     const uint32_t nT = gsTaskCount(R);
     if (block >= R.chunkBase[nT]) return false;                      // (uniform per workgroup)
-    if (threadIdx.x == 0) { uint32_t lo = 0, hi = nT - 1; while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (R.chunkBase[mid] <= block) lo = mid; else hi = mid - 1; } *s_task = lo; }
-    __syncthreads();
-    c.task = *s_task;
+    c.task = R.chunkTask[block];
     const GTask task = R.tasks[c.task];
     c.f = (int)task.first + 1; c.m = (int)task.last - c.f; c.k = block - R.chunkBase[c.task]; c.pk = R.pk[c.task];
     return true;
@@ -989,8 +991,8 @@ SDF_DEV uint32_t gsBlockSum(uint32_t v, uint32_t* s4) {               // sum ove
     return s4[0] + s4[1] + s4[2] + s4[3];
 }
 __global__ void __launch_bounds__(256) k_gs_count(GsRound R) {
-    __shared__ uint32_t s_task; __shared__ uint32_t s4[4];
-    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    __shared__ uint32_t s4[4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x, c)) return;
     const int i0 = (int)(c.k * kGsChunk) + 8 * (int)threadIdx.x;
     uint32_t a = 0, b = 0;
 #pragma unroll
@@ -999,8 +1001,8 @@ __global__ void __launch_bounds__(256) k_gs_count(GsRound R) {
     if (threadIdx.x == 0) { R.cntL[blockIdx.x] = A; R.cntR[blockIdx.x] = B; atomicAdd(&R.totL[c.task], A); atomicAdd(&R.totR[c.task], B); }
 }
 __global__ void __launch_bounds__(256) k_gs_fill(GsRound R) {
-    __shared__ uint32_t s_task; __shared__ uint32_t s4[4]; __shared__ uint32_t s_wave[2][4];
-    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    __shared__ uint32_t s4[4]; __shared__ uint32_t s_wave[2][4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x, c)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // where this chunk's entries start in the range's lists: the counts of the range's chunks before it
     uint32_t pa = 0, pb = 0;
@@ -1025,19 +1027,17 @@ __global__ void __launch_bounds__(256) k_gs_fill(GsRound R) {
     }
 }
 // the exchanges: pair t (1-based) is L_t and the t-th entry of R from its end; pairs that have crossed stay
+// (one pair per thread, eight workgroups per chunk: as eight pairs per thread the exchanges of a thread — two dependent gathers and two
+// scattered stores each, which the compiler must keep in order — ran one after the other)
 __global__ void __launch_bounds__(256) k_gs_swap(GsRound R) {
-    __shared__ uint32_t s_task; __shared__ uint32_t s4[4];
-    GsChunk c; if (!gsLocate(R, blockIdx.x, c, &s_task)) return;
+    __shared__ uint32_t s4[4];
+    GsChunk c; if (!gsLocate(R, blockIdx.x >> 3, c)) return;
     const uint32_t nl = R.totL[c.task], nr = R.totR[c.task], lim = nl < nr ? nl : nr;
-    const uint32_t q0 = c.k * kGsChunk + 8u * threadIdx.x + 1u;
+    const uint32_t q = c.k * kGsChunk + (blockIdx.x & 7u) * 256u + threadIdx.x + 1u;
     uint32_t done = 0;
-#pragma unroll
-    for (uint32_t j = 0; j < 8; j++) {
-        const uint32_t q = q0 + j;
-        if (q <= lim) {
-            const uint32_t a = R.Ll[c.f + (int)(q - 1)], b = R.Rl[c.f + (int)(nr - q)];
-            if (a < b) { devSwap(R.K, c.f + (int)a, c.f + (int)b); done++; }
-        }
+    if (q <= lim) {
+        const uint32_t a = R.Ll[c.f + (int)(q - 1)], b = R.Rl[c.f + (int)(nr - q)];
+        if (a < b) { devSwap(R.K, c.f + (int)a, c.f + (int)b); done = 1; }
     }
     const uint32_t D = gsBlockSum(done, s4);
     if (threadIdx.x == 0 && D) atomicAdd(&R.swapped[c.task], D);
@@ -1837,13 +1837,13 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     levelAt[nTop] = tableNodes;
     const uint32_t maxTasks = 2u * (T / partMax) + 16u, maxParts = T / 16u + 16u, maxTiny = T / 2u + 16u;
     const uint32_t maxChunks = T / kGsChunk + maxTasks + 1u;
-    DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, totL, totR, swapped, cntL, cntR, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
+    DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, totL, totR, swapped, cntL, cntR, chunkTask, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
     DevBuf<int> dims; DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
     DevBuf<uint32_t> sumBase, sumStatus; DevBuf<double> csum, cin; std::vector<uint32_t> sumBaseH; std::vector<size_t> sumChunkAt;
     SDF_TRY(K.reserve(T)); SDF_TRY(snaps.reserve((size_t)T * (nTop ? nTop : 1))); SDF_TRY(ctr.reserve(8)); SDF_TRY(dFail.reserve(1));
     if (nTop) {
         SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(totL.reserve(maxTasks)); SDF_TRY(totR.reserve(maxTasks));
-        SDF_TRY(swapped.reserve(maxTasks)); SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
+        SDF_TRY(swapped.reserve(maxTasks)); SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(chunkTask.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
         SDF_TRY(tiny.reserve(maxTiny)); SDF_TRY(dNodes.reserve(tableNodes)); SDF_TRY(dims.reserve(tableNodes)); SDF_TRY(centres.reserve(3 * tableNodes)); SDF_TRY(r2.reserve(tableNodes));
         std::vector<TopNode> flat; flat.reserve(tableNodes);
         for (size_t l = 0; l < nTop; l++) flat.insert(flat.end(), levels[l].begin(), levels[l].end());
@@ -1914,7 +1914,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         // (rounds 1-4: always four at a time, 156 rounds for the 9 levels of the 1.31 M mesh, of which the levels needed about 60).
         uint32_t longest = 0; for (const TopNode& nd : nodes) longest = std::max(longest, nd.e - nd.b);
         int groupRounds = 1; for (uint32_t m = longest; m > partMax; m >>= 1) groupRounds++;
-        auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p}; };
+        auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p, chunkTask.p}; };
         k_gs_prepare<<<1, 1024, 0, st>>>(roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
         while (pending > 0) {
             uint32_t bound = pending;
@@ -1924,7 +1924,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
                 const unsigned chunkGrid = (unsigned)(T / kGsChunk + bound + 1u);
                 k_gs_count<<<chunkGrid, 256, 0, st>>>(R);
                 k_gs_fill<<<chunkGrid, 256, 0, st>>>(R);
-                k_gs_swap<<<chunkGrid, 256, 0, st>>>(R);
+                k_gs_swap<<<8u * chunkGrid, 256, 0, st>>>(R);
                 k_gs_emit_prepare<<<1, 1024, 0, st>>>(R, Rn, ctr.p + curBuf, parts.p, ctr.p + 2, maxParts, tiny.p, ctr.p + 3, maxTiny, partMax, ctr.p + 4);
                 curBuf ^= 1;
                 rounds++;
