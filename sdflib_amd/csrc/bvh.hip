@@ -924,24 +924,27 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
 // scope), prepare + emit on workgroup 0.  Identical trees, but 9 levels of the 1.31 M mesh took 19.4 ms instead of 9.2 ms: a barrier
 // across the eight XCDs costs ~25 us (every workgroup's release writes its L2 back, every acquire invalidates it), 624 of them per build,
 // while a launch of the five-kernel form costs ~7 us in a queue the host fills ahead.  The launches stay.
+struct TopNode { int id; uint32_t b, e, slot; };                    // slot: where the node's sphere goes, in units of 4 doubles (NONE32: the root's, nowhere)
 struct GTask { uint32_t first, last, depth; };
 constexpr uint32_t kGsChunk = 2048;          // elements per workgroup in the round kernels (256 threads x 8)
+constexpr uint32_t kGsMaxRangeChunks = 7000; // chunks of the longest range k_gs_swap can hold prefix sums for (56 KB of LDS): 14 M triangles; beyond -> host planner
 struct GsRound {
-    KeyTri* K; uint32_t* Ll; uint32_t* Rl;                          // keys; index lists by position
+    KeyTri* K; uint32_t* Ll; uint32_t* Rl;                          // keys; index lists, chunk by chunk (a chunk's entries start at its first position)
     const GTask* tasks; const uint32_t* nTasksPtr; uint32_t maxTasks;
-    float* pk; uint32_t* chunkBase; uint32_t* totL; uint32_t* totR; uint32_t* swapped;       // per range
+    float* pk; uint32_t* chunkBase; uint32_t* cut;                   // per range
     uint32_t* cntL; uint32_t* cntR; uint32_t* chunkTask;             // per chunk (chunkTask: the range a chunk belongs to, written with the round's layout)
 };
 SDF_DEV uint32_t gsTaskCount(const GsRound& R) { const uint32_t n = *R.nTasksPtr; return n < R.maxTasks ? n : R.maxTasks; }
 
-// one workgroup: pivots (median of three to the front), chunk layout of the round; zeroes the next round's counter
+// one workgroup of BLOCK threads: pivots (median of three to the front), chunk layout of the round; zeroes the next round's counter
+template <int BLOCK>
 SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) {
-    __shared__ uint32_t s_part[16]; __shared__ uint32_t s_carry;
+    __shared__ uint32_t s_part[BLOCK / 64]; __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t nT = gsTaskCount(R);
     if (tid == 0) { s_carry = 0; *nextCount = 0; if (*R.nTasksPtr > R.maxTasks) atomicOr(flags, 1u); }
     __syncthreads();
-    for (uint32_t base = 0; base < nT; base += 1024u) {
+    for (uint32_t base = 0; base < nT; base += (uint32_t)BLOCK) {
         const uint32_t t = base + (uint32_t)tid;
         uint32_t nch = 0;
         if (t < nT) {
@@ -951,7 +954,6 @@ SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint3
             else devMedianToFirst(R.K, first, first + 1, first + (last - first) / 2, last - 1);
             R.pk[t] = R.K[first].key;
             nch = ((uint32_t)(last - first - 1) + kGsChunk - 1u) / kGsChunk;
-            R.totL[t] = 0; R.totR[t] = 0; R.swapped[t] = 0;
         }
         uint32_t incl = nch;                                          // inclusive scan over the workgroup
 #pragma unroll
@@ -963,15 +965,23 @@ SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint3
         if (t < nT) {
             const uint32_t cb = s_carry + before + incl - nch;
             R.chunkBase[t] = cb;
-            for (uint32_t k = 0; k < nch; k++) R.chunkTask[cb + k] = t;      // (the round kernels' workgroups read their range here: a binary search of chunkBase by
-        }                                                                    //  one thread was ten dependent loads at the head of every workgroup of three kernels per round)
+            for (uint32_t k = 0; k < nch; k++) R.chunkTask[cb + k] = t;      // (the round kernels' workgroups read their range here)
+        }
         __syncthreads();
-        if (tid == 1023) s_carry += before + incl;
+        if (tid == BLOCK - 1) s_carry += before + incl;
         __syncthreads();
     }
     if (tid == 0) R.chunkBase[nT] = s_carry;
 }
-__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) { gsPrepare(R, nextCount, flags); }
+__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) { gsPrepare<1024>(R, nextCount, flags); }
+// the ranges of a level's first round: its nodes (introsort's depth limit 2 floor(log2 n)); the level's counters
+__global__ void k_gs_first(const TopNode* __restrict__ nodes, uint32_t count, GTask* __restrict__ tasks, uint32_t* __restrict__ ctr) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) { ctr[0] = count; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+    if (j >= count) return;
+    const uint32_t len = nodes[j].e - nodes[j].b;
+    tasks[j] = GTask{nodes[j].b, nodes[j].e, 2u * (31u - (uint32_t)__clz((int)(len | 1u)))};
+}
 // which range and which of its chunks a workgroup of the round kernels works on
 struct GsChunk { uint32_t task; int f, m; uint32_t k; float pk; };
 SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c) {
@@ -982,32 +992,14 @@ SDF_DEV bool gsLocate(const GsRound& R, uint32_t block, GsChunk& c) {
     c.f = (int)task.first + 1; c.m = (int)task.last - c.f; c.k = block - R.chunkBase[c.task]; c.pk = R.pk[c.task];
     return true;
 }
-SDF_DEV uint32_t gsBlockSum(uint32_t v, uint32_t* s4) {               // sum over 256 threads, result in every thread
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return s4[0] + s4[1] + s4[2] + s4[3];
-}
-__global__ void __launch_bounds__(256) k_gs_count(GsRound R) {
-    __shared__ uint32_t s4[4];
-    GsChunk c; if (!gsLocate(R, blockIdx.x, c)) return;
-    const int i0 = (int)(c.k * kGsChunk) + 8 * (int)threadIdx.x;
-    uint32_t a = 0, b = 0;
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (i0 + j < c.m) { const float key = R.K[c.f + i0 + j].key; a += !(key < c.pk); b += !(c.pk < key); }
-    const uint32_t A = gsBlockSum(a, s4), B = gsBlockSum(b, s4);
-    if (threadIdx.x == 0) { R.cntL[blockIdx.x] = A; R.cntR[blockIdx.x] = B; atomicAdd(&R.totL[c.task], A); atomicAdd(&R.totR[c.task], B); }
-}
-__global__ void __launch_bounds__(256) k_gs_fill(GsRound R) {
-    __shared__ uint32_t s4[4]; __shared__ uint32_t s_wave[2][4];
+// A round is THREE launches (four until round 5: count, fill, swap, emit + prepare, each ~15 us of a dependent chain whatever it does).
+// k_gs_mark, a workgroup per chunk: the chunk's entries of the two index lists — positions (relative to the range) of the elements not
+// less / not greater than the pivot, ascending — written from the chunk's first position on, and their numbers.  No workgroup needs
+// another's result.
+__global__ void __launch_bounds__(256) k_gs_mark(GsRound R) {
+    __shared__ uint32_t s_wave[2][4];
     GsChunk c; if (!gsLocate(R, blockIdx.x, c)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // where this chunk's entries start in the range's lists: the counts of the range's chunks before it
-    uint32_t pa = 0, pb = 0;
-    for (uint32_t q = R.chunkBase[c.task] + (uint32_t)tid; q < blockIdx.x; q += 256u) { pa += R.cntL[q]; pb += R.cntR[q]; }
-    const uint32_t offL = gsBlockSum(pa, s4), offR = gsBlockSum(pb, s4);
     const int i0 = (int)(c.k * kGsChunk) + 8 * tid;
     uint32_t a = 0, b = 0; unsigned fl = 0, fr = 0;
 #pragma unroll
@@ -1017,40 +1009,22 @@ __global__ void __launch_bounds__(256) k_gs_fill(GsRound R) {
     for (int o = 1; o < 64; o <<= 1) { const uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o); if (lane >= o) { ia += va; ib += vb; } }
     if (lane == 63) { s_wave[0][wave] = ia; s_wave[1][wave] = ib; }
     __syncthreads();
-    uint32_t ba = offL, bb = offR;
+    uint32_t ba = 0, bb = 0;
     for (int w = 0; w < wave; w++) { ba += s_wave[0][w]; bb += s_wave[1][w]; }
+    const int base = c.f + (int)(c.k * kGsChunk);
     uint32_t wa = ba + ia - a, wb = bb + ib - b;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        if ((fl >> j) & 1u) R.Ll[c.f + (int)wa++] = (uint32_t)(i0 + j);
-        if ((fr >> j) & 1u) R.Rl[c.f + (int)wb++] = (uint32_t)(i0 + j);
+        if ((fl >> j) & 1u) R.Ll[base + (int)wa++] = (uint32_t)(i0 + j);
+        if ((fr >> j) & 1u) R.Rl[base + (int)wb++] = (uint32_t)(i0 + j);
     }
+    if (tid == 0) { R.cntL[blockIdx.x] = s_wave[0][0] + s_wave[0][1] + s_wave[0][2] + s_wave[0][3]; R.cntR[blockIdx.x] = s_wave[1][0] + s_wave[1][1] + s_wave[1][2] + s_wave[1][3]; }
 }
-// the exchanges: pair t (1-based) is L_t and the t-th entry of R from its end; pairs that have crossed stay
-// (one pair per thread, eight workgroups per chunk: as eight pairs per thread the exchanges of a thread — two dependent gathers and two
-// scattered stores each, which the compiler must keep in order — ran one after the other)
-__global__ void __launch_bounds__(256) k_gs_swap(GsRound R) {
-    __shared__ uint32_t s4[4];
-    GsChunk c; if (!gsLocate(R, blockIdx.x >> 3, c)) return;
-    const uint32_t nl = R.totL[c.task], nr = R.totR[c.task], lim = nl < nr ? nl : nr;
-    const uint32_t q = c.k * kGsChunk + (blockIdx.x & 7u) * 256u + threadIdx.x + 1u;
-    uint32_t done = 0;
-    if (q <= lim) {
-        const uint32_t a = R.Ll[c.f + (int)(q - 1)], b = R.Rl[c.f + (int)(nr - q)];
-        if (a < b) { devSwap(R.K, c.f + (int)a, c.f + (int)b); done = 1; }
-    }
-    const uint32_t D = gsBlockSum(done, s4);
-    if (threadIdx.x == 0 && D) atomicAdd(&R.swapped[c.task], D);
-}
-// the cut of every range and what becomes of its two parts
+// the cut of a range and what becomes of its two parts
 SDF_DEV void gsEmitOne(const GsRound& R, uint32_t t, GTask* __restrict__ next, uint32_t* __restrict__ nextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
                        GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
     const GTask task = R.tasks[t];
-    const int f = (int)task.first + 1, m = (int)task.last - f;
-    const uint32_t nl = R.totL[t], nr = R.totR[t], ms = R.swapped[t];
-    uint32_t stop = (ms < nl) ? R.Ll[f + (int)ms] : (uint32_t)m;
-    if (ms > 0) { const uint32_t r = R.Rl[f + (int)(nr - ms)]; if (r < stop) stop = r; }
-    const uint32_t cut = (uint32_t)f + stop;
+    const uint32_t cut = R.cut[t];
     const uint32_t pb[2] = {task.first, cut}, pe[2] = {cut, task.last};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -1061,9 +1035,71 @@ SDF_DEV void gsEmitOne(const GsRound& R, uint32_t t, GTask* __restrict__ next, u
         else if (len > 1u) { const uint32_t at = atomicAdd(tinyCount, 1u); if (at < maxTiny) tiny[at] = out; else atomicOr(flags, 1u); }
     }
 }
-// ONE workgroup ends a round and begins the next: the cuts of the round's ranges (their parts go to the next round's list, to the LDS
-// sorts or to the tiny sorts), then — the list complete — the next round's pivots and chunk layout (gsPrepare).  One launch per round
-// less than as two kernels; a range's pivot is still taken exactly once (the level's first round is prepared by k_gs_prepare).
+// k_gs_swap, eight workgroups per chunk, a thread per exchange: pair q (1-based) is the q-th entry of the range's L list and the q-th entry
+// of its R list from the END, exchanged while they have not crossed (see IntroSortLike::parallelPartition).  Where the q-th entry lies
+// follows from the prefix sums of the range's chunk counts, which every workgroup builds in LDS (a range has at most a few hundred chunks);
+// since the L entries ascend and the R entries from the end descend, "not crossed" holds for q <= ms and for no q beyond: the thread that
+// sees the boundary knows ms and writes the range's cut — __unguarded_partition's result — itself.
+__global__ void __launch_bounds__(256) k_gs_swap(GsRound R, uint32_t nchCap) {
+    extern __shared__ uint32_t s_pre[];                               // pL[0 .. nchCap], pR[0 .. nchCap]
+    __shared__ uint32_t s_scan[2][4]; __shared__ unsigned char s_sq[256];
+    GsChunk c; if (!gsLocate(R, blockIdx.x >> 3, c)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t* pL = s_pre; uint32_t* pR = s_pre + (nchCap + 1u);
+    const uint32_t cb = R.chunkBase[c.task], nch = R.chunkBase[c.task + 1u] - cb;
+    {   // exclusive prefix sums of the range's chunk counts
+        const uint32_t per = (nch + 255u) / 256u, k0 = ((uint32_t)tid * per < nch) ? (uint32_t)tid * per : nch, k1 = (k0 + per < nch) ? k0 + per : nch;
+        uint32_t sa = 0, sb = 0;
+        for (uint32_t k = k0; k < k1; k++) { sa += R.cntL[cb + k]; sb += R.cntR[cb + k]; }
+        uint32_t ia = sa, ib = sb;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t va = __shfl_up(ia, o), vb = __shfl_up(ib, o); if (lane >= o) { ia += va; ib += vb; } }
+        if (lane == 63) { s_scan[0][wave] = ia; s_scan[1][wave] = ib; }
+        __syncthreads();
+        uint32_t ea = ia - sa, eb = ib - sb;
+        for (int w = 0; w < wave; w++) { ea += s_scan[0][w]; eb += s_scan[1][w]; }
+        for (uint32_t k = k0; k < k1; k++) { pL[k] = ea; pR[k] = eb; ea += R.cntL[cb + k]; eb += R.cntR[cb + k]; }
+        if (tid == 0) { pL[nch] = s_scan[0][0] + s_scan[0][1] + s_scan[0][2] + s_scan[0][3]; pR[nch] = s_scan[1][0] + s_scan[1][1] + s_scan[1][2] + s_scan[1][3]; }
+        __syncthreads();
+    }
+    const uint32_t nl = pL[nch], nr = pR[nch], lim = nl < nr ? nl : nr;
+    auto nth = [&](const uint32_t* pre, const uint32_t* list, uint32_t idx) {       // the idx-th entry (0-based) of a list
+        uint32_t lo = 0, hi = nch - 1u;
+        while (lo < hi) { const uint32_t mid = (lo + hi + 1u) >> 1; if (pre[mid] <= idx) lo = mid; else hi = mid - 1u; }
+        return list[c.f + (int)(lo * kGsChunk + (idx - pre[lo]))];
+    };
+    const uint32_t q = c.k * kGsChunk + (blockIdx.x & 7u) * 256u + (uint32_t)tid + 1u;
+    uint32_t a = 0, b = 0; bool sq = false;
+    if (q <= lim) {
+        a = nth(pL, R.Ll, q - 1u); b = nth(pR, R.Rl, nr - q);
+        sq = a < b;
+        if (sq) devSwap(R.K, c.f + (int)a, c.f + (int)b);
+    }
+    s_sq[tid] = sq ? 1 : 0;
+    __syncthreads();
+    {   // the boundary: ms = the number of exchanges of the range
+        uint32_t ms = 0xFFFFFFFFu;
+        if (lim == 0u) { if (q == 1u) ms = 0u; }
+        else if (q <= lim) {
+            if (sq) { if (q == lim) ms = lim; }
+            else {
+                bool prev = true;                                     // pair q - 1 exchanged?  (q == 1: there is none)
+                if (q > 1u) prev = (tid > 0) ? (s_sq[tid - 1] != 0) : (nth(pL, R.Ll, q - 2u) < nth(pR, R.Rl, nr - (q - 1u)));
+                if (prev) ms = q - 1u;
+            }
+        }
+        if (ms != 0xFFFFFFFFu) {
+            uint32_t stop = (ms < nl) ? nth(pL, R.Ll, ms) : (uint32_t)c.m;
+            if (ms > 0u) { const uint32_t r = nth(pR, R.Rl, nr - ms); if (r < stop) stop = r; }
+            R.cut[c.task] = (uint32_t)c.f + stop;
+        }
+    }
+}
+// ONE workgroup ends a round and begins the next: the parts of every range go to the next round's list, to the LDS sorts or to the tiny
+// sorts; then — the list complete — the next round's pivots and chunk layout (gsPrepare).  (Round 5 also tried this as the tail of
+// k_gs_swap, run by the workgroup that finishes last behind a device-scope fence and a ticket: identical trees, but every workgroup's
+// fence writes its XCD's L2 back — 9 levels of the 1.31 M mesh took 30 ms instead of 7.4.  A kernel boundary is the cheap way to make
+// eight L2s agree, as round 4's persistent form had already shown.)
 __global__ void __launch_bounds__(1024) k_gs_emit_prepare(GsRound R, GsRound Rnext, uint32_t* __restrict__ afterNextCount, GTask* __restrict__ parts, uint32_t* __restrict__ partCount, uint32_t maxParts,
                                                           GTask* __restrict__ tiny, uint32_t* __restrict__ tinyCount, uint32_t maxTiny, uint32_t ldsMax, uint32_t* __restrict__ flags) {
     const uint32_t nT = gsTaskCount(R);
@@ -1071,7 +1107,7 @@ __global__ void __launch_bounds__(1024) k_gs_emit_prepare(GsRound R, GsRound Rne
         gsEmitOne(R, t, const_cast<GTask*>(Rnext.tasks), const_cast<uint32_t*>(Rnext.nTasksPtr), parts, partCount, maxParts, tiny, tinyCount, maxTiny, ldsMax, flags);
     __threadfence_block();           // (the list and its count are read by this workgroup only)
     __syncthreads();
-    gsPrepare(Rnext, afterNextCount, flags);
+    gsPrepare<1024>(Rnext, afterNextCount, flags);
 }
 // a part that fits in LDS: the rest of its introsort in one workgroup
 __global__ void __launch_bounds__(256) k_sort_parts(KeyTri* __restrict__ K, const GTask* __restrict__ parts, uint32_t ldsMax, uint32_t* __restrict__ flags) {
@@ -1097,7 +1133,6 @@ __global__ void k_sort_tiny(KeyTri* __restrict__ K, const GTask* __restrict__ ti
 }
 
 // ---- per level: AABB -> axis, keys; afterwards the centre sums and radii of its nodes
-struct TopNode { int id; uint32_t b, e, slot; };                    // slot: where the node's sphere goes, in units of 4 doubles (NONE32: the root's, nowhere)
 SDF_DEV uint32_t topNodeOf(const TopNode* __restrict__ nodes, uint32_t count, uint32_t i) {
     uint32_t lo = 0, hi = count - 1;
     while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (nodes[mid].b <= i) lo = mid; else hi = mid - 1; }
@@ -1837,13 +1872,13 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     levelAt[nTop] = tableNodes;
     const uint32_t maxTasks = 2u * (T / partMax) + 16u, maxParts = T / 16u + 16u, maxTiny = T / 2u + 16u;
     const uint32_t maxChunks = T / kGsChunk + maxTasks + 1u;
-    DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, totL, totR, swapped, cntL, cntR, chunkTask, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
+    DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, cutAt, cntL, cntR, chunkTask, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
     DevBuf<int> dims; DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
     DevBuf<uint32_t> sumBase, sumStatus; DevBuf<double> csum, cin; std::vector<uint32_t> sumBaseH; std::vector<size_t> sumChunkAt;
     SDF_TRY(K.reserve(T)); SDF_TRY(snaps.reserve((size_t)T * (nTop ? nTop : 1))); SDF_TRY(ctr.reserve(8)); SDF_TRY(dFail.reserve(1));
     if (nTop) {
-        SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(totL.reserve(maxTasks)); SDF_TRY(totR.reserve(maxTasks));
-        SDF_TRY(swapped.reserve(maxTasks)); SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(chunkTask.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
+        SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(cutAt.reserve(maxTasks));
+        SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(chunkTask.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
         SDF_TRY(tiny.reserve(maxTiny)); SDF_TRY(dNodes.reserve(tableNodes)); SDF_TRY(dims.reserve(tableNodes)); SDF_TRY(centres.reserve(3 * tableNodes)); SDF_TRY(r2.reserve(tableNodes));
         std::vector<TopNode> flat; flat.reserve(tableNodes);
         for (size_t l = 0; l < nTop; l++) flat.insert(flat.end(), levels[l].begin(), levels[l].end());
@@ -1890,7 +1925,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     struct SideGuard { hipStream_t a, b; ~SideGuard() { if (a) (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); } } sideGuard{useSide ? side.s : nullptr, useSide ? side1.s : nullptr};
     // ctr: [0], [1] = pending ranges of this / the next round (alternating), [2] = parts for k_sort_parts, [3] = for k_sort_tiny, [4] = flags
     uint32_t hostCtr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t rounds = 0;
+    uint32_t rounds = 0, groups = 0;
     for (size_t l = 0; l < nTop; l++) {
         const std::vector<TopNode>& nodes = levels[l];
         const uint32_t count = (uint32_t)nodes.size();
@@ -1899,22 +1934,21 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         k_top_dims<<<gridFor(count, 256), 256, 0, st>>>(box.p + 6 * levelAt[l], count, dims.p + levelAt[l]);
         k_top_keys<<<gridFor(T, 256), 256, 0, st>>>(K.p, triV, dN, count, T, dims.p + levelAt[l]);
         // the level's nodes are the first round's ranges
-        std::vector<GTask> first(count);
-        for (uint32_t j = 0; j < count; j++) { const uint32_t len = nodes[j].e - nodes[j].b; int lg = 0; for (uint32_t m = len; m > 1; m >>= 1) lg++; first[j] = GTask{nodes[j].b, nodes[j].e, (uint32_t)(2 * lg)}; }
         SDF_REQUIRE(count <= maxTasks, "internal: more nodes on a level than ranges provided for");
         int curBuf = 0;
         hostCtr[0] = count; hostCtr[1] = 0; hostCtr[2] = 0; hostCtr[3] = 0;
-        SDF_HIP_CHECK(hipMemcpyAsync(tasks.p, first.data(), sizeof(GTask) * count, hipMemcpyHostToDevice, st));
-        SDF_HIP_CHECK(hipMemcpyAsync(ctr.p, hostCtr, 16, hipMemcpyHostToDevice, st));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        k_gs_first<<<gridFor(count, 256), 256, 0, st>>>(dN, count, tasks.p, ctr.p);
         uint32_t pending = count;
         // The host learns a round's outcome only by waiting for it: rounds are queued in groups, sized for the most ranges they can have (a
-        // range leaves at most two); a round without ranges costs four empty launches.  The first group of a level is as long as its longest
-        // node needs with halving cuts (+ 1: ranges of at most partMax keys leave the rounds), the groups behind it take two rounds each
+        // range leaves at most two); a round without ranges costs three empty launches.  The first group of a level is as long as its longest
+        // node needs with halving cuts (+ 2: ranges of at most partMax keys leave the rounds), the groups behind it take three rounds each
         // (rounds 1-4: always four at a time, 156 rounds for the 9 levels of the 1.31 M mesh, of which the levels needed about 60).
         uint32_t longest = 0; for (const TopNode& nd : nodes) longest = std::max(longest, nd.e - nd.b);
         int groupRounds = 1; for (uint32_t m = longest; m > partMax; m >>= 1) groupRounds++;
-        auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, totL.p, totR.p, swapped.p, cntL.p, cntR.p, chunkTask.p}; };
+        groupRounds++;             // (one more: 36 -> 23 read-backs for the 9 levels of the 1.31 M mesh, same number of rounds run)
+        const uint32_t nchCap = longest / kGsChunk + 2u;            // chunks of the level's longest range (ranges only get shorter)
+        if (nchCap > kGsMaxRangeChunks) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: a range of %u triangles is more than the round kernels hold prefix sums for\n", longest); return SDFHIP_E_UNSUPPORTED; }
+        auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, cutAt.p, cntL.p, cntR.p, chunkTask.p}; };
         k_gs_prepare<<<1, 1024, 0, st>>>(roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
         while (pending > 0) {
             uint32_t bound = pending;
@@ -1922,15 +1956,15 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
             for (int q = 0; q < nowRounds; q++) {
                 const GsRound R = roundOf(curBuf), Rn = roundOf(curBuf ^ 1);
                 const unsigned chunkGrid = (unsigned)(T / kGsChunk + bound + 1u);
-                k_gs_count<<<chunkGrid, 256, 0, st>>>(R);
-                k_gs_fill<<<chunkGrid, 256, 0, st>>>(R);
-                k_gs_swap<<<8u * chunkGrid, 256, 0, st>>>(R);
+                k_gs_mark<<<chunkGrid, 256, 0, st>>>(R);
+                k_gs_swap<<<8u * chunkGrid, 256, 8u * (nchCap + 1u), st>>>(R, nchCap);
                 k_gs_emit_prepare<<<1, 1024, 0, st>>>(R, Rn, ctr.p + curBuf, parts.p, ctr.p + 2, maxParts, tiny.p, ctr.p + 3, maxTiny, partMax, ctr.p + 4);
                 curBuf ^= 1;
                 rounds++;
                 bound = (bound > maxTasks / 2u) ? maxTasks : 2u * bound;
             }
-            groupRounds = 2;
+            groupRounds = 3;
+            groups++;
             SDF_TRY(readBackWords(st, ctr.p, nullptr, 5, hostCtr));
             if (hostCtr[4]) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: gave up at level %zu (flags %u: 1 = a work list overflowed, 2 = a long range out of introsort's depth)\n", l, hostCtr[4]); return SDFHIP_E_UNSUPPORTED; }
             pending = hostCtr[curBuf];
@@ -1986,8 +2020,8 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         if (hipMemcpy(&serial, sumStatus.p + tableNodes, 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
         fprintf(stderr, "[sdfhip] bvh on the device: centre sums of %zu nodes in parallel (verified chunk by chunk), %u of them redone by the serial chain\n", tableNodes - levels[0].size(), serial);
     }
-    if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
-                        nTop, rounds, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
+    if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds in %u groups) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
+                        nTop, rounds, groups, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
     if (failed || hostCtr[4]) return SDFHIP_E_UNSUPPORTED;
     return SDFHIP_OK;
 }
