@@ -573,7 +573,7 @@ constexpr int kWaveSortLen = 160;        // pending ranges from this length on a
 // parallel), a short one by sixteen lanes — and lists the parts for the next round; parts of at most 16 are finished by insertion sort (by
 // rank), a range out of depth by libstdc++'s heap sort.  Every comparison and exchange is the sequential algorithm's, so is the order among ties.
 // s_count[1] = next round's count, s_count[2] |= 4 when the lists (maxTasks entries) overflow.
-SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in, uint32_t* out, uint32_t* s_count, uint32_t nSort, uint32_t maxTasks, int tid) {
+SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in, uint32_t* out, uint32_t* s_count, uint32_t nSort, uint32_t maxTasks, int tid, uint32_t nThreads = 256u) {
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned long long ltMask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     auto push = [&](int f, int l, int depth) {
@@ -585,7 +585,7 @@ SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in
         if (tid == 0) s_count[1] = 0;
         __syncthreads();
         // long ranges: one wave each
-        for (uint32_t t = (uint32_t)wave; t < nSort; t += 4u) {
+        for (uint32_t t = (uint32_t)wave; t < nSort; t += nThreads >> 6) {
             const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
             if (last - first < kWaveSortLen) continue;
             if (depth == 0) { if (lane == 0) stdHeapSort(keys + first, last - first); continue; }
@@ -638,7 +638,7 @@ SDF_DEV void devSortRounds(KeyArr keys, IdxArr listL, IdxArr listR, uint32_t* in
                 else if (mine) keys[first + rank] = e;
                 devWaveSync();
             };
-            for (uint32_t t = (uint32_t)(tid >> 4); t < nSort; t += 16u) {
+            for (uint32_t t = (uint32_t)(tid >> 4); t < nSort; t += nThreads >> 4) {
                 const int first = (int)in[3 * t], last = (int)in[3 * t + 1], depth = (int)in[3 * t + 2];
                 if (last - first >= kWaveSortLen) continue;
                 if (last - first <= 16) { rankSort(first, last); continue; }
@@ -693,7 +693,10 @@ SDF_DEV void devTriVerts(const float4* __restrict__ triV, int t, DevV3& a, DevV3
 }
 SDF_DEV float devComp(const DevV3& v, int d) { return d == 0 ? v.x : (d == 1 ? v.y : v.z); }
 
-__global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict__ tasks, const uint32_t* __restrict__ order, const float4* __restrict__ triV,
+// kSubThreads threads per workgroup — 1024, 512 or 256 (256 until round 5), by how many workgroups there are: the sort rounds and the per-element passes
+// have a subtree's hundreds of ranges to share out, but 128 registers per thread leave room for 2048 threads per CU
+template <int kSubThreads>
+__global__ void __launch_bounds__(kSubThreads) k_bvh_subtrees(const BvhTask* __restrict__ tasks, const uint32_t* __restrict__ order, const float4* __restrict__ triV,
                                                       double* __restrict__ sph, int* __restrict__ kids, BvhDevNode* __restrict__ nodeScratch, uint32_t* __restrict__ failed, uint32_t kDevSubtreeMax, unsigned long long* __restrict__ phaseClocks /* SDFHIP_TIMING: 100 MHz ticks of block 0 in A (workgroup), A (lane per node), B, C; else null */) {
     extern __shared__ unsigned char s_bvh_raw[];
     const KeyArr keys{reinterpret_cast<KeyTri*>(s_bvh_raw), 0};
@@ -710,7 +713,7 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
     const int tid = threadIdx.x;
     BvhDevNode* cur = nodeScratch + (size_t)blockIdx.x * 2u * (kDevSubtreeMax / 2u + 1u);
     BvhDevNode* nxt = cur + (kDevSubtreeMax / 2u + 1u);
-    for (uint32_t i = tid; i < n; i += 256) keys[i] = KeyTri{0.f, (int)order[T.begin + i]};
+    for (uint32_t i = tid; i < n; i += kSubThreads) keys[i] = KeyTri{0.f, (int)order[T.begin + i]};
     if (tid == 0) { cur[0] = BvhDevNode{T.innerId, T.begin, T.end, T.parentSlot}; s_count[2] = 0; }
     uint32_t nCur = 1, level = 0;
     __syncthreads();
@@ -727,14 +730,14 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
         const bool coop = level < 31u && (n >> level) > kCoopMin && nCur <= kCoopNodes;
         if (coop) {
             const float fhi = 3.402823466e+38f;
-            for (uint32_t j = tid; j < nCur; j += 256) {
+            for (uint32_t j = tid; j < nCur; j += kSubThreads) {
                 s_nb[j] = cur[j].b - T.begin; s_r2[j] = 0ull;
 #pragma unroll
                 for (int k = 0; k < 3; k++) { s_box[j][k] = devOrdKey(-fhi); s_box[j][3 + k] = devOrdKey(fhi); }
             }
             if (tid == 0) s_nb[nCur] = n;
             __syncthreads();
-            const uint32_t per = (n + 255u) / 256u, i0 = (uint32_t)tid * per, i1 = (i0 + per < n) ? i0 + per : n;
+            const uint32_t per = (n + (uint32_t)kSubThreads - 1u) / (uint32_t)kSubThreads, i0 = (uint32_t)tid * per, i1 = (i0 + per < n) ? i0 + per : n;
             uint32_t node0 = 0;
             if (i0 < i1) { uint32_t lo_ = 0, hi_ = nCur - 1; while (lo_ < hi_) { const uint32_t m_ = (lo_ + hi_ + 1) >> 1; if (s_nb[m_] <= i0) lo_ = m_; else hi_ = m_ - 1; } node0 = lo_; }
             {   // 1. AABB per node
@@ -758,7 +761,7 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
             }
             __syncthreads();
             // 2. one lane per node: split axis, centre = the vertices summed in range order
-            for (uint32_t j = tid; j < nCur; j += 256) {
+            for (uint32_t j = tid; j < nCur; j += kSubThreads) {
                 const double d0 = (double)devOrdVal(s_box[j][0]) - (double)devOrdVal(s_box[j][3]), d1 = (double)devOrdVal(s_box[j][1]) - (double)devOrdVal(s_box[j][4]),
                              d2 = (double)devOrdVal(s_box[j][2]) - (double)devOrdVal(s_box[j][5]);
                 int dim = 0; double dm = d0;
@@ -814,7 +817,7 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
             }
             __syncthreads();
             // 4. spheres and the level's sort tasks (every range is longer than 16)
-            for (uint32_t j = tid; j < nCur; j += 256) {
+            for (uint32_t j = tid; j < nCur; j += kSubThreads) {
                 const BvhDevNode nd = cur[j];
                 if (nd.slot != 0xFFFFFFFFu) { double* o = sph + 4 * (size_t)nd.slot; o[0] = s_ctr[j][0]; o[1] = s_ctr[j][1]; o[2] = s_ctr[j][2]; o[3] = sqrt(__longlong_as_double((long long)s_r2[j])); }
                 const int nn = (int)(nd.e - nd.b);
@@ -825,7 +828,7 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
         }
         lapClock(0);
         // ---- A. one lane per node: centre (ordered fp64 sum), AABB -> axis, radius, keys; short ranges sorted at once
-        for (uint32_t j = tid; j < (coop ? 0u : nCur); j += 256) {
+        for (uint32_t j = tid; j < (coop ? 0u : nCur); j += kSubThreads) {
             const BvhDevNode nd = cur[j];
             const int lo = (int)(nd.b - T.begin), nn = (int)(nd.e - nd.b);
             double sx = 0.0, sy = 0.0, sz = 0.0;
@@ -872,11 +875,11 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
         {
             const uint32_t nSort = s_count[1] < kDevSortTasks ? s_count[1] : kDevSortTasks;
             __syncthreads();
-            devSortRounds(keys, listL, listR, sortA, sortB, s_count, nSort, kDevSortTasks, tid);
+            devSortRounds(keys, listL, listR, sortA, sortB, s_count, nSort, kDevSortTasks, tid, (uint32_t)kSubThreads);
         }
         lapClock(2);
         // ---- C. one lane per node: the children (leaves get their sphere here, inner children at the next level)
-        for (uint32_t j = tid; j < nCur; j += 256) {
+        for (uint32_t j = tid; j < nCur; j += kSubThreads) {
             const BvhDevNode nd = cur[j];
             const uint32_t mid = (nd.b + nd.e) >> 1;           // (int)(0.5 * (begin + end))
             const uint32_t rb[2] = {nd.b, mid}, re[2] = {mid, nd.e};
@@ -909,6 +912,21 @@ __global__ void __launch_bounds__(256) k_bvh_subtrees(const BvhTask* __restrict_
         __syncthreads();
     }
     if (tid == 0 && s_count[2]) atomicOr(failed, s_count[2]);
+}
+
+static int raiseSubtreeLds(int bytes) {
+    SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees<256>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees<512>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return SDFHIP_OK;
+}
+// one workgroup per CU at 1024 threads (128 registers each), two at 512: as many threads as leave every workgroup resident at once
+// (327 680 triangles, 128 subtrees: 1.5 -> 1.2 ms; 1.31 M, 512 subtrees: 1024 threads would run them in two turns, 2.4 ms against 1.9)
+template <typename... A>
+static void launchSubtrees(unsigned nt, size_t lds, hipStream_t st, A... a) {
+    if (nt <= 256u) k_bvh_subtrees<1024><<<nt, 1024, lds, st>>>(a...);
+    else if (nt <= 512u) k_bvh_subtrees<512><<<nt, 512, lds, st>>>(a...);
+    else k_bvh_subtrees<256><<<nt, 256, lds, st>>>(a...);
 }
 
 // ---- the top of the tree on the device too ------------------------------------------------------------------------------------------------
@@ -1110,7 +1128,8 @@ __global__ void __launch_bounds__(1024) k_gs_emit_prepare(GsRound R, GsRound Rne
     gsPrepare<1024>(Rnext, afterNextCount, flags);
 }
 // a part that fits in LDS: the rest of its introsort in one workgroup
-__global__ void __launch_bounds__(256) k_sort_parts(KeyTri* __restrict__ K, const GTask* __restrict__ parts, uint32_t ldsMax, uint32_t* __restrict__ flags) {
+// (1024 threads: a round's ranges are shared out among the waves and the groups of sixteen lanes, and a part of 4096 keys has hundreds of them)
+__global__ void __launch_bounds__(1024) k_sort_parts(KeyTri* __restrict__ K, const GTask* __restrict__ parts, uint32_t ldsMax, uint32_t* __restrict__ flags) {
     extern __shared__ unsigned char s_bvh_raw[];
     const KeyArr keys{reinterpret_cast<KeyTri*>(s_bvh_raw), 0};
     const IdxArr listL{reinterpret_cast<unsigned short*>(s_bvh_raw + KeyArr::bytes(ldsMax))};
@@ -1120,11 +1139,11 @@ __global__ void __launch_bounds__(256) k_sort_parts(KeyTri* __restrict__ K, cons
     __shared__ uint32_t s_count[4];
     const GTask part = parts[blockIdx.x];
     const int n = (int)(part.last - part.first), tid = threadIdx.x;
-    for (int i = tid; i < n; i += 256) keys[i] = K[part.first + i];
+    for (int i = tid; i < n; i += (int)blockDim.x) keys[i] = K[part.first + i];
     if (tid == 0) { sortA[0] = 0; sortA[1] = (uint32_t)n; sortA[2] = part.depth; s_count[1] = 1; s_count[2] = 0; }
     __syncthreads();
-    devSortRounds(keys, listL, listR, sortA, sortB, s_count, 1u, kDevSortTasks, tid);
-    for (int i = tid; i < n; i += 256) K[part.first + i] = keys[i];
+    devSortRounds(keys, listL, listR, sortA, sortB, s_count, 1u, kDevSortTasks, tid, blockDim.x);
+    for (int i = tid; i < n; i += (int)blockDim.x) K[part.first + i] = keys[i];
     if (tid == 0 && s_count[2]) atomicOr(flags, s_count[2]);
 }
 __global__ void k_sort_tiny(KeyTri* __restrict__ K, const GTask* __restrict__ tiny, uint32_t count) {
@@ -1907,7 +1926,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         static bool raised = false;
         if (!raised) {
             const int most = (int)(KeyArr::bytes(kDevSubtreeMaxLimit) + 2 * IdxArr::bytes(kDevSubtreeMaxLimit) + 2 * 3 * 4 * kDevSortTasks);
-            SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, most));
+            SDF_TRY(raiseSubtreeLds(most));
             SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_parts), hipFuncAttributeMaxDynamicSharedMemorySize, most));
             raised = true;
         }
@@ -1969,7 +1988,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
             if (hostCtr[4]) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: gave up at level %zu (flags %u: 1 = a work list overflowed, 2 = a long range out of introsort's depth)\n", l, hostCtr[4]); return SDFHIP_E_UNSUPPORTED; }
             pending = hostCtr[curBuf];
         }
-        if (hostCtr[2]) k_sort_parts<<<hostCtr[2], 256, KeyArr::bytes(partMax) + 2 * IdxArr::bytes(partMax) + 2 * 3 * 4 * kDevSortTasks, st>>>(K.p, parts.p, partMax, ctr.p + 4);
+        if (hostCtr[2]) k_sort_parts<<<hostCtr[2], 1024, KeyArr::bytes(partMax) + 2 * IdxArr::bytes(partMax) + 2 * 3 * 4 * kDevSortTasks, st>>>(K.p, parts.p, partMax, ctr.p + 4);
         if (hostCtr[3]) k_sort_tiny<<<gridFor(hostCtr[3], 64), 64, 0, st>>>(K.p, tiny.p, hostCtr[3]);
         uint32_t* snap = snaps.p + (size_t)T * l;
         k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snap);
@@ -2006,7 +2025,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     SDF_HIP_CHECK(hipMemcpyAsync(dTasks.p, ht.data(), sizeof(BvhTask) * nt, hipMemcpyHostToDevice, st));
     unsigned long long clk[4] = {0, 0, 0, 0};
     if (timing) { SDF_TRY(dClk.reserve(4)); SDF_HIP_CHECK(hipMemsetAsync(dClk.p, 0, 32, st)); }
-    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, order, triV, mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, S, timing ? dClk.p : nullptr);
+    launchSubtrees((unsigned)nt, lds, st, dTasks.p, order, triV, mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, S, timing ? dClk.p : nullptr);
     SDF_HIP_CHECK(hipGetLastError());
     uint32_t failed = 0;
     SDF_HIP_CHECK(hipMemcpyAsync(&failed, dFail.p, 4, hipMemcpyDeviceToHost, st));
@@ -2061,8 +2080,8 @@ static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st
     k_bvh_scatter_top<<<gridFor(nh, 256), 256, 0, st>>>(dIds.p, dS8.p, dK2.p, dOwn.p, (uint32_t)nh, mesh->dBvhSph.p, mesh->dBvhKids.p);
     const size_t lds = KeyArr::bytes(kDevSubtreeMax) + 2 * IdxArr::bytes(kDevSubtreeMax) + 2 * 3 * 4 * kDevSortTasks;
     static bool ldsRaised = false;
-    if (!ldsRaised && lds > (48u << 10)) { SDF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bvh_subtrees), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(KeyArr::bytes(kDevSubtreeMaxLimit) + 2 * IdxArr::bytes(kDevSubtreeMaxLimit) + 2 * 3 * 4 * kDevSortTasks))); ldsRaised = true; }
-    k_bvh_subtrees<<<(unsigned)nt, 256, lds, st>>>(dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, kDevSubtreeMax, timing ? dClk.p : nullptr);
+    if (!ldsRaised && lds > (48u << 10)) { SDF_TRY(raiseSubtreeLds((int)(KeyArr::bytes(kDevSubtreeMaxLimit) + 2 * IdxArr::bytes(kDevSubtreeMaxLimit) + 2 * 3 * 4 * kDevSortTasks))); ldsRaised = true; }
+    launchSubtrees((unsigned)nt, lds, st, dTasks.p, dOrder.p, reinterpret_cast<const float4*>(mesh->dTriVerts.p), mesh->dBvhSph.p, mesh->dBvhKids.p, dScratch.p, dFail.p, kDevSubtreeMax, timing ? dClk.p : nullptr);
     SDF_HIP_CHECK(hipGetLastError());
     uint32_t failed = 0;
     if (timing) SDF_HIP_CHECK(hipMemcpyAsync(clk, dClk.p, 32, hipMemcpyDeviceToHost, st));
