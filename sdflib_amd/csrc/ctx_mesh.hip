@@ -45,6 +45,18 @@ __global__ void k_triangle_frames(const float* __restrict__ verts, const uint32_
     for (int i = 0; i < TD_FLOATS; i++) dst[i] = out[i];
 }
 
+// The largest triangle index and the largest |coordinate| as a bit pattern (sign cleared: the patterns of non-negative floats order like
+// their values, an infinity is 0x7F800000 and every NaN lies above it).
+__global__ void __launch_bounds__(256) k_mesh_validate(const float* __restrict__ xyz, uint64_t nCoords, const uint32_t* __restrict__ idx, uint64_t nIdx, uint32_t* __restrict__ out2) {
+    uint32_t mi = 0, mc = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nIdx; i += stride) { const uint32_t v = idx[i]; mi = v > mi ? v : mi; }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nCoords; i += stride) { const uint32_t v = __float_as_uint(xyz[i]) & 0x7FFFFFFFu; mc = v > mc ? v : mc; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t a = (uint32_t)__shfl_xor((int)mi, o), b = (uint32_t)__shfl_xor((int)mc, o); mi = a > mi ? a : mi; mc = b > mc ? b : mc; }
+    if ((threadIdx.x & 63) == 0) { atomicMax(&out2[0], mi); atomicMax(&out2[1], mc); }
+}
+
 __global__ void k_halfedge_keys(const uint32_t* __restrict__ idx, uint32_t numHalfEdges, uint64_t* __restrict__ edgeKey,
                                 uint32_t* __restrict__ vertKey, uint32_t* __restrict__ value) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -474,23 +486,15 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
     SDF_REQUIRE(nv >= 3 && nt >= 1, "empty mesh");
     SDF_REQUIRE((uint64_t)nt * 3 < (1ull << 32), "too many triangles");
-    for (uint64_t i = 0; i < 3ull * nt; i++) SDF_REQUIRE(indices[i] < nv, "triangle index out of range");
-    // NaN / infinite coordinates make the reference's std::sort comparator inconsistent (undefined behaviour): rejected here
-    float coordScale = 0.f;          // max |coordinate|: bounds the fp32 rounding of the BVH's sphere centres (sdfhip_mesh::bvhCoordScale)
-    for (uint64_t i = 0; i < 3ull * nv; i++) { const float a = std::fabs(xyz[i]); coordScale = a > coordScale ? a : coordScale; }          // (branch-free: vectorises; a NaN never wins the comparison, an infinity does)
-    {
-        uint32_t anyNaN = 0;
-        for (uint64_t i = 0; i < 3ull * nv; i++) anyNaN |= (xyz[i] != xyz[i]) ? 1u : 0u;
-        SDF_REQUIRE(!anyNaN && coordScale <= 3.402823466e+38f, "non-finite vertex coordinate");
-    }
+    // (the arrays are checked on the DEVICE, below: as host loops in front of the upload — the largest index, the largest |coordinate|, a NaN
+    // test — they were 2 - 6 ms of pure latency per 1.31 M-triangle mesh)
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     std::unique_ptr<sdfhip_mesh> owner(new sdfhip_mesh());      // released on success only: every early return below frees it
     sdfhip_mesh* m = owner.get();
-    m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt; m->bvhCoordScale = coordScale;
+    m->ctx = ctx; m->numVertices = nv; m->numTriangles = nt;
     // host copies of the arrays are what the HOST planner reads: with the tree built on the device (the default) they are fetched back from
     // the device only if that build hands over (bvh.hip, hostArrays) — 24 MB of copies and page faults less per 1.31 M-triangle mesh
     if (!sdfhip::bvhBuildOnDevice()) { m->hVerts.assign(xyz, xyz + 3ull * nv); m->hIdx.assign(indices, indices + 3ull * nt); }
-    if (flags & SDFHIP_MESH_PLAN_BVH_EARLY) sdfhip::startEarlyBvhPlan(m);      // the planner (host threads) runs under everything below
     hipStream_t st = ctx->stream;
     const uint32_t nhe = 3 * nt;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
@@ -499,6 +503,19 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     if ((rc = m->dVerts.reserve(3ull * nv)) || (rc = m->dIdx.reserve(nhe)) || (rc = m->dTri.reserve((size_t)TD_FLOATS * nt)) || (rc = m->dFrames.reserve((size_t)FRAME_FLOATS * nt))) return fail(rc);
     SDF_HIP_CHECK(hipMemcpyAsync(m->dVerts.p, xyz, sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
     SDF_HIP_CHECK(hipMemcpyAsync(m->dIdx.p, indices, sizeof(uint32_t) * nhe, hipMemcpyHostToDevice, st));
+    {   // nothing below may index the vertices before the indices are known to be in range; NaN / infinite coordinates make the
+        // reference's std::sort comparator inconsistent (undefined behaviour): rejected
+        DevBuf<uint32_t> chk;
+        if ((rc = chk.reserve(2))) return fail(rc);
+        SDF_HIP_CHECK(hipMemsetAsync(chk.p, 0, 8, st));
+        k_mesh_validate<<<1024, 256, 0, st>>>(m->dVerts.p, 3ull * nv, m->dIdx.p, (uint64_t)nhe, chk.p);
+        uint32_t h[2] = {0, 0};
+        if ((rc = readBackWords(st, chk.p, nullptr, 2, h))) return fail(rc);
+        SDF_REQUIRE(h[0] < nv, "triangle index out of range");
+        SDF_REQUIRE(h[1] <= 0x7F7FFFFFu, "non-finite vertex coordinate");
+        memcpy(&m->bvhCoordScale, &h[1], 4);          // max |coordinate|: bounds the fp32 rounding of the BVH's sphere centres
+    }
+    if (flags & SDFHIP_MESH_PLAN_BVH_EARLY) sdfhip::startEarlyBvhPlan(m);      // the planner (host threads) runs under everything below
     k_triangle_frames<<<gridFor(nt, 256), 256, 0, st>>>(m->dVerts.p, m->dIdx.p, nt, m->dTri.p);
     DevBuf<float> cornerAngle;
     if ((rc = cornerAngle.reserve(nhe))) return fail(rc);
