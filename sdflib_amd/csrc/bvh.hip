@@ -1451,12 +1451,53 @@ __global__ void k_tri_at_rank(const uint32_t* __restrict__ triRank, uint32_t num
 // thin along it) and r', W measured against those decoded values here, so that nothing about the quantisation has to be bounded
 // analytically.  Subtrees above WIDE_SLAB_MAX triangles get no slab (W = +inf): it would not be thin, and the loops below are per thread.
 constexpr uint32_t WIDE_SLAB_MAX = 2048;
-constexpr uint32_t WIDE_SLAB_SPLIT = 192;          // children with more triangles get their slab from k_wide_slabs_big (a block each) instead of 16 lanes
-__global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
-                             uint32_t numTriangles, uint4* __restrict__ wide, uint4* __restrict__ bigList, uint32_t* __restrict__ bigCount, uint32_t bigCap) {
-    // 16 lanes per node: they share the (cheap) header work and stride over the children's triangles for the two reductions
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = gid >> 4, sub = gid & 15u;
+constexpr uint32_t WIDE_SLAB_SPLIT = 192;          // children with more triangles get their slab from k_wide_slabs_big (a block each)
+constexpr uint32_t WIDE_SLAB_TINY = 8;             // children with at most this many get it from the node's own thread; between: k_wide_slabs_mid, 16 lanes each
+// the slab of triangles [rb, re) of the rank order around the decoded centre (dcx, dcy, dcz), by ONE lane: direction words and W as a half
+__device__ __forceinline__ void wideSlabSerial(const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank, uint32_t rb, uint32_t re, double dcx, double dcy, double dcz,
+                                               uint32_t& mxy, uint32_t& mzw) {
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t k = rb; k < re; k++) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double ux = (double)q0.w - q0.x, uy = (double)q1.x - q0.y, uz = (double)q1.y - q0.z, vx = (double)q1.z - q0.x, vy = (double)q1.w - q0.y, vz = (double)q2.x - q0.z;
+        sx += uy * vz - uz * vy; sy += uz * vx - ux * vz; sz += ux * vy - uy * vx;
+    }
+    const double len = sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(len > 1e-300 && len < 1e300)) return;
+    auto snorm = [&](double v) { double q = rint(v / len * 32767.0); if (q < -32767.0) q = -32767.0; if (q > 32767.0) q = 32767.0; return (int)q; };
+    const int ix = snorm(sx), iy = snorm(sy), iz = snorm(sz);
+    const double dmx = (double)((float)ix * (1.0f / 32767.0f)), dmy = (double)((float)iy * (1.0f / 32767.0f)), dmz = (double)((float)iz * (1.0f / 32767.0f));   // the decoded direction
+    double W = 0.0;
+    for (uint32_t k = rb; k < re; k++) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double px[3] = {q0.x, q0.w, q1.z}, py[3] = {q0.y, q1.x, q1.w}, pz[3] = {q0.z, q1.y, q2.x};
+        for (int j = 0; j < 3; j++) W = fmax(W, fabs(dmx * (px[j] - dcx) + dmy * (py[j] - dcy) + dmz * (pz[j] - dcz)));
+    }
+    const double Winfl = W * (1.0 + 1e-9) + 1e-300;
+    float wf = (float)Winfl; if ((double)wf < Winfl) wf = nextafterf(wf, 3.0e38f);
+    mxy = (uint32_t)(ix & 0xFFFF) | ((uint32_t)(iy & 0xFFFF) << 16); mzw = (uint32_t)(iz & 0xFFFF) | ((uint32_t)halfRoundedUp(wf) << 16);
+}
+// a slot of a work list for every lane that wants one: one atomic per wave (0xFFFFFFFF for the lanes that do not)
+__device__ __forceinline__ uint32_t waveAppend(uint32_t* __restrict__ counter, bool want) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0xFFFFFFFFu;
+    const uint32_t lane = __lane_id(); const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader);
+    return want ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+}
+// One THREAD per binary inner node (nodes at odd depths are skipped).  Until round 5 sixteen lanes shared a node - for the loops over its
+// children's triangles - and all sixteen ran the header's fp64 arithmetic (divisions, square roots, roundings) with it: four nodes per
+// wave, 1.6 ms for the 1.31 M-triangle tree.  Now the thread does the header and the slabs of its TINY children (<= 8 triangles: nearly all
+// of them) itself; larger children are listed for k_wide_slabs_mid (16 lanes each) / k_wide_slabs_big (a workgroup each), which fill in the
+// slab words of the child's record (until then: no slab, W = +inf).
+__global__ void __launch_bounds__(256) k_wide_nodes(const int2* __restrict__ kids, const double2* __restrict__ sph, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
+                                                    uint32_t numTriangles, uint4* __restrict__ wide, uint4* __restrict__ midList, uint32_t* __restrict__ midCount, uint32_t midCap,
+                                                    uint4* __restrict__ bigList, uint32_t* __restrict__ bigCount, uint32_t bigCap) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (numTriangles < 2u || i >= numTriangles - 1u) return;
     uint32_t node = 0, b = 0, e = numTriangles, depth = 0;
     while (node != i) {
@@ -1491,10 +1532,10 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
     float scale = (float)(fmax(fmax(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]) / 65535.0);
     if (!(scale > 1e-30f)) scale = 1e-30f;
     uint4* out = wide + 8 * (size_t)i;
-    if (sub == 0u) out[0] = make_uint4(__float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz), __float_as_uint(scale));
+    out[0] = make_uint4(__float_as_uint(ox), __float_as_uint(oy), __float_as_uint(oz), __float_as_uint(scale));
     uint32_t refs[4] = {0u, 0u, 0u, 0u};
     for (int c = 0; c < 4; c++) {
-        uint32_t qx = 0, qy = 0, qz = 0, mx = 0, my = 0, mz = 0; unsigned short rh = 0xFC00u, wh = 0x7C00u;       // empty slot: radius -inf
+        uint32_t qx = 0, qy = 0, qz = 0, mxy = 0, mzw = 0x7C00u << 16, cnt = 0; unsigned short rh = 0xFC00u;       // empty slot: radius -inf; no slab: W = +inf
         if (c < n) {
             auto quant = [&](double v, float o) { double q = rint((v - (double)o) / (double)scale); if (!(q >= 0.0)) q = 0.0; if (q > 65535.0) q = 65535.0; return (uint32_t)q; };
             qx = quant(cx[c], ox); qy = quant(cy[c], oy); qz = quant(cz[c], oz);
@@ -1504,45 +1545,58 @@ __global__ void k_wide_nodes(const int2* __restrict__ kids, const double2* __res
             float rf = (float)rInfl; if ((double)rf < rInfl) rf = nextafterf(rf, 3.0e38f);
             rh = halfRoundedUp(rf);                      // +inf when the radius exceeds the half range: the child is then always visited
             refs[c] = (uint32_t)ref[c];
-            const uint32_t cnt = re[c] - rb[c];
-            if (cnt > WIDE_SLAB_SPLIT && cnt <= WIDE_SLAB_MAX) {
-                // a long strided loop here would hold the 16 lanes (and the wave) for thousands of steps: listed for k_wide_slabs_big, which
-                // fills in the slab words of this child (until then: no slab, W = +inf)
-                if (sub == 0u) { const uint32_t at = atomicAdd(bigCount, 1u); if (at < bigCap) bigList[at] = make_uint4(i, (uint32_t)c, rb[c], re[c]); }
-            } else if (cnt <= WIDE_SLAB_MAX) {
-                double sx = 0, sy = 0, sz = 0;
-                for (uint32_t k = rb[c] + sub; k < re[c]; k += 16u) {
-                    const uint32_t t = triAtRank[k];
-                    const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
-                    const double ux = (double)q0.w - q0.x, uy = (double)q1.x - q0.y, uz = (double)q1.y - q0.z, vx = (double)q1.z - q0.x, vy = (double)q1.w - q0.y, vz = (double)q2.x - q0.z;
-                    sx += uy * vz - uz * vy; sy += uz * vx - ux * vz; sz += ux * vy - uy * vx;
-                }
-#pragma unroll
-                for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sy += __shfl_xor(sy, o, 16); sz += __shfl_xor(sz, o, 16); }
-                const double len = sqrt(sx * sx + sy * sy + sz * sz);
-                if (len > 1e-300 && len < 1e300) {
-                    auto snorm = [&](double v) { double q = rint(v / len * 32767.0); if (q < -32767.0) q = -32767.0; if (q > 32767.0) q = 32767.0; return (int)q; };
-                    const int ix = snorm(sx), iy = snorm(sy), iz = snorm(sz);
-                    const double dmx = (double)((float)ix * (1.0f / 32767.0f)), dmy = (double)((float)iy * (1.0f / 32767.0f)), dmz = (double)((float)iz * (1.0f / 32767.0f));   // the decoded direction
-                    double W = 0.0;
-                    for (uint32_t k = rb[c] + sub; k < re[c]; k += 16u) {
-                        const uint32_t t = triAtRank[k];
-                        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
-                        const double px[3] = {q0.x, q0.w, q1.z}, py[3] = {q0.y, q1.x, q1.w}, pz[3] = {q0.z, q1.y, q2.x};
-                        for (int j = 0; j < 3; j++) W = fmax(W, fabs(dmx * (px[j] - dcx) + dmy * (py[j] - dcy) + dmz * (pz[j] - dcz)));
-                    }
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) W = fmax(W, __shfl_xor(W, o, 16));
-                    const double Winfl = W * (1.0 + 1e-9) + 1e-300;
-                    float wf = (float)Winfl; if ((double)wf < Winfl) wf = nextafterf(wf, 3.0e38f);
-                    wh = halfRoundedUp(wf);
-                    mx = (uint32_t)(ix & 0xFFFF); my = (uint32_t)(iy & 0xFFFF); mz = (uint32_t)(iz & 0xFFFF);
-                }
-            }
+            cnt = re[c] - rb[c];
+            if (cnt <= WIDE_SLAB_TINY) wideSlabSerial(triV, triAtRank, rb[c], re[c], dcx, dcy, dcz, mxy, mzw);
         }
-        if (sub == 0u) out[1 + c] = make_uint4(qx | (qy << 16), qz | ((uint32_t)rh << 16), mx | (my << 16), mz | ((uint32_t)wh << 16));
+        // (one atomic per wave and list: hundreds of thousands of single increments of one counter would cost what the kernel saves)
+        const uint32_t atMid = waveAppend(midCount, cnt > WIDE_SLAB_TINY && cnt <= WIDE_SLAB_SPLIT), atBig = waveAppend(bigCount, cnt > WIDE_SLAB_SPLIT && cnt <= WIDE_SLAB_MAX);
+        if (atMid != 0xFFFFFFFFu && atMid < midCap) midList[atMid] = make_uint4(i, (uint32_t)c, rb[c], re[c]);
+        if (atBig != 0xFFFFFFFFu && atBig < bigCap) bigList[atBig] = make_uint4(i, (uint32_t)c, rb[c], re[c]);
+        out[1 + c] = make_uint4(qx | (qy << 16), qz | ((uint32_t)rh << 16), mxy, mzw);
     }
-    if (sub == 0u) out[5] = make_uint4(refs[0], refs[1], refs[2], refs[3]);
+    out[5] = make_uint4(refs[0], refs[1], refs[2], refs[3]);
+}
+// The slab of a child of 9 .. WIDE_SLAB_SPLIT triangles: sixteen lanes per listed (node, child) stride over its triangles for the two
+// reductions.  Same construction as everywhere: direction = normalised sum of the area normals, quantised; W measured against the DECODED
+// centre and direction, rounded up - conservative whatever the summation order.
+__global__ void __launch_bounds__(256) k_wide_slabs_mid(const uint4* __restrict__ midList, uint32_t count, const float4* __restrict__ triV, const uint32_t* __restrict__ triAtRank,
+                                                        uint4* __restrict__ wide) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t jb = gid >> 4, sub = gid & 15u;
+    if (jb >= count) return;                               // (uniform per group of sixteen lanes)
+    const uint4 job = midList[jb];
+    uint4* out = wide + 8 * (size_t)job.x;
+    const uint4 hdr = out[0], rec = out[1 + job.y];
+    const float ox = __uint_as_float(hdr.x), oy = __uint_as_float(hdr.y), oz = __uint_as_float(hdr.z), scale = __uint_as_float(hdr.w);
+    const double dcx = (double)fmaf((float)(rec.x & 0xFFFFu), scale, ox), dcy = (double)fmaf((float)(rec.x >> 16), scale, oy), dcz = (double)fmaf((float)(rec.y & 0xFFFFu), scale, oz);
+    double sx = 0, sy = 0, sz = 0;
+    for (uint32_t k = job.z + sub; k < job.w; k += 16u) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double ux = (double)q0.w - q0.x, uy = (double)q1.x - q0.y, uz = (double)q1.y - q0.z, vx = (double)q1.z - q0.x, vy = (double)q1.w - q0.y, vz = (double)q2.x - q0.z;
+        sx += uy * vz - uz * vy; sy += uz * vx - ux * vz; sz += ux * vy - uy * vx;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { sx += __shfl_xor(sx, o, 16); sy += __shfl_xor(sy, o, 16); sz += __shfl_xor(sz, o, 16); }
+    const double len = sqrt(sx * sx + sy * sy + sz * sz);
+    if (!(len > 1e-300 && len < 1e300)) return;           // (the sixteen lanes hold the same sums)
+    auto snorm = [&](double v) { double q = rint(v / len * 32767.0); if (q < -32767.0) q = -32767.0; if (q > 32767.0) q = 32767.0; return (int)q; };
+    const int ix = snorm(sx), iy = snorm(sy), iz = snorm(sz);
+    const double dmx = (double)((float)ix * (1.0f / 32767.0f)), dmy = (double)((float)iy * (1.0f / 32767.0f)), dmz = (double)((float)iz * (1.0f / 32767.0f));
+    double W = 0.0;
+    for (uint32_t k = job.z + sub; k < job.w; k += 16u) {
+        const uint32_t t = triAtRank[k];
+        const float4 q0 = triV[3 * (size_t)t], q1 = triV[3 * (size_t)t + 1], q2 = triV[3 * (size_t)t + 2];
+        const double px[3] = {q0.x, q0.w, q1.z}, py[3] = {q0.y, q1.x, q1.w}, pz[3] = {q0.z, q1.y, q2.x};
+        for (int j = 0; j < 3; j++) W = fmax(W, fabs(dmx * (px[j] - dcx) + dmy * (py[j] - dcy) + dmz * (pz[j] - dcz)));
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) W = fmax(W, __shfl_xor(W, o, 16));
+    if (sub == 0u) {
+        const double Winfl = W * (1.0 + 1e-9) + 1e-300;
+        float wf = (float)Winfl; if ((double)wf < Winfl) wf = nextafterf(wf, 3.0e38f);
+        out[1 + job.y] = make_uint4(rec.x, rec.y, (uint32_t)(ix & 0xFFFF) | ((uint32_t)(iy & 0xFFFF) << 16), (uint32_t)(iz & 0xFFFF) | ((uint32_t)halfRoundedUp(wf) << 16));
+    }
 }
 
 // The slab of one large child (WIDE_SLAB_SPLIT < triangles <= WIDE_SLAB_MAX): a block per listed (node, child).  Same construction as
@@ -1704,18 +1758,19 @@ static int installBvh(sdfhip_mesh* mesh, const double* sph, const int* kids, int
     SDF_TRY(triAtRank.reserve(T));
     k_tri_at_rank<<<gridFor(T, 256), 256, 0, st>>>(mesh->dTriRank.p, T, triAtRank.p);
     SDF_TRY(mesh->dBvhWide.reserve(32 * (size_t)(nn ? nn : 1)));
-    DevBuf<uint32_t> bigList, bigCount;                  // children too large for 16 lanes: at most T / WIDE_SLAB_SPLIT per level pair, 12 level pairs
-    const size_t bigCap = (size_t)T / WIDE_SLAB_SPLIT * 16 + 64;
-    SDF_TRY(bigList.reserve(4 * bigCap)); SDF_TRY(bigCount.reserve(1));
-    SDF_HIP_CHECK(hipMemsetAsync(bigCount.p, 0, 4, st));
-    k_wide_nodes<<<gridFor(16ull * T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), reinterpret_cast<const float4*>(mesh->dTriVerts.p),
-                                               triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p), reinterpret_cast<uint4*>(bigList.p), bigCount.p, (uint32_t)bigCap);
+    DevBuf<uint32_t> bigList, midList, listCount;        // children whose slab the node's thread leaves to sixteen lanes / to a workgroup
+    const size_t bigCap = (size_t)T / WIDE_SLAB_SPLIT * 16 + 64, midCap = (size_t)T / WIDE_SLAB_TINY * 4 + 64;      // (sizes of a level pair's children x level pairs that fall in the class)
+    SDF_TRY(bigList.reserve(4 * bigCap)); SDF_TRY(midList.reserve(4 * midCap)); SDF_TRY(listCount.reserve(2));
+    SDF_HIP_CHECK(hipMemsetAsync(listCount.p, 0, 8, st));
+    k_wide_nodes<<<gridFor(T, 256), 256, 0, st>>>(reinterpret_cast<const int2*>(mesh->dBvhKids.p), reinterpret_cast<const double2*>(mesh->dBvhSph.p), reinterpret_cast<const float4*>(mesh->dTriVerts.p),
+                                                 triAtRank.p, T, reinterpret_cast<uint4*>(mesh->dBvhWide.p), reinterpret_cast<uint4*>(midList.p), listCount.p, (uint32_t)midCap,
+                                                 reinterpret_cast<uint4*>(bigList.p), listCount.p + 1, (uint32_t)bigCap);
     {
-        uint32_t nBig = 0;
-        SDF_HIP_CHECK(hipMemcpyAsync(&nBig, bigCount.p, 4, hipMemcpyDeviceToHost, st));
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
-        SDF_REQUIRE(nBig <= bigCap, "wide-node work list overflow");
-        if (nBig) k_wide_slabs_big<<<nBig, 256, 0, st>>>(reinterpret_cast<const uint4*>(bigList.p), nBig, reinterpret_cast<const float4*>(mesh->dTriVerts.p), triAtRank.p, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
+        uint32_t nList[2] = {0, 0};
+        SDF_TRY(readBackWords(st, listCount.p, nullptr, 2, nList));
+        SDF_REQUIRE(nList[0] <= midCap && nList[1] <= bigCap, "wide-node work list overflow");
+        if (nList[0]) k_wide_slabs_mid<<<gridFor(16ull * nList[0], 256), 256, 0, st>>>(reinterpret_cast<const uint4*>(midList.p), nList[0], reinterpret_cast<const float4*>(mesh->dTriVerts.p), triAtRank.p, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
+        if (nList[1]) k_wide_slabs_big<<<nList[1], 256, 0, st>>>(reinterpret_cast<const uint4*>(bigList.p), nList[1], reinterpret_cast<const float4*>(mesh->dTriVerts.p), triAtRank.p, reinterpret_cast<uint4*>(mesh->dBvhWide.p));
     }
     SDF_HIP_CHECK(hipGetLastError());
     bool shapeOk = true;
