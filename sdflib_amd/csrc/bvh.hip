@@ -2094,8 +2094,8 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         if (hipMemcpy(&serial, sumStatus.p + tableNodes, 4, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
         fprintf(stderr, "[sdfhip] bvh on the device: centre sums of %zu nodes in parallel (verified chunk by chunk), %u of them redone by the serial chain\n", tableNodes - levels[0].size(), serial);
     }
-    if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds in %u groups) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: sorts %.3f ms of %.3f), waiting for the centre sums %.4f s\n",
-                        nTop, rounds, groups, tTop - t0, nt, S, tSub - tTop, clk[2] * 1e-5, (clk[0] + clk[1] + clk[2] + clk[3]) * 1e-5, nowSeconds() - tSub);
+    if (timing) fprintf(stderr, "[sdfhip] bvh on the device: %zu levels in global memory (%u rounds in %u groups) %.4f s, %zu ranges of <= %u in LDS %.4f s (block 0: levels prepared by the workgroup %.3f ms, by a lane per node %.3f, sorts %.3f, children %.3f), waiting for the centre sums %.4f s\n",
+                        nTop, rounds, groups, tTop - t0, nt, S, tSub - tTop, clk[0] * 1e-5, clk[1] * 1e-5, clk[2] * 1e-5, clk[3] * 1e-5, nowSeconds() - tSub);
     if (failed || hostCtr[4]) return SDFHIP_E_UNSUPPORTED;
     return SDFHIP_OK;
 }
