@@ -291,6 +291,11 @@ __global__ void __launch_bounds__(256) kc_children(CLevelDev L, CLevelDev N, uin
     else N.word[child] = NONE32;
 }
 
+// the totals of three exclusive scans (last offset + last value each), side by side for one read-back
+__global__ void kc_totals3(const uint32_t* __restrict__ s0, const uint32_t* __restrict__ v0, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ v1,
+                           const uint32_t* __restrict__ s2, const uint32_t* __restrict__ v2, uint32_t* __restrict__ out3) {
+    if (threadIdx.x == 0) { out3[0] = *s0 + *v0; out3[1] = *s1 + *v1; out3[2] = *s2 + *v2; }
+}
 __global__ void kc_flag_cand(const uint32_t* __restrict__ cand, uint32_t n, uint32_t* __restrict__ flag) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flag[i] = (cand[i] != NONE32) ? 1u : 0u;
@@ -887,7 +892,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     SS.near = &ctx->nearScratch; ctx->nearScratch.counterReady = false;      // (builds on one context are serialised by its buildLock)
     if (ctx->exchange.world >= 1 && ctx->exchange.acquire) SS.exchange = &ctx->exchange;      // multi-GPU: every rank traverses its share of each sample batch
     DevBuf<float> ppPos; DevBuf<uint32_t> ppSlot, ppTri, ppCount;      // post-pass samples through the two-phase search
-    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> cflag, cscan, clist;      // post-pass device buffers, grow-only
+    DevBuf<OpDev> dops; DevBuf<float> scratch; DevBuf<uint32_t> cflag, cscan, clist, totals3;      // post-pass device buffers, grow-only
     {   // Levels down to the start depth exist a priori (every node above it subdivides): create their geometry now — kc_children will
         // write the same centres / coordinates again together with everything else — and take the root corners and all their
         // mid-point samples in ONE deduplicated batch instead of one latency-bound launch per level.
@@ -924,15 +929,22 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         kc_fit_rule<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, P->rule, sqThr, param1, oc.p);
         // ---------------- Iter 2
         kc_iter2_masks<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, NM, oc.p);
+        // the three counts the host needs before it can go on - words to allocate, inner nodes, post-pass candidates - all follow from
+        // kc_iter2_masks: their scans run back to back and ONE read-back brings the totals (three read-backs per level until round 5)
+        SDF_TRY(cflag.reserve(24ull * n)); SDF_TRY(cscan.reserve(24ull * n)); SDF_TRY(totals3.reserve(3));
         SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->allocSize.p, L->allocOff.p, n));
-        uint32_t allocTotal = 0; SDF_TRY(lastPlus(st, L->allocOff.p, L->allocSize.p, n, allocTotal));
+        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->inner.p, L->childSlot.p, n));
+        kc_flag_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, 24 * n, cflag.p);
+        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, cflag.p, cscan.p, 24 * n));
+        kc_totals3<<<1, 64, 0, st>>>(L->allocOff.p + (n - 1), L->allocSize.p + (n - 1), L->childSlot.p + (n - 1), L->inner.p + (n - 1), cscan.p + (24ull * n - 1), cflag.p + (24ull * n - 1), totals3.p);
+        uint32_t h3[3] = {0, 0, 0};
+        SDF_TRY(readBackWords(st, totals3.p, nullptr, 3, h3));
+        const uint32_t allocTotal = h3[0], numInner = h3[1], numCand = h3[2];
         SDF_REQUIRE((uint64_t)ocSize + allocTotal < (uint64_t)INDEX_MASK, "octree exceeds the 30-bit node index of the reference layout");
         const uint32_t base = ocSize;
         SDF_TRY(ensureOc((size_t)ocSize + allocTotal));
         kc_iter2_write<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, cd, startDepth, base, oc.p, stats.p);
         if (cd >= startDepth) kc_register_leaves<<<gridFor(n, 256), 256, 0, st>>>(Ld, cd, base, G3, recOf.p);
-        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, L->inner.p, L->childSlot.p, n));
-        uint32_t numInner = 0; SDF_TRY(lastPlus(st, L->childSlot.p, L->inner.p, n, numInner));
         kc_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childSlot.p);
         if (numInner > 0) {
             if (!LV[cd + 1]) {
@@ -944,11 +956,6 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
             kc_children<<<gridFor(64ull * n, 256), 256, 0, st>>>(Ld, LV[cd + 1]->dev(), cd, startDepth, base, G);
         }
         // candidates of the post-pass, in node order then slot order
-        uint32_t numCand = 0;
-        SDF_TRY(cflag.reserve(24ull * n)); SDF_TRY(cscan.reserve(24ull * n));
-        kc_flag_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, 24 * n, cflag.p);
-        SDF_TRY(scanExclusive(st, scanTmp, scanTmpBytes, cflag.p, cscan.p, 24 * n));
-        SDF_TRY(lastPlus(st, cscan.p, cflag.p, 24 * n, numCand));
         if (numCand) {
             SDF_TRY(clist.reserve(numCand));
             kc_compact_cand<<<gridFor(24ull * n, 256), 256, 0, st>>>(L->cand.p, cflag.p, cscan.p, 24 * n, clist.p);
