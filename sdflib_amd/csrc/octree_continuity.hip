@@ -810,7 +810,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<uint32_t> recOf, firstOcc; size_t recCap = 0;      // per coefficient block: its owner / the first candidate naming it (device post-pass)
     auto ensureOc = [&](size_t need) -> int {
         if (need <= ocCap) return SDFHIP_OK;
-        size_t cap = ocCap ? ocCap : (size_t)1 << 22;
+        size_t cap = ocCap ? ocCap : std::max<size_t>((size_t)1 << 22, ctx->contCaps[0]);      // (every growth is an allocation, copies and two waits: a repeated build starts where the last one ended)
         while (cap < need) cap *= 2;
         DevBuf<uint32_t> bigger; SDF_TRY(bigger.reserve(cap));
         if (oc.p) SDF_HIP_CHECK(hipMemcpyAsync(bigger.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
@@ -833,7 +833,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<float> pCenter, pHalf, pVv; DevBuf<PoolRec> pRec; size_t poolCap = 0; uint32_t poolCount = 0;
     auto ensurePool = [&](size_t need) -> int {
         if (need <= poolCap) return SDFHIP_OK;
-        size_t cap = poolCap ? poolCap : 4096;
+        size_t cap = poolCap ? poolCap : std::max<size_t>(4096, ctx->contCaps[1]);
         while (cap < need) cap *= 2;
         DevBuf<float> c2, h2, v2; DevBuf<PoolRec> r2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
         SDF_TRY(r2.reserve(cap));
@@ -850,7 +850,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<PPNode> ppNodesBuf; size_t ppNodesCap = 0;
     auto ensureNodes = [&](size_t have, size_t need) -> int {
         if (need <= ppNodesCap) return SDFHIP_OK;
-        size_t cap = ppNodesCap ? ppNodesCap : 4096;
+        size_t cap = ppNodesCap ? ppNodesCap : std::max<size_t>(4096, ctx->contCaps[2]);
         while (cap < need) cap *= 2;
         DevBuf<PPNode> b2; SDF_TRY(b2.reserve(cap));
         if (have) { SDF_HIP_CHECK(hipMemcpyAsync(b2.p, ppNodesBuf.p, sizeof(PPNode) * have, hipMemcpyDeviceToDevice, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); }
@@ -1068,6 +1068,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         lap(tOps);
     }
     SDF_TRY(sampleBatchEnd(st, md, SS));
+    ctx->contCaps[0] = ocCap; ctx->contCaps[1] = poolCap; ctx->contCaps[2] = ppNodesCap;
     if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] continuity: level kernels %.3f s, post-pass planning (device) %.3f s, post-pass ops %.3f s (host clock; phases overlap unless timing is on); post-pass: %llu scheduled, %llu still leaves, %llu nodes visited, %llu splits\n", tIter, tPlan, tOps,
                                             (unsigned long long)numRescheduled, (unsigned long long)ppRoots, (unsigned long long)ppNodes, (unsigned long long)ppSplits);
     // final statistics on the device
