@@ -950,7 +950,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             SDF_HIP_CHECK(hipGetLastError());
             LV[d + 1 - sod] = std::move(N);
         }
-        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        // (no wait: the blocks go back to the stream's cache, whose next user is queued behind the kernels that still read them)
         L->midTri.release(); L->center.release(); L->cornerTri.release();
         prevList = L->list.p;
         levelSeconds.push_back(nowSeconds() - tLevel);
