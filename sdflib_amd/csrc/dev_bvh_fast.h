@@ -732,14 +732,15 @@ struct NearPlainAlloc { AllocState saved; NearPlainAlloc() { saved = tlsAlloc();
 static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
 
 // Launch constants of the candidate search, each the winner of a measured sweep (profiles/r04g_near_seeds_roundtrip_ab.txt):
-constexpr uint32_t NEAR_TWO_PASS_MIN = 32768;   // batches of this many queries and more run as leaders + followers
+constexpr uint32_t NEAR_TWO_PASS_MIN = 524288;  // batches of this many queries and more run as leaders + followers (32768 until late round 5: below ~0.5 M the leaders' pass is a
+                                                // second latency-bound sweep that costs more than its seeds save - a C2 build 11.85 -> 11.65 ms, an eighth of it as a shard 5.6 -> 5.1 ms)
 constexpr uint32_t NEAR_LEAD = 8;               // every 8th query of the Morton order is a leader (4: 9.2 ms, 16: 9.0 ms against 8.8 per C2 build); a power of two <= 128
 constexpr uint32_t NEAR_QBLOCKS_PER_CU = 6;     // resident workgroups of 256 per CU (7: 9.06 ms, 8: 9.44 ms: more waves only add L2 misses)
 constexpr uint32_t NEAR_QCHUNK = 16;            // queries a wave (16 quads) takes per atomic (32, 64: slower)
 constexpr uint32_t NEAR_MULTISEED = 2;          // leaders a follower is seeded from: the one before it and the one after it
 constexpr uint32_t NEAR_REFILL_MIN = 1;         // idle quads a refill waits for (2 - 4: 8.71 / 8.82 / 8.93 ms, within noise of 1)
 constexpr int NEAR_DRAIN_QUAD_LANES = 40;       // lanes with a triangle to test that make a drain round worth its instructions (32: 8.85, 48: 9.0 ms)
-constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query)
+constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query; 768 / 384: the same build times, 256: +10 %, 160: x2.4)
 
 // Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  seedTri (dev probe, sdfhip_mesh_nearest_stats): the
 // search of query r starts from the bound of triangle seedTri[r].

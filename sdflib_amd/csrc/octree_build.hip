@@ -128,20 +128,35 @@ __global__ void k_scale8(uint32_t n, uint32_t* __restrict__ v) {
     if (i < n) v[i] *= 8u;
 }
 
-// Index of a node in a COMPLETE level built by repeated k_expand_geometry from the root level: one octal digit per depth, most
-// significant first, digit = x_bit | y_bit << 1 | z_bit << 2 (the root level itself is stored in that order).
-SDF_DEV uint32_t completeLevelIndex(uint32_t co, uint32_t depth) {
-    const uint32_t x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
-    uint32_t idx = 0;
-    for (int b = (int)depth - 1; b >= 0; b--) idx = (idx << 3) | ((x >> b) & 1u) | (((y >> b) & 1u) << 1) | (((z >> b) & 1u) << 2);
+// The speculative levels descend from THIS build's start cells only, in cell order (z-major, the shard's range): a shard of an N-GPU build
+// samples its own eighth of them, not the whole level (until round 5 every shard sampled all of it: 6.9 ms per shard at world 8 against
+// 11.9 ms for the whole build).  Geometry of the start cells [cellBegin, cellEnd) out of the complete start level:
+__global__ void k_spec_base(const float* __restrict__ center, const uint32_t* __restrict__ coord, uint32_t n, uint32_t G, uint32_t cellBegin, uint32_t cellEnd,
+                            float* __restrict__ ocenter, uint32_t* __restrict__ ocoord) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t co = coord[i];
+    const uint32_t cell = (co >> 20) * G * G + ((co >> 10) & 1023u) * G + (co & 1023u);
+    if (cell < cellBegin || cell >= cellEnd) return;
+    const uint32_t d = cell - cellBegin;
+    ocenter[3 * (size_t)d] = center[3 * (size_t)i]; ocenter[3 * (size_t)d + 1] = center[3 * (size_t)i + 1]; ocenter[3 * (size_t)d + 2] = center[3 * (size_t)i + 2];
+    ocoord[d] = co;
+}
+// index of a node in a speculative level: its start cell's place in the range, then one octal digit per depth below the start depth
+// (digit = x_bit | y_bit << 1 | z_bit << 2, the order k_expand_geometry writes children in)
+SDF_DEV uint32_t specLevelIndex(uint32_t co, uint32_t depth, uint32_t startDepth, uint32_t G, uint32_t cellBegin) {
+    const uint32_t s = depth - startDepth, x = co & 1023u, y = (co >> 10) & 1023u, z = co >> 20;
+    uint32_t idx = (z >> s) * G * G + (y >> s) * G + (x >> s) - cellBegin;
+    for (int b = (int)s - 1; b >= 0; b--) idx = (idx << 3) | ((x >> b) & 1u) | (((y >> b) & 1u) << 1) | (((z >> b) & 1u) << 2);
     return idx;
 }
-// mid-points of the nodes that turned out to exist, taken from the speculatively sampled complete level
-__global__ void k_gather_spec_mids(const uint32_t* __restrict__ coord, uint32_t n, uint32_t depth, const float* __restrict__ specMid, float* __restrict__ mid) {
+// mid-points of the nodes that turned out to exist, taken from the speculatively sampled level
+__global__ void k_gather_spec_mids(const uint32_t* __restrict__ coord, uint32_t n, uint32_t depth, uint32_t startDepth, uint32_t G, uint32_t cellBegin,
+                                   const float* __restrict__ specMid, float* __restrict__ mid) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t i = gid / 19u, m = gid - 19u * i;
     if (i >= n) return;
-    reinterpret_cast<float4*>(mid)[gid] = reinterpret_cast<const float4*>(specMid)[19 * (size_t)completeLevelIndex(coord[i], depth) + m];
+    reinterpret_cast<float4*>(mid)[gid] = reinterpret_cast<const float4*>(specMid)[19 * (size_t)specLevelIndex(coord[i], depth, startDepth, G, cellBegin) + m];
 }
 
 struct ScatterArgs {
@@ -439,8 +454,16 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
         // traversals: the batch is latency bound up to ~1e6 samples); the nodes that really exist pick their samples out of them
         // (k_gather_spec_mids) and two more dependent launches disappear from the critical path.  Identical values: a sample
         // depends only on its position, and the complete level computes the node centres with the same operations.
+        std::unique_ptr<BuildLevel> specBase;          // this build's start cells, in cell order
+        if (startDepth + 1 < maxDepth && T->levels[startDepth - sod]) {
+            const BuildLevel* full = T->levels[startDepth - sod].get();
+            specBase.reset(new BuildLevel());
+            specBase->depth = startDepth; specBase->n = cellEnd - cellBegin; specBase->half = full->half;
+            SDF_TRY(specBase->center.reserve(3ull * specBase->n)); SDF_TRY(specBase->coord.reserve(specBase->n));
+            k_spec_base<<<gridFor(full->n, 256), 256, 0, st>>>(full->center.p, full->coord.p, full->n, G, cellBegin, cellEnd, specBase->center.p, specBase->coord.p);
+        }
         for (uint32_t d = startDepth + 1; d <= startDepth + 2 && d < maxDepth; d++) {
-            const BuildLevel* prev = (d == startDepth + 1) ? T->levels[startDepth - sod].get() : spec[d - startDepth - 2].get();
+            const BuildLevel* prev = (d == startDepth + 1) ? specBase.get() : spec[d - startDepth - 2].get();
             if (!prev || 19ull * 8ull * prev->n > SPEC_SAMPLE_LIMIT) break;
             std::unique_ptr<BuildLevel> N(new BuildLevel());
             N->depth = d; N->n = 8u * prev->n; N->half = 0.5f * prev->half;
@@ -520,7 +543,7 @@ static int buildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_par
                 const uint32_t si = d + 1 - startDepth - 1;      // 0 or 1 for the two speculative levels
                 if (d + 1 > startDepth && si < 2 && spec[si] && d + 1 < maxDepth) {
                     SDF_TRY(fresh->mid.reserve(76ull * fresh->n));
-                    k_gather_spec_mids<<<gridFor(19ull * fresh->n, 256), 256, 0, st>>>(fresh->coord.p, fresh->n, d + 1, spec[si]->mid.p, fresh->mid.p);
+                    k_gather_spec_mids<<<gridFor(19ull * fresh->n, 256), 256, 0, st>>>(fresh->coord.p, fresh->n, d + 1, startDepth, G, cellBegin, spec[si]->mid.p, fresh->mid.p);
                     SDF_HIP_CHECK(hipGetLastError());
                     fresh->presampled = true;
                     T->info.num_samples += 19ull * fresh->n;
