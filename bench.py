@@ -350,7 +350,7 @@ def main():
         dist.destroy_process_group()
 
 
-NEAR_KERNEL = "sdfhip::k_near_quads<256>"
+NEAR_KERNEL = "sdfhip::k_near_quads<256,false>"
 KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip", "sdflib_amd/csrc/Makefile"]
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 GPU_CLOCK_HZ, GPU_SIMDS = 2.4e9, 1024          # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)

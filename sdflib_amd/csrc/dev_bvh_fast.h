@@ -160,12 +160,27 @@ template <int CTRL> SDF_DEV float quadPermF(float x) { return __int_as_float(__b
 template <int CTRL> SDF_DEV uint32_t quadPermU(uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, false); }
 SDF_DEV uint32_t quadBallot(bool pred, uint32_t lane) { return (uint32_t)(__ballot(pred) >> (lane & ~3u)) & 0xFu; }
 
-template <int BLOCK>
+// Launch constants of the candidate search, each the winner of a measured sweep (profiles/r04g_near_seeds_roundtrip_ab.txt, DESIGN.md section 5):
+constexpr uint32_t NEAR_TWO_PASS_MIN = 524288;  // batches of this many queries and more run as leaders + followers (32768 until late round 5: below ~0.5 M the leaders' pass is a
+                                                // second latency-bound sweep that costs more than its seeds save - a C2 build 11.85 -> 11.65 ms, an eighth of it as a shard 5.6 -> 5.1 ms)
+constexpr uint32_t NEAR_LEAD = 8;               // every 8th query of the Morton order is a leader (4: 9.2 ms, 16: 9.0 ms against 8.8 per C2 build); a power of two <= 128
+constexpr uint32_t NEAR_QBLOCKS_PER_CU = 6;     // resident workgroups of 256 per CU (7: 9.06 ms, 8: 9.44 ms: more waves only add L2 misses)
+constexpr uint32_t NEAR_QCHUNK = 16;            // queries a wave (16 quads) takes per atomic (32, 64: slower)
+constexpr uint32_t NEAR_MULTISEED = 2;          // leaders a follower is seeded from: the one before it and the one after it
+constexpr uint32_t NEAR_REFILL_MIN = 1;         // idle quads a refill waits for (2 - 4: 8.71 / 8.82 / 8.93 ms, within noise of 1)
+constexpr int NEAR_DRAIN_QUAD_LANES = 40;       // lanes with a triangle to test that make a drain round worth its instructions (32: 8.85, 48: 9.0 ms)
+constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query; 768 / 384: the same build times, 256: +10 %, 160: x2.4)
+
+// PROBE: the per-query counters and seeds of the dev probes (sdfhip_mesh_nearest_stats); the builds' instantiation has neither.  The launch
+// constants above are compile-time values in the kernel (kernel arguments until late round 5: seven scalar registers and a division by `lead`).
+template <int BLOCK, bool PROBE>
 __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
                                                       uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, uint32_t* __restrict__ counters,
-                                                      uint32_t maxSteps, uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount, int drainQuads, uint32_t chunk,
-                                                      bool seedFromNeighbour, uint32_t* __restrict__ perQuery, const uint32_t* __restrict__ seedTri, int pass,
-                                                      uint32_t* __restrict__ best, uint32_t lead, uint32_t multiSeed, uint32_t refillMin) {
+                                                      uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
+                                                      uint32_t* __restrict__ perQueryArg, const uint32_t* __restrict__ seedTriArg, int pass, uint32_t* __restrict__ best) {
+    constexpr uint32_t maxSteps = NEAR_MAX_STEPS, chunk = NEAR_QCHUNK, lead = NEAR_LEAD, multiSeed = NEAR_MULTISEED, refillMin = NEAR_REFILL_MIN;
+    constexpr int drainQuads = NEAR_DRAIN_QUAD_LANES; constexpr bool seedFromNeighbour = true;
+    uint32_t* const perQuery = PROBE ? perQueryArg : nullptr; const uint32_t* const seedTri = PROBE ? seedTriArg : nullptr;
     __shared__ uint32_t s_ref[BLOCK / 64][QUAD_STACK][16];
     __shared__ unsigned short s_lb[BLOCK / 64][QUAD_STACK][16];
     __shared__ uint32_t s_tq[BLOCK / 64][QUAD_TQ][16];
@@ -731,17 +746,6 @@ typedef sdfhip_near_scratch NearScratch;
 struct NearPlainAlloc { AllocState saved; NearPlainAlloc() { saved = tlsAlloc(); tlsAlloc().active = false; } ~NearPlainAlloc() { tlsAlloc() = saved; } };
 static inline bool nearestExactOnly() { static const bool v = getenv("SDFHIP_NEAREST") && !strcmp(getenv("SDFHIP_NEAREST"), "exact"); return v; }
 
-// Launch constants of the candidate search, each the winner of a measured sweep (profiles/r04g_near_seeds_roundtrip_ab.txt, DESIGN.md section 5):
-constexpr uint32_t NEAR_TWO_PASS_MIN = 524288;  // batches of this many queries and more run as leaders + followers (32768 until late round 5: below ~0.5 M the leaders' pass is a
-                                                // second latency-bound sweep that costs more than its seeds save - a C2 build 11.85 -> 11.65 ms, an eighth of it as a shard 5.6 -> 5.1 ms)
-constexpr uint32_t NEAR_LEAD = 8;               // every 8th query of the Morton order is a leader (4: 9.2 ms, 16: 9.0 ms against 8.8 per C2 build); a power of two <= 128
-constexpr uint32_t NEAR_QBLOCKS_PER_CU = 6;     // resident workgroups of 256 per CU (7: 9.06 ms, 8: 9.44 ms: more waves only add L2 misses)
-constexpr uint32_t NEAR_QCHUNK = 16;            // queries a wave (16 quads) takes per atomic (32, 64: slower)
-constexpr uint32_t NEAR_MULTISEED = 2;          // leaders a follower is seeded from: the one before it and the one after it
-constexpr uint32_t NEAR_REFILL_MIN = 1;         // idle quads a refill waits for (2 - 4: 8.71 / 8.82 / 8.93 ms, within noise of 1)
-constexpr int NEAR_DRAIN_QUAD_LANES = 40;       // lanes with a triangle to test that make a drain round worth its instructions (32: 8.85, 48: 9.0 ms)
-constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query; 768 / 384: the same build times, 256: +10 %, 160: x2.4)
-
 // Nearest triangle of pos[0..n) into out (this rank's blocks only when world > 1).  seedTri (dev probe, sdfhip_mesh_nearest_stats): the
 // search of query r starts from the bound of triangle seedTri[r].
 static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, uint32_t n, uint32_t* out, NearScratch& S, int stackDepth, uint32_t rank, uint32_t world,
@@ -771,8 +775,10 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     uint32_t qgrid = 256u * NEAR_QBLOCKS_PER_CU;          // all resident (72 VGPRs: 7 waves per SIMD)
     const uint32_t needBlocks = (mine * 128u + 63u) / 64u;           // 64 queries per block of 256 lanes
     if (qgrid > needBlocks) qgrid = needBlocks;
-    k_near_quads<256><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, NEAR_MAX_STEPS, S.longList.p, S.fbCount.p + 10,
-                                                    NEAR_DRAIN_QUAD_LANES, NEAR_QCHUNK, true, perQuery, seedTri, twoPass ? 1 : 0, S.best.p, NEAR_LEAD, NEAR_MULTISEED, NEAR_REFILL_MIN);
+    if (perQuery || seedTri)
+        k_near_quads<256, true><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, perQuery, seedTri, twoPass ? 1 : 0, S.best.p);
+    else
+        k_near_quads<256, false><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, nullptr, nullptr, twoPass ? 1 : 0, S.best.p);
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[1], st));
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, S.fbCount.p + 24);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);
