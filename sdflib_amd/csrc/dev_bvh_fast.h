@@ -528,6 +528,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
     bool adopted = false;
     int fsp = 0;
     uint32_t node = 0, b = 0, e = bvh.numTriangles; int lo = 0, hi = n2;
+    uint32_t rmin = rk[0], rmax = rk[(n2 - 1) * BLOCK];      // the ranks of candidates lo and hi - 1: most levels of the way down need no more (every candidate on one side)
     bool pending = true;           // a subproblem (node, [b,e), [lo,hi)) is loaded
     for (;;) {
         if (!pending) {
@@ -540,6 +541,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
             const uint32_t mid = (pb + pe) >> 1;
             node = side ? pn + (mid - pb) : pn + 1u; b = side ? mid : pb; e = side ? pe : mid;
             lo = (int)(info & 0xFFu); hi = (int)((info >> 8) & 0xFFu);
+            rmin = rk[lo * BLOCK]; rmax = rk[(hi - 1) * BLOCK];
             pending = true;
         }
         if (e - b == 1u) {                                           // a leaf: exactly one candidate left, this triangle
@@ -551,7 +553,8 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
         }
         const uint32_t mid = (b + e) >> 1;
         int s = lo;
-        while (s < hi && rk[s * BLOCK] < mid) s++;
+        if (rmax < mid) s = hi;
+        else if (rmin < mid) while (s < hi && rk[s * BLOCK] < mid) s++;
         if (s == lo || s == hi) {                                    // all candidates on one side: the other subtree cannot touch a tie
             const int side = (s == lo) ? 1 : 0;
             if (adopted && !sphereCloser(sphereTerms(bvh.sph + 4 * (size_t)node, side, p), best)) { pending = false; continue; }
@@ -570,7 +573,7 @@ SDF_DEV uint32_t resolveTies(const BvhDev& bvh, D3 p, double dmin2, int n2, uint
         fsp++;
         if (adopted && !((leftFirst ? dL : dR) < best)) { pending = false; continue; }
         const uint32_t nn = leftFirst ? node + 1u : node + (mid - b);
-        if (leftFirst) { e = mid; hi = s; } else { b = mid; lo = s; }
+        if (leftFirst) { e = mid; hi = s; rmax = rk[(s - 1) * BLOCK]; } else { b = mid; lo = s; rmin = rk[s * BLOCK]; }
         node = nn;
     }
     return bestTri < 0 ? NEAR_UNRESOLVED : (uint32_t)bestTri;
