@@ -116,3 +116,26 @@ def test_bench_two_ranks_on_one_gpu(launcher):
         sp = b["split"]
         assert sp["serial_s"] > 0 and sp["sharded_s"] > 0 and sp["exchange_s"] >= 0 and sp["exchange_bytes_per_rank"] == 4 * b["words"]
         assert b["end_to_end_s"] >= sp["serial_s"] + sp["sharded_s"]
+
+
+def test_bench_runs_a_mesh_file(tmp_path):
+    """`bench.py --mesh PATH`: the loaders take a PLY / OBJ when one is supplied — here a small PLY written by meshio —
+    and the line says so (`data: "file"`, the file's name and triangle count in `config.workload`)."""
+    import json
+    import subprocess
+    from sdflib_amd import meshio
+    from sdflib_amd.meshgen import bumpy_icosphere
+    v, f = bumpy_icosphere(4)
+    path = os.path.join(str(tmp_path), "bumpy4.ply")
+    meshio.write_ply(path, v, f)
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mesh", path, "--depth", "6", "--steps", "2", "--warmup", "1", "--queries", "500000", "--no-cpu-baseline", "--no-build-1m", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["data"] == "file" and "bumpy4.ply" in d["config"]["workload"] and str(len(f)) in d["config"]["workload"]
+    assert d["value"] > 0 and d["build"]["time_to_first_query_s"] > 0
