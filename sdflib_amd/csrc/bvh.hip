@@ -473,6 +473,7 @@ struct HostBvhBuilder {
 //     records straight into the device arrays, and its own sphere into its parent's record (planned on the host).
 struct BvhDevNode { int id; uint32_t b, e, slot; };
 constexpr uint32_t kDevSubtreeMaxLimit = 8192;           // 64 KB of LDS for the keys + the sort task lists + the per-node tables below
+constexpr uint32_t kSumChunk = 32;          // triangles per chunk: 96 additions per chain and lane
 constexpr uint32_t kCoopNodes = 128;                     // levels of at most this many nodes ...
 constexpr uint32_t kCoopMin = 32;                        // ... of more than this many triangles each are prepared by the whole workgroup
 SDF_DEV uint32_t devOrdKey(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // monotone float -> uint
@@ -760,7 +761,65 @@ __global__ void __launch_bounds__(kSubThreads) k_bvh_subtrees(const BvhTask* __r
                 if (i0 < i1) flush();
             }
             __syncthreads();
-            // 2. one lane per node: split axis, centre = the vertices summed in range order
+            // 2a. the centre sums, in parallel and verified like the top levels' (k_csum_*): every chunk of 8 - 32 triangles is added up from zero, a
+            // per-node scan gives each chunk the value it would start from, every chunk is re-run from that value with the reference's very
+            // additions and its end compared with the next chunk's start bit for bit; a node with a disagreeing boundary is summed by one
+            // lane below.  (One lane per node was the longest part of this kernel: 2560 + 1280 + 640 + ... dependent steps per subtree.)  The
+            // scratch is the sort's index lists and task lists, free until the level's sorts begin.
+            const size_t scratchBytes = 2 * IdxArr::bytes(kDevSubtreeMax) + 2 * 3 * 4 * (size_t)kDevSortTasks;
+            uint32_t CH = 8u;                                        // triangles per chunk: the smallest of 8 / 16 / 32 whose tables fit (more chunks = more lanes at work)
+            while (CH < 32u && (size_t)(n / CH + nCur) * 50u + 4u * (size_t)nCur + 8u > scratchBytes) CH *= 2u;
+            const uint32_t maxChunks = n / CH + nCur;
+            double* cs = reinterpret_cast<double*>(s_bvh_raw + KeyArr::bytes(kDevSubtreeMax));
+            double* ci = cs + 3 * (size_t)maxChunks;
+            unsigned short* cnode = reinterpret_cast<unsigned short*>(ci + 3 * (size_t)maxChunks);
+            unsigned short* cbase = cnode + maxChunks;               // nCur + 1
+            unsigned short* cbad = cbase + (nCur + 1u);              // nCur
+            const bool par = (size_t)maxChunks * 50u + 4u * (size_t)nCur + 8u <= scratchBytes;
+            auto chunkAdd = [&](uint32_t lo_, uint32_t hi_, double& sx, double& sy, double& sz) {
+                for (uint32_t i = lo_; i < hi_; i++) {
+                    const size_t t = (size_t)keys[i].tri;
+                    const float4 q0 = triV[3 * t], q1 = triV[3 * t + 1]; const float q2 = reinterpret_cast<const float*>(triV)[12 * t + 8];
+                    sx += (double)q0.x; sy += (double)q0.y; sz += (double)q0.z;
+                    sx += (double)q0.w; sy += (double)q1.x; sz += (double)q1.y;
+                    sx += (double)q1.z; sy += (double)q1.w; sz += (double)q2;
+                }
+            };
+            if (par) {
+                for (uint32_t j = tid; j < nCur; j += kSubThreads) { cbase[j] = (unsigned short)((s_nb[j + 1] - s_nb[j] + CH - 1u) / CH); cbad[j] = 0; }
+                __syncthreads();
+                if (tid == 0) { uint32_t run = 0; for (uint32_t j = 0; j < nCur; j++) { const uint32_t c = cbase[j]; cbase[j] = (unsigned short)run; run += c; } cbase[nCur] = (unsigned short)run; }
+                __syncthreads();
+                for (uint32_t j = tid; j < nCur; j += kSubThreads) for (uint32_t c = cbase[j]; c < cbase[j + 1]; c++) cnode[c] = (unsigned short)j;
+                __syncthreads();
+                const uint32_t total = cbase[nCur];
+                for (uint32_t c = tid; c < total; c += kSubThreads) {
+                    const uint32_t j = cnode[c], lo_ = s_nb[j] + (c - cbase[j]) * CH, hi_ = (lo_ + CH < s_nb[j + 1]) ? lo_ + CH : s_nb[j + 1];
+                    double sx = 0.0, sy = 0.0, sz = 0.0;
+                    chunkAdd(lo_, hi_, sx, sy, sz);
+                    cs[3 * c] = sx; cs[3 * c + 1] = sy; cs[3 * c + 2] = sz;
+                }
+                __syncthreads();
+                for (uint32_t j = tid; j < nCur; j += kSubThreads) {
+                    double px = 0.0, py = 0.0, pz = 0.0;
+                    for (uint32_t c = cbase[j]; c < cbase[j + 1]; c++) { ci[3 * c] = px; ci[3 * c + 1] = py; ci[3 * c + 2] = pz; px += cs[3 * c]; py += cs[3 * c + 1]; pz += cs[3 * c + 2]; }
+                }
+                __syncthreads();
+                for (uint32_t c = tid; c < total; c += kSubThreads) {
+                    const uint32_t j = cnode[c], lo_ = s_nb[j] + (c - cbase[j]) * CH, hi_ = (lo_ + CH < s_nb[j + 1]) ? lo_ + CH : s_nb[j + 1];
+                    double sx = ci[3 * c], sy = ci[3 * c + 1], sz = ci[3 * c + 2];
+                    chunkAdd(lo_, hi_, sx, sy, sz);
+                    if (c + 1u < cbase[j + 1]) {
+                        if (__double_as_longlong(sx) != __double_as_longlong(ci[3 * (c + 1)]) || __double_as_longlong(sy) != __double_as_longlong(ci[3 * (c + 1) + 1]) ||
+                            __double_as_longlong(sz) != __double_as_longlong(ci[3 * (c + 1) + 2])) cbad[j] = 1;
+                    } else {
+                        const double cnt = (double)(3 * (s_nb[j + 1] - s_nb[j]));
+                        s_ctr[j][0] = sx / cnt; s_ctr[j][1] = sy / cnt; s_ctr[j][2] = sz / cnt;
+                    }
+                }
+                __syncthreads();
+            }
+            // 2b. one lane per node: split axis; the centre by the serial chain where the parallel form was not verified
             for (uint32_t j = tid; j < nCur; j += kSubThreads) {
                 const double d0 = (double)devOrdVal(s_box[j][0]) - (double)devOrdVal(s_box[j][3]), d1 = (double)devOrdVal(s_box[j][1]) - (double)devOrdVal(s_box[j][4]),
                              d2 = (double)devOrdVal(s_box[j][2]) - (double)devOrdVal(s_box[j][5]);
@@ -768,29 +827,10 @@ __global__ void __launch_bounds__(kSubThreads) k_bvh_subtrees(const BvhTask* __r
                 if (dm < d1) { dim = 1; dm = d1; }
                 if (dm < d2) dim = 2;
                 s_dim[j] = dim;
-                const int lo = (int)s_nb[j], nn = (int)(s_nb[j + 1] - s_nb[j]);
+                if (par && !cbad[j]) continue;
                 double sx = 0.0, sy = 0.0, sz = 0.0;
-                int i = 0;
-                for (; i + 8 <= nn; i += 8) {
-                    float4 q0[8], q1[8]; float q2[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const size_t t = (size_t)keys[lo + i + u].tri;
-                        q0[u] = triV[3 * t]; q1[u] = triV[3 * t + 1]; q2[u] = reinterpret_cast<const float*>(triV)[12 * t + 8];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        sx += (double)q0[u].x; sy += (double)q0[u].y; sz += (double)q0[u].z;
-                        sx += (double)q0[u].w; sy += (double)q1[u].x; sz += (double)q1[u].y;
-                        sx += (double)q1[u].z; sy += (double)q1[u].w; sz += (double)q2[u];
-                    }
-                }
-                for (; i < nn; i++) {
-                    DevV3 v[3]; devTriVerts(triV, keys[lo + i].tri, v[0], v[1], v[2]);
-#pragma unroll
-                    for (int k = 0; k < 3; k++) { sx += (double)v[k].x; sy += (double)v[k].y; sz += (double)v[k].z; }
-                }
-                const double cnt = (double)(3 * nn);
+                chunkAdd(s_nb[j], s_nb[j + 1], sx, sy, sz);
+                const double cnt = (double)(3 * (s_nb[j + 1] - s_nb[j]));
                 s_ctr[j][0] = sx / cnt; s_ctr[j][1] = sy / cnt; s_ctr[j][2] = sz / cnt;
             }
             __syncthreads();
@@ -1245,7 +1285,6 @@ __global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_
 // (3.9 M additions of the 1.31 M-triangle mesh's longest chain: none rounds); a node with a disagreeing boundary is flagged and summed by
 // the serial chain (k_top_sums, which then runs for flagged nodes only).  Rounds 3-4 ran the serial chain for every node (13 ms per
 // 655 360 triangles on a lane, bound by the latency of dependent additions) and sent the longest nodes' coordinates to HOST threads.
-constexpr uint32_t kSumChunk = 32;          // triangles per chunk: 96 additions per chain and lane
 struct CsumLevel { const uint32_t* order; const float4* triV; const TopNode* nodes; uint32_t count; const uint32_t* chunkBase; uint32_t totalChunks; double* csum; double* cin; uint32_t* status; double* centres; };
 SDF_DEV uint32_t csumNodeOf(const uint32_t* __restrict__ chunkBase, uint32_t count, uint32_t c) {
     uint32_t lo = 0, hi = count - 1;
