@@ -1031,14 +1031,18 @@ SDF_DEV void gsPrepare(const GsRound& R, uint32_t* __restrict__ nextCount, uint3
     }
     if (tid == 0) R.chunkBase[nT] = s_carry;
 }
-__global__ void __launch_bounds__(1024) k_gs_prepare(GsRound R, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) { gsPrepare<1024>(R, nextCount, flags); }
-// the ranges of a level's first round: its nodes (introsort's depth limit 2 floor(log2 n)); the level's counters
-__global__ void k_gs_first(const TopNode* __restrict__ nodes, uint32_t count, GTask* __restrict__ tasks, uint32_t* __restrict__ ctr) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) { ctr[0] = count; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
-    if (j >= count) return;
-    const uint32_t len = nodes[j].e - nodes[j].b;
-    tasks[j] = GTask{nodes[j].b, nodes[j].e, 2u * (31u - (uint32_t)__clz((int)(len | 1u)))};
+// a level's first round: its ranges are the level's nodes (introsort's depth limit 2 floor(log2 n)), the level's counters start over; then
+// the round is prepared like every other (one workgroup; the ranges and their count are read by this workgroup only)
+__global__ void __launch_bounds__(1024) k_gs_first_prepare(const TopNode* __restrict__ nodes, uint32_t count, GTask* __restrict__ tasks, uint32_t* __restrict__ ctr, GsRound R,
+                                                           uint32_t* __restrict__ nextCount, uint32_t* __restrict__ flags) {
+    if (threadIdx.x == 0) { ctr[0] = count; ctr[1] = 0; ctr[2] = 0; ctr[3] = 0; }
+    for (uint32_t j = threadIdx.x; j < count; j += 1024u) {
+        const uint32_t len = nodes[j].e - nodes[j].b;
+        tasks[j] = GTask{nodes[j].b, nodes[j].e, 2u * (31u - (uint32_t)__clz((int)(len | 1u)))};
+    }
+    __threadfence_block();
+    __syncthreads();
+    gsPrepare<1024>(R, nextCount, flags);
 }
 // which range and which of its chunks a workgroup of the round kernels works on
 struct GsChunk { uint32_t task; int f, m; uint32_t k; float pk; };
@@ -1257,24 +1261,25 @@ __global__ void __launch_bounds__(256) k_top_aabb(const KeyTri* __restrict__ K, 
         else if (threadIdx.x < 6) atomicMin(&box[6 * nodeFirst + threadIdx.x], s_fold[threadIdx.x]);
     }
 }
-__global__ void k_top_dims(const uint32_t* __restrict__ box, uint32_t count, int* __restrict__ dims) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= count) return;
-    double d[3];
-    for (int k = 0; k < 3; k++) d[k] = (double)devOrdVal(box[6 * j + k]) - (double)devOrdVal(box[6 * j + 3 + k]);
-    int dim = 0;                                       // std::max_element: the first of equal maxima
-    for (int k = 1; k < 3; k++) if (d[dim] < d[k]) dim = k;
-    dims[j] = dim;
-}
-__global__ void __launch_bounds__(256) k_top_keys(KeyTri* __restrict__ K, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, uint32_t n, const int* __restrict__ dims) {
+// (the split axis of the element's node straight from the node's box — std::max_element: the first of equal maxima — a launch per level of its own until round 5)
+__global__ void __launch_bounds__(256) k_top_keys(KeyTri* __restrict__ K, const float4* __restrict__ triV, const TopNode* __restrict__ nodes, uint32_t count, uint32_t n, const uint32_t* __restrict__ box) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const int dim = dims[topNodeOf(nodes, count, i)];
+    const uint32_t j = topNodeOf(nodes, count, i);
+    double d[3];
+    for (int k = 0; k < 3; k++) d[k] = (double)devOrdVal(box[6 * j + k]) - (double)devOrdVal(box[6 * j + 3 + k]);
+    int dim = 0;
+    for (int k = 1; k < 3; k++) if (d[dim] < d[k]) dim = k;
     const size_t t = (size_t)K[i].tri;
     const float4 q0 = triV[3 * t];
     K[i].key = dim == 0 ? q0.x : (dim == 1 ? q0.y : q0.z);
 }
-__global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_t* __restrict__ snap) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) snap[i] = (uint32_t)K[i].tri; }
+// the order a level's sorts left (the centre sums of the next level's nodes run over it on a side stream); its first threads also write the level's child links
+__global__ void k_top_snapshot(const KeyTri* __restrict__ K, uint32_t n, uint32_t* __restrict__ snap, const TopNode* __restrict__ nodes, uint32_t count, int* __restrict__ kids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) snap[i] = (uint32_t)K[i].tri;
+    if (i < count) { const TopNode nd = nodes[i]; const uint32_t mid = (nd.b + nd.e) >> 1; kids[2 * (size_t)nd.id] = nd.id + 1; kids[2 * (size_t)nd.id + 1] = nd.id + (int)(mid - nd.b); }
+}
 // Centre of a node = its vertices summed in range order by the reference, three chains (x, y, z) of 3 n dependent fp64 additions each.
 // Round 5: the chains are reproduced IN PARALLEL and verified.  A chain is cut into chunks of kSumChunk triangles; (1) k_csum_local adds
 // every chunk up from zero, (2) k_csum_scan turns the chunk sums of a node into the value each chunk would START from, (3) k_csum_check
@@ -1952,7 +1957,7 @@ void startEarlyBvhPlan(sdfhip_mesh* mesh) {
 }
 }
 
-// The whole tree on the device (see k_gs_prepare); SDFHIP_BVH_BUILD=host plans on the host instead.  SDFHIP_E_UNSUPPORTED: a long range ran out of introsort's depth
+// The whole tree on the device (see k_gs_first_prepare); SDFHIP_BVH_BUILD=host plans on the host instead.  SDFHIP_E_UNSUPPORTED: a long range ran out of introsort's depth
 // limit or a work list overflowed — the caller plans on the host.
 static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     const uint32_t T = mesh->numTriangles;
@@ -1986,13 +1991,13 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     const uint32_t maxTasks = 2u * (T / partMax) + 16u, maxParts = T / 16u + 16u, maxTiny = T / 2u + 16u;
     const uint32_t maxChunks = T / kGsChunk + maxTasks + 1u;
     DevBuf<KeyTri> K; DevBuf<uint32_t> Ll, Rl, snaps, box, ctr, chunkBase, cutAt, cntL, cntR, chunkTask, dFail; DevBuf<float> pk; DevBuf<GTask> tasks, parts, tiny; DevBuf<TopNode> dNodes;
-    DevBuf<int> dims; DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
+    DevBuf<double> centres; DevBuf<unsigned long long> r2, dClk; DevBuf<BvhTask> dTasks; DevBuf<BvhDevNode> dScratch;
     DevBuf<uint32_t> sumBase, sumStatus; DevBuf<double> csum, cin; std::vector<uint32_t> sumBaseH; std::vector<size_t> sumChunkAt;
     SDF_TRY(K.reserve(T)); SDF_TRY(snaps.reserve((size_t)T * (nTop ? nTop : 1))); SDF_TRY(ctr.reserve(8)); SDF_TRY(dFail.reserve(1));
     if (nTop) {
         SDF_TRY(Ll.reserve(T)); SDF_TRY(Rl.reserve(T)); SDF_TRY(box.reserve(6 * tableNodes)); SDF_TRY(chunkBase.reserve(maxTasks + 1)); SDF_TRY(cutAt.reserve(maxTasks));
         SDF_TRY(cntL.reserve(maxChunks)); SDF_TRY(cntR.reserve(maxChunks)); SDF_TRY(chunkTask.reserve(maxChunks)); SDF_TRY(pk.reserve(maxTasks)); SDF_TRY(tasks.reserve(2 * (size_t)maxTasks)); SDF_TRY(parts.reserve(maxParts));
-        SDF_TRY(tiny.reserve(maxTiny)); SDF_TRY(dNodes.reserve(tableNodes)); SDF_TRY(dims.reserve(tableNodes)); SDF_TRY(centres.reserve(3 * tableNodes)); SDF_TRY(r2.reserve(tableNodes));
+        SDF_TRY(tiny.reserve(maxTiny)); SDF_TRY(dNodes.reserve(tableNodes)); SDF_TRY(centres.reserve(3 * tableNodes)); SDF_TRY(r2.reserve(tableNodes));
         std::vector<TopNode> flat; flat.reserve(tableNodes);
         for (size_t l = 0; l < nTop; l++) flat.insert(flat.end(), levels[l].begin(), levels[l].end());
         SDF_HIP_CHECK(hipMemcpyAsync(dNodes.p, flat.data(), sizeof(TopNode) * tableNodes, hipMemcpyHostToDevice, st));
@@ -2044,13 +2049,11 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         const uint32_t count = (uint32_t)nodes.size();
         const TopNode* dN = dNodes.p + levelAt[l];
         k_top_aabb<<<gridFor(T, 1024), 256, 0, st>>>(K.p, triV, dN, count, T, box.p + 6 * levelAt[l]);
-        k_top_dims<<<gridFor(count, 256), 256, 0, st>>>(box.p + 6 * levelAt[l], count, dims.p + levelAt[l]);
-        k_top_keys<<<gridFor(T, 256), 256, 0, st>>>(K.p, triV, dN, count, T, dims.p + levelAt[l]);
+        k_top_keys<<<gridFor(T, 256), 256, 0, st>>>(K.p, triV, dN, count, T, box.p + 6 * levelAt[l]);
         // the level's nodes are the first round's ranges
         SDF_REQUIRE(count <= maxTasks, "internal: more nodes on a level than ranges provided for");
         int curBuf = 0;
         hostCtr[0] = count; hostCtr[1] = 0; hostCtr[2] = 0; hostCtr[3] = 0;
-        k_gs_first<<<gridFor(count, 256), 256, 0, st>>>(dN, count, tasks.p, ctr.p);
         uint32_t pending = count;
         // The host learns a round's outcome only by waiting for it: rounds are queued in groups, sized for the most ranges they can have (a
         // range leaves at most two); a round without ranges costs three empty launches.  The first group of a level is as long as its longest
@@ -2062,7 +2065,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         const uint32_t nchCap = longest / kGsChunk + 2u;            // chunks of the level's longest range (ranges only get shorter)
         if (nchCap > kGsMaxRangeChunks) { if (timing) fprintf(stderr, "[sdfhip] bvh on the device: a range of %u triangles is more than the round kernels hold prefix sums for\n", longest); return SDFHIP_E_UNSUPPORTED; }
         auto roundOf = [&](int buf) { return GsRound{K.p, Ll.p, Rl.p, tasks.p + (size_t)buf * maxTasks, ctr.p + buf, maxTasks, pk.p, chunkBase.p, cutAt.p, cntL.p, cntR.p, chunkTask.p}; };
-        k_gs_prepare<<<1, 1024, 0, st>>>(roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
+        k_gs_first_prepare<<<1, 1024, 0, st>>>(dN, count, tasks.p, ctr.p, roundOf(curBuf), ctr.p + (curBuf ^ 1), ctr.p + 4);      // the level's first round; every other round is prepared by the round before it
         while (pending > 0) {
             uint32_t bound = pending;
             const int nowRounds = groupRounds;
@@ -2085,8 +2088,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
         if (hostCtr[2]) k_sort_parts<<<hostCtr[2], 1024, KeyArr::bytes(partMax) + 2 * IdxArr::bytes(partMax) + 2 * 3 * 4 * kDevSortTasks, st>>>(K.p, parts.p, partMax, ctr.p + 4);
         if (hostCtr[3]) k_sort_tiny<<<gridFor(hostCtr[3], 64), 64, 0, st>>>(K.p, tiny.p, hostCtr[3]);
         uint32_t* snap = snaps.p + (size_t)T * l;
-        k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snap);
-        k_top_write<<<gridFor(count, 256), 256, 0, st>>>(dN, count, nullptr, nullptr, 0, mesh->dBvhSph.p, mesh->dBvhKids.p);
+        k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snap, dN, count, mesh->dBvhKids.p);
         SDF_HIP_CHECK(hipGetLastError());
         // behind this level's sort, on the side stream: centres (sums in this order), radii and sphere records of the NEXT level's nodes
         if (l + 1 < nTop) {
@@ -2114,7 +2116,7 @@ static int buildTreeOnDevice(sdfhip_mesh* mesh, hipStream_t st) {
     std::vector<BvhTask> ht(nt);
     for (size_t i = 0; i < nt; i++) ht[i] = BvhTask{cur[i].id, cur[i].b, cur[i].e, cur[i].slot};
     const uint32_t* order = snaps.p + (size_t)T * (nTop ? nTop - 1 : 0);
-    if (!nTop) k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snaps.p);
+    if (!nTop) k_top_snapshot<<<gridFor(T, 256), 256, 0, st>>>(K.p, T, snaps.p, nullptr, 0u, nullptr);
     SDF_TRY(dTasks.reserve(nt)); SDF_TRY(dScratch.reserve(nt * 2 * (S / 2 + 1)));
     SDF_HIP_CHECK(hipMemcpyAsync(dTasks.p, ht.data(), sizeof(BvhTask) * nt, hipMemcpyHostToDevice, st));
     unsigned long long clk[4] = {0, 0, 0, 0};
