@@ -712,6 +712,10 @@ struct ScanHelper {
     }
 };
 
+// two scan totals (last offset + last value; a null pair counts 0) side by side for one read-back
+__global__ void k_ex_totals2(const uint32_t* __restrict__ s0, const uint32_t* __restrict__ v0, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ v1, uint32_t* __restrict__ out2) {
+    if (threadIdx.x == 0) { out2[0] = s0 ? *s0 + *v0 : 0u; out2[1] = s1 ? *s1 + *v1 : 0u; }
+}
 static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, uint32_t n, uint32_t& total) {
     total = 0;
     if (n == 0) return SDFHIP_OK;
@@ -891,7 +895,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
         }
         const uint32_t n = L->n;
         // ---- cull the parent lists into this level's lists
-        DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp, longCount; DevBuf<uint2> longItems; DevBuf<unsigned long long> longKeys;
+        DevBuf<float> region, minDist; DevBuf<uint32_t> nChunks, chunkBase, chunkNode, chunkCount, chunkScan, tmp, longCount, totals2; DevBuf<uint2> longItems; DevBuf<unsigned long long> longKeys;
         SDF_TRY(region.reserve(64ull * n)); SDF_TRY(minDist.reserve(8ull * n)); SDF_TRY(nChunks.reserve(n)); SDF_TRY(chunkBase.reserve(n));
         k_node_regions<<<gridFor(64ull * n, 256), 256, 0, st>>>(md, L->center.p, L->half, n, L->cornerTri.p, region.p, minDist.p);
         k_chunk_counts<<<gridFor(n, 256), 256, 0, st>>>(n, L->pLen.p, nChunks.p);
@@ -909,20 +913,24 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             { uint32_t pw = numChunks / 32768u; if (pw < 1u) pw = 1u; if (pw > 16u) pw = 16u; ca.perWave = pw; }      // (divisors 4096 .. 65536 and caps 16 .. 64 measured: a plateau, profiles/r04_cull_experiments.txt)
             k_cull<<<gridFor(gridFor(numChunks, ca.perWave), 4), 256, 0, st>>>(ca);
             SDF_TRY(scan.exclusive(chunkCount.p, chunkScan.p, numChunks));
-            SDF_TRY(lastPlus(st, chunkScan.p, chunkCount.p, numChunks, total));
+        }
+        // The lists' lengths follow from the chunk counts alone, so leaf / inner is decided and the inner nodes are counted BEFORE the host
+        // asks how long the level's list is: one read-back brings both totals (two per level until round 5).
+        k_node_list_ranges<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkScan.p, chunkCount.p, numChunks, L->listOff.p, L->listLen.p);
+        SDF_TRY(L->flag.reserve(n)); SDF_TRY(L->inner.reserve(n)); SDF_TRY(L->childBase.reserve(n)); SDF_TRY(totals2.reserve(2));
+        k_ex_decide<<<gridFor(n, 256), 256, 0, st>>>(n, d, startDepth, maxDepth, minTri, L->listLen.p, L->flag.p, L->inner.p, stats.p);
+        if (d < maxDepth) SDF_TRY(scan.exclusive(L->inner.p, L->childBase.p, n));
+        k_ex_totals2<<<1, 64, 0, st>>>(numChunks ? chunkScan.p + (numChunks - 1) : nullptr, numChunks ? chunkCount.p + (numChunks - 1) : nullptr,
+                                       d < maxDepth ? L->childBase.p + (n - 1) : nullptr, d < maxDepth ? L->inner.p + (n - 1) : nullptr, totals2.p);
+        uint32_t h2[2] = {0, 0};
+        SDF_TRY(readBackWords(st, totals2.p, nullptr, 2, h2));
+        total = h2[0]; L->numInner = h2[1];
+        if (numChunks) {
             SDF_TRY(L->list.reserve(total));
             k_compact<<<gridFor(numChunks, 4), 256, 0, st>>>(tmp.p, chunkCount.p, chunkScan.p, numChunks, L->list.p);
         } else SDF_TRY(L->list.reserve(1));
-        k_node_list_ranges<<<gridFor(n, 256), 256, 0, st>>>(n, nChunks.p, chunkBase.p, chunkScan.p, chunkCount.p, numChunks, L->listOff.p, L->listLen.p);
         L->listTotal = total;
-        // ---- leaf / inner
-        SDF_TRY(L->flag.reserve(n)); SDF_TRY(L->inner.reserve(n)); SDF_TRY(L->childBase.reserve(n));
-        k_ex_decide<<<gridFor(n, 256), 256, 0, st>>>(n, d, startDepth, maxDepth, minTri, L->listLen.p, L->flag.p, L->inner.p, stats.p);
-        if (d < maxDepth) {
-            SDF_TRY(scan.exclusive(L->inner.p, L->childBase.p, n));
-            SDF_TRY(lastPlus(st, L->childBase.p, L->inner.p, n, L->numInner));
-            k_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childBase.p);
-        } else L->numInner = 0;
+        if (d < maxDepth) k_mul8<<<gridFor(n, 256), 256, 0, st>>>(n, L->childBase.p);
         SDF_HIP_CHECK(hipGetLastError());
         if (L->numInner > 0) {
             SDF_TRY(L->midTri.reserve(19ull * n));
