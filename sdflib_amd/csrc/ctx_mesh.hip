@@ -535,15 +535,16 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
         (rc = vnormal.reserve(3ull * nv))) return fail(rc);
     k_halfedge_keys<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, eKey.p, vKey.p, val.p);
     size_t tb1 = 0, tb2 = 0;
-    SDF_HIP_CHECK(devSortPairs(nullptr, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, (unsigned)64, st));
-    SDF_HIP_CHECK(devSortPairs(nullptr, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, (unsigned)32, st));
+    unsigned vbits = 1; while (vbits < 32u && (1ull << vbits) < (unsigned long long)nv) vbits++;      // bits of a vertex index: the sorts skip the passes over bits that are zero in every key
+    SDF_HIP_CHECK(devSortPairs(nullptr, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, 32u + vbits, st));
+    SDF_HIP_CHECK(devSortPairs(nullptr, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, vbits, st));
     if ((rc = tmp.reserve(tb1 > tb2 ? tb1 : tb2))) return fail(rc);
-    SDF_HIP_CHECK(devSortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, (unsigned)64, st));
+    SDF_HIP_CHECK(devSortPairs(tmp.p, tb1, eKey.p, eKeyS.p, val.p, valS.p, (size_t)nhe, 0, 32u + vbits, st));
     SDF_HIP_CHECK(hipMemsetAsync(counter.p, 0, sizeof(uint32_t), st));
     DevBuf<uint64_t> openKey; DevBuf<uint32_t> openHe;
     if (bbox6 && ((rc = openKey.reserve(nhe)) || (rc = openHe.reserve(nhe)))) return fail(rc);
     k_edge_pair<<<gridFor(nhe, 256), 256, 0, st>>>(eKeyS.p, valS.p, nhe, m->dTri.p, counter.p, bbox6 ? openKey.p : nullptr, bbox6 ? openHe.p : nullptr);
-    SDF_HIP_CHECK(devSortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, (unsigned)32, st));
+    SDF_HIP_CHECK(devSortPairs(tmp.p, tb2, vKey.p, vKeyS.p, val.p, valS2.p, (size_t)nhe, 0, vbits, st));
     SDF_HIP_CHECK(hipMemsetAsync(vnormal.p, 0, sizeof(float) * 3ull * nv, st));
     if (hostAcos) {   // the arc cosines on host threads while the device sorts (see k_corner_cos)
         unsigned parts = (unsigned)(nhe / 65536u); const unsigned hc = std::thread::hardware_concurrency();
