@@ -173,60 +173,71 @@ __global__ void __launch_bounds__(128) kc_fit_rule(CLevelDev L, uint32_t cd, uin
     if (w != NONE32) oc[w] = INDEX_MASK | (terminal ? LEAF_BIT : 0u);
 }
 
-// Iter 2a: which shared samples can be taken from this node's own polynomial, which coarse neighbours must be refined
-__global__ void __launch_bounds__(128) kc_iter2_masks(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t maxDepth, int G, float sqThr, MaskTable NM,
+// Iter 2a: which shared samples can be taken from this node's own polynomial, which coarse neighbours must be refined.
+// THIRTY-TWO lanes per node since round 5 (a lane per node before: 0.10 lanes per vector instruction — few nodes border a coarser leaf, and
+// those then evaluated up to nineteen 64-term polynomials alone): lane k < 18 looks at neighbour k, the sample masks are OR-ed over the
+// lanes, the node's 64 coefficients go through LDS, lane m < 19 evaluates mid-point m, lane k < 24 writes candidate slot k.
+__global__ void __launch_bounds__(256) kc_iter2_masks(CLevelDev L, uint32_t cd, uint32_t startDepth, uint32_t maxDepth, int G, float sqThr, MaskTable NM,
                                                       const uint32_t* __restrict__ oc) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= L.n) return;
+    __shared__ float s_c[8][64];
+    __shared__ uint32_t s_nb[8][24];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = gid >> 5, sub = gid & 31u, slot = threadIdx.x >> 5;
+    if (i >= L.n) return;                                            // (uniform per group of 32 lanes; nothing below synchronises more than a wave)
     uint32_t* cand = L.cand + 24 * (size_t)i;
-#pragma unroll
-    for (int k = 0; k < 24; k++) cand[k] = NONE32;
+    if (sub < 24u) { cand[sub] = NONE32; s_nb[slot][sub] = NONE32; }
     const bool inner = !(cd >= maxDepth) && !L.terminal[i];
-    L.inner[i] = inner ? 1u : 0u;
-    L.allocSize[i] = inner ? (cd >= startDepth ? 8u : 0u) : 64u;
+    if (sub == 0u) { L.inner[i] = inner ? 1u : 0u; L.allocSize[i] = inner ? (cd >= startDepth ? 8u : 0u) : 64u; }
     if (!inner || cd < startDepth) return;
-    uint32_t samplesMask = 0; uint32_t nb[24];
+    auto orOverGroup = [&](uint32_t v) {
 #pragma unroll
-    for (int k = 0; k < 24; k++) nb[k] = NONE32;
-    if (cd > startDepth) {
-        const uint32_t c = L.path[i] & 7u, pci = L.pci[i];
-        const uint32_t* N = L.nIdx + 6 * (size_t)i;
-        forEach18(c, [&](int sel, uint32_t dir, uint32_t sign) {
-            const uint32_t nodeId = (sel < 6) ? N[sel] : pci;
-            if ((nodeId >> 31) || (!(nodeId >> 30) && (oc[nodeId + (dir ^ c)] & LEAF_BIT))) {
-                nb[4 * (dir - 1) + sign] = (nodeId >> 31) ? (nodeId & ~B31) : nodeId + (dir ^ c);
-                samplesMask |= NM.m[4 * (dir - 1) + sign];
+        for (int o = 16; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o, 32);
+        return v;
+    };
+    // neighbour `sub` of the eighteen
+    uint32_t myMask = 0;
+    if (sub < 18u) {
+        int idx = 0;
+        if (cd > startDepth) {
+            const uint32_t c = L.path[i] & 7u, pci = L.pci[i];
+            const uint32_t* N = L.nIdx + 6 * (size_t)i;
+            int mySel = 0; uint32_t myDir = 1u, mySign = 0u;
+            forEach18(c, [&](int sel, uint32_t dir, uint32_t sign) { if (idx++ == (int)sub) { mySel = sel; myDir = dir; mySign = sign; } });
+            const uint32_t nodeId = (mySel < 6) ? N[mySel] : pci;
+            if ((nodeId >> 31) || (!(nodeId >> 30) && (oc[nodeId + (myDir ^ c)] & LEAF_BIT))) {
+                const uint32_t k = 4u * (myDir - 1u) + mySign;
+                s_nb[slot][k] = (nodeId >> 31) ? (nodeId & ~B31) : nodeId + (myDir ^ c);
+                myMask = NM.m[k];
             }
-        });
-    } else {
-        const uint32_t co = L.coord[i];
-        const int gx = (int)(co & 1023u), gy = (int)((co >> 10) & 1023u), gz = (int)(co >> 20);
-        forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) {
-            const int x = gx + dx, y = gy + dy, z = gz + dz;
+        } else {
+            const uint32_t co = L.coord[i];
+            const int gx = (int)(co & 1023u), gy = (int)((co >> 10) & 1023u), gz = (int)(co >> 20);
+            int mx = 0, my = 0, mz = 0; uint32_t myDir = 1u, mySign = 0u;
+            forEach18Grid([&](int dx, int dy, int dz, uint32_t dir, uint32_t sign) { if (idx++ == (int)sub) { mx = dx; my = dy; mz = dz; myDir = dir; mySign = sign; } });
+            const int x = gx + mx, y = gy + my, z = gz + mz;
             if (x >= 0 && x < G && y >= 0 && y < G && z >= 0 && z < G) {
                 const uint32_t at = (uint32_t)(z * G * G + y * G + x);
-                if (oc[at] & LEAF_BIT) { nb[4 * (dir - 1) + sign] = at; samplesMask |= NM.m[4 * (dir - 1) + sign]; }
+                if (oc[at] & LEAF_BIT) { const uint32_t k = 4u * (myDir - 1u) + mySign; s_nb[slot][k] = at; myMask = NM.m[k]; }
             }
-        });
+        }
     }
+    const uint32_t samplesMask = orOverGroup(myMask);
     if (samplesMask == 0) return;
-    float c[64];
-#pragma unroll
-    for (int k = 0; k < 64; k++) c[k] = L.coeff[64 * (size_t)i + k];
-    auto cf = [&](int n) { return c[n]; };
-    uint32_t subdivisionMask = 0;
-#pragma unroll 1
-    for (int mi = 0; mi < 19; mi++) {
-        if (!(samplesMask & (1u << (18 - mi)))) continue;
-        float* md = L.mid + 152 * (size_t)i + 8 * mi;
-        const F3 f = midFrac(mi);
+    s_c[slot][sub] = L.coeff[64 * (size_t)i + sub]; s_c[slot][sub + 32u] = L.coeff[64 * (size_t)i + sub + 32u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t mySub = 0;
+    if (sub < 19u && (samplesMask & (1u << (18u - sub)))) {
+        const float* cs = s_c[slot];
+        auto cf = [&](int n) { return cs[n]; };
+        float* md = L.mid + 152 * (size_t)i + 8 * sub;
+        const F3 f = midFrac((int)sub);
         const float iv = tricubicValueExact(cf, f);
         const float e = md[0] - iv;
-        if (e * e > sqThr) subdivisionMask |= (samplesMask & (1u << (18 - mi)));
+        if (e * e > sqThr) mySub = samplesMask & (1u << (18u - sub));
         else vertexValuesExact(cf, f, 2.0f * L.half, md);
     }
-#pragma unroll
-    for (int k = 0; k < 24; k++) if ((subdivisionMask & NM.m[k]) && !(nb[k] >> 30)) cand[k] = nb[k];
+    const uint32_t subdivisionMask = orOverGroup(mySub);
+    if (sub < 24u) { const uint32_t nbk = s_nb[slot][sub]; if ((subdivisionMask & NM.m[sub]) && !(nbk >> 30)) cand[sub] = nbk; }
 }
 
 // Iter 2b: node words, children blocks, leaf payloads
@@ -928,7 +939,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
         }
         kc_fit_rule<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, P->rule, sqThr, param1, oc.p);
         // ---------------- Iter 2
-        kc_iter2_masks<<<gridFor(n, 128), 128, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, NM, oc.p);
+        kc_iter2_masks<<<gridFor(32ull * n, 256), 256, 0, st>>>(Ld, cd, startDepth, maxDepth, G, sqThr, NM, oc.p);
         // the three counts the host needs before it can go on - words to allocate, inner nodes, post-pass candidates - all follow from
         // kc_iter2_masks: their scans run back to back and ONE read-back brings the totals (three read-backs per level until round 5)
         SDF_TRY(cflag.reserve(24ull * n)); SDF_TRY(cscan.reserve(24ull * n)); SDF_TRY(totals3.reserve(3));
