@@ -40,7 +40,6 @@ static inline bool isNearMinimize(float half, const float radius[8], const V3 tr
     bool isNear = false;
     const float sqThr = thr * thr;
     V3 cur = -tri[0];
-    bool result; bool early = false;
     do {
         const V3 g = normalize(-cur);
         const V3 p = furthestOnHull(half, radius, g) - furthestOnTriangle(tri, -g);
@@ -48,12 +47,11 @@ static inline bool isNearMinimize(float half, const float radius[8], const V3 tr
         distToO = dot(g, -cur);
         const V3 dir = p - cur;
         const float d = dot(dir, -cur);
-        if (d < 1.0e-5) { result = distToO <= distToP + thr; early = true; break; }
-        cur = cur + dir * gmin(d / dot(dir, dir), 1.0f);
+        if (d < 1.0e-5) { if (iters) *iters = iter; return distToO <= distToP + thr; }
+        cur += dir * gmin(d / dot(dir, dir), 1.0f);
         isNear = dot(cur, cur) < sqThr;
     } while (!isNear && distToO <= distToP + thr && ++iter < MAX_ITER);
     if (iters) *iters = iter;
-    if (early) return result;
     return isNear || iter >= MAX_ITER;
 }
 
@@ -121,7 +119,8 @@ struct ExactBuilder {
             const V3 pt = 0.3333333f * (tri[0] + tri[1] + tri[2]);
             const uint32_t vId = ((pt.z > 0) ? 4 : 0) + ((pt.y > 0) ? 2 : 0) + ((pt.x > 0) ? 1 : 0);
             bool keep = true;
-            if (n.vi[vId] != idx) { cullTests++; keep = isNearMinimize(n.size, region[vId], tri, minDist[vId]); }
+            if (n.vi[vId] != idx) cullTests++;
+            if (n.vi[vId] != idx && !isNearMinimize(n.size, region[vId], tri, minDist[vId])) keep = false;
             if (keep) outList.push_back(idx);
         }
     }

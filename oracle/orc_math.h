@@ -40,6 +40,8 @@ static inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}
 static inline V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 static inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 static inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+static inline V3& operator+=(V3& a, V3 b) { a = a + b; return a; }
+static inline V3& operator-=(V3& a, V3 b) { a = a - b; return a; }
 
 static inline float dot(V3 a, V3 b) { V3 t = a * b; return t.x + t.y + t.z; }
 static inline float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
