@@ -54,6 +54,10 @@ static inline V2 normalize(V2 v) { float s = 1.0f / std::sqrt(dot(v, v)); return
 
 static inline float gmin(float a, float b) { return (b < a) ? b : a; }
 static inline float gmax(float a, float b) { return (a < b) ? b : a; }
+static inline uint32_t gmin(uint32_t a, uint32_t b) { return (b < a) ? b : a; }
+static inline uint32_t gmax(uint32_t a, uint32_t b) { return (a < b) ? b : a; }
+struct IV3 { int x, y, z; };
+static inline IV3 iv3(V3 v) { return IV3{(int)v.x, (int)v.y, (int)v.z}; }   // glm::ivec3(vec3): per-component conversion
 static inline float gclamp(float x, float lo, float hi) { return gmin(gmax(x, lo), hi); }
 static inline float gsign(float x) { return float(0.0f < x) - float(x < 0.0f); }
 static inline float gfract(float x) { return x - std::floor(x); }

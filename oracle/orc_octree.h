@@ -309,7 +309,7 @@ static inline void computeMinBorder(OctreeSdfData& out) {
     }
 }
 
-static inline uint32_t roundFloatGE(float a) { return (a >= 0.5f) ? 1u : 0u; }
+static inline uint32_t roundFloatGE(float a) { return (a >= 0.5f) ? 1 : 0; }
 
 // OctreeSdf::getDistance; returns also the leaf's coefficient offset through outLeaf (for tests).
 static inline float octreeDistance(const OctreeSdfData& o, V3 p, V3* grad = nullptr) {

@@ -199,62 +199,63 @@ struct MeshBox { V3 min, max; };
 static inline std::vector<TriangleData> meshTriangleData(const V3* vertices, uint32_t numVertices,
                                                          const uint32_t* indices, uint32_t numTriangles, const MeshBox* meshBox = nullptr) {
     std::vector<TriangleData> tris(numTriangles);
-    for (uint32_t t = 0; t < numTriangles; t++)
-        tris[t] = makeTriangleData(vertices[indices[3 * t]], vertices[indices[3 * t + 1]], vertices[indices[3 * t + 2]]);
+    const uint32_t numIndices = 3 * numTriangles;
+    for (uint32_t i = 0, t = 0; i < numIndices; i += 3, t++)
+        tris[t] = makeTriangleData(vertices[indices[i]], vertices[indices[i + 1]], vertices[indices[i + 2]]);
 
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> openEdges;   // (vmin,vmax) -> 3*t+k of the first owner
     std::vector<V3> vertexNormal(numVertices, v3(0.f));
-    for (uint32_t t = 0; t < numTriangles; t++) {
+    for (uint32_t i = 0, t = 0; i < numIndices; i += 3, t++) {
         for (uint32_t k = 0; k < 3; k++) {
-            const uint32_t a = indices[3 * t + k], b = indices[3 * t + (k + 1) % 3], c = indices[3 * t + (k + 2) % 3];
-            auto key = std::make_pair(a < b ? a : b, a < b ? b : a);
-            auto ins = openEdges.insert(std::make_pair(key, 3 * t + k));
+            const uint32_t a = indices[i + k], b = indices[i + ((k + 1) % 3)], c = indices[i + ((k + 2) % 3)];
+            auto ins = openEdges.insert(std::make_pair(std::make_pair(gmin(a, b), gmax(a, b)), i + k));
             if (!ins.second) {
-                const uint32_t other = ins.first->second;
-                const uint32_t t2 = other / 3;
+                const uint32_t t2 = ins.first->second / 3;
                 V3 en = tris[t].normal() + tris[t2].normal();
                 tris[t].edgesNormal[k] = mul(tris[t].transform, en);
-                tris[t2].edgesNormal[other % 3] = mul(tris[t2].transform, en);
+                tris[t2].edgesNormal[ins.first->second % 3] = mul(tris[t2].transform, en);
                 openEdges.erase(ins.first);
             }
             const float cosang = gclamp(dot(normalize(vertices[b] - vertices[a]), normalize(vertices[c] - vertices[a])), -1.0f, 1.0f);
             const float angle = std::acos(cosang);
-            V3 add = angle * tris[t].normal();
-            vertexNormal[a] = vertexNormal[a] + add;
+            vertexNormal[a] += angle * tris[t].normal();
         }
     }
     if (!openEdges.empty() && meshBox) {
         // seam welding: vertices of single-owner edges that coincide (within 1e-5 / size) are merged, their edges re-paired
         std::map<uint32_t, uint32_t> vmap;
         auto parentOf = [&](uint32_t v) { auto it = vmap.find(v); while (it != vmap.end() && it->second != v) { v = it->second; it = vmap.find(v); } return v; };
-        std::vector<uint32_t> nm;
-        for (auto& e : openEdges) { nm.push_back(e.first.first); nm.push_back(e.first.second); }
+        std::vector<uint32_t> nm(2 * openEdges.size());
+        uint32_t fill = 0;
+        for (auto& e : openEdges) { nm[fill++] = e.first.first; nm[fill++] = e.first.second; }
         std::sort(nm.begin(), nm.end()); nm.erase(std::unique(nm.begin(), nm.end()), nm.end());
         const V3 bb = meshBox->max - meshBox->min; const V3 start = meshBox->min;
         const uint32_t axisRes = 2048;
         const float big = gmax(bb.x, gmax(bb.y, bb.z));
-        const float gridScale = (float)axisRes / big;
-        const float threshold = (float)(1e-5 / big);
+        const float gridScale = static_cast<float>(axisRes) / big;
+        const float threshold = 1e-5 / big;          // double quotient, rounded to float by the declaration (as in the reference)
         const float sqThr = threshold * threshold;
         std::map<uint64_t, std::vector<uint32_t>> set1, set2;
-        auto cellId = [axisRes](V3 q) -> uint64_t { const int x = (int)q.x, y = (int)q.y, z = (int)q.z; return (uint32_t)((uint32_t)x + (uint32_t)y * axisRes + (uint32_t)z * axisRes * axisRes); };
-        for (uint32_t v : nm) {
-            const V3 p = vertices[v];
-            set1[cellId((p - start) * gridScale)].push_back(v);
-            set2[cellId((p - start) * gridScale + 0.5f)].push_back(v);
+        // int + int * uint32: evaluated in uint32 and widened to the 64-bit key, exactly as the reference's expression is
+        auto cellId = [axisRes](IV3 id) { return id.x + id.y * axisRes + id.z * axisRes * axisRes; };
+        auto bucket = [](std::map<uint64_t, std::vector<uint32_t>>& m, uint64_t key) -> std::vector<uint32_t>& { return m.insert(std::make_pair(key, std::vector<uint32_t>())).first->second; };
+        for (uint32_t i = 0; i < nm.size(); i++) {
+            const V3 p = vertices[nm[i]];
+            bucket(set1, cellId(iv3((p - start) * gridScale))).push_back(nm[i]);
+            bucket(set2, cellId(iv3((p - start) * gridScale + 0.5f))).push_back(nm[i]);
         }
         std::map<uint64_t, std::vector<uint32_t>>* sets[2] = {&set1, &set2};
-        for (uint32_t v : nm) {
+        for (uint32_t i = 0; i < nm.size(); i++) {
             float offset = 0.0f;
-            for (auto* ps : sets) {
-                const V3 p = vertices[v];
-                auto it = ps->find(cellId((p - start) * gridScale + offset));
+            for (std::map<uint64_t, std::vector<uint32_t>>* ps : sets) {
+                const V3 p = vertices[nm[i]];
+                auto it = ps->find(cellId(iv3((p - start) * gridScale + offset)));
                 if (it != ps->end()) {
                     for (uint32_t other : it->second) {
                         const V3 d = p - vertices[other];
                         if (dot(d, d) < sqThr) {
-                            const uint32_t p1 = parentOf(v), p2 = parentOf(other);
-                            if (v == p1) vmap[p1] = p1;
+                            const uint32_t p1 = parentOf(nm[i]), p2 = parentOf(other);
+                            if (nm[i] == p1) vmap[p1] = p1;
                             vmap[p2] = p1;
                             break;
                         }
@@ -264,9 +265,9 @@ static inline std::vector<TriangleData> meshTriangleData(const V3* vertices, uin
             }
         }
         std::map<std::pair<uint32_t, uint32_t>, uint32_t> repaired;
-        for (auto it = openEdges.begin(); it != openEdges.end(); ++it) {
+        for (auto it = openEdges.begin(); it != openEdges.end(); it++) {
             const uint32_t a = parentOf(it->first.first), b = parentOf(it->first.second);
-            auto ins = repaired.insert(std::make_pair(std::make_pair(a < b ? a : b, a < b ? b : a), it->second));
+            auto ins = repaired.insert(std::make_pair(std::make_pair(gmin(a, b), gmax(a, b)), it->second));
             if (!ins.second) {
                 const uint32_t t = it->second / 3, t2 = ins.first->second / 3;
                 V3 en = tris[t].normal() + tris[t2].normal();
@@ -275,10 +276,10 @@ static inline std::vector<TriangleData> meshTriangleData(const V3* vertices, uin
                 repaired.erase(ins.first);
             }
         }
-        for (uint32_t v : nm) { const uint32_t p = parentOf(v); if (p != v) vertexNormal[p] = vertexNormal[p] + vertexNormal[v]; }
-        for (uint32_t v : nm) vertexNormal[v] = vertexNormal[parentOf(v)];
+        for (uint32_t v : nm) { const uint32_t p = parentOf(v); if (p != v) vertexNormal[p] += vertexNormal[v]; }
+        for (uint32_t v : nm) { const uint32_t p = parentOf(v); vertexNormal[v] = vertexNormal[p]; }
     }
-    for (uint32_t i = 0; i < 3 * numTriangles; i++)
+    for (uint32_t i = 0; i < numIndices; i++)
         tris[i / 3].verticesNormal[i % 3] = mul(tris[i / 3].transform, vertexNormal[indices[i]]);
     return tris;
 }

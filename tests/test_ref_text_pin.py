@@ -1,0 +1,91 @@
+"""Pins the glm-side half of the ORACLE (the box / query routines) and the `.bin` field order
+(row f1) to the TEXT of the reference.
+
+glm, cereal and spdlog are not vendored under /root/reference, so that code cannot be compiled here without stand-in
+headers (which would pin nothing).  Instead tools/refpin parses the reference's functions and oracle/orc_*.h's
+restatements, executes both symbolically (locals substituted, literal-bound loops unrolled, every branch forked) and
+demands identical canonical forms: the same operations on the same operands in the same order under the same
+conditions.  What this cannot see is inside glm's own operators (dot, cross, normalize, inverse, mat*vec, min/max/sign,
+fract): those are restated in oracle/orc_math.h from glm 0.9.8's published sources and remain unpinned.
+
+Each group also has a negative control: one operation of the oracle's text is perturbed and the comparison must fail.
+
+CPU only; reads /root/reference, which exists in the build container.  The GPU box receives the repo alone, and there
+(a GPU is visible, the reference is not) these tests skip; anywhere else a missing reference is a FAILURE, not a skip."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from tools.refpin import groups  # noqa: E402
+
+
+def need_reference():
+    if os.path.isdir("/root/reference/include/SdfLib"):
+        return
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: /root/reference does not travel")
+    pytest.fail("/root/reference is absent: the reference-text pin cannot run (this is not the GPU box, so it is not skipped)")
+
+
+@pytest.mark.parametrize("group", groups.GROUPS, ids=lambda g: g.__name__)
+def test_group_identical_to_the_reference(group):
+    need_reference()
+    msg = group()
+    assert "identical" in msg
+
+
+def oracle_text(name):
+    return open(os.path.join(ROOT, "oracle", name)).read()
+
+
+def perturbed(name, old, new):
+    t = oracle_text(name)
+    assert t.count(old) >= 1, (name, old)
+    return t.replace(old, new, 1)
+
+
+NEGATIVE = [
+    # (group, keyword argument, oracle file, original text, perturbed text)
+    (groups.group_triangle_data, "orc_triangle", "orc_triangle.h", "V3 sy = cross(sz, sx);", "V3 sy = cross(sx, sz);"),
+    (groups.group_triangle_data, "orc_triangle", "orc_triangle.h", "d.c = normalize(V2{e.x, e.y});", "d.c = normalize(V2{e.y, e.x});"),
+    (groups.group_point_triangle, "orc_triangle", "orc_triangle.h", "o.de2 = (p.x - d.v2) * d.b.y - p.y * d.b.x;", "o.de2 = (p.x - d.v2) * d.b.y + p.y * d.b.x;"),
+    (groups.group_point_triangle, "orc_triangle", "orc_triangle.h", "else if (p.x >= d.v2) o.r = R_V2;", "else if (p.x > d.v2) o.r = R_V2;"),
+    (groups.group_point_triangle, "orc_triangle", "orc_triangle.h", "case R_E3: return gsign(dot(d.edgesNormal[2], p)) * std::sqrt(o.de3 * o.de3 + p.z * p.z);",
+     "case R_E3: return gsign(dot(d.edgesNormal[2], p)) * std::sqrt(p.z * p.z + o.de3 * o.de3);"),
+    (groups.group_gjk, "orc_exact", "orc_exact.h", "if (d < 1.0e-5)", "if (d < 1.0e-5f)"),
+    (groups.group_gjk, "orc_exact", "orc_exact.h", "cur += dir * gmin(d / dot(dir, dir), 1.0f);", "cur += dir * gmin(d / dot(dir, dir), 0.5f);"),
+    (groups.group_gjk, "orc_exact", "orc_exact.h", "if (v > best) { best = v; bi = i; }", "if (v >= best) { best = v; bi = i; }"),
+    (groups.group_filter_triangles, "orc_exact", "orc_exact.h", "const V3 pt = 0.3333333f * (tri[0] + tri[1] + tri[2]);", "const V3 pt = (tri[0] + tri[1] + tri[2]) * 0.3333333f;"),
+    (groups.group_filter_triangles, "orc_exact", "orc_exact.h", "for (int c = 0; c < 8; c++) region[i][c] -= minDist[i];", "for (int c = 0; c < 7; c++) region[i][c] -= minDist[i];"),
+    (groups.group_min_border, "orc_octree", "orc_octree.h", "sp.x < 1e-4 ||", "sp.x < 1e-4f ||"),
+    (groups.group_min_border, "orc_octree", "orc_octree.h", "const V3 cp = pos + 0.5f * half * CORNER_REL[i];", "const V3 cp = pos + half * 0.5f * CORNER_REL[i];"),
+    (groups.group_box_and_query, "orc_octree", "orc_octree.h", "f = gfract(2.0f * f);", "f = gfract(f * 2.0f);"),
+    (groups.group_box_and_query, "orc_octree", "orc_octree.h", "V3 a = gabs(p) - b.size();", "V3 a = gabs(p) - 0.5f * b.size();"),
+    (groups.group_mesh_triangle_data, "orc_triangle", "orc_triangle.h", "vertexNormal[a] += angle * tris[t].normal();", "vertexNormal[a] += tris[t].normal() * angle;"),
+    (groups.group_mesh_triangle_data, "orc_triangle", "orc_triangle.h", "const float threshold = 1e-5 / big;", "const float threshold = 1e-5f / big;"),
+    (groups.group_mesh_triangle_data, "orc_triangle", "orc_triangle.h", "if (nm[i] == p1) vmap[p1] = p1;\n                            vmap[p2] = p1;",
+     "vmap[p2] = p1;\n                            if (nm[i] == p1) vmap[p1] = p1;"),
+]
+
+
+@pytest.mark.parametrize("case", NEGATIVE, ids=lambda c: "%s:%s" % (c[0].__name__, c[3][:28].replace(" ", "_")))
+def test_a_perturbed_oracle_expression_is_caught(case):
+    need_reference()
+    group, kw, fname, old, new = case
+    with pytest.raises(AssertionError):
+        group(**{kw: perturbed(fname, old, new)})
+
+
+def test_a_reordered_bin_field_is_caught(monkeypatch):
+    need_reference()
+    from sdflib_amd import serialization as S
+    f = list(S.OCTREE_FIELDS)
+    f[3], f[4] = f[4], f[3]
+    monkeypatch.setattr(S, "OCTREE_FIELDS", f)
+    with pytest.raises(AssertionError):
+        groups.group_archive()

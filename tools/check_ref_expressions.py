@@ -1,4 +1,8 @@
-"""Dev-time pinning of the oracle's tricubic rules against the reference's literal expressions.
+"""Dev-time pinning of the oracle against the reference's literal expressions.
+
+Part 1 (below): the generated straight-line code of InterpolationMethods.h and the rule / stencil / mask tables.
+Part 2 (tools/refpin): a C++-subset parser + symbolic path executor compares, function by function, the reference's
+hand-written geometry / GJK / culling / border / query code and its archive(...) lists with oracle/orc_*.h and the .bin writers.
 
 Parses (never copies) the generated straight-line code in /root/reference/include/SdfLib/
 InterpolationMethods.h and checks, term by term, that the rule-based restatement in oracle/orc_tricubic.h
@@ -176,6 +180,9 @@ def main():
     assert len(terms) == 19 and len(pts_d) == 19 and [int(t[1]) for t in terms] == list(range(19))
     assert [float(t[0]) for t in terms] == wt.tolist() and pts_d == frac
     print("by-distance rule: 19 weights, points, order and the max(|e| - decay |v|, 0) form identical")
+    from tools.refpin import groups
+    for g in groups.GROUPS:
+        print(g())
     return 0
 
 

@@ -177,8 +177,9 @@ def leaf_rewrites(x):
 
 def coeff_rewrites(x):
     """`reinterpret_cast<...>(&data[i])` and its dereference name the 64 coefficients that start at word i, on both sides"""
-    if x[0] == "cast" and isinstance(x[2], tuple) and x[2][0] == "un" and x[2][1] == "&":
-        return ("coeffs", x[2][2])
+    if x[0] == "cast" and x[1].rstrip().endswith("*"):
+        inner = x[2]
+        return ("coeffs", inner[2] if isinstance(inner, tuple) and inner[0] == "un" and inner[1] == "&" else inner)
     if x[0] == "un" and x[1] == "*" and isinstance(x[2], tuple) and x[2][0] == "coeffs":
         return x[2]
     return x
@@ -209,3 +210,302 @@ def group_min_border(orc_octree=None):
 
 
 GROUPS += [group_filter_triangles, group_min_border]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def group_box_and_query(orc_octree=None):
+    """BoundingBox::getSize/getCenter/getDistance x2 (Mesh.h:26-63) and OctreeSdf::getDistance x2 + roundFloat (OctreeSdf.cpp:88-152)."""
+    mesh_h = read(REF + "/include/SdfLib/utils/Mesh.h")
+    ref = read(REF + "/src/sdf/OctreeSdf.cpp")
+    orc = orc_octree or read(REPO + "/oracle/orc_octree.h")
+    box = mesh_h[mesh_h.index("struct BoundingBox"):]
+
+    def rw_box(x):                       # oracle: free functions over a Box b; reference: methods of the box
+        if x[0] == "mcall" and x[1] == ("id", "b") and x[2] in ("size", "center"):
+            return ("call", "getSize" if x[2] == "size" else "getCenter", ())
+        if x[0] == "call" and x[1] == "boxDistance" and len(x[2]) == 2 and x[2][0] == ("id", "b"):
+            return ("call", "getDistance", (x[2][1],))
+        return x
+    n = 0
+    for name, rh, oh in [("getSize", r"glm::vec3 getSize\s*\(", r"V3 size\s*\("), ("getCenter", r"glm::vec3 getCenter\s*\(", r"V3 center\s*\(")]:
+        r = symex.Exec().run([], fn(box, rh)[1])
+        eo = symex.Exec(); eo.rewrite = lambda x: ("call", "getSize", ()) if x == ("call", "size", ()) else x
+        compare("BoundingBox::" + name, r, eo.run([], fn(orc, oh)[1]))
+    for name, rh, nth, oh in [("getDistance(point)", r"float getDistance\s*\(glm::vec3 point\)", 0, r"float boxDistance\s*\("),
+                              ("getDistance(point, outGradient)", r"float getDistance\s*\(glm::vec3 point, glm::vec3& outGradient\)", 0, r"float boxDistanceGrad\s*\(")]:
+        r = symex.Exec().run([], fn(box, rh, nth)[1])
+        eo = symex.Exec(id_alias={"p": "point", "g": "outGradient"}); eo.rewrite = rw_box
+        o = eo.run([], fn(orc, oh)[1])
+        compare("BoundingBox::" + name, r, o)
+        n += len(r)
+    # roundFloat
+    compare("roundFloat", symex.Exec().run(*fn(ref, r"inline uint32_t roundFloat\s*\(")), symex.Exec().run(*fn(orc, r"uint32_t roundFloatGE\s*\(")))
+
+    # OctreeSdf::getDistance: the oracle holds both variants in one function, selected by `grad`
+    def rw_ref(x):
+        x = coeff_rewrites(x)
+        if x[0] == "un" and x[1] in ("&", "*"):                     # node pointers: `currentNode = &data[i]`, `currentNode->f()`
+            return x[2]
+        if x[0] == "mcall" and x[1] == ("id", "mBox") and x[2] == "getDistance":
+            return ("call", "boxDistance", x[3])
+        return x
+
+    def rw_orc(x):
+        x = coeff_rewrites(leaf_rewrites(x))
+        if x[0] == "un" and x[1] in ("&", "*"):
+            return x[2]
+        if x[0] == "member" and x[1] == ("id", "o"):
+            return ("id", {"box": "mBox", "startGridCellSize": "mStartGridCellSize", "startGridSize": "mStartGridSize", "startGridXY": "mStartGridXY",
+                           "data": "mOctreeData", "minBorderValue": "mMinBorderValue"}[x[2]])
+        if x[0] == "call" and x[1] in ("boxDistance", "boxDistanceGrad") and x[2][0] == ("id", "mBox"):
+            return ("call", "boxDistance", x[2][1:])
+        return x
+    for k, (name, flag) in enumerate([("getDistance(sample)", "false"), ("getDistance(sample, outGradient)", "true")]):
+        rp, rb = fn(ref, r"float OctreeSdf::getDistance\s*\(", k)
+        orc_p = orc.replace("if (grad)", "if (%s)" % flag)
+        assert orc_p.count("if (%s)" % flag) == 2
+        op, ob = fn(orc_p, r"float octreeDistance\s*\(")
+        er = symex.Exec(); er.rewrite = rw_ref
+        eo = symex.Exec(fn_alias={"tricubicValue": "interpolateValue", "tricubicGradient": "interpolateGradient", "roundFloatGE": "roundFloat"},
+                        id_alias={"p": "sample", "grad": "outGradient"}, local_alias={"w": "currentNode", "f": "fracPart"})
+        eo.rewrite = rw_orc
+        r = er.run([], rb)
+        o = eo.run([], ob)
+        compare("OctreeSdf::" + name, r, o)
+        n += len(r)
+    return "BoundingBox size / centre / distance / distance+gradient, roundFloat, OctreeSdf::getDistance x2 (start cell, descent, child index, fract, leaf evaluation): identical (%d paths)" % n
+
+
+GROUPS.append(group_box_and_query)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def block_after(text, anchor_regex, nth=0):
+    """the `{...}` block that follows the nth match of anchor_regex"""
+    m = list(re.finditer(anchor_regex, text))[nth]
+    b = text.index("{", m.end() - 1)
+    depth, e = 0, b
+    while True:
+        depth += (text[e] == "{") - (text[e] == "}")
+        e += 1
+        if depth == 0:
+            return text[b:e]
+
+
+def statement_at(text, anchor_regex, nth=0):
+    """the `for (...) {...}` statement that starts at the nth match of anchor_regex (which matches its `for`)"""
+    m = list(re.finditer(anchor_regex, text))[nth]
+    i = text.index("(", m.start())
+    depth, j = 0, i
+    while True:
+        depth += (text[j] == "(") - (text[j] == ")")
+        j += 1
+        if depth == 0:
+            break
+    k = j
+    while text[k].isspace():
+        k += 1
+    if text[k] == "{":
+        return text[m.start():m.start() + len(text[m.start():k]) + len(block_after(text[k:], r"\{"))]
+    return text[m.start():text.index(";", k) + 1]
+
+
+def without_conds(paths):
+    """paths that differ only in conditions that select nothing (dead locals) collapse to one record"""
+    out = []
+    for p in paths:
+        r = {k: v for k, v in p.items() if k != "conds"}
+        if r not in out:
+            out.append(r)
+    return out
+
+
+def group_mesh_triangle_data(orc_triangle=None):
+    """calculateMeshTriangleData, live branches (TriangleUtils.cpp:20-57 constructor loop, :58-86 edge / vertex pseudonormals,
+    :292-420 seam welding, :422-425 vertex normals into the triangle frames)."""
+    ref = cparse.preprocess(read(REF + "/src/utils/TriangleUtils.cpp"))
+    orc = cparse.preprocess(orc_triangle or read(REPO + "/oracle/orc_triangle.h"))
+    orc = orc[orc.index("meshTriangleData("):]
+    # the degenerate-triangle machinery of the reference is dead code: its only entry is guarded by `if(false && ...)`
+    assert "if(false && triangleArea < zeroAngleThreshold" in ref
+    ids_o = {"tris": "triangles", "vertexNormal": "verticesNormal", "openEdges": "edgesNormal", "numIndices": "indices.size()"}
+
+    def rw_ref(x):
+        if x == ("mcall", ("id", "indices"), "size", ()):
+            return ("id", "indices.size()")
+        if x[0] == "mcall" and x[2] == "getSize" and x[1] == ("mcall", ("id", "mesh"), "getBoundingBox", ()):
+            return ("bin", "-", ("id", "meshBox.max"), ("id", "meshBox.min"))          # BoundingBox::getSize is pinned as max - min
+        if x[0] == "member" and x[1] == ("mcall", ("id", "mesh"), "getBoundingBox", ()):
+            return ("id", "meshBox." + x[2])
+        return x
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] == ("id", "meshBox"):
+            return ("id", "meshBox." + x[2])
+        if x == ("un", "*", ("id", "meshBox")):
+            return ("id", "meshBox")
+        return x
+
+    def run_ref(text, **kw):
+        e = symex.Exec(**kw); e.rewrite = rw_ref
+        return e.run([], cparse.parse_body("{" + text + "}"))
+
+    def run_orc(text, **kw):
+        kw.setdefault("id_alias", ids_o)
+        e = symex.Exec(fn_alias={"makeTriangleData": "TriangleData"}, member_alias={"normal": "getTriangleNormal"}, **kw); e.rewrite = rw_orc
+        return e.run([], cparse.parse_body("{" + text + "}"))
+    # 1. constructor loop (the reference's loop also computes area / degeneracy values that only the dead branch reads)
+    r = run_ref(statement_at(ref, r"for \(int i = 0, tIndex = 0;"))
+    o = run_orc(statement_at(orc, r"for \(uint32_t i = 0, t = 0;", 0), local_alias={"t": "tIndex"})
+    compare("calculateMeshTriangleData / constructor loop", without_conds(r), without_conds(o))
+    # 2. edge pseudonormals (insert / pair / erase) and angle-weighted vertex normals
+    loop2 = statement_at(ref, r"for\(int i = 0, tIndex = 0;").replace("if(isTriangleDegenerated[tIndex]) continue;", "")
+    r = run_ref(loop2)
+    o = run_orc(statement_at(orc, r"for \(uint32_t i = 0, t = 0;", 1), local_alias={"t": "tIndex"})
+    compare("calculateMeshTriangleData / edge and vertex pseudonormals", r, o)
+    n = len(r)
+    # 3. seam welding
+    r = run_ref(block_after(ref, r"if\(edgesNormal\.size\(\) > 0\)\s*\{")[1:-1])
+    o = run_orc(block_after(orc, r"if \(!openEdges\.empty\(\) && meshBox\)\s*\{")[1:-1],
+                id_alias=dict(ids_o, start="gridStartPos"),
+                local_alias={"vmap": "verticesMap", "nm": "nonManifoldVertices", "set1": "pointSet1", "set2": "pointSet2", "repaired": "newEdgesNormals",
+                             "v": "vId", "fill": "index"})
+    compare("calculateMeshTriangleData / seam welding", r, o)
+    n += len(r)
+    # 4. vertex normals into each triangle's frame
+    r = run_ref(statement_at(ref, r"for\(int i = 0; i < indices\.size\(\); i\+\+\)"))
+    o = run_orc(statement_at(orc, r"for \(uint32_t i = 0; i < numIndices; i\+\+\)"))
+    compare("calculateMeshTriangleData / vertex normals to triangle frames", r, o)
+    return ("calculateMeshTriangleData: constructor loop, edge pairing + angle weights, seam welding (grid keys, threshold, union-find, "
+            "re-pairing, parent sums), final transform identical (%d paths)" % n)
+
+
+GROUPS.append(group_mesh_triangle_data)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+SCALARS = {"float": "f4", "int": "i4", "uint32_t": "u4", "uint8_t": "u1", "int32_t": "i4"}
+
+
+def archive_list(text, fn_name="save"):
+    """argument names of the archive(...) / ar(...) calls inside `fn_name` (in order)"""
+    m = re.search(r"void " + fn_name + r"\s*\(\s*Archive\s*&\s*(\w+)\s*\)(?:\s*const)?\s*\{", text)
+    body = block_after(text[m.start():], r"\{")
+    out = []
+    for call in re.findall(re.escape(m.group(1)) + r"\s*\(([^;]*)\)\s*;", body):
+        out += [a.strip() for a in call.split(",")]
+    return out
+
+
+def member_type(text, name):
+    m = re.search(r"^\s*([A-Za-z_][\w:<>, ]*?)\s+" + re.escape(name) + r"\s*(?:=[^;]*)?;", text, re.M)
+    assert m, name
+    return re.sub(r"\s+", "", m.group(1))
+
+
+def group_archive():
+    """The on-disk field order: archive(...) lists and member types of OctreeSdf.h:222-226, ExactOctreeSdf.h:138-142, the two OctreeNode
+    serialize bodies, TriangleUtils.h:50-54, Mesh.h:65-69, UsefullSerializations.h:6-35, the SdfFormat enum — against the tables that
+    drive sdflib_amd/serialization.py and against the put() sequence of the C++ writers in include/SdfLib/."""
+    import sys
+    sys.path.insert(0, REPO)
+    from sdflib_amd import serialization as S
+    octree_h = cparse.preprocess(read(REF + "/include/SdfLib/OctreeSdf.h"))
+    exact_h = cparse.preprocess(read(REF + "/include/SdfLib/ExactOctreeSdf.h"))
+    tri_h = cparse.preprocess(read(REF + "/include/SdfLib/utils/TriangleUtils.h"))
+    mesh_h = cparse.preprocess(read(REF + "/include/SdfLib/utils/Mesh.h"))
+    ser_h = cparse.preprocess(read(REF + "/include/SdfLib/utils/UsefullSerializations.h"))
+    fn_h = cparse.preprocess(read(REF + "/include/SdfLib/SdfFunction.h"))
+    # glm types: which scalars, in which order
+    glm = {}
+    for m in re.finditer(r"glm::(\w+)\s*&\s*m\s*\)\s*\{\s*archive\(([^;]*)\);", ser_h):
+        glm[m.group(1)] = [a.strip() for a in m.group(2).split(",")]
+    assert glm["vec3"] == ["m.x", "m.y", "m.z"] and glm["vec2"] == ["m.x", "m.y"] and glm["mat3"] == ["m[0]", "m[1]", "m[2]"], glm
+    flat = {"glm::vec3": "3f4", "glm::vec2": "2f4", "glm::mat3x3": "9f4", "glm::mat3": "9f4"}
+    box = mesh_h[mesh_h.index("struct BoundingBox"):]
+    assert archive_list(box, "serialize") == ["min", "max"] and member_type(box, "min") == "glm::vec3" and member_type(box, "max") == "glm::vec3"
+    flat["BoundingBox"] = "6f4"
+    # TriangleData
+    td = tri_h[tri_h.index("struct TriangleData"):]
+    td = td[:td.index("calculateMeshTriangleData")]
+    td_fields = []
+    for name in archive_list(td, "serialize"):
+        t = member_type(td, name)
+        am = re.fullmatch(r"std::array<(glm::\w+),(\d+)>", t)
+        if am:
+            lay = "%df4" % (int(flat[am.group(1)][:-2]) * int(am.group(2)))
+        else:
+            lay = flat.get(t) or ("1" + SCALARS[t])
+        td_fields.append((name, lay))
+    assert td_fields == S.TRIANGLE_DATA_FIELDS, (td_fields, S.TRIANGLE_DATA_FIELDS)
+    flat["TriangleUtils::TriangleData"] = "%df4" % sum(int(l[:-2]) for _, l in td_fields)
+    # node types
+    onode = octree_h[octree_h.index("struct OctreeNode"):]
+    assert archive_list(onode, "serialize") == ["childrenIndex"] and re.search(r"uint32_t childrenIndex;", onode)
+    enode = exact_h[exact_h.index("struct OctreeNode"):]
+    assert archive_list(enode, "serialize") == ["childrenIndex", "trianglesArrayIndex"]
+    assert re.search(r"uint32_t childrenIndex;", enode) and re.search(r"uint32_t trianglesArrayIndex;", enode)
+
+    def fields(header, node_layout):
+        assert archive_list(header, "save") == archive_list(header, "load")
+        out = []
+        for name in archive_list(header, "save"):
+            t = member_type(header, name)
+            vm = re.fullmatch(r"std::vector<([\w:]+)>", t)
+            if vm:
+                e = vm.group(1)
+                lay = "vec:" + (node_layout if e == "OctreeNode" else flat.get(e) or ("1" + SCALARS[e]))
+            else:
+                lay = flat.get(t) or ("1" + SCALARS[t])
+            out.append((name, lay))
+        return out
+    ref_oct = fields(octree_h, "1u4")
+    ref_ex = fields(exact_h, "2u4")
+    assert ref_oct == [(n, l) for n, l, _ in S.OCTREE_FIELDS], (ref_oct, S.OCTREE_FIELDS)
+    assert ref_ex == [(n, l) for n, l, _ in S.EXACT_FIELDS], (ref_ex, S.EXACT_FIELDS)
+    # the format tag: SdfFormat enumerators in order, written before the object (SdfFunction.cpp:27-33)
+    en = re.search(r"enum SdfFormat\s*\{([^}]*)\}", fn_h).group(1)
+    assert [e.strip() for e in en.split(",")] == ["GRID", "OCTREE", "EXACT_OCTREE", "NONE"]
+    assert (S.FORMAT_GRID, S.FORMAT_OCTREE, S.FORMAT_EXACT_OCTREE, S.FORMAT_NONE) == (0, 1, 2, 3)
+    cpp = cparse.preprocess(read(REF + "/src/sdf/SdfFunction.cpp"))
+    save = cpp[cpp.index("SdfFunction::saveToFile"):cpp.index("SdfFunction::loadFromFile")]
+    assert re.search(r"SdfFormat::OCTREE\)\s*\{\s*archive\(format\);\s*archive\(\*reinterpret_cast<OctreeSdf\*>\(this\)\);", save)
+    assert re.search(r"SdfFormat::EXACT_OCTREE\)\s*\{\s*archive\(format\);\s*archive\(\*reinterpret_cast<ExactOctreeSdf\*>\(this\)\);", save)
+    # the C++ writers of the drop-in headers: order and width of every put()
+    info_decl = read(REPO + "/include/sdfhip.h")
+    info_decl = info_decl[info_decl.index("typedef struct sdfhip_exact_info"):info_decl.index("} sdfhip_exact_info")]
+    info_types = {}
+    for t, names in re.findall(r"^\s*(int32_t|uint32_t|uint64_t|float|double)\s+([^;]+);", info_decl, re.M):
+        for nm in names.split(","):
+            info_types[nm.strip().split("[")[0]] = t
+
+    def cpp_sequence(path, member_types, vec_elems):
+        text = cparse.preprocess(read(path))
+        body = block_after(text[text.index("void writePayload(std::ostream& os) const override"):], r"\{")
+        seq = []
+        for kind, arg in re.findall(r"detail::(put|putVec)\(os,\s*([^;]*?)\)\s*;", body):
+            arg = arg.strip()
+            if kind == "put":
+                cm = re.fullmatch(r"\((int32_t|uint32_t)\)\s*([\w.]+)", arg)
+                if cm:
+                    seq.append((cm.group(2), "1" + SCALARS[cm.group(1)]))
+                elif arg == "box":
+                    assert re.search(r"const float box\[6\] = \{mBox\.min\.x, mBox\.min\.y, mBox\.min\.z, mBox\.max\.x, mBox\.max\.y, mBox\.max\.z\};", body)
+                    seq.append(("mBox", "6f4"))
+                else:
+                    seq.append((arg, "1" + SCALARS[member_types[arg.split(".")[-1]]]))
+            else:
+                first = arg.split(",")[0].strip()
+                key = re.sub(r"reinterpret_cast<const uint32_t\*>\((\w+)\.data\(\)\)", r"\1", first).replace(".data()", "")
+                seq.append((key, "vec:" + vec_elems[key]))
+        return seq
+    ours_oct = cpp_sequence(REPO + "/include/SdfLib/OctreeSdf.h", {"mValueRange": "float", "mMinBorderValue": "float"}, {"mOctreeData": "1u4"})
+    assert ours_oct == ref_oct, (ours_oct, ref_oct)
+    ours_ex = cpp_sequence(REPO + "/include/SdfLib/ExactOctreeSdf.h", info_types, {"nodes": "2u4", "sets": "1u4", "masks": "1u1", "td": "37f4"})
+    key_of = {"mInfo." + k: n for n, _, k in S.EXACT_FIELDS}
+    key_of.update({"mBox": "mBox", "nodes": "mOctreeData", "sets": "mTrianglesSets", "masks": "mTrianglesMasks", "td": "mTrianglesData"})
+    assert [(key_of[k], l) for k, l in ours_ex] == ref_ex, (ours_ex, ref_ex)
+    return ".bin layout: SdfFormat tag, %d OctreeSdf fields, %d ExactOctreeSdf fields, 8 TriangleData fields (37 floats), node words: names, order and scalar types identical in serialization.py and the C++ writers" % (len(ref_oct), len(ref_ex))
+
+
+GROUPS.append(group_archive)

@@ -131,7 +131,15 @@ class Exec:
         for i, (t, n) in enumerate(params):
             st.scopes[0][n] = ("arg", i)
         paths = []
+        self.params, self.ctor_rec, self.paths = params, ctor, paths
         for s, c in self.exec_stmt(body, st):
+            self.finished(s, c)
+        return [self.finish(p) for p in paths]
+
+    def finished(self, s, c):
+        """a path ended (function end / return, or the back edge of a summarised loop — possibly inside an inlined callee)"""
+        params, ctor, paths = self.params, self.ctor_rec, self.paths
+        if True:
             rec = {"conds": tuple(s.conds), "events": tuple(s.events), "end": c}
             outs = {}
             for i, (t, n) in enumerate(params):          # parameters written through (references / out-parameters)
@@ -142,7 +150,6 @@ class Exec:
             if ctor:
                 rec["obj"] = {k: self.snapshot(v) for k, v in s.obj.items()}
             paths.append(rec)
-        return [self.finish(p) for p in paths]
 
     def finish(self, p):
         def fix(x):
@@ -429,6 +436,8 @@ class Exec:
                         continue
                 if raw in VEC3_CTORS or raw in VEC2_CTORS or raw in MAT3_CTORS:
                     yield s1, self.ctor(raw, a); continue
+                if raw in ("ivec3", "iv3") and len(a) == 1:            # component-wise conversion of a vec3 expression to int
+                    yield s1, ("vec3",) + tuple(("cast", "int", self.component(self.snapshot(a[0]), ax)) for ax in "xyz"); continue
                 name = self.canon_fn(fn[1])
                 a = [self.snapshot(v) for v in a]
                 if name == "mul" and len(a) == 2:
@@ -486,6 +495,8 @@ class Exec:
                 yield s1, c[1]
             elif c is None:
                 yield s1, ("void",)
+            elif isinstance(c, tuple) and c[0] == "back":
+                self.finished(s1, c)             # back edge of a loop inside the callee: the path ends here
             else:
                 raise PinError("control %r escapes inlined %s" % (c, name))
             self.call_stack.append(name)
@@ -674,7 +685,10 @@ class Exec:
         name, dims, init, kind = s[2][i]
         tt = strip_ns(t.replace("&", "").replace("*", ""))
         if init is None:
-            if dims or tt.startswith("array<") or tt in ("M3", "Proj", "TriangleData", "V3", "V2") or (tt[:1].isupper() and not tt.startswith("INF")):
+            if self.is_container(tt):
+                v = ("id", self.local_alias.get(name, name))           # an object with identity (map / vector / function): named, not valued
+                st.events.append(("construct", v, ()))
+            elif dims or tt.startswith("array<") or tt in ("M3", "Proj", "TriangleData", "V3", "V2") or (tt[:1].isupper() and not tt.startswith("INF")):
                 v = Agg(tt)
             else:
                 v = ("undef",)
@@ -684,6 +698,9 @@ class Exec:
             for s1, a in self.ev_list(init, st):
                 if tt in VEC3_CTORS or tt in VEC2_CTORS or tt in MAT3_CTORS:
                     v = self.ctor(tt, a)
+                elif self.is_container(tt):
+                    v = ("id", self.local_alias.get(name, name))
+                    s1.events.append(("construct", v, tuple(self.snapshot(q) for q in a)))
                 elif len(a) == 1:
                     v = a[0]
                 else:
@@ -695,7 +712,7 @@ class Exec:
             st.scopes[-1][name] = ("closure", init[1], init[2])
             yield from self.exec_decl(s, i + 1, st); return
         for s1, v in self.ev_init(init, st):
-            if tt == "ivec3" and not isinstance(v, Agg):       # ivec3(vec3 expression): component-wise conversion to int
+            if tt == "ivec3" and not isinstance(v, Agg) and not (v[0] == "vec3" and all(c[0] == "cast" and c[1] == "int" for c in v[1:])):
                 v = ("vec3",) + tuple(("cast", "int", self.component(v, ax)) for ax in "xyz")
             if isinstance(v, Agg):
                 v = v.clone()
@@ -707,6 +724,9 @@ class Exec:
                 pass
             s1.scopes[-1][name] = v
             yield from self.exec_decl(s, i + 1, s1)
+
+    def is_container(self, tt):
+        return tt.split("<")[0].strip() in ("map", "vector", "unordered_map", "set")
 
     # ------------------------------------------------------------------ loops
     def assigned(self, *nodes):
