@@ -128,16 +128,29 @@ class Profile:
         out.update(self.valu_issue(kernel, n_threads))
         return out
 
+    def valu_ceiling(self):
+        """SQ_ACTIVE_INST_VALU per second of the calibration kernel (k_valu_peak: nothing but independent unpacked v_fma_f32, 32 waves per CU)
+        in the SAME profile: the counter's own ceiling, whatever the shader clock did and whatever a count stands for.  None without the row."""
+        sq, st = self.sq_row("sdfhip::k_valu_peak"), self.stats_row("sdfhip::k_valu_peak")
+        if not (sq and st and float(st["avg_ns"]) > 0):
+            return None
+        return float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"]) / (float(st["avg_ns"]) * 1e-9)
+
     def valu_issue(self, kernel, n_threads=0):
-        """Share of the chip's VALU issue slots the kernel filled: SQ_ACTIVE_INST_VALU counts quad-cycles of vector-ALU execution (a wave64
-        instruction occupies its 16-lane SIMD for four cycles), so busy = 4 x counter / (dispatch time x 2.4 GHz x 1024 SIMDs), with the
-        dispatch time of the SAME profile.  This — not the 157 TFLOP/s sheet figure, which needs packed FMAs — is the ceiling of the kernels
-        that must reproduce the reference's separate fp32 multiplies and adds (-ffp-contract=off): 39.3 T lane-operations/s."""
+        """Share of the chip's VALU issue capacity the kernel used = its SQ_ACTIVE_INST_VALU per second / the same counter per second of the
+        calibration kernel in the same profile (valu_ceiling) - self-calibrating: no clock, SIMD count or cycles-per-instruction constant enters.
+        Profiles recorded before the calibration kernel existed fall back to 4 x counter / (time x 2.4 GHz x 1024 SIMDs), labelled as such
+        (that constant-based form read 1.03 for k_exact_lists: the sustained clock is not the 2.4 GHz sheet figure)."""
         sq, st = self.sq_row(kernel, n_threads), self.stats_row(kernel, n_threads)
         if not (sq and st and float(st["avg_ns"]) > 0):
             return {}
-        busy = 4.0 * float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"]) / (float(st["avg_ns"]) * 1e-9 * GPU_CLOCK_HZ * GPU_SIMDS)
-        return {"valu_issue_frac": round(busy, 3), "valu_issue_basis": f"4 x SQ_ACTIVE_INST_VALU / (profiled dispatch {float(st['avg_ns']) / 1e6:.3f} ms x {GPU_CLOCK_HZ / 1e9:.1f} GHz x {GPU_SIMDS} SIMDs)"}
+        rate = float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"]) / (float(st["avg_ns"]) * 1e-9)
+        ceil = self.valu_ceiling()
+        if ceil:
+            return {"valu_issue_frac": round(rate / ceil, 3),
+                    "valu_issue_basis": f"SQ_ACTIVE_INST_VALU per second of the kernel ({rate:.4g}) / of k_valu_peak in the same profile ({ceil:.4g}: unpacked v_fma_f32 back to back on every SIMD)"}
+        busy = 4.0 * rate / (GPU_CLOCK_HZ * GPU_SIMDS)
+        return {"valu_issue_frac": round(busy, 3), "valu_issue_basis": f"UNCALIBRATED (no k_valu_peak row in {self.prefix}): 4 x SQ_ACTIVE_INST_VALU / (profiled dispatch {float(st['avg_ns']) / 1e6:.3f} ms x {GPU_CLOCK_HZ / 1e9:.1f} GHz x {GPU_SIMDS} SIMDs)"}
 
 
 def roofline_block(kernel, kernel_ms, algorithmic_bytes, compulsory_bytes, tr):
@@ -164,7 +177,7 @@ def roofline_block(kernel, kernel_ms, algorithmic_bytes, compulsory_bytes, tr):
 CALIB_BLOCKS = 10_000_000      # 256-B blocks of the calibration array (2.56 GB: ten times the Infinity Cache)
 
 
-def octree_query_roofline(info, start_depth, n, kernel_ms, gradient, prof, kernel):
+def octree_query_roofline(info, start_depth, n, kernel_ms, gradient, prof, kernel, ic_ceiling=None):
     """SURVEY.md 8(d) "Q": algorithmic bytes per query = point 12 + distance 4 (+ gradient 12) + 256 coefficients + 4 x mean dependent node loads
     (mean over uniform-random points, from the leaf-per-depth histogram).  Compulsory bytes per launch = the streams + every coefficient block and
     node word that can be touched, once.  See roofline_block for what `achieved` / `frac` count."""
@@ -178,15 +191,31 @@ def octree_query_roofline(info, start_depth, n, kernel_ms, gradient, prof, kerne
     fits = working_set < 256 * 2 ** 20
     compulsory = io_bytes + min(tree_bytes, int((256 + 4 * mean_loads) * n))
     r = roofline_block(kernel, kernel_ms, bytes_per_query * n, compulsory, prof.traffic("octree_query", kernel, n))
-    # what the bytes counted actually cross: the L2 -> fabric boundary into the 256 MB Infinity Cache when the working set fits in it, the HBM
-    # pins otherwise; the peak the fraction is taken against stays the 8 TB/s HBM figure either way (no separate fabric peak is documented)
-    r["bound"] = "fabric" if fits else "hbm"
-    r["bound_regime"] = "fabric / Infinity Cache (working set below 256 MB: see roofline_hbm for the HBM-resident figure of this kernel)" if fits else "hbm"
-    r.update({"bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "working_set_bytes": int(working_set),
-              "infinity_cache_resident": bool(fits),
-              "regime": ("L2-miss gather served by the 256 MB Infinity Cache (working set below it): the bytes counted cross the L2 -> fabric boundary, not the "
-                         "HBM pins; peak used is still the 8 TB/s HBM figure.  The HBM-resident figure of the same kernel is extras.deep_tree_d9.roofline") if fits
-                        else "HBM gather (working set exceeds the 256 MB Infinity Cache)"})
+    r.update({"bytes_per_query": round(bytes_per_query, 2), "mean_node_loads": round(mean_loads, 3), "working_set_bytes": int(working_set), "infinity_cache_resident": bool(fits)})
+    if not fits:
+        r["bound_regime"] = "hbm"
+        r["regime"] = "HBM gather (working set exceeds the 256 MB Infinity Cache)"
+        return r
+    # Cache-resident regime: the working set (tree + streams) fits the 256 MB Infinity Cache, so the bytes that leave the L2s never reach the HBM
+    # pins and SURVEY 8(d)'s formula (algorithmic bytes / time / 8 TB/s) is not a fraction of anything: it is printed, labelled, under
+    # "hbm_formula".  The ceiling those bytes DO meet is the fabric + Infinity Cache serving 256-byte gathers, measured in this same run with the
+    # query kernel's own load pattern on a 200 MB array (ic_ceiling: sdfhip_test_gather_blocks, random blocks, same byte accounting per lane).
+    t = kernel_ms * 1e-3
+    r["hbm_formula"] = {"achieved": r["algorithmic_gb_s"], "peak": HBM_PEAK_GBS, "frac": round(r["algorithmic_gb_s"] / HBM_PEAK_GBS, 4),
+                        "label": "cache-resident: not an HBM fraction (algorithmic bytes / kernel time / 8 TB/s; the bytes are served by the L2s and the Infinity Cache)"}
+    r["bound"] = "infinity_cache"
+    r["bound_regime"] = "fabric / Infinity Cache (working set below 256 MB: see roofline_hbm for the HBM-resident figure of this kernel)"
+    if ic_ceiling:
+        moved = r["traffic"] if r.get("traffic") else compulsory
+        r["achieved"] = round(min(bytes_per_query * n, moved) / t / 1e9, 1)
+        r["peak"] = ic_ceiling["gb_s"]
+        r["peak_name"] = "measured Infinity-Cache 256-B gather ceiling: k_gather_blocks_coop over a 200 MB array in this run (%d random blocks, %d B per lane) = %.0f GB/s" % (
+            ic_ceiling["lanes"], ic_ceiling["bytes_per_lane"], ic_ceiling["gb_s"])
+        r["frac"] = round(r["achieved"] / r["peak"], 4)
+        r["frac_basis"] = ("min(algorithmic bytes, measured L2 -> fabric traffic) / kernel time / measured Infinity-Cache gather ceiling" if r.get("traffic")
+                           else "compulsory bytes / kernel time / measured Infinity-Cache gather ceiling (no accepted counter profile)")
+    r["regime"] = ("L2-miss gather served by the 256 MB Infinity Cache: numerator = bytes that crossed the L2 -> fabric boundary (counters), denominator = the rate "
+                   "at which the same boundary serves the calibration gather in this run; the HBM-resident figure of the same kernel is roofline_hbm")
     return r
 
 
@@ -306,9 +335,15 @@ def main():
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     prof = Profile(enabled=(not args.mesh and args.subdiv == 7 and args.depth == 8 and args.start_depth == 3))
-    build_roof = build_roofline(rebuild_info, rebuild_s, len(v), len(f), prof) if world == 1 else None
+    valu_cal = valu_calibration(ctx, dev) if world == 1 else None
+    build_roof = build_roofline(rebuild_info, rebuild_s, len(v), len(f), prof, valu_cal) if world == 1 else None
     kname = f"sdfhip::k_octree_query_coop<{0 if args.eval == 'exact' else 1},{'true' if args.gradient else 'false'}>"
-    roof = octree_query_roofline(info, args.start_depth, args.queries, kernel_ms, args.gradient, prof, kname)
+    ic_ceiling = ic_gather_ceiling(ctx, dev) if rank == 0 else None           # outside the timed region
+    roof = octree_query_roofline(info, args.start_depth, args.queries, kernel_ms, args.gradient, prof, kname, ic_ceiling)
+    if ic_ceiling:
+        roof["ic_gather_ceiling"] = ic_ceiling
+    if build_roof and valu_cal:
+        build_roof["valu_calibration"] = valu_cal
 
     total_queries = args.queries * world * args.steps
     value = total_queries / elapsed / 1e6
@@ -356,7 +391,7 @@ FP32_VECTOR_PEAK_TFLOPS = 157.3
 GPU_CLOCK_HZ, GPU_SIMDS = 2.4e9, 1024          # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 
 
-def build_roofline(info, build_s, nv, nt, prof):
+def build_roofline(info, build_s, nv, nt, prof, valu_cal=None):
     """SURVEY.md 8(d) "B" for the build's dominant kernel, the fp32 candidate search of the nearest-triangle queries (k_near_quads, ~2/3 of a
     NO_CONTINUITY build's GPU time).  Live: the kernel's device time inside the build just run (HIP events on the build's stream, summed over
     its batches) and its work counters (wide-node expansions, triangle tests: counted by the kernel).  From the committed counter profile,
@@ -376,11 +411,13 @@ def build_roofline(info, build_s, nv, nt, prof):
     # second = lanes active per VALU instruction x VALU instructions issued per second (both from the committed counter profile of this command,
     # when its sources are unchanged), `peak` = what 1024 SIMDs of 16 lanes issue at 2.4 GHz (39.3 T lane-operations/s: separate multiplies and
     # adds, no packed FMA), `frac` = lanes x issue.  Without an accepted profile achieved / frac are null; the L2-served byte figure stays as a note.
-    valu_peak = GPU_CLOCK_HZ * GPU_SIMDS * 16 / 1e12
+    # (rounds 1-5 priced this against 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-ops/s, which a CDNA4 SIMD exceeds: it retires a wave64 fp32
+    # instruction in 2 cycles, not 4 - hence the "issue fractions" above 1 of round 5.  The ceiling is now MEASURED: k_valu_peak, live in this run.)
+    valu_peak = valu_cal["t_lane_ops_s"] if valu_cal else GPU_CLOCK_HZ * GPU_SIMDS * 32 / 1e12
     r = {"bound": "valu", "kernel": NEAR_KERNEL.split("::")[-1], "kernel_ms_per_build": round(t * 1e3, 3), "search_ms_per_build": round(float(info.seconds_near_search) * 1e3, 3),
          "share_of_build": round(t / build_s, 3), "queries": q, "mqueries_s": round(q / t / 1e6, 1),
          "expansions_per_query": round(ex / q, 1), "triangle_tests_per_query": round(tr / q, 1),
-         "achieved": None, "peak": round(valu_peak, 1), "unit": "T lane-ops/s", "frac": None,
+         "achieved": None, "peak": round(valu_peak, 1), "peak_name": ("measured in this run: k_valu_peak, unpacked v_fma_f32 back to back on every SIMD" if valu_cal else "1024 SIMDs x 32 lanes x 2.4 GHz"), "unit": "T lane-ops/s", "frac": None,
          "l2_served_bytes_per_build": int(alg), "l2_served_gb_s": round(alg / t / 1e9, 1), "l2_served_over_hbm_peak": round(alg / t / 1e9 / HBM_PEAK_GBS, 4),
          "child_tests_per_s_g": round(4 * ex / t / 1e9, 1), "fp32_vector_frac": round((4 * ex * 55 + tr * 130) / t / 1e12 / FP32_VECTOR_PEAK_TFLOPS * 2, 4),
          "build_compulsory_bytes": int(compulsory_build), "build_compulsory_gb_s": round(compulsory_build / build_s / 1e9, 1), "build_compulsory_frac": round(compulsory_build / build_s / 1e9 / HBM_PEAK_GBS, 4),
@@ -697,11 +734,16 @@ def mfma_roofline(prof):
 DEEP_QUERIES = 12_000_000      # not 10 M: the profile summaries tell the two launches of the same kernel apart by grid size
 
 
+DEEP_THRESHOLD = 1e-4
+
+
 def deep_tree(mesh, box, dev, prof):
-    """The same query kernel on a tree that does NOT fit the 256 MB Infinity Cache: depth 9, threshold 2e-4 (about 1.7 GB of node array; the
-    tree tests/test_gpu_octree.py::test_deep_tree_depth_9_matches_oracle checks against the oracle) -> an HBM-bound gather figure."""
+    """The same query kernel on a tree that does NOT fit the 256 MB Infinity Cache: depth 9, threshold 1e-4 = 3.1 GB of node array (12 M leaves;
+    the reference layout's 30-bit word index allows 4.29 GB, and 5e-5 already needs 4.9), so at most 256 MB / 3.1 GB = 8 % of the gathered bytes
+    can be cache-served -> an HBM-bound figure.  (tests/test_gpu_octree.py::test_deep_tree_depth_9_matches_oracle checks the 2e-4 tree, 1.6 GB,
+    against the oracle: same kernel, same builder.)"""
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    t = S.OctreeSdf(mesh, box, 9, 3, 2e-4, num_threads=2)
+    t = S.OctreeSdf(mesh, box, 9, 3, DEEP_THRESHOLD, num_threads=2)
     torch.cuda.synchronize(); build_s = time.perf_counter() - t0
     i = t.info
     gen = torch.Generator(device=dev); gen.manual_seed(4321)
@@ -807,6 +849,36 @@ def gather_calibration(ctx, dev):
     byts = CALIB_BLOCKS * (256 + 4 + 4)
     return {"blocks": CALIB_BLOCKS, "ms": round(ms, 4), "known_bytes": byts, "gb_s": round(byts / ms / 1e6, 1), "hbm_frac": round(byts / ms / 1e6 / HBM_PEAK_GBS, 4),
             "note": "random permutation of 256-B blocks over 2.56 GB, fetched like the query kernel fetches a leaf (16 lanes x dwordx4 per block, rows through LDS): the HBM ceiling of that access pattern"}
+
+
+IC_BLOCKS = 781_250            # 200 MB of 256-byte blocks: inside the 256 MB Infinity Cache, fifty times one XCD's L2
+
+
+def ic_gather_ceiling(ctx, dev, lanes=9_000_000):        # (not 10 M: the profile summaries tell launches of one kernel apart by grid size)
+    """The rate at which L2 -> fabric -> Infinity Cache serves random 256-byte gathers: the query kernel's cooperative block loads
+    (k_gather_blocks_coop) on a 200 MB array, block ids uniform-random (with repeats, like leaves), bytes per lane = 256 block + 4 id + 4 out."""
+    import ctypes as C
+    from sdflib_amd._lib import lib, check
+    data = torch.empty(64 * IC_BLOCKS, dtype=torch.int32, device=dev).fill_(1)
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    ids = torch.randint(0, IC_BLOCKS, (lanes,), generator=g, device=dev, dtype=torch.int64).to(torch.int32).contiguous()
+    out = torch.empty(lanes, dtype=torch.float32, device=dev)
+    fn = lambda: check(lib().sdfhip_test_gather_blocks(ctx.h, C.c_void_p(data.data_ptr()), C.c_void_p(ids.data_ptr()), lanes, C.c_void_p(out.data_ptr())))
+    ms = _time_ms(fn, reps=10)
+    return {"array_mb": round(IC_BLOCKS * 256 / 1e6, 1), "lanes": lanes, "bytes_per_lane": 264, "ms": round(ms, 4), "gb_s": round(lanes * 264 / ms / 1e6, 1)}
+
+
+def valu_calibration(ctx, dev, blocks=4096, iters=20000):
+    """The chip's unpacked fp32 VALU issue rate, live: k_valu_peak = 8 independent v_fma_f32 chains per lane, 16 waves per SIMD."""
+    import ctypes as C
+    from sdflib_amd._lib import lib, check
+    out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+    ms = _time_ms(lambda: check(lib().sdfhip_test_valu_peak(ctx.h, blocks, iters, C.c_void_p(out.data_ptr()))), reps=5)
+    winst = blocks * 4 * 8 * iters
+    rate = winst / ms * 1e3
+    return {"ms": round(ms, 4), "wave_instructions_per_s": float(f"{rate:.4g}"), "t_lane_ops_s": round(rate * 64 / 1e12, 2),
+            "implied_clock_ghz": round(rate * 2 / GPU_SIMDS / 1e9, 3), "implied_clock_basis": "a wave64 fp32 instruction occupies a CDNA4 SIMD for 2 cycles (157 TFLOP/s = 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz), 1024 SIMDs; GRBM_GUI_ACTIVE of the profiled run reads 2.05 GHz",
+            "tflops_fma": round(rate * 128 / 1e12, 1)}
 
 
 def build_1m(ctx, rank, world, dev):

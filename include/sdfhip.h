@@ -104,7 +104,7 @@ int sdfhip_ctx_create(int device_id, void* stream, int stream_mode, sdfhip_ctx**
 int sdfhip_ctx_destroy(sdfhip_ctx* ctx);
 int sdfhip_ctx_synchronize(sdfhip_ctx* ctx);
 /* Device memory the context keeps for reuse (transient blocks of past builds in per-stream caches, the nearest search's candidate
- * lists, host-pointer staging buffers).  Kept automatically below a high-water mark (SDFHIP_CACHE_KEEP_MB, default 1/32 of the device memory, applied when a
+ * lists, host-pointer staging buffers).  Kept automatically below a high-water mark (SDFHIP_CACHE_KEEP_MB, default 1/32 of the device memory: ONE mark per device, shared by all of its contexts and streams; applied when a
  * build returns); sdfhip_ctx_trim waits for the context's stream and frees what exceeds keep_bytes (0: everything). */
 int sdfhip_ctx_trim(sdfhip_ctx* ctx, uint64_t keep_bytes);
 int sdfhip_ctx_cached_bytes(sdfhip_ctx* ctx, uint64_t* out_bytes);
@@ -161,21 +161,6 @@ int sdfhip_mesh_bvh_export(sdfhip_mesh* mesh, double* out_spheres, int32_t* out_
 int sdfhip_mesh_bvh_import(sdfhip_mesh* mesh, const double* spheres, const int32_t* children, int where);
 /* nearest triangle id per point (fp64 BVH traversal on the device) */
 int sdfhip_mesh_nearest(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out_ids, int where);
-/* test hook, host only: mismatches between the BVH planner's threaded restatement of std::sort and std::sort itself on n keys */
-int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads);
-int sdfhip_test_heap_sort_matches_std(const double* keys, uint64_t n);     /* the restated libstdc++ heap sort vs std::make_heap + std::sort_heap */
-/* test hooks: the restated glibc acosf of the mesh preparation (dev_math.h::acosfGlibc) against the running libm on the bit patterns
- * first_bits + i * stride, i < count (values outside [-1, 1] skipped) - its host compilation (no device needed; 0, 1, 2^32 = every float),
- * and its device compilation.  Both return / store the number of differing results. */
-uint64_t sdfhip_test_acosf_mismatches(uint32_t first_bits, uint32_t stride, uint64_t count, int threads);
-int sdfhip_test_acosf_device(sdfhip_ctx* ctx, uint32_t first_bits, uint32_t stride, uint32_t count, uint64_t* out_mismatches);
-/* Which acosf the corner angles use is decided by the first mesh of a process (a self-check of the restatement against the running libm:
- * on a host whose libm is another function the arc cosines are taken there, as the reference does).  Test hook: 1 forces the host's,
- * 0 the device's, -1 makes the next mesh decide again. */
-void sdfhip_test_set_host_acos(int mode);
-/* the BVH planner alone, host memory in and out (no device needed): 8 doubles + 2 ints per inner node, max(num_triangles - 1, 1) nodes.
- * Replaces the tree half of tmd::TriangleMeshDistance::construct (TriangleMeshDistance.h:421-490); CPU tests compare it with the oracle's. */
-int sdfhip_test_plan_bvh(const float* xyz, uint32_t num_vertices, const uint32_t* indices, uint32_t num_triangles, double* out_spheres, int32_t* out_children, double* seconds);
 /* development probe: per query [triangle id, inner nodes entered, deferred children popped, triangles evaluated] */
 int sdfhip_mesh_nearest_stats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4);
 /* the same counters for a second run in which every query starts from the bound of its own answer: the fewest visits ANY visiting order
@@ -357,10 +342,7 @@ int sdfhip_multi_exact_build(sdfhip_multi* multi, const float* xyz, uint32_t num
 int sdfhip_tricubic_fit(sdfhip_ctx* ctx, const float* values_8x8, const float* node_sizes, uint64_t n, float* out64, int fit_mode);
 int sdfhip_is_near_minimize(sdfhip_ctx* ctx, const float* half, const float* radius8, const float* tri9, const float* thr,
                             uint64_t n, uint8_t* out);
-/* Profiling aid (device pointers, enqueued on the context's stream): lane i reads the 256-byte block dev_block_ids[i] of dev_data with the
- * query kernel's load pattern (16 x dwordx4) and writes one float.  With a permutation of block ids the bytes that must cross the fabric
- * are known exactly, which calibrates rocprofv3's FETCH_SIZE for this access pattern (bench.py, tools/profile_bench.sh). */
-int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const uint32_t* dev_block_ids, uint64_t n, float* dev_out);
+/* (test / calibration hooks: include/sdfhip_test.h) */
 
 #ifdef __cplusplus
 }

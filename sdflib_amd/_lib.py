@@ -116,6 +116,7 @@ SIGNATURES = {
     "sdfhip_tricubic_fit": (_int, [_vp, _vp, _vp, _u64, _vp, _int]),
     "sdfhip_is_near_minimize": (_int, [_vp, _vp, _vp, _vp, _vp, _u64, _vp]),
     "sdfhip_test_gather_blocks": (_int, [_vp, _vp, _vp, _u64, _vp]),
+    "sdfhip_test_valu_peak": (_int, [_vp, _u32, _u32, _vp]),
     "sdfhip_multi_create": (_int, [_vp, _int, C.POINTER(_vp)]),
     "sdfhip_multi_destroy": (_int, [_vp]),
     "sdfhip_multi_size": (_int, [_vp]),

@@ -58,6 +58,21 @@ __global__ void __launch_bounds__(256) k_gather_blocks_coop(const uint32_t* __re
     if (live) out[i] = acc;
 }
 
+// VALU issue-ceiling calibration: 8 independent chains of plain (unpacked) v_fma_f32 per lane - the instruction class the reference-ordered
+// kernels are made of (-ffp-contract=off gives separate v_mul / v_add, same issue rate); inline assembly, because the compiler would pair
+// the chains into v_pk_fma_f32 (two lanes' worth per instruction), which those kernels cannot use.
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t iters, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float a0 = 1.0f + 1e-7f * (float)(i & 7), a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    const float m = 0.9999999f, c = 1e-9f;
+    for (uint32_t k = 0; k < iters; k++) {
+        asm volatile("v_fma_f32 %0, %0, %8, %9\n\tv_fma_f32 %1, %1, %8, %9\n\tv_fma_f32 %2, %2, %8, %9\n\tv_fma_f32 %3, %3, %8, %9\n\t"
+                     "v_fma_f32 %4, %4, %8, %9\n\tv_fma_f32 %5, %5, %8, %9\n\tv_fma_f32 %6, %6, %8, %9\n\tv_fma_f32 %7, %7, %8, %9"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+    }
+    out[i] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
 }  // namespace sdfhip
 
 using namespace sdfhip;
@@ -70,6 +85,16 @@ int sdfhip_test_gather_blocks(sdfhip_ctx* ctx, const uint32_t* dev_data, const u
     if (n == 0) return SDFHIP_OK;
     SDF_HIP_CHECK(hipSetDevice(ctx->device));
     k_gather_blocks_coop<<<gridFor(n, 256), 256, 0, ctx->stream>>>(dev_data, dev_block_ids, n, dev_out);          // the load pattern of k_octree_query_coop
+    SDF_HIP_CHECK(hipGetLastError());
+    return SDFHIP_OK;
+    SDF_API_END
+}
+
+int sdfhip_test_valu_peak(sdfhip_ctx* ctx, uint32_t blocks, uint32_t iters, float* dev_out) {
+    SDF_API_BEGIN
+    SDF_REQUIRE(ctx && dev_out && blocks > 0, "NULL argument");
+    SDF_HIP_CHECK(hipSetDevice(ctx->device));
+    k_valu_peak<<<blocks, 256, 0, ctx->stream>>>(iters, dev_out);
     SDF_HIP_CHECK(hipGetLastError());
     return SDFHIP_OK;
     SDF_API_END

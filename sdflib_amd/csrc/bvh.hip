@@ -2193,6 +2193,7 @@ static int finishOnDevice(sdfhip_mesh* mesh, const PlannedBvh& P, hipStream_t st
 // from the device when the device builder hands a tree over to it
 static int hostArrays(sdfhip_mesh* mesh) {
     if (!mesh->hVerts.empty() && !mesh->hIdx.empty()) return SDFHIP_OK;
+    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));        // the caller's current device need not be the context's
     hipStream_t st = mesh->ctx->stream;
     mesh->hVerts.resize(3ull * mesh->numVertices); mesh->hIdx.resize(3ull * mesh->numTriangles);
     SDF_HIP_CHECK(hipMemcpyAsync(mesh->hVerts.data(), mesh->dVerts.p, 4 * mesh->hVerts.size(), hipMemcpyDeviceToHost, st));
@@ -2208,6 +2209,7 @@ int sdfhip_mesh_build_bvh(sdfhip_mesh* mesh, double* seconds) {
     SDF_REQUIRE(mesh != nullptr, "mesh is NULL");
     std::lock_guard<std::recursive_mutex> building(mesh->ctx->buildLock);
     if (mesh->hasBvh) { if (seconds) *seconds = 0.0; return SDFHIP_OK; }
+    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
     { int depth = 1; while ((1ull << (depth - 1)) < mesh->numTriangles) depth++; SDF_REQUIRE(depth + 1 <= BVH_STACK, "mesh too large for the traversal stack"); }
     const double t0 = nowSeconds();
     const uint32_t offload = bvhOffloadMax();
@@ -2348,6 +2350,7 @@ int sdfhip_test_sort_matches_std(const double* keys, uint64_t n, int threads) {
 static int nearestStats(sdfhip_mesh* mesh, const float* xyz, uint64_t n, uint32_t* out4, bool preseed) {
     SDF_API_BEGIN
     SDF_REQUIRE(mesh && xyz && out4, "NULL argument");
+    SDF_HIP_CHECK(hipSetDevice(mesh->ctx->device));
     SDF_TRY(sdfhip_mesh_ensure_bvh(mesh));
     hipStream_t st = mesh->ctx->stream;
     DevBuf<float> dp; DevBuf<uint32_t> dout;

@@ -263,7 +263,9 @@ int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int coun
     SDF_HIP_CHECK(hipGetDevice(&device));
     Mailbox M;
     if (device >= 0 && device < 16 && mailboxes().take(device, M)) {
-        struct Return { int device; Mailbox& M; ~Return() { mailboxes().give(device, M); } } giveBack{device, M};
+        // the mailbox goes back to the pool when the wait ends normally; on an error return k_mailbox may still be queued to write into it,
+        // so it is dropped instead (a few bytes of pinned memory leak on a path that ends the build anyway)
+        struct Return { int device; Mailbox& M; bool ok; ~Return() { if (ok) mailboxes().give(device, M); } } giveBack{device, M, false};
         const uint32_t seq = ++M.seq ? M.seq : ++M.seq;          // never 0
         k_mailbox<<<1, 1, 0, st>>>(a, b, count, M.dev, seq);
         SDF_HIP_CHECK(hipGetLastError());
@@ -279,6 +281,7 @@ int readBackWords(hipStream_t st, const uint32_t* a, const uint32_t* b, int coun
             }
         }
         for (int i = 0; i < count; i++) out[i] = mb[2 + i];
+        giveBack.ok = true;
         return SDFHIP_OK;
     }
     // (no pinned memory to be had: two pageable copies)
@@ -430,6 +433,7 @@ int sdfhip_ctx_trim(sdfhip_ctx* ctx, uint64_t keep_bytes) {
     {   // the context's own grow-only scratch: the nearest search's candidate lists and the host-pointer staging buffers
         std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
         if (ctx->nearScratch.bytes() > keep_bytes) ctx->nearScratch.release();
+        ctx->contCaps[0] = ctx->contCaps[1] = ctx->contCaps[2] = 0;         // the next CONTINUITY build sizes itself from scratch
         std::lock_guard<std::mutex> staging(ctx->stage.lock);
         if (4 * (ctx->stage.pts.n + ctx->stage.dist.n + ctx->stage.grad.n + ctx->stage.ids.n) > keep_bytes) { ctx->stage.pts.release(); ctx->stage.dist.release(); ctx->stage.grad.release(); ctx->stage.ids.release(); }
     }

@@ -781,7 +781,7 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     hipStream_t st = ctx->stream;
     AllocScope allocScope(st);       // device buffers of this call come from the stream-ordered pool
     const double tStart = nowSeconds();
-    static const bool timing = getenv("SDFHIP_TIMING") != nullptr;      // per-level wall times (every level ends in a stream synchronisation) and the allocator's share
+    static const bool timing = getenv("SDFHIP_TIMING") != nullptr;      // per-level wall times up to the level's last read-back (kernels enqueued after it are billed to the next level) and the allocator's share
     const double alloc0 = g_allocSeconds(); const long allocCalls0 = g_allocCalls();
     std::vector<double> levelSeconds;
     std::unique_ptr<sdfhip_exact> E(new sdfhip_exact());
@@ -958,7 +958,8 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
             SDF_HIP_CHECK(hipGetLastError());
             LV[d + 1 - sod] = std::move(N);
         }
-        // (no wait: the blocks go back to the stream's cache, whose next user is queued behind the kernels that still read them)
+        // (no wait: the blocks go back to the stream's cache, whose next user is queued behind the kernels that still read them.  This holds
+        // because the whole exact build enqueues on ctx->stream only - a side stream or an exchange consumer here would need an event first)
         L->midTri.release(); L->center.release(); L->cornerTri.release();
         prevList = L->list.p;
         levelSeconds.push_back(nowSeconds() - tLevel);

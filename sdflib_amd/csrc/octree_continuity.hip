@@ -821,7 +821,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<uint32_t> recOf, firstOcc; size_t recCap = 0;      // per coefficient block: its owner / the first candidate naming it (device post-pass)
     auto ensureOc = [&](size_t need) -> int {
         if (need <= ocCap) return SDFHIP_OK;
-        size_t cap = ocCap ? ocCap : std::max<size_t>((size_t)1 << 22, ctx->contCaps[0]);      // (every growth is an allocation, copies and two waits: a repeated build starts where the last one ended)
+        size_t cap = ocCap ? ocCap : std::max<size_t>((size_t)1 << 22, std::min<size_t>(ctx->contCaps[0], (size_t)1 << 27));      // at most 512 MB up front, however large the last tree was      // (every growth is an allocation, copies and two waits: a repeated build starts where the last one ended)
         while (cap < need) cap *= 2;
         DevBuf<uint32_t> bigger; SDF_TRY(bigger.reserve(cap));
         if (oc.p) SDF_HIP_CHECK(hipMemcpyAsync(bigger.p, oc.p, 4ull * ocSize, hipMemcpyDeviceToDevice, st));
@@ -844,7 +844,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<float> pCenter, pHalf, pVv; DevBuf<PoolRec> pRec; size_t poolCap = 0; uint32_t poolCount = 0;
     auto ensurePool = [&](size_t need) -> int {
         if (need <= poolCap) return SDFHIP_OK;
-        size_t cap = poolCap ? poolCap : std::max<size_t>(4096, ctx->contCaps[1]);
+        size_t cap = poolCap ? poolCap : std::max<size_t>(4096, std::min<size_t>(ctx->contCaps[1], (size_t)1 << 21));
         while (cap < need) cap *= 2;
         DevBuf<float> c2, h2, v2; DevBuf<PoolRec> r2; SDF_TRY(c2.reserve(3 * cap)); SDF_TRY(h2.reserve(cap)); SDF_TRY(v2.reserve(64 * cap));
         SDF_TRY(r2.reserve(cap));
@@ -861,7 +861,7 @@ int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_
     DevBuf<PPNode> ppNodesBuf; size_t ppNodesCap = 0;
     auto ensureNodes = [&](size_t have, size_t need) -> int {
         if (need <= ppNodesCap) return SDFHIP_OK;
-        size_t cap = ppNodesCap ? ppNodesCap : std::max<size_t>(4096, ctx->contCaps[2]);
+        size_t cap = ppNodesCap ? ppNodesCap : std::max<size_t>(4096, std::min<size_t>(ctx->contCaps[2], (size_t)1 << 22));
         while (cap < need) cap *= 2;
         DevBuf<PPNode> b2; SDF_TRY(b2.reserve(cap));
         if (have) { SDF_HIP_CHECK(hipMemcpyAsync(b2.p, ppNodesBuf.p, sizeof(PPNode) * have, hipMemcpyDeviceToDevice, st)); SDF_HIP_CHECK(hipStreamSynchronize(st)); }

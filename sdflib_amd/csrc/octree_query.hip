@@ -279,7 +279,7 @@ static int ensureQueryLayout(sdfhip_octree* T) {
     // a query runs outside any allocation scope, so nothing else would apply the cache's high-water mark)
     if (4ull * numWords >= compactAbove && total + 64ull * leaves == numWords && !T->dataPinned) {
         T->data.release();
-        BigBlockCache::get().trimTo(ctx->device, st, BigBlockCache::keepBytes());
+        BigBlockCache::get().trimTo(ctx->device, st, BigBlockCache::get().keepFor(ctx->device, st));
     }
     return SDFHIP_OK;
 }
@@ -726,7 +726,7 @@ int sdfhip_octree_compact(sdfhip_octree* T) {
     if (T->data.p && T->qNodes + 64ull * T->qLeaves == T->info.num_words) {
         SDF_HIP_CHECK(hipStreamSynchronize(T->ctx->stream));
         T->data.release(); T->dataPinned = false;          // an explicit request: pointers from sdfhip_octree_device_words are invalid from here on (sdfhip.h)
-        BigBlockCache::get().trimTo(T->ctx->device, T->ctx->stream, BigBlockCache::keepBytes());
+        BigBlockCache::get().trimTo(T->ctx->device, T->ctx->stream, BigBlockCache::get().keepFor(T->ctx->device, T->ctx->stream));
     }
     return SDFHIP_OK;
     SDF_API_END

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <thread>
 #include "../../include/sdfhip.h"
+#include "../../include/sdfhip_test.h"
 
 namespace sdfhip {
 
@@ -77,7 +78,8 @@ struct AllocScope {
 // (a build asks for ~250 of them) are carved out of 64 MB slabs in power-of-two size classes, a released block waits in its class — a
 // context's first build costs a handful of hipMalloc calls, later ones none (250 runtime calls of ~14 us each before).
 // How long cached memory lives: (i) a HIGH-WATER MARK — when an API call that allocated through the cache returns (~AllocScope) and the
-// (device, stream) lists hold more than keepBytes() (SDFHIP_CACHE_KEEP_MB, default 1/32 of the device's memory), the largest blocks, then idle slabs, are freed
+// (device, stream) list holds more than its share of the DEVICE's mark (SDFHIP_CACHE_KEEP_MB, default 1/32 of that device's memory, minus what the
+// device's other streams hold: keepFor), the largest blocks, then idle slabs, are freed
 // until they do not: a process that built one huge tree does not sit on that build's peak scratch for ever; (ii) sdfhip_ctx_trim(ctx,
 // keep_bytes) on request; (iii) when the last context of a (device, stream) is destroyed (trimStream) — blocks released after that are
 // freed at once; (iv) when an allocation fails, everything cached on the device is freed and the request retried once (trimDevice).
@@ -94,14 +96,29 @@ struct BigBlockCache {
     // the bench run (ExactOctreeSdf depth 7: 5.7 GB of cull scratch; OctreeSdf depth 9: 1.6 GB) stay below it, so a rebuild asks the runtime
     // for nothing: multi-GB hipMalloc calls are usually lazy (1-3 ms for 5.7 GB) but were seen to take 0.2-0.3 s each on some boxes
     // (profiles/r05z_bench_n1.json's exact leg, the round-4 "one rebuild in four"); with 512 MB every large build paid them again.
-    static size_t keepBytes() {
-        static const size_t v = [] {
-            if (const char* e = getenv("SDFHIP_CACHE_KEEP_MB")) return (size_t)strtoull(e, nullptr, 10) << 20;
+    // The mark is per DEVICE (1/32 of that device's memory, or SDFHIP_CACHE_KEEP_MB), shared by all (device, stream) lists of the device:
+    // what one stream's list may keep is the mark minus what the device's other streams hold (keepFor).
+    static size_t deviceMark(int dev) {
+        static std::mutex mm; static size_t mark[64]; static bool known[64];
+        if (const char* e = getenv("SDFHIP_CACHE_KEEP_MB")) return (size_t)strtoull(e, nullptr, 10) << 20;
+        std::lock_guard<std::mutex> g(mm);
+        if (dev < 0 || dev >= 64) return (size_t)512 << 20;
+        if (!known[dev]) {
+            int cur = 0; (void)hipGetDevice(&cur);
             size_t freeB = 0, totalB = 0;
-            if (hipMemGetInfo(&freeB, &totalB) != hipSuccess || totalB == 0) { (void)hipGetLastError(); return (size_t)512 << 20; }
-            return totalB / 32;
-        }();
-        return v;
+            const bool ok = hipSetDevice(dev) == hipSuccess && hipMemGetInfo(&freeB, &totalB) == hipSuccess && totalB != 0;
+            (void)hipSetDevice(cur); (void)hipGetLastError();
+            mark[dev] = ok ? totalB / 32 : (size_t)512 << 20; known[dev] = true;
+        }
+        return mark[dev];
+    }
+    static size_t keepBytes() { int dev = 0; (void)hipGetDevice(&dev); return deviceMark(dev); }      // the current device's mark
+    size_t keepFor(int dev, hipStream_t st) {
+        const size_t mark = deviceMark(dev);
+        std::lock_guard<std::mutex> g(m);
+        size_t others = 0;
+        for (auto& e : lists) if (e.first.device == dev && e.first.stream != st) others += heldBytes(e.second);
+        return others >= mark ? 0 : mark - others;
     }
     Lists& listOf(Key k) { for (auto& e : lists) if (!(e.first < k) && !(k < e.first)) return e.second; lists.emplace_back(k, Lists()); return lists.back().second; }
     void addRef(int dev, hipStream_t st) { std::lock_guard<std::mutex> g(m); for (auto& r : refs) if (r.first.device == dev && r.first.stream == st) { r.second++; return; } refs.emplace_back(Key{dev, st}, 1); }
@@ -224,9 +241,10 @@ inline AllocScope::~AllocScope() {
     tlsAlloc() = prev;
     if (mine.active && !prev.active) {               // the outermost scope of an API call
         int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && BigBlockCache::get().cachedBytes(dev, mine.stream) > BigBlockCache::keepBytes()) {
+        size_t keep = 0;
+        if (hipGetDevice(&dev) == hipSuccess && BigBlockCache::get().cachedBytes(dev, mine.stream) > (keep = BigBlockCache::get().keepFor(dev, mine.stream))) {
             const double t0 = nowSeconds(); const size_t before = BigBlockCache::get().cachedBytes(dev, mine.stream);
-            BigBlockCache::get().trimTo(dev, mine.stream, BigBlockCache::keepBytes());
+            BigBlockCache::get().trimTo(dev, mine.stream, keep);
             if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] block cache: %zu MB above the mark given back to the device in %.1f ms\n", (before - BigBlockCache::get().cachedBytes(dev, mine.stream)) >> 20, 1e3 * (nowSeconds() - t0));
         }
     }

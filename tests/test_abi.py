@@ -1,4 +1,4 @@
-"""CPU tests: the C-ABI library loads and exports every symbol include/sdfhip.h declares; it fails loudly
+"""CPU tests: the C-ABI library loads and exports every symbol include/sdfhip.h and include/sdfhip_test.h declare; it fails loudly
 (no CPU fallback) when no HIP device is present.  No compute calls are made here."""
 import ctypes
 import os
@@ -11,7 +11,7 @@ from conftest import ROOT
 
 
 def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "sdfhip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "sdfhip.h")).read() + open(os.path.join(ROOT, "include", "sdfhip_test.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(sdfhip_[a-z0-9_]+)\s*\(", hdr)))
 

@@ -3,7 +3,7 @@
 # Usage: tools/keep_profile.sh <tag> [bench-json]
 TAG=$1
 SRC=gpurun_out/prof_$TAG
-for k in kernel_stats pmc pmc_sq; do cp $SRC/summary_$k.csv profiles/${TAG}_bench_$k.csv; done
+for k in kernel_stats pmc pmc_sq pmc_ea; do [ -f $SRC/summary_$k.csv ] && cp $SRC/summary_$k.csv profiles/${TAG}_bench_$k.csv; done
 [ -f $SRC/summary_copies.txt ] && cp $SRC/summary_copies.txt profiles/${TAG}_bench_copies.txt
 python - <<PY
 import json, subprocess

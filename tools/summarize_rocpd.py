@@ -44,8 +44,9 @@ def main(src, prefix):
         for k, (n, s, mn, mx) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             w.writerow([k, n, int(s), int(s / n), int(mn), int(mx), f"{100 * s / tot:.3f}"])
     out = {}
-    SQ = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU"]
-    for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]), ("pmc_sq", SQ)):
+    SQ = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"]
+    EA = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+    for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]), ("pmc_l2", ["TCC_HIT_sum", "TCC_MISS_sum"]), ("pmc_sq", SQ), ("pmc_ea", EA)):
         p = os.path.join(src, sub, "bench_results.db")
         if not os.path.exists(p):
             continue
@@ -66,6 +67,13 @@ def main(src, prefix):
                 continue
             n = max(x[0] for x in v.values())
             w.writerow([k, n] + [f"{v[c][1]:.3f}" if c in v else "" for c in cols] + ["FETCH/WRITE_SIZE in KB as reported; kernel@N = launches over N work-items"])
+    if any(c in v for v in out.values() for c in EA):
+        with open(prefix + "_pmc_ea.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "dispatches"] + [c + "_avg_per_dispatch" for c in EA])
+            for k, v in sorted(out.items()):
+                if k.startswith("sdfhip") and any(c in v for c in EA):
+                    w.writerow([k, max(v[c][0] for c in EA if c in v)] + [f"{v[c][1]:.6g}" if c in v else "" for c in EA])
     with open(prefix + "_pmc_sq.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "dispatches"] + [c + "_avg_per_dispatch" for c in SQ])
