@@ -227,6 +227,198 @@ static void weldSeams(const float* verts, const float* bbox6, const std::vector<
     for (uint32_t v : seam) { const uint32_t p = parentOf(v); vnormal[3 * v] = vnormal[3 * p]; vnormal[3 * v + 1] = vnormal[3 * p + 1]; vnormal[3 * v + 2] = vnormal[3 * p + 2]; }
 }
 
+
+// ---- seam welding on the device (round 6) --------------------------------------------------------------------------------------------
+// The same pass as weldSeams above, for meshes whose open edges number in the millions (an unwelded export: every edge is open).  What is
+// independent of the union-find's state runs on the device: the seam-vertex list (ascending), the two 2048^3 hash grids (a stable sort by
+// cell keeps each bucket in ascending vertex order = the reference's push_back order), per seam vertex and grid the FIRST bucket member
+// within the threshold (TriangleUtils.cpp:361-369: the loop breaks there), the re-pairing of the open edges under the merged ids and the
+// per-root normal sums (ascending member order, plain fp32 adds).  The union-find itself (:370-376) depends on the order of the unions
+// (`verticesMap[p2] = p1`, no ranks): it stays sequential, on the host, over dense arrays - two words per seam vertex go down, one comes back.
+__global__ void k_weld_flag_vertices(const uint64_t* __restrict__ openKey, uint32_t no, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= no) return;
+    const uint64_t k = openKey[i];
+    flag[(uint32_t)(k >> 32)] = 1u; flag[(uint32_t)k] = 1u;
+}
+__global__ void k_weld_compact(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ rank, uint32_t nv, uint32_t* __restrict__ seam) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nv && flag[v]) seam[rank[v]] = v;
+}
+struct WeldGrid { float sx, sy, sz, gridScale, sqThr; };
+SDF_DEV uint32_t weldCell(const float* __restrict__ verts, uint32_t v, const WeldGrid& G, float offset, bool plain) {
+    const uint32_t axisRes = 2048;
+    // (p - start) * scale, then `+ offset` only where the reference's expression has it (the first grid is filled without the term)
+    const float fx = (verts[3 * v] - G.sx) * G.gridScale, fy = (verts[3 * v + 1] - G.sy) * G.gridScale, fz = (verts[3 * v + 2] - G.sz) * G.gridScale;
+    const int x = plain ? (int)fx : (int)(fx + offset), y = plain ? (int)fy : (int)(fy + offset), z = plain ? (int)fz : (int)(fz + offset);
+    return (uint32_t)x + (uint32_t)y * axisRes + (uint32_t)z * axisRes * axisRes;
+}
+__global__ void k_weld_cells(const float* __restrict__ verts, const uint32_t* __restrict__ seam, uint32_t ns, WeldGrid G, uint32_t* __restrict__ key0, uint32_t* __restrict__ key1,
+                             uint32_t* __restrict__ ident) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    key0[i] = weldCell(verts, seam[i], G, 0.0f, true); key1[i] = weldCell(verts, seam[i], G, 0.5f, false); ident[i] = i;
+}
+SDF_DEV uint32_t weldLowerBound(const uint32_t* __restrict__ keys, uint32_t n, uint32_t k) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < k) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// first[g][i] = seam index of the first member (ascending vertex id) of seam vertex i's bucket in grid g that lies within the threshold, or NONE
+__global__ void k_weld_first(const float* __restrict__ verts, const uint32_t* __restrict__ seam, uint32_t ns, WeldGrid G,
+                             const uint32_t* __restrict__ sKey0, const uint32_t* __restrict__ sIdx0, const uint32_t* __restrict__ sKey1, const uint32_t* __restrict__ sIdx1,
+                             uint32_t* __restrict__ first0, uint32_t* __restrict__ first1) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t v = seam[i];
+    const float px = verts[3 * v], py = verts[3 * v + 1], pz = verts[3 * v + 2];
+    for (int g = 0; g < 2; g++) {
+        const uint32_t* sKey = g ? sKey1 : sKey0; const uint32_t* sIdx = g ? sIdx1 : sIdx0;
+        // the LOOK-UP key carries `+ offset` in both grids (offset = 0.0f for the first: x + 0.0f truncates like x)
+        const uint32_t k = weldCell(verts, v, G, g ? 0.5f : 0.0f, false);
+        uint32_t found = 0xFFFFFFFFu;
+        for (uint32_t j = weldLowerBound(sKey, ns, k); j < ns && sKey[j] == k; j++) {
+            const uint32_t o = seam[sIdx[j]];
+            const float dx = px - verts[3 * o], dy = py - verts[3 * o + 1], dz = pz - verts[3 * o + 2];
+            const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+            if ((xx + yy) + zz < G.sqThr) { found = sIdx[j]; break; }
+        }
+        (g ? first1 : first0)[i] = found;
+    }
+}
+// open edge j of the key-sorted sequence (= the reference's std::map order) under the merged vertex ids
+__global__ void k_weld_rekey(const uint64_t* __restrict__ sKey, uint32_t no, const uint32_t* __restrict__ rank, const uint32_t* __restrict__ root, const uint32_t* __restrict__ seam,
+                             uint64_t* __restrict__ newKey, uint32_t* __restrict__ ident) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= no) return;
+    const uint64_t k = sKey[j];
+    const uint32_t a = seam[root[rank[(uint32_t)(k >> 32)]]], b = seam[root[rank[(uint32_t)k]]];
+    newKey[j] = a < b ? ((uint64_t)a << 32 | b) : ((uint64_t)b << 32 | a);
+    ident[j] = j;
+}
+// runs of equal merged keys, in insertion order: members 0-1, 2-3, ... pair up (insert, meet-and-erase, insert ...: TriangleUtils.cpp:384-400)
+__global__ void k_weld_pair(const uint64_t* __restrict__ key, const uint32_t* __restrict__ seq, uint32_t no, const uint32_t* __restrict__ sHe, float* __restrict__ td, uint32_t* __restrict__ paired) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= no) return;
+    const uint64_t k = key[i];
+    uint32_t r = 0;
+    while (r < i && key[i - 1 - r] == k) r++;
+    if (r & 1u) { writeEdgeNormalPair(td, sHe[seq[i]], sHe[seq[i - 1]]); atomicAdd(paired, 2u); }
+}
+__global__ void k_weld_rootkeys(const uint32_t* __restrict__ root, uint32_t ns, uint32_t* __restrict__ key, uint32_t* __restrict__ ident) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ns) { key[i] = root[i]; ident[i] = i; }
+}
+// one thread per root (run head of the root-sorted member list): root's normal + its members' in ascending vertex order (:404-408)
+__global__ void k_weld_sum(const uint32_t* __restrict__ sRoot, const uint32_t* __restrict__ sMember, uint32_t ns, const uint32_t* __restrict__ seam, const float* __restrict__ vn, float* __restrict__ sums) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t r = sRoot[i];
+    if (i > 0 && sRoot[i - 1] == r) return;
+    const uint32_t vr = seam[r];
+    float ax = vn[3 * vr], ay = vn[3 * vr + 1], az = vn[3 * vr + 2];
+    for (uint32_t j = i; j < ns && sRoot[j] == r; j++) {
+        const uint32_t m = sMember[j];
+        if (m == r) continue;
+        const uint32_t vm = seam[m];
+        ax = ax + vn[3 * vm]; ay = ay + vn[3 * vm + 1]; az = az + vn[3 * vm + 2];
+    }
+    sums[3 * r] = ax; sums[3 * r + 1] = ay; sums[3 * r + 2] = az;
+}
+__global__ void k_weld_spread(const uint32_t* __restrict__ root, uint32_t ns, const uint32_t* __restrict__ seam, const float* __restrict__ sums, float* __restrict__ vn) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t v = seam[i], r = root[i];
+    vn[3 * v] = sums[3 * r]; vn[3 * v + 1] = sums[3 * r + 1]; vn[3 * v + 2] = sums[3 * r + 2];
+}
+
+template <typename K, typename V>
+static int weldSort(hipStream_t st, DevBuf<unsigned char>& tmp, const K* kIn, K* kOut, const V* vIn, V* vOut, size_t n, unsigned bits) {
+    size_t need = 0;
+    SDF_HIP_CHECK(devSortPairs(nullptr, need, kIn, kOut, vIn, vOut, n, 0, bits, st));
+    if (need > tmp.n) SDF_TRY(tmp.reserve(need));
+    SDF_HIP_CHECK(devSortPairs(tmp.p, need, kIn, kOut, vIn, vOut, n, 0, bits, st));
+    return SDFHIP_OK;
+}
+
+// dVerts / td / vnormal on the device; openKey / openHe = the `no` single-owner edges in any order.  Returns the number of welded half-edges.
+static int weldSeamsDevice(hipStream_t st, const float* dVerts, uint32_t nv, const float* bbox6, const uint64_t* openKey, const uint32_t* openHe, uint32_t no,
+                           float* td, float* vnormal, uint32_t* weldedHalfEdges, double* hostSeconds) {
+    *weldedHalfEdges = 0;
+    unsigned vbits = 1; while (vbits < 32u && (1ull << vbits) < (unsigned long long)nv) vbits++;
+    DevBuf<unsigned char> tmp;
+    // the reference's map order of the open edges
+    DevBuf<uint64_t> sKey; DevBuf<uint32_t> sHe;
+    SDF_TRY(sKey.reserve(no)); SDF_TRY(sHe.reserve(no));
+    SDF_TRY(weldSort(st, tmp, openKey, sKey.p, openHe, sHe.p, no, 32u + vbits));
+    // seam vertices, ascending
+    DevBuf<uint32_t> flag, rank, counts; SDF_TRY(flag.reserve(nv)); SDF_TRY(rank.reserve(nv)); SDF_TRY(counts.reserve(2));
+    SDF_HIP_CHECK(hipMemsetAsync(flag.p, 0, 4ull * nv, st));
+    k_weld_flag_vertices<<<gridFor(no, 256), 256, 0, st>>>(openKey, no, flag.p);
+    { size_t need = 0; SDF_HIP_CHECK(devExclusiveSum(nullptr, need, flag.p, rank.p, (size_t)nv, st)); if (need > tmp.n) SDF_TRY(tmp.reserve(need));
+      SDF_HIP_CHECK(devExclusiveSum(tmp.p, need, flag.p, rank.p, (size_t)nv, st)); }
+    uint32_t ns = 0;
+    SDF_TRY(readBackWords(st, rank.p + (nv - 1), flag.p + (nv - 1), 1, &ns));
+    if (ns == 0) return SDFHIP_OK;
+    DevBuf<uint32_t> seam; SDF_TRY(seam.reserve(ns));
+    k_weld_compact<<<gridFor(nv, 256), 256, 0, st>>>(flag.p, rank.p, nv, seam.p);
+    // the grids
+    WeldGrid G;
+    {
+        const float sx = bbox6[3] - bbox6[0], sy = bbox6[4] - bbox6[1], sz = bbox6[5] - bbox6[2];
+        const float big = fmaxf(sx, fmaxf(sy, sz));
+        const float threshold = (float)(1e-5 / big);
+        G = WeldGrid{bbox6[0], bbox6[1], bbox6[2], (float)2048u / big, threshold * threshold};
+    }
+    DevBuf<uint32_t> key0, key1, ident, sKey0, sIdx0, sKey1, sIdx1, first0, first1;
+    SDF_TRY(key0.reserve(ns)); SDF_TRY(key1.reserve(ns)); SDF_TRY(ident.reserve(no > ns ? no : ns)); SDF_TRY(sKey0.reserve(ns)); SDF_TRY(sIdx0.reserve(ns));
+    SDF_TRY(sKey1.reserve(ns)); SDF_TRY(sIdx1.reserve(ns)); SDF_TRY(first0.reserve(ns)); SDF_TRY(first1.reserve(ns));
+    k_weld_cells<<<gridFor(ns, 256), 256, 0, st>>>(dVerts, seam.p, ns, G, key0.p, key1.p, ident.p);
+    SDF_TRY(weldSort(st, tmp, key0.p, sKey0.p, ident.p, sIdx0.p, ns, 32u));
+    SDF_TRY(weldSort(st, tmp, key1.p, sKey1.p, ident.p, sIdx1.p, ns, 32u));
+    k_weld_first<<<gridFor(ns, 128), 128, 0, st>>>(dVerts, seam.p, ns, G, sKey0.p, sIdx0.p, sKey1.p, sIdx1.p, first0.p, first1.p);
+    SDF_HIP_CHECK(hipGetLastError());
+    // the union-find, sequential over the seam vertices in ascending order (host; dense arrays over seam indices)
+    std::vector<uint32_t> f0(ns), f1(ns), parent(ns, 0xFFFFFFFFu), root(ns);
+    SDF_HIP_CHECK(hipMemcpyAsync(f0.data(), first0.p, 4ull * ns, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipMemcpyAsync(f1.data(), first1.p, 4ull * ns, hipMemcpyDeviceToHost, st));
+    SDF_HIP_CHECK(hipStreamSynchronize(st));
+    const double t0 = nowSeconds();
+    {
+        uint32_t* P = parent.data();
+        auto parentOf = [P](uint32_t x) { while (P[x] != 0xFFFFFFFFu && P[x] != x) x = P[x]; return x; };
+        for (uint32_t i = 0; i < ns; i++) {
+            for (int g = 0; g < 2; g++) {
+                const uint32_t o = g ? f1[i] : f0[i];
+                if (o == 0xFFFFFFFFu) continue;
+                const uint32_t p1 = parentOf(i), p2 = parentOf(o);
+                if (i == p1) P[p1] = p1;
+                P[p2] = p1;
+            }
+        }
+        for (uint32_t i = 0; i < ns; i++) root[i] = parentOf(i);
+    }
+    if (hostSeconds) *hostSeconds = nowSeconds() - t0;
+    DevBuf<uint32_t> dRoot; SDF_TRY(dRoot.reserve(ns));
+    SDF_HIP_CHECK(hipMemcpyAsync(dRoot.p, root.data(), 4ull * ns, hipMemcpyHostToDevice, st));
+    // re-pair the open edges under the merged ids
+    DevBuf<uint64_t> newKey, newKeyS; DevBuf<uint32_t> seq, paired; SDF_TRY(newKey.reserve(no)); SDF_TRY(newKeyS.reserve(no)); SDF_TRY(seq.reserve(no)); SDF_TRY(paired.reserve(1));
+    SDF_HIP_CHECK(hipMemsetAsync(paired.p, 0, 4, st));
+    k_weld_rekey<<<gridFor(no, 256), 256, 0, st>>>(sKey.p, no, rank.p, dRoot.p, seam.p, newKey.p, ident.p);
+    SDF_TRY(weldSort(st, tmp, newKey.p, newKeyS.p, ident.p, seq.p, no, 32u + vbits));
+    k_weld_pair<<<gridFor(no, 256), 256, 0, st>>>(newKeyS.p, seq.p, no, sHe.p, td, paired.p);
+    // parents' normals: root + members in ascending order, then handed to every member
+    DevBuf<uint32_t> rKey, rKeyS, rMem; DevBuf<float> sums; SDF_TRY(rKey.reserve(ns)); SDF_TRY(rKeyS.reserve(ns)); SDF_TRY(rMem.reserve(ns)); SDF_TRY(sums.reserve(3ull * ns));
+    k_weld_rootkeys<<<gridFor(ns, 256), 256, 0, st>>>(dRoot.p, ns, rKey.p, ident.p);
+    unsigned sbits = 1; while (sbits < 32u && (1ull << sbits) < (unsigned long long)ns) sbits++;
+    SDF_TRY(weldSort(st, tmp, rKey.p, rKeyS.p, ident.p, rMem.p, ns, sbits));
+    k_weld_sum<<<gridFor(ns, 256), 256, 0, st>>>(rKeyS.p, rMem.p, ns, seam.p, vnormal, sums.p);
+    k_weld_spread<<<gridFor(ns, 256), 256, 0, st>>>(dRoot.p, ns, seam.p, sums.p, vnormal);
+    SDF_HIP_CHECK(hipGetLastError());
+    SDF_TRY(readBackWords(st, paired.p, nullptr, 1, weldedHalfEdges));       // (also: the host vectors above outlive every copy that reads them)
+    return SDFHIP_OK;
+}
+
 }  // namespace sdfhip
 
 namespace sdfhip {
@@ -569,6 +761,12 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
     SDF_HIP_CHECK(hipStreamSynchronize(st));
     if (bbox6 && m->unmatchedEdges > 0) {
         const uint32_t no = m->unmatchedEdges;
+        static const bool hostWeld = getenv("SDFHIP_WELD") && !strcmp(getenv("SDFHIP_WELD"), "host");       // the round-1..5 planner (std::map based), kept as a cross-check
+        if (!hostWeld) {
+            double hs = 0.0;
+            if ((rc = weldSeamsDevice(st, m->dVerts.p, nv, bbox6, openKey.p, openHe.p, no, m->dTri.p, vnormal.p, &m->weldedEdges, &hs))) return fail(rc);
+            if (getenv("SDFHIP_TIMING")) fprintf(stderr, "[sdfhip] seam welding: %u open edges, %u half-edges welded, union-find on the host %.2f ms\n", no, m->weldedEdges, 1e3 * hs);
+        } else {
         std::vector<uint64_t> hKey(no); std::vector<uint32_t> hHe(no); std::vector<float> hVn(3ull * nv);
         SDF_HIP_CHECK(hipMemcpyAsync(hKey.data(), openKey.p, sizeof(uint64_t) * no, hipMemcpyDeviceToHost, st));
         SDF_HIP_CHECK(hipMemcpyAsync(hHe.data(), openHe.p, sizeof(uint32_t) * no, hipMemcpyDeviceToHost, st));
@@ -585,6 +783,8 @@ int sdfhip_mesh_create_opt(sdfhip_ctx* ctx, const float* xyz, uint32_t nv, const
             SDF_HIP_CHECK(hipStreamSynchronize(st));
         }
         SDF_HIP_CHECK(hipMemcpyAsync(vnormal.p, hVn.data(), sizeof(float) * 3ull * nv, hipMemcpyHostToDevice, st));
+        SDF_HIP_CHECK(hipStreamSynchronize(st));
+        }
     }
     k_vertex_normal_apply<<<gridFor(nhe, 256), 256, 0, st>>>(m->dIdx.p, nhe, vnormal.p, m->dTri.p);
     SDF_HIP_CHECK(hipGetLastError());

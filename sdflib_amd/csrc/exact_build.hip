@@ -774,7 +774,8 @@ static int exactBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const float box_mi
     SDF_REQUIRE(ctx && mesh && box_min && box_max && out, "NULL argument");
     SDF_REQUIRE(mesh->ctx == ctx, "mesh belongs to another context");
     std::lock_guard<std::recursive_mutex> building(ctx->buildLock);
-    SDF_REQUIRE(maxDepth >= 2 && maxDepth <= 10, "max_depth must be in [2,10]");
+    SDF_REQUIRE(maxDepth >= 2, "depth must be at least 2");
+    if (maxDepth > 10) { setError("depth %u is above this build's limit of 10: node coordinates are packed 10 bits per axis (the reference's own limit is its 30-bit word index, OctreeSdf.h:53-55, which a depth-11 tree of a real surface exceeds anyway)", (unsigned)maxDepth); return SDFHIP_E_UNSUPPORTED; }
     SDF_REQUIRE(startDepth + 2 <= maxDepth, "start_depth must be <= max_depth - 2 (the reference dereferences a null node otherwise)");
     SDF_REQUIRE(mesh->numTriangles >= 2, "at least 2 triangles are needed (bits per index)");
     SDF_HIP_CHECK(hipSetDevice(ctx->device));

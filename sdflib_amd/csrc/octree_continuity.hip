@@ -786,7 +786,8 @@ static int lastPlus(hipStream_t st, const uint32_t* scan, const uint32_t* val, u
 }
 
 int continuityBuildImpl(sdfhip_ctx* ctx, sdfhip_mesh* mesh, const sdfhip_octree_params* P, sdfhip_octree** out) {
-    SDF_REQUIRE(P->depth >= 1 && P->depth <= 10, "depth must be in [1,10]");
+    SDF_REQUIRE(P->depth >= 1, "depth must be at least 1");
+    if (P->depth > 10) { setError("depth %u is above this build's limit of 10: node coordinates are packed 10 bits per axis (the reference's own limit is its 30-bit word index, OctreeSdf.h:53-55, which a depth-11 tree of a real surface exceeds anyway)", (unsigned)P->depth); return SDFHIP_E_UNSUPPORTED; }
     SDF_REQUIRE(P->start_depth <= P->depth, "start_depth > depth");
     SDF_REQUIRE(P->rule >= SDFHIP_RULE_NONE && P->rule <= SDFHIP_RULE_BY_DISTANCE, "unknown termination rule");
     SDF_REQUIRE(P->fit_mode == SDFHIP_FIT_EXACT, "the CONTINUITY builder feeds coefficients back into the tree: only FIT_EXACT is provided");

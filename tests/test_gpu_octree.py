@@ -374,8 +374,13 @@ def test_edge_cases_and_error_codes(small, gpu_ctx):
     vn = small["v"].copy(); vn[3, 1] = np.inf
     with pytest.raises(S.SdfHipError):
         S.Mesh(vn, small["f"], gpu_ctx)                                          # non-finite vertex
-    with pytest.raises(S.SdfHipError):
-        S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3, num_threads=2)                      # depth beyond the 10-bit lattice coordinates
+    # depth 11: beyond the 10-bit-per-axis node coordinates of this build -> SDFHIP_E_UNSUPPORTED (-5) from all three builders, with a text
+    # that says why (the reference's own limit is its 30-bit word index, OctreeSdf.h:53-55); INTEGRATION.md documents it
+    for build in (lambda: S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3, num_threads=2),
+                  lambda: S.OctreeSdf(small["gm"], small["box"], 11, 2, 1e-3, init_algorithm=S.ALG_CONTINUITY, num_threads=2),
+                  lambda: S.ExactOctreeSdf(small["gm"], small["box"], 11, 3, 16)):
+        with pytest.raises(S.SdfHipError, match=r"sdfhip error -5: depth 11 is above this build's limit of 10"):
+            build()
     with pytest.raises(S.SdfHipError):
         S.OctreeSdf(small["gm"], small["box"], 4, 2, 1e-3, termination_rule=7, num_threads=2)   # unknown rule
     # NaN / infinite query points are answered (NaN in, NaN or the box distance out), never a fault

@@ -15,7 +15,9 @@ timeout 700 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o bench
 timeout 700 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_l2 -o bench -- $CMD > $OUT/bench_pmc_l2.log 2>&1
 timeout 700 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o bench -- $CMD > $OUT/bench_pmc_sq.log 2>&1
 # the L2 -> fabric read requests by size and by destination (is there a DRAM-side count that excludes Infinity-Cache hits?)
-timeout 700 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $OUT/pmc_ea -o bench -- $CMD > $OUT/bench_pmc_ea.log 2>&1
+# (five TCC counters in one pass exceed the hardware's counter slots: two passes)
+timeout 700 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum -d $OUT/pmc_ea -o bench -- $CMD > $OUT/bench_pmc_ea.log 2>&1
+timeout 700 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d $OUT/pmc_ea2 -o bench -- $CMD > $OUT/bench_pmc_ea2.log 2>&1
 cd $REPO
 python tools/summarize_rocpd.py gpurun_out/prof_$TAG gpurun_out/prof_$TAG/summary > gpurun_out/prof_$TAG/summary.txt 2>&1
 # what ties the counters to the code: hashes of the sources the profiled library was built from (bench.py refuses a profile whose hashes

@@ -21,6 +21,13 @@ for i in range(1,len(rows)):
 R=rows[cut:]
 busy=sum(e-s for _,s,e in R); span=R[-1][2]-R[0][1]
 print(f"last burst: {len(R)} launches, span {span/1e6:.2f} ms, GPU busy {busy/1e6:.2f} ms, idle {(span-busy)/1e6:.2f} ms")
+per=collections.defaultdict(lambda:[0,0])
+for n,s,e in R:
+    per[short(n)][0]+=e-s; per[short(n)][1]+=1
+print("  GPU time by kernel:")
+for key,(g,c) in sorted(per.items(), key=lambda kv:-kv[1][0])[:24]:
+    print(f"  {g/1e6:7.3f} ms in {c:3d} launches  {key}")
+print("  idle gaps:")
 gaps=collections.defaultdict(lambda:[0,0])
 for a,b in zip(R[:-1],R[1:]):
     g=b[1]-a[2]
