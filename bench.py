@@ -377,7 +377,7 @@ def main():
     # the HBM-honest figure of the headline kernel beside the headline (whose working set sits in the Infinity Cache): the depth-9 tree's block
     deep = (result.get("extras") or {}).get("deep_tree_d9")
     if deep and deep.get("roofline"):
-        result["roofline_hbm"] = {**deep["roofline"], "workload": f"same kernel, depth-9 tree ({deep['words'] * 4 / 1e9:.2f} GB, beyond the 256 MB Infinity Cache), {deep['queries']} uniform-random queries: extras.deep_tree_d9"}
+        result["roofline_hbm"] = {**deep["roofline"], "workload": f"same kernel, depth-9 tree ({deep['words'] * 4 / 1e9:.2f} GB, beyond the 256 MB Infinity Cache), {deep['queries']} queries, one per distinct depth-9 cell near the surface (every coefficient block fetched once): extras.deep_tree_d9; the volume-uniform 12 M figure on the same tree is extras.deep_tree_d9.uniform_random"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -385,7 +385,7 @@ def main():
         dist.destroy_process_group()
 
 
-NEAR_KERNEL = "sdfhip::k_near_quads<256,false>"
+NEAR_KERNEL = "sdfhip::k_near_quads<256,false,1536u>"
 KERNEL_SOURCES["near_search"] = ["sdflib_amd/csrc/dev_bvh_fast.h", "sdflib_amd/csrc/dev_bvh.h", "sdflib_amd/csrc/dev_math.h", "sdflib_amd/csrc/octree_sampler.h", "sdflib_amd/csrc/octree_build.hip", "sdflib_amd/csrc/Makefile"]
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 GPU_CLOCK_HZ, GPU_SIMDS = 2.4e9, 1024          # MI355X: 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
@@ -737,24 +737,62 @@ DEEP_QUERIES = 12_000_000      # not 10 M: the profile summaries tell the two la
 DEEP_THRESHOLD = 1e-4
 
 
+def band_cell_points(t, dev, want=8_000_000, res=512, seed=4321):
+    """Centres of `want` DISTINCT depth-9 lattice cells nearest the surface, in random order: the tree's own values on the 512^3 lattice pick the
+    band |d| < w (w by bisection), so almost every point falls into a depth-9 leaf of its own -> every 256-byte block is fetched once."""
+    bb = t.get_grid_bounding_box(); size = float(bb[3] - bb[0])
+    step = np.full(3, size / res, dtype=np.float32); origin = (bb[:3] + 0.5 * step).astype(np.float32)
+    d = t.get_distance_grid(origin, step, (res, res, res), gradient=False, eval_mode=S.EVAL_FAST, device_out=True).abs_()
+    lo, hi = 0.0, 64.0 * size / res
+    for _ in range(24):
+        mid = 0.5 * (lo + hi)
+        if int((d < mid).sum().item()) > want: hi = mid
+        else: lo = mid
+    idx = torch.nonzero(d < lo).squeeze(1)
+    del d
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    idx = idx[torch.randperm(idx.numel(), generator=g, device=dev)]
+    x, y, z = idx % res, (idx // res) % res, idx // (res * res)
+    o = torch.tensor(origin, device=dev); st = torch.tensor(step, device=dev)
+    return (o + torch.stack([x, y, z], dim=1).to(torch.float32) * st).contiguous(), lo
+
+
 def deep_tree(mesh, box, dev, prof):
     """The same query kernel on a tree that does NOT fit the 256 MB Infinity Cache: depth 9, threshold 1e-4 = 3.1 GB of node array (12 M leaves;
-    the reference layout's 30-bit word index allows 4.29 GB, and 5e-5 already needs 4.9), so at most 256 MB / 3.1 GB = 8 % of the gathered bytes
-    can be cache-served -> an HBM-bound figure.  (tests/test_gpu_octree.py::test_deep_tree_depth_9_matches_oracle checks the 2e-4 tree, 1.6 GB,
-    against the oracle: same kernel, same builder.)"""
+    the reference layout's 30-bit word index allows 4.29 GB, and 5e-5 already needs 4.9).  Two query sets:
+      * `distinct_cells` (the roofline_hbm figure): one query per distinct depth-9 cell of the band around the surface, random order - every
+        coefficient block is fetched ONCE, so at most the Infinity Cache's 256 MB of the ~2 GB gathered can be cache-served: an HBM figure;
+      * `uniform_random`: 12 M volume-uniform points, the metric's distribution - 12 M such points fall into only ~2.6 M distinct leaves (large
+        leaves are hit again and again), every XCD's L2 re-fetches them through the fabric and the Infinity Cache serves an unknown share of
+        those re-reads: its fabric traffic (7.2 TB/s in profiles/r06d) exceeds what the HBM pins deliver - reported, but not an HBM fraction.
+    (tests/test_gpu_octree.py::test_deep_tree_depth_9_matches_oracle checks the 2e-4 tree, 1.6 GB, against the oracle: same kernel, same builder.)"""
     torch.cuda.synchronize(); t0 = time.perf_counter()
     t = S.OctreeSdf(mesh, box, 9, 3, DEEP_THRESHOLD, num_threads=2)
     torch.cuda.synchronize(); build_s = time.perf_counter() - t0
     i = t.info
+    kern = "sdfhip::k_octree_query_coop<0,false>"
     gen = torch.Generator(device=dev); gen.manual_seed(4321)
     bb = t.get_grid_bounding_box(); size = float(bb[3] - bb[0])
     pts = (torch.tensor(bb[:3], device=dev) + torch.rand((DEEP_QUERIES, 3), generator=gen, device=dev) * (size * 0.999999)).contiguous()
     out = torch.empty(DEEP_QUERIES, dtype=torch.float32, device=dev)
-    ms = _time_ms(lambda: t.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out), reps=10)
-    roof = octree_query_roofline(i, 3, DEEP_QUERIES, ms, False, prof, "sdfhip::k_octree_query_coop<0,false>")
+    ms_u = _time_ms(lambda: t.get_distance(pts, eval_mode=S.EVAL_EXACT, out=out), reps=10)
+    roof_u = octree_query_roofline(i, 3, DEEP_QUERIES, ms_u, False, prof, kern)
+    del pts
+    cpts, band = band_cell_points(t, dev)
+    nq = int(cpts.shape[0])
+    ms = _time_ms(lambda: t.get_distance(cpts, eval_mode=S.EVAL_EXACT, out=out[:nq]), reps=10)
+    # algorithmic bytes of THIS query set: every query walks to a depth-9 leaf (7 dependent node words from the start grid) and reads its own block
+    alg = nq * (16 + 256 + 4 * 7)
+    distinct = nq * 256
+    roof = roofline_block(kern, ms, alg, nq * 16 + distinct, prof.traffic("octree_query", kern, nq))
+    roof.update({"bound_regime": "hbm", "queries": nq, "bytes_per_query": 300, "distinct_block_bytes": distinct,
+                 "cache_servable_share_max": round(256 * 2 ** 20 / distinct, 3),
+                 "hbm_bytes_at_least": int(distinct - 256 * 2 ** 20), "hbm_gb_s_at_least": round((distinct - 256 * 2 ** 20) / ms / 1e6, 1),
+                 "regime": "HBM gather: one query per distinct depth-9 cell within %.4f of the surface, random order; each 256-byte block is needed once per launch" % band})
     t.close()
-    return {"build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves), "queries": DEEP_QUERIES, "query_ms": round(ms, 4),
-            "mqueries_s": round(DEEP_QUERIES / ms / 1e3, 1), "roofline": roof}
+    return {"build_s": round(build_s, 4), "words": int(i.num_words), "leaves": int(i.num_leaves), "queries": nq, "query_ms": round(ms, 4),
+            "mqueries_s": round(nq / ms / 1e3, 1), "roofline": roof,
+            "uniform_random": {"queries": DEEP_QUERIES, "query_ms": round(ms_u, 4), "mqueries_s": round(DEEP_QUERIES / ms_u / 1e3, 1), "roofline": roof_u}}
 
 
 def host_pointer(tree, ex, pts, dev):

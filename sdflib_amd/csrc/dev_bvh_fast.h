@@ -170,15 +170,19 @@ constexpr uint32_t NEAR_MULTISEED = 2;          // leaders a follower is seeded 
 constexpr uint32_t NEAR_REFILL_MIN = 1;         // idle quads a refill waits for (2 - 4: 8.71 / 8.82 / 8.93 ms, within noise of 1)
 constexpr int NEAR_DRAIN_QUAD_LANES = 40;       // lanes with a triangle to test that make a drain round worth its instructions (32: 8.85, 48: 9.0 ms)
 constexpr uint32_t NEAR_MAX_STEPS = 1536;       // pops after which a query is handed to k_near_long (one wave per query; 768 / 384: the same build times, 256: +10 %, 160: x2.4)
+// ... of a LARGE batch.  A pop is one dependent memory round trip (~0.5 us), so the longest query a launch may hold takes 1536 x 0.5 us = 0.75 ms
+// however few queries there are.  Round 6 tried handing queries of batches below NEAR_TWO_PASS_MIN over after fewer pops, because every launch of
+// a 1/8 shard (47 k / 172 k / 331 k queries) costs ~0.45 ms more than its work: no gain (profiles/r06_near_small_batches.txt) - the switch stays.
+constexpr uint32_t NEAR_MAX_STEPS_SMALL = 1536;     // (measured: no gain from 768 / 384, a loss at 192 - the chains that set a small launch's time are a few hundred pops long)
 
 // PROBE: the per-query counters and seeds of the dev probes (sdfhip_mesh_nearest_stats); the builds' instantiation has neither.  The launch
 // constants above are compile-time values in the kernel (kernel arguments until late round 5: seven scalar registers and a division by `lead`).
-template <int BLOCK, bool PROBE>
+template <int BLOCK, bool PROBE, uint32_t MAXSTEPS = NEAR_MAX_STEPS>
 __global__ void __launch_bounds__(BLOCK) k_near_quads(BvhDev b, const float* __restrict__ pos, uint32_t numReps, uint32_t* __restrict__ cand, float* __restrict__ candLo,
                                                       uint8_t* __restrict__ candCount, float* __restrict__ candU2, uint32_t rank, uint32_t world, uint32_t* __restrict__ counters,
                                                       uint32_t* __restrict__ longList, uint32_t* __restrict__ longCount,
                                                       uint32_t* __restrict__ perQueryArg, const uint32_t* __restrict__ seedTriArg, int pass, uint32_t* __restrict__ best) {
-    constexpr uint32_t maxSteps = NEAR_MAX_STEPS, chunk = NEAR_QCHUNK, lead = NEAR_LEAD, multiSeed = NEAR_MULTISEED, refillMin = NEAR_REFILL_MIN;
+    constexpr uint32_t maxSteps = MAXSTEPS, chunk = NEAR_QCHUNK, lead = NEAR_LEAD, multiSeed = NEAR_MULTISEED, refillMin = NEAR_REFILL_MIN;
     constexpr int drainQuads = NEAR_DRAIN_QUAD_LANES; constexpr bool seedFromNeighbour = true;
     uint32_t* const perQuery = PROBE ? perQueryArg : nullptr; const uint32_t* const seedTri = PROBE ? seedTriArg : nullptr;
     __shared__ uint32_t s_ref[BLOCK / 64][QUAD_STACK][16];
@@ -780,8 +784,14 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     if (qgrid > needBlocks) qgrid = needBlocks;
     if (perQuery || seedTri)
         k_near_quads<256, true><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, perQuery, seedTri, twoPass ? 1 : 0, S.best.p);
-    else
-        k_near_quads<256, false><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, nullptr, nullptr, twoPass ? 1 : 0, S.best.p);
+    else {
+        // (A/B switch of the round-6 measurement: SDFHIP_NEAR_SMALL_STEPS = 1536 | 768 | 384 | 192; default NEAR_MAX_STEPS_SMALL)
+        static const uint32_t smallSteps = getenv("SDFHIP_NEAR_SMALL_STEPS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_SMALL_STEPS")) : NEAR_MAX_STEPS_SMALL;
+        const uint32_t steps = n >= NEAR_TWO_PASS_MIN ? NEAR_MAX_STEPS : smallSteps;
+#define SDF_NEAR_LAUNCH(M) k_near_quads<256, false, M><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, nullptr, nullptr, twoPass ? 1 : 0, S.best.p)
+        if (steps >= 1536u) SDF_NEAR_LAUNCH(1536u); else if (steps >= 768u) SDF_NEAR_LAUNCH(768u); else if (steps >= 384u) SDF_NEAR_LAUNCH(384u); else SDF_NEAR_LAUNCH(192u);
+#undef SDF_NEAR_LAUNCH
+    }
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[1], st));
     k_near_long<<<2048, 64, 0, st>>>(bvh, pos, n, S.longList.p, S.fbCount.p + 10, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, S.fbCount.p + 24);
     k_near_resolve<128><<<mine, 128, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, out, S.fbList.p, S.fbCount.p, rank, world);

@@ -51,3 +51,20 @@ for name, pts in ((f"level-{level} samples", lvl), ("uniform", uni)):
         torch.cuda.synchronize(); best = min(best, time.time() - t)
     ids = to.cpu().numpy()
     print(f"[{mode}] {name}: {n} points, {best*1e3:.2f} ms = {n/best/1e6:.1f} M/s, crc {zlib.crc32(ids.tobytes()):08x}", flush=True)
+if os.environ.get("PROBE_PREFIX"):
+    # T(n) of the search on contiguous pieces of the level's Morton-ordered samples (same difficulty per query): a fixed cost per launch shows
+    # as an intercept.  Slices from the MIDDLE of the order, k pieces each (the mean over pieces is printed).
+    tp = torch.from_numpy(lvl).cuda(); N = len(lvl)
+    for n in (4096, 16384, 65536, 131072, 262144, 524287, 524288, 1048576, N):
+        n = min(n, N); ts = []
+        for piece in range(4):
+            off = ((N - n) * piece // 3) // 128 * 128 if n < N else 0
+            sub = tp[off:off + n].contiguous(); to = torch.empty(n, dtype=torch.int32, device="cuda")
+            best = 1e9
+            for _ in range(4):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); a.record()
+                check(lib().sdfhip_mesh_nearest(m.h, C.c_void_p(sub.data_ptr()), n, C.c_void_p(to.data_ptr()), 1))
+                b.record(); torch.cuda.synchronize(); best = min(best, a.elapsed_time(b))
+            ts.append(best)
+        print(f"prefix n={n:8d}: {np.mean(ts):.3f} ms (min {min(ts):.3f}, max {max(ts):.3f}) = {n/np.mean(ts)/1e3:.1f} M/s", flush=True)

@@ -13,6 +13,10 @@ tabs=[r[0] for r in db.execute("select name from sqlite_master where type='table
 k=[t for t in tabs if t.startswith('kernels')][0]
 cols=[r[1] for r in db.execute(f"pragma table_info({k})")]
 rows=list(db.execute(f"select name,start,end from {k} order by start"))
+try:
+    grids={(n,s):g for n,s,g in db.execute(f"select name,start,grid_x from {k}")}
+except Exception:
+    grids={}
 short=lambda n: n.replace('(anonymous namespace)::','').replace('void ','').split('(')[0][-40:]
 # the last build = the launches after the last idle gap longer than 2 ms
 cut=0
@@ -27,6 +31,9 @@ for n,s,e in R:
 print("  GPU time by kernel:")
 for key,(g,c) in sorted(per.items(), key=lambda kv:-kv[1][0])[:24]:
     print(f"  {g/1e6:7.3f} ms in {c:3d} launches  {key}")
+print("  longest launches (offset in the burst, duration, work-items):")
+for n,s,e in sorted(R, key=lambda r: r[1]-r[2])[:10]:
+    print(f"   +{(s-R[0][1])/1e6:7.3f} ms  {(e-s)/1e6:7.3f} ms  {grids.get((n,s),0):>9}  {short(n)}")
 print("  idle gaps:")
 gaps=collections.defaultdict(lambda:[0,0])
 for a,b in zip(R[:-1],R[1:]):
