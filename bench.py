@@ -919,6 +919,41 @@ def valu_calibration(ctx, dev, blocks=4096, iters=20000):
             "tflops_fma": round(rate * 128 / 1e12, 1)}
 
 
+XGMI_LINK_GBS = 153.0       # per direction and link (7 links per GPU, point to point); MI355X_MICROARCH.md
+
+
+def shard_forecast(mesh, box, depth, start_depth, steady, words):
+    """What an N-GPU run of this build should show (N = 2, 4, 8), from THIS GPU: every rank's shard of the start cells is built here on its
+    own (the other ranks absent, best of two), the slowest one is the sharded part; the serial part (mesh preparation + BVH) is what every
+    rank repeats; the exchange is the all-gather-v of the shard bodies: each rank receives the other ranks' words, at best over its N - 1
+    direct xGMI links in parallel.  A later SCALE curve can be held against these numbers."""
+    from sdflib_amd import api
+    serial = float(steady.get("mesh_prep_s", 0.0)) + float(steady.get("bvh_s_after_mesh", 0.0))
+    G3 = 8 ** start_depth
+    weights = sdist.cell_weights(mesh.vertices, box, start_depth)
+    out = {"serial_s": round(serial, 4), "single_gpu_octree_s": steady.get("octree_s"), "tree_bytes": 4 * words}
+    for world in (2, 4, 8):
+        ranges = sdist.partition_cells(G3, world, weights)
+        ts, sizes = [], []
+        for rk in range(world):
+            best = 1e9
+            for _ in range(2):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                sh = api.OctreeShard(mesh, box, depth, start_depth, 1e-3, cells=ranges[rk]); torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+                nb = int(sh.info.body_words)
+                sh.close()
+            ts.append(best); sizes.append(4 * nb)
+        recv = sum(sizes) - min(sizes)                     # the rank with the smallest shard receives the most
+        exch = recv / ((world - 1) * XGMI_LINK_GBS * 1e9)
+        out[f"n{world}"] = {"slowest_shard_s": round(max(ts), 4), "mean_shard_s": round(float(np.mean(ts)), 4), "exchange_bytes_received_max": int(recv),
+                            "exchange_s_at_link_rate": round(exch, 5), "end_to_end_s": round(serial + max(ts) + exch, 4),
+                            "speedup_over_one": round((serial + float(steady.get("octree_s", 0.0))) / (serial + max(ts) + exch), 2)}
+    out["note"] = ("shards measured one at a time on this GPU; the sharded part does not shrink like 1/N because a launch of the nearest search costs ~0.45 ms "
+                   "however few queries it holds (profiles/r06_near_small_batches.txt) and the serial part is repeated by every rank")
+    return out
+
+
 def build_1m(ctx, rank, world, dev):
     v, f = bumpy_icosphere(8)
     box = box_with_margin(v)
@@ -945,6 +980,7 @@ def build_1m(ctx, rank, world, dev):
     if world == 1:
         r["steady_state"] = end_to_end_build(ctx, v, f, box, 8, 3, dev)
         r["end_to_end_s"] = r["steady_state"]["end_to_end_s"]
+        r["forecast"] = shard_forecast(mesh, box, 8, 3, r["steady_state"], int(i.num_words))
     else:
         # what north_star asks of the N-GPU build: seconds at N and where they go.  serial = what every rank repeats (mesh upload +
         # TriangleData, the sphere BVH - built by every rank on its own device, or planned by rank 0 and broadcast under
