@@ -135,9 +135,9 @@ struct ExactBuilder {
         out.sets[at++] = n;
         uint32_t bIdx = 0;
         for (uint32_t t = 0; t < n; t++, bIdx += out.bitsPerIndex) {
-            const uint32_t index = list[t], w = bIdx >> 5, bit = bIdx & 31u;
+            const uint32_t index = list[t], w = bIdx >> 5, bit = bIdx & 31;
             out.sets[at + w] |= (index << inv) >> bit;
-            out.sets[at + w + 1] |= (uint32_t)((uint64_t)index << (64 - (bit + out.bitsPerIndex)));
+            out.sets[at + w + 1] |= (static_cast<uint64_t>(index) << (64 - (bit + out.bitsPerIndex)));      // (the 64-bit value is narrowed by the compound assignment, as in the reference)
         }
     }
 
@@ -324,7 +324,7 @@ struct ExactBuilder {
 static inline uint32_t roundFloatGT(float a) { return (a > 0.5f) ? 1u : 0u; }
 
 static inline uint32_t unpackIndex(const uint32_t* set, uint32_t bIdx, uint32_t bits) {
-    const uint32_t w = bIdx >> 5, bit = bIdx & 31u;
+    const uint32_t w = bIdx >> 5, bit = bIdx & 31;
     return ((set[w] << bit) >> (32 - bits)) | (uint32_t)((uint64_t)set[w + 1] >> (64 - (bit + bits)));
 }
 

@@ -509,3 +509,86 @@ def group_archive():
 
 
 GROUPS.append(group_archive)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def group_exact_bits(orc_exact=None):
+    """ExactOctreeSdf's bit-packed triangle sets: the writer (ExactOctreeSdfDepthFirst.h:261-283) and the four reader expressions of
+    ExactOctreeSdf::getDistance (ExactOctreeSdf.cpp:80-81, 125-126 and their gradient twins), roundFloat (:33-36, '>' not '>=')."""
+    hdr = cparse.preprocess(read(REF + "/include/SdfLib/ExactOctreeSdfDepthFirst.h"))
+    cpp = cparse.preprocess(read(REF + "/src/sdf/ExactOctreeSdf.cpp"))
+    orc = orc_exact or read(REPO + "/oracle/orc_exact.h")
+    # ---- writer
+    blk = block_after(hdr, r"if\(node\.depth == tContext\.bitEncodingStartDepth\)\s*\{")
+    cut = blk.index("tContext.maxTrianglesEncodedInLeafs = ")          # (a statistic the oracle keeps elsewhere)
+    ref_w = blk[:cut] + "}"
+    orc_p = orc.replace("out.nodeHasTriIdx[nodeIndex] = 1;", "")          # oracle-only bookkeeping ("this node's index was written")
+    assert orc_p != orc
+    op, ob = fn(orc_p, r"void emitSet\s*\(")
+
+    def rw_ref(x):
+        if x[0] == "member" and x[1] == ("id", "tContext"):
+            return ("id", x[2])
+        if x == ("mcall", ("id", "nodeTriangles"), "size", ()):
+            return ("id", "numTriangles@list")
+        return x
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] == ("id", "out"):
+            return ("id", {"sets": "outputTrianglesSets", "bitsPerIndex": "bitsPerIndex", "nodes": "nodes"}[x[2]])
+        if x == ("mcall", ("id", "nodeTriangles"), "size", ()):
+            return ("id", "numTriangles@list")
+        if x[0] == "mcall" and x[2] == "resize" and len(x[3]) == 2 and x[3][1] == ("lit", "uint", 0):
+            return ("mcall", x[1], "resize", x[3][:1])                       # resize(n, 0u) == resize(n): value-initialised words
+        if x[0] == "cast" and x[1] == "uint32_t" and x[2] in (("id", "numTriangles@list"), ("mcall", ("id", "outputTrianglesSets"), "size", ())):
+            return x[2]                                                      # (uint32_t)vector.size(): the reference converts implicitly
+        if x[0] == "index" and x[1] == ("id", "nodes"):
+            return ("member", ("id", "octreeNode"), "trianglesArrayIndex")  # the node's second word
+        return x
+    er = symex.Exec(); er.rewrite = rw_ref
+    eo = symex.Exec(id_alias={"list": "nodeTriangles"}, local_alias={"at": "arrayStartIndex", "bIdx": "bIdx"}); eo.rewrite = rw_orc
+    r = er.run([], cparse.parse_body(ref_w))
+    o = eo.run([], ob)
+
+    def strip(paths):          # `octreeNode->x = v` stores through a pointer on one side, names the node's word on the other: compare target names only
+        out = []
+        for p in paths:
+            ev = tuple(("store", ("member", ("id", "octreeNode"), "trianglesArrayIndex"), e[2]) if e[0] == "store" and symex.show(e[1]).endswith("trianglesArrayIndex") else e for e in p["events"])
+            out.append(dict(p, events=ev))
+        return out
+    compare("bit-packed set writer", strip(r), strip(o))
+    # ---- readers
+    exprs = re.findall(r"=\s*(\(\(mTrianglesSets\[(\w+) \+ idx\] << bit\) >> \(32-mBitsPerIndex\)\)\s*\|\s*static_cast<uint32_t>\(static_cast<uint64_t>\(mTrianglesSets\[\w+ \+ idx \+ 1\]\) >> \(64 - \(bit \+ mBitsPerIndex\)\)\))", cpp)
+    assert len(exprs) == 4, len(exprs)
+    assert len(re.findall(r"uint32_t idx = bIdx >> 5;\s*uint32_t bit = bIdx & 0b0011111;", cpp)) == 4
+    op, ob = fn(orc, r"uint32_t unpackIndex\s*\(")
+    want = symex.Exec().run(op, ob)
+    assert len(want) == 1
+    for text, base in exprs:
+        body = cparse.parse_body("{ uint32_t idx = bIdx >> 5; uint32_t bit = bIdx & 0b0011111; return %s; }" % text)
+
+        def rw(x, base=base):
+            if x[0] == "index" and x[1] == ("id", "mTrianglesSets") and x[2][0] == "bin" and x[2][1] == "+":
+                inner = x[2]
+                if inner[2] == ("id", base):
+                    return ("index", ("arg", 0), inner[3])
+                if inner[2][0] == "bin" and inner[2][2] == ("id", base):        # (base + idx) + 1
+                    return ("index", ("arg", 0), ("bin", "+", inner[2][3], inner[3]))
+            return x
+        e = symex.Exec(id_alias={"bIdx": "$1", "mBitsPerIndex": "$2"}); e.rewrite = rw
+        got = e.run([], body)
+
+        def argify(x):
+            if isinstance(x, tuple):
+                if x == ("id", "$1"):
+                    return ("arg", 1)
+                if x == ("id", "$2"):
+                    return ("arg", 2)
+                return tuple(argify(y) for y in x)
+            return x
+        compare("bit-packed set reader", [dict(p, end=argify(p["end"])) for p in got], want)
+    compare("ExactOctreeSdf roundFloat", symex.Exec().run(*fn(cpp, r"inline uint32_t roundFloat\s*\(")), symex.Exec().run(*fn(orc.replace("? 1u : 0u", "? 1 : 0"), r"uint32_t roundFloatGT\s*\(")))
+    return "ExactOctreeSdf bit-packed sets: writer (word count, MSB-first shifts, the spill into the next word), 4 reader expressions, roundFloat ('>'): identical"
+
+
+GROUPS.append(group_exact_bits)

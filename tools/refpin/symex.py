@@ -467,7 +467,7 @@ class Exec:
                     o = self.snapshot(o)
                     if m in MUTATORS:
                         r = self.root_of(o)
-                        s2.events.append(("mcall", o, m, a))
+                        s2.events.append(self.rw(("mcall", o, m, a)))
                         s2.epoch[r] = s2.epoch.get(r, 0) + 1
                         yield s2, ("mresult", len(s2.events) - 1, m)
                     else:
