@@ -785,11 +785,10 @@ static int nearestTwoPhase(hipStream_t st, const BvhDev& bvh, const float* pos, 
     if (perQuery || seedTri)
         k_near_quads<256, true><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, perQuery, seedTri, twoPass ? 1 : 0, S.best.p);
     else {
-        // (A/B switch of the round-6 measurement: SDFHIP_NEAR_SMALL_STEPS = 1536 | 768 | 384 | 192; default NEAR_MAX_STEPS_SMALL)
-        static const uint32_t smallSteps = getenv("SDFHIP_NEAR_SMALL_STEPS") ? (uint32_t)atoi(getenv("SDFHIP_NEAR_SMALL_STEPS")) : NEAR_MAX_STEPS_SMALL;
-        const uint32_t steps = n >= NEAR_TWO_PASS_MIN ? NEAR_MAX_STEPS : smallSteps;
+        // (the small-batch hand-over of round 6 was measured through an environment switch, profiles/r06_near_small_batches.txt; no gain, the switch is gone)
+        const uint32_t steps = n >= NEAR_TWO_PASS_MIN ? NEAR_MAX_STEPS : NEAR_MAX_STEPS_SMALL;
 #define SDF_NEAR_LAUNCH(M) k_near_quads<256, false, M><<<xcdGrid(qgrid), 256, 0, st>>>(bvh, pos, n, S.cand.p, S.candLo.p, S.candCount.p, S.candU2.p, rank, world, S.fbCount.p + 2, S.longList.p, S.fbCount.p + 10, nullptr, nullptr, twoPass ? 1 : 0, S.best.p)
-        if (steps >= 1536u) SDF_NEAR_LAUNCH(1536u); else if (steps >= 768u) SDF_NEAR_LAUNCH(768u); else if (steps >= 384u) SDF_NEAR_LAUNCH(384u); else SDF_NEAR_LAUNCH(192u);
+        if (steps >= 1536u) SDF_NEAR_LAUNCH(1536u); else SDF_NEAR_LAUNCH(NEAR_MAX_STEPS_SMALL);
 #undef SDF_NEAR_LAUNCH
     }
     if (timed) SDF_HIP_CHECK(hipEventRecord(ev[1], st));

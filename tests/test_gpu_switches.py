@@ -1,4 +1,4 @@
-"""Every environment switch the library still reads (20 after round 5's pruning; `grep -o 'getenv("SDFHIP_[A-Z_0-9]*")' sdflib_amd/csrc/*`)
+"""Every environment switch the library still reads (20 after round 5's pruning, 21 with round 6's SDFHIP_WELD; `grep -o 'getenv("SDFHIP_[A-Z_0-9]*")' sdflib_amd/csrc/*`)
 is flipped by a test: the ones below, plus SDFHIP_BVH_BUILD / _DEVICE_SUBTREES / SDFHIP_TIMING (test_gpu_octree.py: the hybrid BVH walk),
 SDFHIP_BVH_SORT_THREADS / _PAR_DEPTH / _MIN_PARALLEL / _PAR_PARTITION (test_planner_cpu.py), SDFHIP_MULTI_CUTS (test_gpu_baseline_configs.py),
 SDFHIP_EXACT_LISTS_MB (test_gpu_exact.py) and SDFHIP_QUERY_CHUNK (test_gpu_octree.py).  The switches are read once per process, hence the
@@ -46,6 +46,16 @@ _CASES = {
     "nearest-exact": ({"SDFHIP_NEAREST": "exact"}, "trees_equal_the_oracle(); assert np.array_equal(gm.nearest_triangle(pts), om.nearest(pts))"),
     # allocation diagnostics: plain hipMalloc for every transient block / fresh blocks filled with a pattern / guard words + overlap registry
     "no-pool": ({"SDFHIP_NO_POOL": "1"}, "trees_equal_the_oracle()"),
+    # the seam welding's round-1..5 host planner (std::map based) instead of the device passes: same TriangleData, same tree on a welded soup
+    "weld-host": ({"SDFHIP_WELD": "host"}, r'''
+from sdflib_amd.meshgen import triangle_soup
+sv, sf = triangle_soup(v, f)
+bbox = np.concatenate([sv.min(axis=0), sv.max(axis=0)])
+wm, wo = S.Mesh(sv, sf, ctx, bbox=bbox), O.Mesh(sv, sf, bbox)
+assert wm.edge_stats()["welded_half_edges"] == 3 * len(sf)
+assert np.array_equal(b(wm.triangle_data()), b(wo.triangle_data()))
+assert np.array_equal(S.OctreeSdf(wm, box, 5, 2, 1e-3, num_threads=2).get_octree_data(), O.Octree(wo, box, 5, 2, 1e-3, vertex_cache=False, layout=O.LAYOUT_SUBTREES).data())
+'''),
     "poison-alloc": ({"SDFHIP_POISON_ALLOC": "0xCD"}, "trees_equal_the_oracle()"),
     "alloc-check": ({"SDFHIP_ALLOC_CHECK": "1"}, "trees_equal_the_oracle()"),
     # nothing may stay cached when a build returns
