@@ -637,6 +637,10 @@ static QueryTree makeQueryTree(const sdfhip_octree* T) {
     return q;
 }
 
+// host-pointer batches of this many points and more are overlapped (SDFHIP_HOST_OVERLAP=0: one upload, one launch, one download, as until round 5)
+constexpr uint64_t kOverlapMin = 1ull << 21, kOverlapPiece = 1ull << 20;
+static inline bool hostOverlap() { static const bool v = !(getenv("SDFHIP_HOST_OVERLAP") && !strcmp(getenv("SDFHIP_HOST_OVERLAP"), "0")); return v; }
+
 template <typename... A>
 static void launchQuery(int eval_mode, bool grad, unsigned blocks, hipStream_t st, A... a) {
     if (eval_mode == SDFHIP_EVAL_EXACT) {
@@ -699,10 +703,50 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         // the box's PCIe bound.  (Rounds 2-3 had a pipeline that pinned the caller's pages in place piece by piece and overlapped upload,
         // kernel and download on two streams — 2.93-3.07 ms — but ended in a GPU memory access fault after mixed registration failures
         // over the same arrays, cause never found; it was removed in round 4: a legal call must not be able to take the process down.)
-        SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, 12 * n, hipMemcpyHostToDevice, st));
         p = dp.p; d = dd.p; g = out_grad ? dg.p : nullptr;
     }
     const QueryTree q = makeQueryTree(T);
+    if (where == SDFHIP_HOST && hostOverlap() && n >= kOverlapMin) {
+        // Large host batches, overlapped (round 6): the batch is cut into pieces; this thread uploads piece k + 1 and evaluates it on the
+        // context's stream while a second host thread sends piece k's results back on `downStream` - PCIe is full duplex, so the call costs
+        // about max(upload, download) + one piece instead of their sum.  Plain copies between the caller's PAGEABLE arrays and device
+        // buffers, as before: nothing of the caller's memory is registered with the runtime (the in-place-pinning pipeline of rounds 2-3,
+        // removed in round 4 after a GPU memory access fault under forced registration failures, is not coming back).  A pageable
+        // hipMemcpyAsync occupies its calling thread until the data are staged, hence the second thread.
+        if (!ctx->downStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->downStream, hipStreamNonBlocking));
+        hipStream_t down = ctx->downStream;
+        const uint64_t piece = kOverlapPiece, pieces = (n + piece - 1) / piece;
+        std::vector<hipEvent_t> ev(pieces, nullptr);
+        struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } evGuard{ev};
+        for (hipEvent_t& e : ev) SDF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        std::atomic<uint64_t> recorded{0}; std::atomic<int> failed{0};
+        const int device = ctx->device;
+        float* const dDist = d; float* const dGrad = g;
+        std::thread downloader([&, device, down] {
+            if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
+            for (uint64_t k = 0; k < pieces; k++) {
+                while (recorded.load(std::memory_order_acquire) <= k) { if (failed.load()) return; std::this_thread::yield(); }
+                const uint64_t off = k * piece, m = n - off < piece ? n - off : piece;
+                if (hipStreamWaitEvent(down, ev[k], 0) != hipSuccess || hipMemcpyAsync(out_dist + off, dDist + off, 4 * m, hipMemcpyDeviceToHost, down) != hipSuccess ||
+                    (out_grad && hipMemcpyAsync(out_grad + 3 * off, dGrad + 3 * off, 12 * m, hipMemcpyDeviceToHost, down) != hipSuccess)) { failed.store(1); return; }
+            }
+            if (hipStreamSynchronize(down) != hipSuccess) failed.store(1);
+        });
+        int rc = SDFHIP_OK;
+        for (uint64_t k = 0; k < pieces && !failed.load(); k++) {
+            const uint64_t off = k * piece, m = n - off < piece ? n - off : piece;
+            if (hipMemcpyAsync(dp.p + 3 * off, xyz + 3 * off, 12 * m, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            launchQuery(eval_mode, g != nullptr, gridFor(m, 256), st, q, (const float*)(dp.p + 3 * off), m, d + off, g ? g + 3 * off : nullptr);
+            if (hipGetLastError() != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
+            recorded.store(k + 1, std::memory_order_release);
+        }
+        if (rc != SDFHIP_OK) failed.store(1);
+        downloader.join();
+        (void)hipStreamSynchronize(st);
+        if (failed.load()) { setError("HIP error in the overlapped host-pointer query: %s", hipGetErrorString(hipGetLastError())); return SDFHIP_E_HIP; }
+        return SDFHIP_OK;
+    }
+    if (where == SDFHIP_HOST) SDF_HIP_CHECK(hipMemcpyAsync(dp.p, xyz, 12 * n, hipMemcpyHostToDevice, st));
     const unsigned blocks = gridFor(n, 256);
     launchQuery(eval_mode, g != nullptr, blocks, st, q, (const float*)p, n, d, g);
     SDF_HIP_CHECK(hipGetLastError());

@@ -914,3 +914,23 @@ def test_scan_like_mesh_with_slivers_t_junctions_self_intersection(oracle, gpu_c
         assert np.array_equal(bits(e0), bits(e1)) and np.array_equal(t0, t1.astype(np.uint32)), "exact queries"
         eg0 = oe.query(pts, grad=True); eg1 = ge.get_distance(pts, gradient=True)
         assert np.array_equal(bits(eg0[0]), bits(eg1[0])) and (np.array_equal(bits(eg0[1]), bits(eg1[1])) or np.array_equal(eg0[1], eg1[1], equal_nan=True)), "exact gradients"
+
+
+def test_large_host_batches_are_overlapped_and_bit_identical(small, gpu_ctx):
+    """Host-pointer batches of 2^21 points and more are cut into pieces whose upload + evaluation overlaps the previous piece's download
+    (two host threads, two streams, plain pageable copies): values and gradients equal the device-pointer path's, for sizes around the
+    piece boundaries, repeatedly (the second stream and the events are created and destroyed per call)."""
+    import torch
+    import sdflib_amd as S
+    from sdflib_amd.meshgen import random_points_in_box
+    t = S.OctreeSdf(small["gm"], small["box"], 6, 2, 1e-3, num_threads=2)
+    for n in (2_097_152, 2_097_153, 3_145_728 + 17, 5_000_001):
+        pts = random_points_in_box(small["box"], n, seed=n % 1000)
+        pts[::7919] *= 3.0                                  # some points outside the box
+        dt, gt = t.get_distance(torch.from_numpy(pts).cuda(), gradient=True)
+        for rep in range(2):
+            d, g = t.get_distance(pts, gradient=True)
+            assert np.array_equal(bits(d), bits(dt.cpu().numpy())), n
+            assert np.array_equal(bits(g), bits(gt.cpu().numpy())), n
+        d1 = t.get_distance(pts)
+        assert np.array_equal(bits(d1), bits(dt.cpu().numpy())), n

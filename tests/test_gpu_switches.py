@@ -1,4 +1,4 @@
-"""Every environment switch the library still reads (20 after round 5's pruning, 21 with round 6's SDFHIP_WELD; `grep -o 'getenv("SDFHIP_[A-Z_0-9]*")' sdflib_amd/csrc/*`)
+"""Every environment switch the library still reads (20 after round 5's pruning, 22 with round 6's SDFHIP_WELD and SDFHIP_HOST_OVERLAP; `grep -o 'getenv("SDFHIP_[A-Z_0-9]*")' sdflib_amd/csrc/*`)
 is flipped by a test: the ones below, plus SDFHIP_BVH_BUILD / _DEVICE_SUBTREES / SDFHIP_TIMING (test_gpu_octree.py: the hybrid BVH walk),
 SDFHIP_BVH_SORT_THREADS / _PAR_DEPTH / _MIN_PARALLEL / _PAR_PARTITION (test_planner_cpu.py), SDFHIP_MULTI_CUTS (test_gpu_baseline_configs.py),
 SDFHIP_EXACT_LISTS_MB (test_gpu_exact.py) and SDFHIP_QUERY_CHUNK (test_gpu_octree.py).  The switches are read once per process, hence the
@@ -46,6 +46,15 @@ _CASES = {
     "nearest-exact": ({"SDFHIP_NEAREST": "exact"}, "trees_equal_the_oracle(); assert np.array_equal(gm.nearest_triangle(pts), om.nearest(pts))"),
     # allocation diagnostics: plain hipMalloc for every transient block / fresh blocks filled with a pattern / guard words + overlap registry
     "no-pool": ({"SDFHIP_NO_POOL": "1"}, "trees_equal_the_oracle()"),
+    # large host-pointer batches as one upload / one launch / one download (the overlapped two-thread path off): same bits as the device-pointer path
+    "host-overlap-0": ({"SDFHIP_HOST_OVERLAP": "0"}, r'''
+import torch
+t = trees_equal_the_oracle()
+big = random_points_in_box(box, 2_600_000, seed=9)
+d, g = t.get_distance(big, gradient=True)
+dt, gt = t.get_distance(torch.from_numpy(big).cuda(), gradient=True)
+assert np.array_equal(b(d), b(dt.cpu().numpy())) and np.array_equal(b(g), b(gt.cpu().numpy()))
+'''),
     # the seam welding's round-1..5 host planner (std::map based) instead of the device passes: same TriangleData, same tree on a welded soup
     "weld-host": ({"SDFHIP_WELD": "host"}, r'''
 from sdflib_amd.meshgen import triangle_soup
