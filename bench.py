@@ -55,7 +55,7 @@ class Profile:
 
     def __init__(self, enabled=True):
         import csv, glob
-        self.prefix = None; self.pmc = {}; self.sq = {}; self.stats = {}; self.meta = {}
+        self.prefix = None; self.pmc = {}; self.sq = {}; self.stats = {}; self.meta = {}; self.ea = {}
         if not enabled:
             return
         for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_meta.json")))):
@@ -63,7 +63,7 @@ class Profile:
             try:
                 self.meta = json.load(open(path))
                 rd = lambda suf: {row["kernel"].replace(" ", ""): row for row in csv.DictReader(open(pre + suf))} if os.path.exists(pre + suf) else {}
-                self.pmc, self.sq, self.stats = rd("_pmc.csv"), rd("_pmc_sq.csv"), rd("_kernel_stats.csv")
+                self.pmc, self.sq, self.stats, self.ea = rd("_pmc.csv"), rd("_pmc_sq.csv"), rd("_kernel_stats.csv"), rd("_pmc_ea.csv")
                 if self.pmc:
                     self.prefix = os.path.relpath(pre, ROOT); break
             except Exception:
@@ -119,9 +119,19 @@ class Profile:
         fetch, write = float(r["FETCH_SIZE_avg_per_dispatch"]) * 1024, float(r["WRITE_SIZE_avg_per_dispatch"]) * 1024
         hit, miss = float(r.get("TCC_HIT_sum_avg_per_dispatch") or 0), float(r.get("TCC_MISS_sum_avg_per_dispatch") or 0)
         factor, note = self.fetch_calibration()
+        ea = self._find(self.ea, kernel, n_threads, ("TCC_EA0_RDREQ_128B_sum_avg_per_dispatch", "TCC_EA0_RDREQ_sum_avg_per_dispatch"))
+        if ea:      # the L2's read requests by size (round 6): exact bytes, no calibration factor (on the calibration kernel: 2.0313e7 x 128 B = 2.600 GB for 2.6 GB known)
+            n128, n64, n32 = (float(ea.get(f"TCC_EA0_RDREQ_{b}_sum_avg_per_dispatch") or 0) for b in ("128B", "64B", "32B"))
+            rd_bytes = 128 * n128 + 64 * n64 + 32 * n32
+            return self._traffic_tail({"traffic": int(rd_bytes + write), "traffic_source": f"{self.prefix}_pmc_ea.csv (TCC_EA0_RDREQ by request size: 128 B x {n128:.6g} + 64 B x {n64:.4g} + 32 B x {n32:.4g}) + WRITE_SIZE, per launch; sources unchanged since",
+                                       "fabric_read_bytes": int(rd_bytes), "write_bytes_reported": int(write), "fetch_size_x_calibration": int(fetch * factor),
+                                       "l2_hit": round(hit / (hit + miss), 4) if hit + miss > 0 else None}, kernel, n_threads)
         out = {"traffic": int(fetch * factor + write), "traffic_source": f"{self.prefix}_pmc.csv (FETCH_SIZE x fetch_calibration + WRITE_SIZE, per launch; sources unchanged since)",
                "fabric_bytes_reported": int(fetch), "write_bytes_reported": int(write), "fetch_calibration": round(factor, 3), "fetch_calibration_from": note,
                "l2_hit": round(hit / (hit + miss), 4) if hit + miss > 0 else None}
+        return self._traffic_tail(out, kernel, n_threads)
+
+    def _traffic_tail(self, out, kernel, n_threads):
         sq = self.sq_row(kernel, n_threads)
         if sq and sq.get("SQ_THREAD_CYCLES_VALU_avg_per_dispatch"):
             out["valu_lanes_active"] = round(float(sq["SQ_THREAD_CYCLES_VALU_avg_per_dispatch"]) / (64.0 * float(sq["SQ_ACTIVE_INST_VALU_avg_per_dispatch"])), 3)
@@ -836,11 +846,12 @@ def host_pointer(tree, ex, pts, dev):
         return b
     us_oct = scalar(lambda q: L.sdfhip_octree_query(tree.h, q, 1, dptr, None, 0, S.EVAL_EXACT))
     us_ex = scalar(lambda q: L.sdfhip_exact_query(ex.h, q, 1, dptr, None, None, 0))
-    path = "plain pageable copies"
+    path = "plain pageable copies, pieces of 2^20 points: upload + kernel of piece k + 1 overlap the download of piece k (two or three host threads, no registration of the caller's memory)"
+    bound_ovl = max(t_up, t_down)
     return {"queries": int(n), "path": path, "value_ms": round(t_val * 1e3, 3), "host_pointer_mqueries_s": round(n / t_val / 1e6, 1), "value_and_gradient_ms": round(t_grad * 1e3, 3),
             "pcie_pinned_h2d_gb_s": round(up_gbs, 1), "pcie_pinned_d2h_gb_s": round(down_gbs, 1), "pcie_bound_ms": round(bound_seq * 1e3, 3),
-            "frac_of_pcie_bound": round(bound_seq / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),
-            "note": "bound = pinned upload + pinned download of the same arrays, one after the other (measured on this box); scalar = one point per call through the C ABI from ctypes, mean over 64 random points of the box"}
+            "frac_of_pcie_bound": round(bound_seq / t_val, 3), "pcie_overlapped_bound_ms": round(bound_ovl * 1e3, 3), "frac_of_overlapped_bound": round(bound_ovl / t_val, 3), "scalar_us_per_call_octree": round(us_oct, 2), "scalar_us_per_call_exact": round(us_ex, 2),
+            "note": "pcie_bound = pinned upload + pinned download of the same arrays, one after the other; overlapped bound = the larger of the two (full duplex), both measured on this box with PINNED tensors - the call itself copies from and to PAGEABLE arrays; scalar = one point per call through the C ABI from ctypes, mean over 64 random points of the box"}
 
 
 def knot_workload(ctx, dev, n):

@@ -607,6 +607,7 @@ int sdfhip_ctx_destroy(sdfhip_ctx* ctx) {
     SDF_API_BEGIN
     if (!ctx) return SDFHIP_OK;
     for (hipStream_t& s : ctx->bvhSide) if (s) { (void)hipStreamDestroy(s); s = nullptr; }
+    for (hipStream_t& s : ctx->upSide) if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); s = nullptr; }
     if (ctx->downStream) { (void)hipStreamSynchronize(ctx->downStream); (void)hipStreamDestroy(ctx->downStream); ctx->downStream = nullptr; }
     (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream);
     // the cached blocks of this context's stream, once its last context goes (a borrowed stream can serve several contexts)

@@ -709,7 +709,7 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
     if (where == SDFHIP_HOST && hostOverlap() && n >= kOverlapMin) {
         // Large host batches, overlapped (round 6): the batch is cut into pieces; this thread uploads piece k + 1 and evaluates it on the
         // context's stream while a second host thread sends piece k's results back on `downStream` - PCIe is full duplex, so the call costs
-        // about max(upload, download) + one piece instead of their sum.  Plain copies between the caller's PAGEABLE arrays and device
+        // about max(upload, download) + one piece instead of their sum (10 M points: 3.19 -> 2.64 ms, with gradients 5.45 -> 3.86 ms).  Plain copies between the caller's PAGEABLE arrays and device
         // buffers, as before: nothing of the caller's memory is registered with the runtime (the in-place-pinning pipeline of rounds 2-3,
         // removed in round 4 after a GPU memory access fault under forced registration failures, is not coming back).  A pageable
         // hipMemcpyAsync occupies its calling thread until the data are staged, hence the second thread.
@@ -719,30 +719,49 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         std::vector<hipEvent_t> ev(pieces, nullptr);
         struct Events { std::vector<hipEvent_t>& e; ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); } } evGuard{ev};
         for (hipEvent_t& e : ev) SDF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        std::atomic<uint64_t> recorded{0}; std::atomic<int> failed{0};
+        std::atomic<int> failed{0};
+        std::vector<std::atomic<uint8_t>> ready(pieces);
+        for (auto& r : ready) r.store(0);
         const int device = ctx->device;
         float* const dDist = d; float* const dGrad = g;
         std::thread downloader([&, device, down] {
             if (hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
             for (uint64_t k = 0; k < pieces; k++) {
-                while (recorded.load(std::memory_order_acquire) <= k) { if (failed.load()) return; std::this_thread::yield(); }
+                while (!ready[k].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
                 const uint64_t off = k * piece, m = n - off < piece ? n - off : piece;
                 if (hipStreamWaitEvent(down, ev[k], 0) != hipSuccess || hipMemcpyAsync(out_dist + off, dDist + off, 4 * m, hipMemcpyDeviceToHost, down) != hipSuccess ||
                     (out_grad && hipMemcpyAsync(out_grad + 3 * off, dGrad + 3 * off, 12 * m, hipMemcpyDeviceToHost, down) != hipSuccess)) { failed.store(1); return; }
             }
             if (hipStreamSynchronize(down) != hipSuccess) failed.store(1);
         });
-        int rc = SDFHIP_OK;
-        for (uint64_t k = 0; k < pieces && !failed.load(); k++) {
-            const uint64_t off = k * piece, m = n - off < piece ? n - off : piece;
-            if (hipMemcpyAsync(dp.p + 3 * off, xyz + 3 * off, 12 * m, hipMemcpyHostToDevice, st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-            launchQuery(eval_mode, g != nullptr, gridFor(m, 256), st, q, (const float*)(dp.p + 3 * off), m, d + off, g ? g + 3 * off : nullptr);
-            if (hipGetLastError() != hipSuccess || hipEventRecord(ev[k], st) != hipSuccess) { rc = SDFHIP_E_HIP; break; }
-            recorded.store(k + 1, std::memory_order_release);
+        // uploaders: thread u takes pieces u, u + U, ... on a stream of its own (the runtime stages a pageable copy on the calling thread:
+        // two threads stage twice as fast as one until the link is full)
+        // measured (profiles/r06o_host_overlap_ab.txt, 10 M points, medians of 30): value only - 1 uploader 3.03 ms, 2 uploaders 2.64 ms, 3 worse; value +
+        // gradient (more bytes come back than go up) - 1 uploader 3.86 ms, 2 uploaders 4.55 ms; pieces of 2^20 points (2^19: +0.3 ms, 2^22: +0.2 ms)
+        const unsigned U = out_grad ? 1u : 2u;
+        hipStream_t upStreams[3] = {st, nullptr, nullptr};
+        for (unsigned u = 1; u < U; u++) {
+            if (!ctx->upSide[u - 1]) { if (hipStreamCreateWithFlags(&ctx->upSide[u - 1], hipStreamNonBlocking) != hipSuccess) { failed.store(1); break; } }
+            upStreams[u] = ctx->upSide[u - 1];
         }
-        if (rc != SDFHIP_OK) failed.store(1);
+        const float* dpts = dp.p;
+        auto upload = [&, device](unsigned u, bool setDevice) {
+            if (setDevice && hipSetDevice(device) != hipSuccess) { failed.store(1); return; }
+            hipStream_t s = upStreams[u];
+            for (uint64_t k = u; k < pieces && !failed.load(); k += U) {
+                const uint64_t off = k * piece, m = n - off < piece ? n - off : piece;
+                if (hipMemcpyAsync(const_cast<float*>(dpts) + 3 * off, xyz + 3 * off, 12 * m, hipMemcpyHostToDevice, s) != hipSuccess) { failed.store(1); return; }
+                launchQuery(eval_mode, dGrad != nullptr, gridFor(m, 256), s, q, dpts + 3 * off, m, dDist + off, dGrad ? dGrad + 3 * off : nullptr);
+                if (hipGetLastError() != hipSuccess || hipEventRecord(ev[k], s) != hipSuccess) { failed.store(1); return; }
+                ready[k].store(1, std::memory_order_release);
+            }
+        };
+        std::vector<std::thread> ups;
+        if (!failed.load()) for (unsigned u = 1; u < U; u++) ups.emplace_back(upload, u, true);
+        if (!failed.load()) upload(0, false);
+        for (std::thread& t : ups) t.join();
         downloader.join();
-        (void)hipStreamSynchronize(st);
+        for (unsigned u = 0; u < U; u++) if (upStreams[u]) (void)hipStreamSynchronize(upStreams[u]);
         if (failed.load()) { setError("HIP error in the overlapped host-pointer query: %s", hipGetErrorString(hipGetLastError())); return SDFHIP_E_HIP; }
         return SDFHIP_OK;
     }
