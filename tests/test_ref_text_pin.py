@@ -70,6 +70,9 @@ NEGATIVE = [
     (groups.group_mesh_triangle_data, "orc_triangle", "orc_triangle.h", "const float threshold = 1e-5 / big;", "const float threshold = 1e-5f / big;"),
     (groups.group_mesh_triangle_data, "orc_triangle", "orc_triangle.h", "if (nm[i] == p1) vmap[p1] = p1;\n                            vmap[p2] = p1;",
      "vmap[p2] = p1;\n                            if (nm[i] == p1) vmap[p1] = p1;"),
+    (groups.group_octree_setup, "orc_octree", "orc_octree.h", "const float maxSize = gmax(gmax(bs.x, bs.y), bs.z);", "const float maxSize = gmax(bs.x, gmax(bs.y, bs.z));"),
+    (groups.group_octree_setup, "orc_octree", "orc_octree.h", "out.box.min = inBox.center() - 0.5f * maxSize;", "out.box.min = inBox.center() - maxSize * 0.5f;"),
+    (groups.group_octree_setup, "orc_tricubic", "orc_tricubic.h", "s[8 * v + 7] = in[v][7] * (sq * nodeSize);", "s[8 * v + 7] = (in[v][7] * sq) * nodeSize;"),
     (groups.group_exact_bits, "orc_exact", "orc_exact.h", "out.sets[at + w] |= (index << inv) >> bit;", "out.sets[at + w] |= (index >> bit) << inv;"),
     (groups.group_exact_bits, "orc_exact", "orc_exact.h", "return ((set[w] << bit) >> (32 - bits)) |", "return ((set[w] << bit) >> (31 - bits)) |"),
 ]

@@ -592,3 +592,133 @@ def group_exact_bits(orc_exact=None):
 
 
 GROUPS.append(group_exact_bits)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def snippet(text, start_regex, end_regex):
+    a = re.search(start_regex, text); assert a, start_regex
+    b = re.search(end_regex, text[a.start():]); assert b, end_regex
+    return text[a.start():a.start() + b.end()]
+
+
+def strip_at(x):
+    if isinstance(x, tuple):
+        if x and x[0] == "at":
+            return strip_at(x[2])
+        return tuple(strip_at(y) for y in x)
+    return x
+
+
+def group_octree_setup(orc_octree=None, orc_tricubic=None):
+    """The float side of OctreeSdf's set-up and of a NO_CONTINUITY node: the box made a cube and the start-grid cell size
+    (OctreeSdf.cpp:40-50), root nodes (OctreeSdfDepthFirst.h:115-125), the start-cell index (:406-410), a node's fit size, rule test, child
+    centres and value range (:205-225, 349-361), calculatePointValues and the derivative scaling of calculateCoefficients
+    (InterpolationMethods.h:273-312)."""
+    cpp = cparse.preprocess(read(REF + "/src/sdf/OctreeSdf.cpp"))
+    df = cparse.preprocess(read(REF + "/src/sdf/OctreeSdfDepthFirst.h"))
+    im = cparse.preprocess(read(REF + "/include/SdfLib/InterpolationMethods.h"))
+    orc = cparse.preprocess(orc_octree or read(REPO + "/oracle/orc_octree.h"))
+    tri = cparse.preprocess(orc_tricubic or read(REPO + "/oracle/orc_tricubic.h"))
+    members = {"box": "mBox", "startGridSize": "mStartGridSize", "startGridXY": "mStartGridXY", "startGridCellSize": "mStartGridCellSize", "maxDepth": "mMaxDepth"}
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] == ("id", "out") and x[2] in members:
+            return ("id", members[x[2]])
+        if x[0] == "mcall" and x[2] in ("size", "center") and x[3] == ():
+            return ("mcall", x[1], "getSize" if x[2] == "size" else "getCenter", ())
+        if x[0] == "cast" and x[1] == "float" and "pow" in symex.show(x[2]):
+            return x[2]                      # std::pow(float, unsigned) is a double in C++; 0.5^k and the products with it are exact either way
+        return x
+
+    def run(text, rewrite=None, **kw):
+        e = symex.Exec(**kw); e.rewrite = rewrite
+        return e.run([], cparse.parse_body("{" + text + "}"))
+    # 1. the cube
+    r = run(snippet(cpp, r"const glm::vec3 bbSize = box\.getSize\(\);", r"mStartGridCellSize = [^;]*;"))
+    o = run(snippet(orc, r"const V3 bs = inBox\.size\(\);", r"out\.startGridCellSize = [^;]*;"), rw_orc, id_alias={"inBox": "box"})
+    compare("buildOctree: cube and start-grid cell size", r, o)
+    # 2. root nodes: size, first centre, centre of node (i, j, k)
+    r = run(snippet(df, r"float newSize = 0\.5f \* mBox\.getSize\(\)\.x", r"const glm::vec3 startCenter = [^;]*;") + " return startCenter + glm::vec3(i, j, k) * 2.0f * newSize;")
+    o = run(snippet(orc, r"const float newSize = \(float\)\(0\.5f \* out\.box\.size\(\)\.x", r"const V3 startCenter = [^;]*;") + " return startCenter + V3{(float)i, (float)j, (float)k} * 2.0f * newSize;", rw_orc)
+
+    def uncast(x):       # glm::vec3(i, j, k) converts its unsigned arguments; the oracle spells the conversion out
+        if isinstance(x, tuple):
+            if x and x[0] == "cast" and x[1] == "float" and x[2][0] == "id":
+                return x[2]
+            return tuple(uncast(y) for y in x)
+        return x
+    compare("initOctree: root nodes", r, [dict(p, end=uncast(p["end"])) for p in o])
+    # 3. start-cell index of a node
+    r = run(snippet(df, r"glm::ivec3 startArrayPos = glm::floor\(\(node\.center - mBox\.min\) / mStartGridCellSize\);", r"node\.nodeIndex = [^;]*;"))
+    o = run(snippet(orc, r"V3 f = \(n\.center - out\.box\.min\) / out\.startGridCellSize;", r"return \(uint32_t\)\([^;]*;"), rw_orc, id_alias={"n": "node"})
+    want = r[0]["events"][-1][2]
+    got = o[0]["end"][1]
+    assert got[0] == "cast" and got[1] == "uint32_t", got
+    compare("initOctree: start-cell index", want, got[2])
+    # 4. a node: the fit's size argument, the rule's comparison, child centres, the value range
+    assert re.search(r"calculateCoefficients\(node\.verticesValues, 2\.0f \* node\.size,", df) and len(re.findall(r"tricubicFit\(node\.vv, 2\.0f \* node\.size, coeff\)", orc)) == 2
+    assert re.search(r"generateTerminalNodes = value < tContext\.sqTerminationThreshold;", df) and re.search(r"sqTerminationThreshold = terminationRuleParams\[0\] \* terminationRuleParams\[0\];", df)
+    assert re.search(r"terminal = ruleValue\(rule, coeff, mid, param1\) < sqThreshold;", orc) and re.search(r"sqThreshold = p0 \* p0;", orc)
+    signs = re.findall(r"node\.center \+ glm::vec3\((-?)newSize, (-?)newSize, (-?)newSize\), newSize", df)
+    assert [tuple(s == "" for s in t) for t in signs] == [((c & 1) != 0, (c & 2) != 0, (c & 4) != 0) for c in range(8)], signs
+    assert re.search(r"const float newSize = 0\.5f \* node\.size;", df) and re.search(r"const float ns = 0\.5f \* node\.size;", orc)
+    assert re.search(r"ch\.center = node\.center \+ V3\{\(c & 1\) \? ns : -ns, \(c & 2\) \? ns : -ns, \(c & 4\) \? ns : -ns\};", orc)
+    r = run(snippet(df, r"for\(uint32_t i=0; i < 8; i\+\+\)\s*\{\s*tContext\.valueRange", r"\}"), lambda x: ("id", "valueRange") if x == ("member", ("id", "tContext"), "valueRange") else (("id", "vv") if x == ("member", ("id", "node"), "verticesValues") else x))
+    o = run("for (int i = 0; i < 8; i++) valueRange = gmax(valueRange, std::fabs(node.vv[i][0]));", lambda x: ("id", "vv") if x == ("member", ("id", "node"), "vv") else x)
+    assert "for (int i = 0; i < 8; i++) valueRange = gmax(valueRange, std::fabs(node.vv[i][0]));" in orc
+    compare("processNode: value range", strip_at(r), strip_at(o))
+    # 5. calculatePointValues
+    tc = im[im.index("struct TriCubicInterpolation"):]
+    # (the gradient local is an out-argument of the distance routine: left undeclared on both sides so that it is one opaque name)
+    ref_pv = tc.replace("glm::vec3 gradient;", "", 1)
+    orc_pv = orc.replace("V3 g;", "", 1)
+    assert ref_pv != tc and orc_pv != orc
+    rp, rb = fn(ref_pv, r"inline static void calculatePointValues\s*\(")
+    op, ob = fn(orc_pv, r"static inline void pointValues\s*\(")
+
+    def rw_pv_ref(x):
+        if x[0] == "mcall" and x[1] == ("arg", 2) and x[2] in ("getIndices", "getVertices"):
+            return ("member", ("arg", 2), "indices" if x[2] == "getIndices" else "vertices")
+        return x
+    er = symex.Exec(); er.rewrite = rw_pv_ref
+    r = er.run(rp, rb)
+    # oracle argument order: (p, t, mesh, td, out) - the same positions as the reference's (point, index, mesh, trianglesData, outValues)
+    o = symex.Exec(fn_alias={"signedDistPointTriangleGrad": "getSignedDistPointAndTriangle"}, id_alias={"g": "gradient"}).run(op, ob)
+    compare("calculatePointValues", strip_at(r), strip_at(o))
+    # 6. derivative scaling in calculateCoefficients: slot q of vertex v is multiplied by nodeSize^order
+    scal = snippet(im[im.index("inline static void calculateCoefficients"):], r"for\(uint32_t i=0; i < 8; i\+\+\)", r"inValues\[i\]\[7\] \*= sqNodeSize \* nodeSize;\s*\}")
+    r = run(scal)
+    refmap = {}
+    for e in r[0]["events"]:
+        assert e[0] == "store"
+        tgt, val = strip_at(e[1]), strip_at(e[2])
+        refmap[(tgt[1][2][2], tgt[2][2])] = val                     # inValues[v][q]
+    o = run(snippet(tri, r"float s\[64\];", r"s\[8 \* v \+ 7\] = [^;]*;\s*\}") + " return s;")
+    got = dict(o[0]["end"][1][1:])
+    assert len(refmap) == 56 and len(got) == 64
+    for (v, q), val in refmap.items():
+        want_val = symex.first_difference(val, got[8 * v + q])
+        # reference: inValues[v][q] * k   (in place);  oracle: in[v][q] * k
+        a = symex.show(val).replace("inValues", "in"); b = symex.show(got[8 * v + q])
+        assert a == b, (v, q, a, b)
+    for v in range(8):
+        assert symex.show(got[8 * v]) == "in[%d][0]" % v
+    # 7. VHQueries::calculateVerticesInfo (TrianglesInfluence.h:951-996): where a sample is taken, the parent-interpolation arguments, the cache key
+    ti = cparse.preprocess(read(REF + "/include/SdfLib/TrianglesInfluence.h"))
+    vh = ti[ti.index("struct VHQueries"):]
+
+    def expr(text, **kw):
+        return run("return %s;" % text, **kw)[0]["end"]
+    assert "inPoints[i] = nodeCenter + pointsRelPos[i] * nodeHalfSize;" in vh and "const V3 p = center + rel[i] * half;" in orc
+    compare("sample position", expr("nodeCenter + pointsRelPos[i] * nodeHalfSize"), expr("center + rel[i] * half", id_alias={"center": "nodeCenter", "rel": "pointsRelPos", "half": "nodeHalfSize"}))
+    assert "InterpolationMethod::interpolateVertexValues(interpolationCoeff, 0.5f * pointsRelPos[i] + 0.5f, 2.0f * nodeHalfSize, outPointsValues[i]);" in vh
+    assert "const glm::uvec3 pointId = glm::uvec3(glm::round((inPoints[i] - minPoint) * coordToId));" in vh and "const V3 q = (p - minPoint) * coordToId;" in orc
+    assert "coordToId = glm::vec3(static_cast<float>((1 << maxDepth)) / box.getSize());" in vh
+    assert re.search(r"const float s = \(float\)\(1 << maxDepth\);\s*const V3 sz = box\.size\(\);\s*coordToId = V3\{s / sz\.x, s / sz\.y, s / sz\.z\};", orc)
+    # (the 32^3 direct-mapped cache is OFF in canonical mode; its key and slot are checked as text: mask (1 << 5) - 1, shifts 2 * 5 and 5)
+    assert "const uint32_t cacheId = ((pointId.z & CACHE_AXIS_MASK) << (2*CACHE_AXIS_POWER)) |" in vh and re.search(r"CACHE_AXIS_MASK = \(1 << CACHE_AXIS_POWER\) - 1;", ti)
+    assert re.search(r"CACHE_AXIS_POWER = 5;", ti) and re.search(r"CACHE_AXIS_MASK = [^;]*;", ti) and "((iz & 31u) << 10) | ((iy & 31u) << 5) | (ix & 31u)" in orc
+    return "OctreeSdf set-up: cube / cell size, root nodes, start-cell index, fit size, rule test, child centres, value range, calculatePointValues, derivative scaling, sample positions: identical"
+
+
+GROUPS.append(group_octree_setup)
