@@ -258,6 +258,7 @@ def main():
                     "Armadillo when supplied); the box is the exporter's: bbox + 20 %% of the largest extent, cube-ified by the build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-build-1m", action="store_true", help="skip the depth-8 build of the 1.31 M-triangle mesh (BASELINE configs[3])")
+    ap.add_argument("--no-forecast", action="store_true", help="skip build_1m.forecast (28 shard builds of the 1.31 M mesh): the profile passes use it so that per-kernel averages describe the benchmark's own builds")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (gradient, fast eval, 256^3 grid, ExactOctreeSdf)")
     args = ap.parse_args()
 
@@ -383,7 +384,7 @@ def main():
     if not args.no_extras:
         result["extras"] = extras(tree, mesh, box, pts, out, dev, rank, world, prof)
     if not args.no_build_1m:
-        result["build_1m"] = build_1m(ctx, rank, world, dev)
+        result["build_1m"] = build_1m(ctx, rank, world, dev, forecast=not args.no_forecast)
     # the HBM-honest figure of the headline kernel beside the headline (whose working set sits in the Infinity Cache): the depth-9 tree's block
     deep = (result.get("extras") or {}).get("deep_tree_d9")
     if deep and deep.get("roofline"):
@@ -965,7 +966,7 @@ def shard_forecast(mesh, box, depth, start_depth, steady, words):
     return out
 
 
-def build_1m(ctx, rank, world, dev):
+def build_1m(ctx, rank, world, dev, forecast=True):
     v, f = bumpy_icosphere(8)
     box = box_with_margin(v)
     t0 = time.perf_counter()
@@ -991,7 +992,8 @@ def build_1m(ctx, rank, world, dev):
     if world == 1:
         r["steady_state"] = end_to_end_build(ctx, v, f, box, 8, 3, dev)
         r["end_to_end_s"] = r["steady_state"]["end_to_end_s"]
-        r["forecast"] = shard_forecast(mesh, box, 8, 3, r["steady_state"], int(i.num_words))
+        if forecast:
+            r["forecast"] = shard_forecast(mesh, box, 8, 3, r["steady_state"], int(i.num_words))
     else:
         # what north_star asks of the N-GPU build: seconds at N and where they go.  serial = what every rank repeats (mesh upload +
         # TriangleData, the sphere BVH - built by every rank on its own device, or planned by rank 0 and broadcast under

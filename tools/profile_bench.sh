@@ -6,7 +6,7 @@ REPO=$PWD
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline ${BENCH_EXTRA:-}"
+CMD="python $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-forecast ${BENCH_EXTRA:-}"
 cd /tmp
 timeout 700 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench -- $CMD > $OUT/bench_trace.log 2>&1
 # PMC passes: counters only, with kernel-trace only (no sys/hip/hsa traces)
