@@ -11,7 +11,9 @@
 //   mat3 * vec3    : m[0][r]*v.x + m[1][r]*v.y + m[2][r]*v.z     (glm/detail/type_mat3x3.inl)
 //   inverse(mat3)  : cofactors * OneOverDeterminant              (glm/detail/func_matrix.inl)
 //   sign           : (0 < x) - (x < 0) ; min(a,b) = (b<a)?b:a ; max(a,b) = (a<b)?b:a ; fract = x - floor(x)
-// PARITY UNPINNED at the ulp level: the reference holds no test that pins results at the glm boundary.
+// PARITY UNPINNED at the ulp level FOR THIS FILE ONLY: the reference holds no test that pins results at the glm boundary, and glm's source is
+// not here to compare with.  Everything that CALLS these helpers (orc_triangle.h, orc_exact.h, orc_octree.h ...) is pinned to the reference's
+// text by tools/refpin (tests/test_ref_text_pin.py): same operations, same operands, same order - with these operators as vocabulary.
 // Must be compiled with -ffp-contract=off (no FMA), like the reference's default x86-64 build.
 #pragma once
 #include <cmath>
