@@ -27,6 +27,7 @@ from sdflib_amd import distributed as sdist  # noqa: E402
 # where sdfhip_mesh_build_bvh builds the tree: on the device (the default: introsort rounds over global memory + k_bvh_subtrees) or by the host planner
 BVH_BUILT_ON = "host" if os.environ.get("SDFHIP_BVH_BUILD") == "host" else "device"
 
+MESH_BBOX, MESH_VERTS = None, -1        # the loader's box of a --mesh file (and its vertex count: build_1m's own mesh has none)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy ceiling
 
 
@@ -291,7 +292,12 @@ def main():
         mesh_name = f"bumpy icosphere s={args.subdiv} ({len(f)} tris, Armadillo-scale stand-in)"
     box = box_with_margin(v)
     ctx = S.Context(dev.index, use_torch_stream=True)
-    mesh = S.Mesh(v, f, ctx)
+    # a mesh that comes from a FILE carries its bounding box like the reference's Mesh(filePath) (src/utils/Mesh.cpp:9-88), which is what
+    # enables calculateMeshTriangleData's seam welding (TriangleUtils.cpp:292-420); the synthetic stand-ins are raw arrays (no box, no welding)
+    global MESH_BBOX, MESH_VERTS
+    MESH_BBOX = np.concatenate([v.min(axis=0), v.max(axis=0)]).astype(np.float32) if args.mesh else None
+    MESH_VERTS = len(v)
+    mesh = S.Mesh(v, f, ctx, bbox=MESH_BBOX)
     bvh_s = sdist.share_bvh(mesh, rank, world, dev) if world > 1 else mesh.build_bvh()      # N > 1: every rank builds it on its own device (host planner: rank 0 + broadcast)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -368,6 +374,7 @@ def main():
         "config": {"workload": f"{mesh_name} OctreeSdf depth {args.depth} "
                                f"start {args.start_depth} thr 1e-3 NO_CONTINUITY; {args.queries} uniform-random getDistance per GPU per step",
                    "eval": args.eval, "gradient": bool(args.gradient), "queries_per_gpu": args.queries,
+                   **({"mesh_edges": mesh.edge_stats(), "mesh_box": "the file's bounding box (loader semantics: seam welding on)"} if args.mesh else {}),
                    "octree_words": int(info.num_words), "octree_leaves": int(info.num_leaves), "parallelism": f"replicated tree x{world}, sharded build"},
         "per_gpu_mqueries_s": round(value / world, 2),
         "roofline": roof,
@@ -461,7 +468,8 @@ def end_to_end_build(ctx, v, f, box, depth, start_depth, dev):
     build), then the first query's one-off cost (none since round 5: the builders emit the query layout; a tree that arrives as an array makes it then).  Steady state of this context: its
     scratch buffers exist already, nothing else is reused."""
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    m = S.Mesh(v, f, ctx, plan_bvh_early=True); torch.cuda.synchronize(); t1 = time.perf_counter()       # as the OctreeSdf constructors do: the BVH plan starts under the mesh preparation
+    box_arg = MESH_BBOX if (MESH_BBOX is not None and len(v) == MESH_VERTS) else None
+    m = S.Mesh(v, f, ctx, plan_bvh_early=True, bbox=box_arg); torch.cuda.synchronize(); t1 = time.perf_counter()       # as the OctreeSdf constructors do: the BVH plan starts under the mesh preparation
     planner_s = m.build_bvh(); torch.cuda.synchronize(); t2 = time.perf_counter()
     t = S.OctreeSdf(m, box, depth, start_depth, 1e-3, num_threads=2); torch.cuda.synchronize(); tb = time.perf_counter()
     bb = t.get_grid_bounding_box()
@@ -504,7 +512,7 @@ def cpu_baseline(v, f, box, args, pts):
     os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # the oracle's idle OpenMP workers must not spin into the GPU measurements that follow
     from oracle import pyoracle as O
     cores = os.cpu_count() or 1
-    om = O.Mesh(v, f)
+    om = O.Mesh(v, f, MESH_BBOX) if MESH_BBOX is not None else O.Mesh(v, f)
     t0 = time.perf_counter()
     # build at the bench depth is minutes of CPU on few cores: bound it by building one level shallower if needed
     cpu_depth = args.depth if cores >= 32 else min(args.depth, 7)

@@ -139,3 +139,15 @@ def test_bench_runs_a_mesh_file(tmp_path):
     d = json.loads(lines[0])
     assert d["data"] == "file" and "bumpy4.ply" in d["config"]["workload"] and str(len(f)) in d["config"]["workload"]
     assert d["value"] > 0 and d["build"]["time_to_first_query_s"] > 0
+    assert d["config"]["mesh_edges"] == {"unmatched_edges": 0, "welded_half_edges": 0}
+    # an unwelded export of the same surface: the file's box switches the seam welding on (loader semantics), every edge is re-paired
+    from sdflib_amd.meshgen import triangle_soup
+    sv, sf = triangle_soup(v, f)
+    spath = os.path.join(str(tmp_path), "soup4.ply")
+    meshio.write_ply(spath, sv, sf)
+    cmd[cmd.index("--mesh") + 1] = spath
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d2["config"]["mesh_edges"] == {"unmatched_edges": 3 * len(sf), "welded_half_edges": 3 * len(sf)}
+    assert d2["build"]["mesh_prep_s"] > 0 and d2["config"]["octree_leaves"] > 0
