@@ -713,7 +713,12 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         // buffers, as before: nothing of the caller's memory is registered with the runtime (the in-place-pinning pipeline of rounds 2-3,
         // removed in round 4 after a GPU memory access fault under forced registration failures, is not coming back).  A pageable
         // hipMemcpyAsync occupies its calling thread until the data are staged, hence the second thread.
-        if (!ctx->downStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->downStream, hipStreamNonBlocking));
+        const unsigned U = out_grad ? 1u : 2u;      // uploader threads (measured below)
+        {
+            std::lock_guard<std::mutex> side(ctx->sideLock);
+            if (!ctx->downStream) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->downStream, hipStreamNonBlocking));
+            for (unsigned u = 1; u < U; u++) if (!ctx->upSide[u - 1]) SDF_HIP_CHECK(hipStreamCreateWithFlags(&ctx->upSide[u - 1], hipStreamNonBlocking));
+        }
         hipStream_t down = ctx->downStream;
         const uint64_t piece = kOverlapPiece, pieces = (n + piece - 1) / piece;
         std::vector<hipEvent_t> ev(pieces, nullptr);
@@ -738,12 +743,8 @@ int sdfhip_octree_query(sdfhip_octree* T, const float* xyz, uint64_t n, float* o
         // two threads stage twice as fast as one until the link is full)
         // measured (profiles/r06o_host_overlap_ab.txt, 10 M points, medians of 30): value only - 1 uploader 3.03 ms, 2 uploaders 2.64 ms, 3 worse; value +
         // gradient (more bytes come back than go up) - 1 uploader 3.86 ms, 2 uploaders 4.55 ms; pieces of 2^20 points (2^19: +0.3 ms, 2^22: +0.2 ms)
-        const unsigned U = out_grad ? 1u : 2u;
         hipStream_t upStreams[3] = {st, nullptr, nullptr};
-        for (unsigned u = 1; u < U; u++) {
-            if (!ctx->upSide[u - 1]) { if (hipStreamCreateWithFlags(&ctx->upSide[u - 1], hipStreamNonBlocking) != hipSuccess) { failed.store(1); break; } }
-            upStreams[u] = ctx->upSide[u - 1];
-        }
+        for (unsigned u = 1; u < U; u++) upStreams[u] = ctx->upSide[u - 1];
         const float* dpts = dp.p;
         auto upload = [&, device](unsigned u, bool setDevice) {
             if (setDevice && hipSetDevice(device) != hipSuccess) { failed.store(1); return; }

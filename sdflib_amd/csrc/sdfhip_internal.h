@@ -379,6 +379,7 @@ struct sdfhip_ctx {
     hipStream_t stream = nullptr;
     bool ownsStream = false;
     size_t contCaps[3] = {0, 0, 0};                   // what the last CONTINUITY build of this context grew its node array / node pool / post-pass list to: the next one starts there (builds are serialised by buildLock)
+    std::mutex sideLock;                              // guards the lazy creation of the three streams below (queries of several host threads may run concurrently)
     hipStream_t upSide[2] = {nullptr, nullptr};       // ... and further uploader threads' streams
     hipStream_t downStream = nullptr;                 // host-pointer query batches: results go back on this stream while the next piece is uploaded and evaluated on `stream` (octree_query.hip)
     hipStream_t bvhSide[2] = {nullptr, nullptr};      // the BVH build's centre sums run on these behind each level's sort (created on first use; builds are serialised by buildLock)

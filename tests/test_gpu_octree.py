@@ -934,3 +934,15 @@ def test_large_host_batches_are_overlapped_and_bit_identical(small, gpu_ctx):
             assert np.array_equal(bits(g), bits(gt.cpu().numpy())), n
         d1 = t.get_distance(pts)
         assert np.array_equal(bits(d1), bits(dt.cpu().numpy())), n
+    # two host threads in the overlapped path at once on one context (queries are documented as concurrent; the side streams are shared)
+    import threading
+    a = random_points_in_box(small["box"], 2_500_000, seed=1); b = random_points_in_box(small["box"], 3_000_000, seed=2)
+    want = [t.get_distance(torch.from_numpy(x).cuda()).cpu().numpy() for x in (a, b)]
+    got = [None, None]
+    def work(i, x):
+        for _ in range(3):
+            got[i] = t.get_distance(x)
+    th = [threading.Thread(target=work, args=(i, x)) for i, x in enumerate((a, b))]
+    for x in th: x.start()
+    for x in th: x.join()
+    assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(bits(got[1]), bits(want[1]))
