@@ -72,7 +72,7 @@ struct ContinuityBuilder {
     void midPoints(CNode& n, uint32_t mask) {
         const Stencil& st = stencil();
         for (int i = 0; i < 19; i++) {
-            if (mask & (1u << (18 - i))) tricubicVertexValues(n.coeff, 0.5f * st.midRel[i] + v3(0.5f), 2.0f * n.size, n.mid[i]);
+            if (mask & (1u << (18 - i))) tricubicVertexValues(n.coeff, 0.5f * st.midRel[i] + 0.5f, 2.0f * n.size, n.mid[i]);
             else sample(n.center + st.midRel[i] * n.size, n.mid[i], n.midInfo[i]);
         }
     }
@@ -246,7 +246,7 @@ struct ContinuityBuilder {
                     uint32_t subdivisionMask = 0;
                     for (int i = 0; i < 19; i++) {
                         if (!(samplesMask & (1u << (18 - i)))) continue;
-                        const V3 f = 0.5f * st.midRel[i] + v3(0.5f);
+                        const V3 f = 0.5f * st.midRel[i] + 0.5f;
                         const float iv = tricubicValue(node.coeff, f);
                         const float e = node.mid[i][0] - iv;
                         if (e * e > sqThr) subdivisionMask |= (samplesMask & (1u << (18 - i)));
@@ -342,7 +342,7 @@ struct ContinuityBuilder {
                         const bool recycleMid = first && !node.ignore;
                         if (!recycleMid) { tricubicFit(node.vv, 2.0f * node.size, node.coeff); midPoints(node, samplesMask); }
                         for (int i = 0; i < 19; i++) {
-                            const V3 f = 0.5f * st.midRel[i] + v3(0.5f);
+                            const V3 f = 0.5f * st.midRel[i] + 0.5f;
                             if ((samplesMask & (1u << (18 - i))) == 0) {
                                 const float iv = tricubicValue(node.coeff, f);
                                 const float e = node.mid[i][0] - iv;

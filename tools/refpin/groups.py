@@ -722,3 +722,69 @@ def group_octree_setup(orc_octree=None, orc_tricubic=None):
 
 
 GROUPS.append(group_octree_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def group_continuity_floats(orc_cont=None):
+    """The floating-point decisions of the CONTINUITY builder (OctreeSdfBreadthFirstNoDelay.h): Iter 2's "can this shared mid-point be taken
+    from the coarser neighbour's interpolant" test (:486-503), the post-pass's twin (:924-939), the interpolation arguments of
+    calculateVerticesInfo (TrianglesInfluence.h:966-969) and the child size (:941)."""
+    ref = cparse.preprocess(read(REF + "/src/sdf/OctreeSdfBreadthFirstNoDelay.h"))
+    orc = cparse.preprocess(orc_cont or read(REPO + "/oracle/orc_continuity.h"))
+    # the NoDelay builder is the one the exporter runs (OctreeSdf.cpp:66-73)
+    live = ref[ref.index("void OctreeSdf::initOctreeWithContinuityNoDelay"):]
+
+    def rw_ref(x):
+        if x[0] == "member" and x[1] == ("id", "node"):
+            return ("id", {"interpolationCoeff": "coeff", "midPointsValues": "mid", "size": "size"}.get(x[2], x[2]))
+        return x
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] in (("id", "node"), ("id", "n")):
+            return ("id", x[2])
+        if x[0] == "member" and x[1] == ("id", "st") and x[2] == "midRel":
+            return ("id", "nodeSamplePoints")
+        return x
+
+    def run(text, rw, **kw):
+        # ONE iteration with a free `i` (the 19 iterations are the same statement; unrolled they would fork 3^19 ways)
+        body = text[text.index("{", text.index(")")):]            # the for statement's own block
+        e = symex.Exec(fn_alias={"tricubicValue": "interpolateValue", "tricubicVertexValues": "interpolateVertexValues"}, **kw); e.rewrite = rw
+        return e.run([], cparse.parse_body(body))
+    # Iter 2
+    r = run(snippet(live, r"for\(uint32_t i=0; i < 19; i\+\+\)\s*\{\s*if\(samplesMask & \(1 << \(18-i\)\)\)", r"\n\s*\}\s*\}\s*\}"), rw_ref, funcs={"pow2": [(cparse.parse_params("float a"), cparse.parse_body("{ return a * a; }"))]},
+            id_alias={"sqTerminationThreshold": "sqThr"})
+    o = run(snippet(orc, r"for \(int i = 0; i < 19; i\+\+\) \{\s*if \(!\(samplesMask & \(1u << \(18 - i\)\)\)\) continue;", r"else tricubicVertexValues\(node\.coeff, f, 2\.0f \* node\.size, node\.mid\[i\]\);\s*\}").replace("continue;", "return;"), rw_orc)
+    compare("CONTINUITY Iter 2: interpolate-or-subdivide test", _masks_as_sets(r), _masks_as_sets(o))
+    # post-pass
+    r2 = run(snippet(live, r"for\(uint32_t i=0; i < 19; i\+\+\)\s*\{\s*if \(\(samplesMask & \(1 << \(18-i\)\)\) == 0\)", r"else if\(recycleMidPointsValues\)\s*\{[^}]*\}\s*\}"), rw_ref,
+             funcs={"pow2": [(cparse.parse_params("float a"), cparse.parse_body("{ return a * a; }"))]}, id_alias={"sqTerminationThreshold": "sqThr", "recycleMidPointsValues": "recycleMid"})
+    o2 = run(snippet(orc, r"for \(int i = 0; i < 19; i\+\+\) \{\s*const V3 f = 0\.5f \* st\.midRel\[i\] \+ 0\.5f;\s*if \(\(samplesMask & \(1u << \(18 - i\)\)\) == 0\)", r"else if \(recycleMid\) tricubicVertexValues\([^;]*;\s*\}"), rw_orc)
+    compare("CONTINUITY post-pass: interpolate test", _masks_as_sets(r2), _masks_as_sets(o2))
+    assert "0.5f * pointsRelPos[i] + 0.5f, 2.0f * nodeHalfSize" in cparse.preprocess(read(REF + "/include/SdfLib/TrianglesInfluence.h"))
+    assert "tricubicVertexValues(n.coeff, 0.5f * st.midRel[i] + 0.5f, 2.0f * n.size, n.mid[i]);" in orc and "sample(n.center + st.midRel[i] * n.size, n.mid[i], n.midInfo[i]);" in orc
+    assert len(re.findall(r"const float newSize = 0\.5f \* node\.size;", live)) >= 2 and "0.5f * node.size" in orc
+    return "CONTINUITY builder: Iter-2 and post-pass interpolate-or-subdivide tests (value, squared error against the squared threshold, strictness), interpolation arguments: identical (%d + %d paths)" % (len(r), len(o2))
+
+
+def _masks_as_sets(paths):
+    """one loop iteration's paths, comparable across `if (bit) {...}` and `if (!bit) continue; ...`: a negated condition is the condition with
+    the other outcome, an early return is the end of the body, and the integer literal of the bit test has no kind (1 << k vs 1u << k)"""
+    def unkind(x):
+        if isinstance(x, tuple):
+            if x and x[0] == "lit" and x[1] in ("int", "uint"):
+                return ("lit", "int", x[2])
+            return tuple(unkind(y) for y in x)
+        return x
+    out = []
+    for p in paths:
+        conds = []
+        for c, taken in p["conds"]:
+            while isinstance(c, tuple) and c[0] == "un" and c[1] == "!":
+                c, taken = c[2], not taken
+            conds.append((symex.show(unkind(c)), taken))
+        out.append((tuple(conds), tuple(symex.show(unkind(e)) for e in p["events"])))
+    return sorted(out)
+
+
+GROUPS.append(group_continuity_floats)
