@@ -788,3 +788,74 @@ def _masks_as_sets(paths):
 
 
 GROUPS.append(group_continuity_floats)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def group_exact_setup(orc_exact=None):
+    """ExactOctreeSdf's set-up and per-node float / index expressions: the cube and cell size (ExactOctreeSdf.cpp:13-22), bits per index and
+    root nodes (ExactOctreeSdfDepthFirst.h:68-71, 130-140), start-cell index (:506), the brute-force argmin of
+    PerNodeRegionTrianglesInfluence::calculateVerticesInfo (TrianglesInfluence.h:712-733), the terminal test and child size (:301, 320)."""
+    cpp = cparse.preprocess(read(REF + "/src/sdf/ExactOctreeSdf.cpp"))
+    df = cparse.preprocess(read(REF + "/include/SdfLib/ExactOctreeSdfDepthFirst.h"))
+    ti = cparse.preprocess(read(REF + "/include/SdfLib/TrianglesInfluence.h"))
+    orc = cparse.preprocess(orc_exact or read(REPO + "/oracle/orc_exact.h"))
+    members = {"box": "mBox", "startGridSize": "mStartGridSize", "startGridXY": "mStartGridXY", "startGridCellSize": "mStartGridCellSize", "maxDepth": "mMaxDepth",
+               "startDepth": "mStartDepth"}
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] == ("id", "out") and x[2] in members:
+            return ("id", members[x[2]])
+        if x[0] == "mcall" and x[2] in ("size", "center") and x[3] == () and x[1] in (("id", "inBox"), ("id", "box"), ("id", "mBox")):
+            return ("mcall", x[1], "getSize" if x[2] == "size" else "getCenter", ())
+        if x[0] == "cast" and x[1] == "float" and "pow" in symex.show(x[2]):
+            return x[2]
+        return x
+
+    def run(text, rewrite=None, **kw):
+        e = symex.Exec(**kw); e.rewrite = rewrite
+        return e.run([], cparse.parse_body("{" + text + "}"))
+    r = run(snippet(cpp, r"const glm::vec3 bbSize = box\.getSize\(\);", r"mStartGridCellSize = [^;]*;"))
+    o = run(snippet(orc, r"const V3 bs = inBox\.size\(\);", r"out\.startGridCellSize = [^;]*;"), rw_orc, id_alias={"inBox": "box"})
+    compare("ExactOctreeSdf: cube and start-grid cell size", r, o)
+    # bits per index: ceil(log2(float(#triangles))) through int32 into uint32
+    r = run("return " + re.search(r"uint32_t bitsPerIndex = ([^;]*);", df).group(1) + ";", id_alias={"trianglesData": "T"})
+    o = run("return " + re.search(r"out\.bitsPerIndex = ([^;]*);", orc).group(1) + ";", lambda x: ("id", "T") if x == ("member", ("id", "out"), "triangles") else x)
+    got = o[0]["end"][1]
+    assert got[0] == "cast" and got[1] == "uint32_t", got                      # the reference's declaration converts; the oracle spells it
+    want = r[0]["end"][1]
+    assert want[0] == "cast" and want[1] == "int32_t" and got[2][0] == "cast" and got[2][1] == "int32_t"
+    compare("bits per index", want[2], got[2][2])
+    assert re.search(r"uint32_t bitEncodingStartDepth = maxDepth - BIT_ENCODING_DEPTH;", df) and re.search(r"BIT_ENCODING_DEPTH = 2;", read(REF + "/include/SdfLib/ExactOctreeSdf.h")) and "out.bitEncodingStartDepth = depth - 2;" in orc
+    # root nodes and the start-cell index: the same statements as OctreeSdf's
+    r = run(snippet(df, r"float newSize = 0\.5f \* mBox\.getSize\(\)\.x", r"const glm::vec3 startCenter = [^;]*;") + " return startCenter + glm::vec3(i, j, k) * 2.0f * newSize;")
+    o = run(snippet(orc, r"const float newSize = \(float\)\(0\.5f \* out\.box\.size\(\)\.x", r"const V3 startCenter = [^;]*;") + " return startCenter + V3{(float)i, (float)j, (float)k} * 2.0f * newSize;", rw_orc,
+            id_alias={"sod": "startOctreeDepth"})
+
+    def uncast(x):
+        if isinstance(x, tuple):
+            if x and x[0] == "cast" and x[1] == "float" and x[2][0] == "id":
+                return x[2]
+            return tuple(uncast(y) for y in x)
+        return x
+    compare("ExactOctreeSdf: root nodes", r, [dict(p, end=uncast(p["end"])) for p in o])
+    assert len(re.findall(r"glm::ivec3 startArrayPos = glm::floor\(\(node\.center - mBox\.min\) / mStartGridCellSize\);", df)) >= 1
+    assert len(re.findall(r"V3 f = \((?:cn|n)\.center - out\.box\.min\) / out\.startGridCellSize;", orc)) == 2
+    # the brute-force nearest triangle of a node's list: first strict minimum in list order
+    arg = snippet(ti[ti.index("struct PerNodeRegionTrianglesInfluence"):], r"for\(const uint32_t& t : triangles\)", r"minDistanceToPoint\[i\] = dist;\s*\}\s*\}")
+    r = run(arg, lambda x: x, fn_alias={}, id_alias={})
+    o = run("uint32_t best = 0; float bd = INFINITY; for (uint32_t t : list) { const float d = sqDistPointTriangle(p, (*tris)[t]); if (d < bd) { best = t; bd = d; } }",
+            lambda x: ("id", "trianglesData") if x == ("un", "*", ("id", "tris")) else x, fn_alias={"sqDistPointTriangle": "getSqDistPointAndTriangle"},
+            id_alias={"list": "triangles", "p": "inPoints[i]"})
+    assert "uint32_t best = 0; float bd = INFINITY;\n        for (uint32_t t : list) { const float d = sqDistPointTriangle(p, (*tris)[t]); if (d < bd) { best = t; bd = d; } }" in orc
+    assert "minDistanceToPoint.fill(INFINITY);" in ti
+
+    def conds_only(paths):         # the reference keeps (id, distance) in arrays, the oracle in two locals: compare what is tested and in which order
+        return [tuple((symex.show(c).replace("minDistanceToPoint[i]", "<bd@loop1>").replace("inPoints[i]", "inPoints[i]"), t) for c, t in p["conds"]) for p in paths]
+    a, b = conds_only(r), conds_only(o)
+    assert len(a) == len(b) == 3 and [x for x in a] == [x for x in b], (a, b)
+    assert re.search(r"isTerminalNode = nodeTriangles\.size\(\) <= tContext\.minTrianglesPerNode;", df) and "terminal = nodeList.size() <= minTriangles;" in orc
+    assert re.search(r"const float newSize = 0\.5f \* node\.size;", df) and "const float ns = 0.5f * n.size;" in orc
+    return "ExactOctreeSdf set-up: cube / cell size, bits per index, root nodes, start-cell index, brute-force argmin (strict <, list order), terminal test, child size: identical"
+
+
+GROUPS.append(group_exact_setup)
