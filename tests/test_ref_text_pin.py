@@ -76,6 +76,8 @@ NEGATIVE = [
     (groups.group_continuity_floats, "orc_cont", "orc_continuity.h", "if (e * e > sqThr) subdivisionMask |= (samplesMask & (1u << (18 - i)));", "if (e * e >= sqThr) subdivisionMask |= (samplesMask & (1u << (18 - i)));"),
     (groups.group_continuity_floats, "orc_cont", "orc_continuity.h", "if (e * e < sqThr) tricubicVertexValues(node.coeff, f, 2.0f * node.size, node.mid[i]);", "if (e * e <= sqThr) tricubicVertexValues(node.coeff, f, 2.0f * node.size, node.mid[i]);"),
     (groups.group_exact_setup, "orc_exact", "orc_exact.h", "out.bitsPerIndex = (uint32_t)(int32_t)std::ceil(std::log2((float)out.triangles.size()));", "out.bitsPerIndex = (uint32_t)(int32_t)std::floor(std::log2((float)out.triangles.size())) + 1;"),
+    (groups.group_exact_query, "orc_exact", "orc_exact.h", "return boxDistance(o.box, p) + std::sqrt(3.0f) * o.box.size().x;", "return boxDistance(o.box, p) + o.box.size().x * std::sqrt(3.0f);"),
+    (groups.group_exact_query, "orc_exact", "orc_exact.h", "if (d < minDist) { minIndex = ti; minDist = d; }", "if (d <= minDist) { minIndex = ti; minDist = d; }"),
     (groups.group_exact_bits, "orc_exact", "orc_exact.h", "out.sets[at + w] |= (index << inv) >> bit;", "out.sets[at + w] |= (index >> bit) << inv;"),
     (groups.group_exact_bits, "orc_exact", "orc_exact.h", "return ((set[w] << bit) >> (32 - bits)) |", "return ((set[w] << bit) >> (31 - bits)) |"),
 ]

@@ -859,3 +859,57 @@ def group_exact_setup(orc_exact=None):
 
 
 GROUPS.append(group_exact_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def group_exact_query(orc_exact=None):
+    """ExactOctreeSdf::getDistance x2 (ExactOctreeSdf.cpp:38-320), the floating-point side: start cell and the outside-the-grid value, the descent
+    (child index from roundFloat, fract(2 f)), the `dist < minDist` scan and the signed distance / gradient of the winner.  (The mask decoding
+    between them is integer bookkeeping: compared only through GPU-vs-oracle equality of every query, not here.)"""
+    cpp = cparse.preprocess(read(REF + "/src/sdf/ExactOctreeSdf.cpp"))
+    orc = cparse.preprocess(orc_exact or read(REPO + "/oracle/orc_exact.h"))
+    members = {"box": "mBox", "startGridSize": "mStartGridSize", "startGridXY": "mStartGridXY", "startGridCellSize": "mStartGridCellSize"}
+
+    def rw_orc(x):
+        if x[0] == "member" and x[1] == ("id", "o") and x[2] in members:
+            return ("id", members[x[2]])
+        if x[0] == "call" and x[1] == "boxDistance" and x[2][0] == ("id", "mBox"):
+            return ("mcall", ("id", "mBox"), "getDistance", x[2][1:])
+        if x[0] == "mcall" and x[1] == ("id", "mBox") and x[2] == "size":
+            return ("mcall", x[1], "getSize", ())
+        return x
+
+    def run(text, rewrite=None, **kw):
+        e = symex.Exec(**kw); e.rewrite = rewrite
+        return e.run([], cparse.parse_body("{" + text + "}"))
+    n = 0
+    for k in range(2):
+        fnc = cpp[[m.start() for m in re.finditer(r"float ExactOctreeSdf::getDistance\(", cpp)][k]:]
+        head = snippet(fnc, r"glm::vec3 fracPart = ", r"return mBox\.getDistance\(sample\) \+ glm::sqrt\(3\.0f\) \* mBox\.getSize\(\)\.x;\s*\}")
+        r = run(head + " return startArrayPos.z * mStartGridXY + startArrayPos.y * mStartGridSize + startArrayPos.x;")
+        o = run(snippet(orc[orc.index("static inline float exactDistance"):], r"V3 f = \(p - o\.box\.min\)", r"return boxDistance\(o\.box, p\) \+ std::sqrt\(3\.0f\) \* o\.box\.size\(\)\.x;")
+                + " return (uint32_t)(iz * o.startGridXY + iy * o.startGridSize + ix);", rw_orc, id_alias={"p": "sample"})
+        # the node index: the oracle converts to uint32_t explicitly where the reference indexes the array with an int expression
+        o = [dict(p, end=("ret", p["end"][1][2]) if (p["end"][1][0] == "cast" and p["end"][1][1] == "uint32_t") else p["end"]) for p in o]
+        compare("ExactOctreeSdf::getDistance #%d: start cell / outside value" % k, r, o)
+        n += len(r)
+        # descent step, three times in the function (before the encoding depth, the step onto the first masked level, below it)
+        assert len(re.findall(r"const uint32_t childIdx = \(roundFloat\(fracPart\.z\) << 2\) \+\s*\(roundFloat\(fracPart\.y\) << 1\) \+\s*roundFloat\(fracPart\.x\);\s*currentNode = &mOctreeData\[currentNode->getChildrenIndex\(\) \+ childIdx\];\s*fracPart = glm::fract\(2\.0f \* fracPart\);", fnc[:fnc.index("float ExactOctreeSdf", 10) if "float ExactOctreeSdf" in fnc[10:] else len(fnc)])) == 3
+        # the scan: strict `<`, first minimum wins; two scans (leaf above the encoding depth, masked leaf)
+        body = fnc[:fnc.index("float ExactOctreeSdf", 10)] if "float ExactOctreeSdf" in fnc[10:] else fnc
+        assert len(re.findall(r"const float dist = TriangleUtils::getSqDistPointAndTriangle\(sample, mTrianglesData\[tIndex\]\);\s*if\(dist < minDist\)\s*\{\s*minIndex = tIndex;\s*minDist = dist;\s*\}", body)) == 2
+        if k == 0:
+            assert len(re.findall(r"return TriangleUtils::getSignedDistPointAndTriangle\(sample, mTrianglesData\[minIndex\]\);", body)) == 2
+        else:
+            assert len(re.findall(r"return TriangleUtils::getSignedDistPointAndTriangle\(sample, mTrianglesData\[minIndex\], outGradient\);", body)) == 2
+    oq = orc[orc.index("static inline float exactDistance"):]
+    assert "const uint32_t c = (roundFloatGT(f.z) << 2) + (roundFloatGT(f.y) << 1) + roundFloatGT(f.x);" in oq and "f = gfract(2.0f * f);" in oq
+    assert "float minDist = INFINITY; uint32_t minIndex = 0;" in oq and len(re.findall(r"const float d = sqDistPointTriangle\(p, o\.triangles\[ti\]\);\s*if \(d < minDist\) \{ minIndex = ti; minDist = d; \}", oq)) == 2
+    assert "if (grad) return signedDistPointTriangleGradLocal(p, o.triangles[minIndex], *grad);" in oq and "return signedDistPointTriangle(p, o.triangles[minIndex]);" in oq
+    assert re.search(r"float minDist = INFINITY;\s*uint32_t minIndex = 0;", cpp)
+    compare("descent step", run("return (roundFloat(fracPart.z) << 2) + (roundFloat(fracPart.y) << 1) + roundFloat(fracPart.x);"),
+            run("return (roundFloatGT(f.z) << 2) + (roundFloatGT(f.y) << 1) + roundFloatGT(f.x);", fn_alias={"roundFloatGT": "roundFloat"}, id_alias={"f": "fracPart"}))
+    return "ExactOctreeSdf::getDistance x2: start cell, outside-the-grid value (box distance + sqrt(3) size), descent step, strict `<` scans, winner's signed distance / gradient: identical (%d paths + text)" % n
+
+
+GROUPS.append(group_exact_query)
